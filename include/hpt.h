@@ -1,0 +1,237 @@
+/* hpt.h — C ABI of the MI355X path-tracing hot path ("hpt" = HIP path tracer).
+ *
+ * This is the ONLY boundary between pbrt-v2's host side and the device code.  It replaces,
+ * behind pbrt's own Renderer plugin surface, the reference's
+ *
+ *     Renderer::Render(const Scene *)                 core/renderer.h:43-54
+ *       = SamplerRenderer::Render                     renderers/samplerrenderer.cpp:283-317
+ *       + SamplerRendererTask::Run                    renderers/samplerrenderer.cpp:155-259
+ *       + SamplerRenderer::Li / PathIntegrator::Li    samplerrenderer.cpp:320-342, integrators/path.cpp:52-123
+ *
+ * The reference has no FFI of its own (plugins are statically linked C++ classes,
+ * README.txt:55-61); the binding a maintainer adds is one Renderer subclass
+ * (host/hip_renderer.cpp, shown in INTEGRATION.md) that fills the POD descriptors below from
+ * the Scene/Camera/Sampler objects pbrt already built and calls hpt_scene_create / hpt_render.
+ *
+ * Conventions
+ *  - plain C, POD only, caller owns every input buffer, the library copies during *_create;
+ *  - every call returns 0 on success or a negative HPT_E_* code; hpt_last_error() gives text
+ *    (the host wrapper maps it to pbrt's Error()/Severe(), core/error.h:49-52);
+ *  - matrices are row-major float[16], exactly Matrix4x4::m (core/transform.h);
+ *  - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *    HPT_E_NODEVICE.
+ */
+#ifndef HPT_H
+#define HPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
+#define HPT_VERSION 2
+
+enum {
+    HPT_OK = 0,
+    HPT_E_NODEVICE = -1,   /* no HIP device / HIP runtime error */
+    HPT_E_INVALID = -2,    /* malformed descriptor */
+    HPT_E_UNSUPPORTED = -3,/* scene uses a feature outside the hot-path scope */
+    HPT_E_IO = -4,
+    HPT_E_HIP = -5
+};
+
+/* ---- scene description (flattened pbrt Scene) ------------------------------------------ */
+
+/* Shape kinds other than triangles.  shapes/sphere.cpp, shapes/disk.cpp */
+enum { HPT_QUADRIC_SPHERE = 1, HPT_QUADRIC_DISK = 2 };
+
+/* Material kinds: materials/matte.cpp:42, plastic.cpp:42, measured.cpp:194 (IrregIsotropicBRDF) */
+enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3 };
+
+/* Light kinds: lights/point.cpp:50, lights/diffuse.cpp:69, lights/infinite.cpp:68 */
+enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3 };
+
+/* One TriangleMesh (shapes/trianglemesh.cpp:42).  Offsets index the float / int pools of the
+ * scene descriptor, in ELEMENTS; -1 = attribute absent.
+ *   P   : nverts*3 floats, WORLD space (the reference transforms at construction, :70-71)
+ *   N   : nverts*3 floats, OBJECT space (transformed per hit, trianglemesh.cpp:323-325)
+ *   uv  : nverts*2 floats
+ *   idx : ntris*3 ints
+ * All triangles of a mesh share material and area light (GeometricPrimitive::Refine,
+ * core/primitive.cpp:147-157). */
+typedef struct hpt_mesh {
+    int64_t p_off, n_off, uv_off, idx_off;
+    int32_t ntris, nverts;
+    int32_t material;            /* index into materials */
+    int32_t arealight;           /* index into lights, or -1 */
+    int32_t reverse_orientation; /* Shape::ReverseOrientation */
+    int32_t swaps_handedness;    /* Shape::TransformSwapsHandedness */
+    float o2w[16];               /* ObjectToWorld->m    */
+    float o2w_inv[16];           /* ObjectToWorld->mInv */
+} hpt_mesh;
+
+/* Sphere (shapes/sphere.cpp:40-49) or Disk (shapes/disk.cpp:40-47). */
+typedef struct hpt_quadric {
+    int32_t kind;
+    int32_t material;
+    int32_t arealight;
+    int32_t reverse_orientation;
+    int32_t swaps_handedness;
+    float radius;
+    float zmin, zmax, theta_min, theta_max; /* sphere */
+    float phi_max;
+    float height, inner_radius;             /* disk */
+    float o2w[16];
+    float o2w_inv[16];
+} hpt_quadric;
+
+/* Material parameter record (textures are constant in the in-scope configs; the host wrapper
+ * refuses non-constant textures with HPT_E_UNSUPPORTED). */
+typedef struct hpt_material {
+    int32_t kind;
+    float kd[3];      /* matte / plastic: Kd (already Clamp()ed as in matte.cpp:53) */
+    float sigma;      /* matte: Oren-Nayar sigma (0 -> Lambertian)                   */
+    float ks[3];      /* plastic                                                      */
+    float roughness;  /* plastic: Blinn exponent = 1/roughness (plastic.cpp:60)       */
+    /* measured (IrregIsotropicBRDF, core/reflection.cpp:259): KdTree<IrregIsotropicBRDFSample>
+     * copied node for node (core/kdtree.h:44-61):
+     *   fpool[kd_split_off + i]      = nodes[i].splitPos
+     *   ipool[kd_bits_off + i]       = splitAxis | hasLeftChild<<2 | rightChild<<3
+     *   fpool[kd_data_off + 6*i ..]  = nodeData[i].p.xyz, nodeData[i].v.rgb           */
+    int64_t kd_split_off, kd_bits_off, kd_data_off;
+    int32_t kd_nnodes;
+    int32_t pad;
+} hpt_material;
+
+typedef struct hpt_light {
+    int32_t kind;
+    int32_t quadric;   /* DIFFUSE_AREA: emitting quadric index (ShapeSet of one shape) */
+    float pos[3];      /* POINT: world-space position (point.cpp:43)                    */
+    float intensity[3];/* POINT: I ; DIFFUSE_AREA: Lemit ; INFINITE: unused             */
+    float area;        /* DIFFUSE_AREA: ShapeSet::Area()                                */
+    /* INFINITE (lights/infinite.cpp:68-105): level-0 texels of the (pow2-resampled) radiance
+     * MIPMap and the Distribution2D tables, copied from the reference objects:
+     *   fpool[tex_off + 3*(v*w+u)]   RGB
+     *   cond_func h*w, cond_cdf h*(w+1), cond_int h, marg_func h, marg_cdf h+1, marg_int 1 */
+    int32_t env_w, env_h;
+    int64_t tex_off, cond_func_off, cond_cdf_off, cond_int_off, marg_func_off, marg_cdf_off;
+    float marg_int;
+    int32_t pad;
+    float l2w[16];     /* LightToWorld->m    */
+    float l2w_inv[16]; /* LightToWorld->mInv */
+} hpt_light;
+
+typedef struct hpt_scene_desc {
+    const hpt_mesh *meshes;        int32_t n_meshes;
+    const hpt_quadric *quadrics;   int32_t n_quadrics;
+    const hpt_material *materials; int32_t n_materials;
+    const hpt_light *lights;       int32_t n_lights;   /* order = Scene::lights */
+    const float *fpool;            int64_t n_f;
+    const int32_t *ipool;          int64_t n_i;
+} hpt_scene_desc;
+
+/* PerspectiveCamera (cameras/perspective.cpp:41-49,81-138; core/camera.cpp:83-102). */
+typedef struct hpt_camera {
+    float raster_to_camera[16]; /* RasterToCamera.m */
+    float camera_to_world[16];  /* CameraToWorld start transform .m (static camera) */
+    float lens_radius, focal_distance;
+    float shutter_open, shutter_close;
+} hpt_camera;
+
+/* Sampler modes.
+ *  HPT_SAMPLER_LD_HASH   : production.  Same (0,2)-sequence sample layout as LDSampler +
+ *                          PathIntegrator::RequestSamples (path.cpp:41-49), scrambles and
+ *                          per-array permutations from a stateless hash of (pixel, seed) so every
+ *                          sample is O(1) computable on any lane (no sample buffer in HBM).
+ *  HPT_SAMPLER_MT_REPLAY : parity tool.  Replays the reference's own random stream: one
+ *                          MT19937 per image tile seeded with the task number
+ *                          (samplerrenderer.cpp:168), LDPixelSample (montecarlo.cpp:200-252),
+ *                          rng draws for bounces >= 3 and Russian roulette in reference order.
+ *                          One lane per tile, serial inside the tile: slow, bit-for-bit sequence. */
+enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1 };
+
+typedef struct hpt_render_desc {
+    int32_t xres, yres;               /* Film::xResolution, yResolution                  */
+    int32_t x_start, x_count;         /* ImageFilm::xPixelStart/xPixelCount (crop window) */
+    int32_t y_start, y_count;
+    int32_t spp;                      /* LDSampler::nPixelSamples (power of two)          */
+    int32_t maxdepth;                 /* PathIntegrator::maxDepth                         */
+    int32_t sampler_mode;
+    uint32_t seed;                    /* LD_HASH seed                                     */
+    int32_t ntasks;                   /* MT_REPLAY: nTasks of samplerrenderer.cpp:298-300 */
+    int32_t shard_rank, shard_count;  /* pixel-tile shard of this device (0,1 = all)      */
+    int32_t count_work;               /* 1: fill the traversal counters of hpt_stats      */
+} hpt_render_desc;
+
+typedef struct hpt_stats {
+    double kernel_ms;          /* HIP-event time of the path kernel(s) on the render stream */
+    uint64_t camera_samples;   /* samples integrated and accumulated                        */
+    uint64_t closest_rays, shadow_rays;
+    uint64_t nodes_visited;    /* 64-byte BVH2 nodes fetched                                */
+    uint64_t tris_tested;      /* 48-byte triangle records fetched                          */
+    uint64_t bad_samples;      /* NaN / negative / inf radiance zeroed (samplerrenderer.cpp:214-228) */
+    uint32_t resident_waves, grid_blocks, block_threads, vgprs;
+} hpt_stats;
+
+typedef struct hpt_scene_info {
+    int64_t n_tris, n_bvh_nodes, n_quadrics;
+    int64_t bvh_bytes, tri_bytes, total_device_bytes;
+    int32_t bvh_max_depth, pad;
+    double build_ms;
+} hpt_scene_info;
+
+typedef struct hpt_scene hpt_scene; /* opaque: device-resident flattened scene + BVH */
+
+int hpt_device_count(void);
+const char *hpt_last_error(void);
+
+/* Build the device BVH (binned SAH, host) and upload everything to HBM of `device`. */
+hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device);
+void hpt_scene_destroy(hpt_scene *scene);
+int hpt_scene_get_info(const hpt_scene *scene, hpt_scene_info *info);
+
+/* Film layout: x_count*y_count pixels, row-major, 4 floats {X, Y, Z, weightSum} — the
+ * Lxyz/weightSum members of ImageFilm::Pixel (film/image.h:69-78).
+ * hpt_render: renders and copies the film to host memory.
+ * hpt_render_device: film stays in HBM (d_film_xyzw is a device pointer, zeroed by the call);
+ *   `stream` is a hipStream_t (NULL = default).  Used by the multi-GPU path: each rank renders
+ *   its pixel-tile shard, the film gather runs over RCCL on the same buffers. */
+int hpt_render(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd,
+               float *film_xyzw_host, hpt_stats *stats);
+int hpt_render_device(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd,
+                      void *d_film_xyzw, void *stream, hpt_stats *stats);
+
+/* ---- scene blob (serialised hpt_scene_desc + camera + render defaults); host only ------ */
+typedef struct hpt_blob hpt_blob;
+int hpt_blob_save(const char *path, const hpt_scene_desc *desc, const hpt_camera *cam,
+                  const hpt_render_desc *rd);
+hpt_blob *hpt_blob_load(const char *path);
+const hpt_scene_desc *hpt_blob_scene(const hpt_blob *b);
+const hpt_camera *hpt_blob_camera(const hpt_blob *b);
+const hpt_render_desc *hpt_blob_render(const hpt_blob *b);
+void hpt_blob_free(hpt_blob *b);
+
+/* ---- function-level parity hooks (each runs the SAME device functions the path kernel
+ *      uses, over arrays of inputs; used by tests/ to compare with the oracle / golden vectors) */
+
+/* rays: n * 8 floats {o.xyz, d.xyz, mint, maxt}.  out_hit: n * 4 floats {t, b1, b2, eps},
+ * out_prim: n ints (global primitive id, -1 = miss).  anyhit != 0 -> BVHAccel::IntersectP. */
+int hpt_test_intersect(hpt_scene *scene, const float *rays, int64_t n, int anyhit,
+                       float *out_hit, int32_t *out_prim);
+
+/* BSDF::f / Pdf / Sample_f at a synthetic hit: in: n * 16 floats
+ *   {wo.xyz, wi.xyz, u1,u2,ucomp, nn.xyz(shading normal), dpdu.xyz, ng_sign}; material index.
+ * out: n * 12 floats {f.rgb, pdf, sample_wi.xyz, sample_f.rgb, sample_pdf, sampled_type}. */
+int hpt_test_bsdf(hpt_scene *scene, int material, const float *in, int64_t n, float *out);
+
+/* Sampler: values of camera sample `s` of pixel (x,y): out 5+37... see hpt_sampler.h; n_out floats
+ * per sample = 5 (imageX,imageY,lensU,lensV,time) + 14 one-D + 18 two-D. */
+int hpt_test_sampler(const hpt_render_desc *rd, int x, int y, float *out /* spp*37 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPT_H */

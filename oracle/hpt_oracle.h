@@ -1,0 +1,46 @@
+/* hpt_oracle.h — CPU oracle for the pbrt-v2 path-tracing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (pbrt-v2_amd/) never links, imports or executes it.
+ *
+ * A plain-C restatement of the reference algorithm (file:line citations in hpt_oracle.c),
+ * operating on the same flattened scene blob the device library consumes (include/hpt.h).
+ * Parity status: PINNED — oracle in MT_REPLAY mode reproduces the images of the reference
+ * binary itself (oracle/_ref/pbrt, built from /root/reference/src by oracle/Makefile);
+ * see tests/test_oracle_pin.py and tests/golden/.
+ */
+#ifndef HPT_ORACLE_H
+#define HPT_ORACLE_H
+#include <stdint.h>
+#include "../include/hpt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+/* Build the oracle scene (reference BVH algorithm, accelerators/bvh.cpp:210-395). */
+orc_scene *orc_scene_create(const hpt_scene_desc *desc);
+void orc_scene_destroy(orc_scene *s);
+
+/* Render: film = x_count*y_count*4 floats {X,Y,Z,weightSum} (ImageFilm::Pixel, film/image.h:69).
+ * Both sampler modes of include/hpt.h; nthreads <= 0 -> all cores.
+ * stats (optional): [0]=camera samples [1]=closest-hit rays [2]=shadow rays
+ *                   [3]=BVH nodes visited (32-byte reference nodes) [4]=triangle tests */
+int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc *rd,
+               float *film_xyzw, int nthreads, uint64_t *stats);
+
+/* Function-level entry points with the same array conventions as hpt_test_* (include/hpt.h). */
+int orc_intersect(const orc_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit,
+                  int32_t *out_prim);
+int orc_bsdf(const orc_scene *s, int material, const float *in, int64_t n, float *out);
+int orc_sampler(const hpt_render_desc *rd, int x, int y, float *out);
+
+/* MT19937 (core/rng.cpp) for known-answer tests. */
+void orc_mt_fill(uint32_t seed, uint32_t *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,196 @@
+"""ctypes mirror of include/hpt.h (the C ABI of the MI355X path-tracing hot path) and the
+scene-blob container ("HPTS" files written by hpt_blob_save / host/hip_renderer.cpp).
+
+Pure Python + numpy: usable without the HIP library (the oracle binding in oracle/orc.py and
+the CPU-side tests read blobs through this module).  Layouts are checked against the compiled
+library by hpt.py (hpt_abi_sizes) so a drift between this file and hpt.h fails loudly.
+"""
+import ctypes as C
+import numpy as np
+
+HPT_MAGIC = 0x53545048
+HPT_VERSION = 2
+
+HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
+HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG = 1, 2, 3
+HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
+HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY = 0, 1
+SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs
+
+f32, i32, i64, u32, u64 = C.c_float, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+M16 = f32 * 16
+
+
+class Mesh(C.Structure):
+    _fields_ = [("p_off", i64), ("n_off", i64), ("uv_off", i64), ("idx_off", i64),
+                ("ntris", i32), ("nverts", i32), ("material", i32), ("arealight", i32),
+                ("reverse_orientation", i32), ("swaps_handedness", i32),
+                ("o2w", M16), ("o2w_inv", M16)]
+
+
+class Quadric(C.Structure):
+    _fields_ = [("kind", i32), ("material", i32), ("arealight", i32),
+                ("reverse_orientation", i32), ("swaps_handedness", i32),
+                ("radius", f32), ("zmin", f32), ("zmax", f32), ("theta_min", f32),
+                ("theta_max", f32), ("phi_max", f32), ("height", f32), ("inner_radius", f32),
+                ("o2w", M16), ("o2w_inv", M16)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", i32), ("kd", f32 * 3), ("sigma", f32), ("ks", f32 * 3),
+                ("roughness", f32), ("kd_split_off", i64), ("kd_bits_off", i64),
+                ("kd_data_off", i64), ("kd_nnodes", i32), ("pad", i32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("kind", i32), ("quadric", i32), ("pos", f32 * 3), ("intensity", f32 * 3),
+                ("area", f32), ("env_w", i32), ("env_h", i32),
+                ("tex_off", i64), ("cond_func_off", i64), ("cond_cdf_off", i64),
+                ("cond_int_off", i64), ("marg_func_off", i64), ("marg_cdf_off", i64),
+                ("marg_int", f32), ("pad", i32), ("l2w", M16), ("l2w_inv", M16)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("meshes", C.POINTER(Mesh)), ("n_meshes", i32),
+                ("quadrics", C.POINTER(Quadric)), ("n_quadrics", i32),
+                ("materials", C.POINTER(Material)), ("n_materials", i32),
+                ("lights", C.POINTER(Light)), ("n_lights", i32),
+                ("fpool", C.POINTER(f32)), ("n_f", i64),
+                ("ipool", C.POINTER(i32)), ("n_i", i64)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("raster_to_camera", M16), ("camera_to_world", M16),
+                ("lens_radius", f32), ("focal_distance", f32),
+                ("shutter_open", f32), ("shutter_close", f32)]
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("xres", i32), ("yres", i32), ("x_start", i32), ("x_count", i32),
+                ("y_start", i32), ("y_count", i32), ("spp", i32), ("maxdepth", i32),
+                ("sampler_mode", i32), ("seed", u32), ("ntasks", i32),
+                ("shard_rank", i32), ("shard_count", i32), ("count_work", i32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("camera_samples", u64), ("closest_rays", u64),
+                ("shadow_rays", u64), ("nodes_visited", u64), ("tris_tested", u64),
+                ("bad_samples", u64), ("resident_waves", u32), ("grid_blocks", u32),
+                ("block_threads", u32), ("vgprs", u32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_tris", i64), ("n_bvh_nodes", i64), ("n_quadrics", i64),
+                ("bvh_bytes", i64), ("tri_bytes", i64), ("total_device_bytes", i64),
+                ("bvh_max_depth", i32), ("pad", i32), ("build_ms", C.c_double)]
+
+
+class BlobHeader(C.Structure):
+    _fields_ = [("magic", u32), ("version", u32), ("n_meshes", i32), ("n_quadrics", i32),
+                ("n_materials", i32), ("n_lights", i32), ("n_f", i64), ("n_i", i64),
+                ("cam", Camera), ("rd", RenderDesc),
+                ("sizeof_mesh", u32), ("sizeof_quadric", u32), ("sizeof_material", u32),
+                ("sizeof_light", u32)]
+
+
+ABI_SIZES = [C.sizeof(Mesh), C.sizeof(Quadric), C.sizeof(Material), C.sizeof(Light),
+             C.sizeof(Camera), C.sizeof(RenderDesc), C.sizeof(Stats), C.sizeof(BlobHeader)]
+
+
+def _arr(ctype, n):
+    return (ctype * max(int(n), 0))()
+
+
+class Scene:
+    """A flattened pbrt scene held in host memory: record arrays + float/int pools, plus the
+    camera and the render defaults it was dumped with.  `.desc` is the hpt_scene_desc view."""
+
+    def __init__(self, meshes=(), quadrics=(), materials=(), lights=(), fpool=None, ipool=None,
+                 camera=None, render=None):
+        self.meshes = _arr(Mesh, len(meshes))
+        for i, m in enumerate(meshes):
+            self.meshes[i] = m
+        self.quadrics = _arr(Quadric, len(quadrics))
+        for i, q in enumerate(quadrics):
+            self.quadrics[i] = q
+        self.materials = _arr(Material, len(materials))
+        for i, m in enumerate(materials):
+            self.materials[i] = m
+        self.lights = _arr(Light, len(lights))
+        for i, l in enumerate(lights):
+            self.lights[i] = l
+        self.fpool = np.ascontiguousarray(fpool if fpool is not None else np.zeros(0), dtype=np.float32)
+        self.ipool = np.ascontiguousarray(ipool if ipool is not None else np.zeros(0), dtype=np.int32)
+        self.camera = camera if camera is not None else Camera()
+        self.render = render if render is not None else RenderDesc()
+
+    @property
+    def desc(self):
+        d = SceneDesc()
+        d.meshes = C.cast(self.meshes, C.POINTER(Mesh)); d.n_meshes = len(self.meshes)
+        d.quadrics = C.cast(self.quadrics, C.POINTER(Quadric)); d.n_quadrics = len(self.quadrics)
+        d.materials = C.cast(self.materials, C.POINTER(Material)); d.n_materials = len(self.materials)
+        d.lights = C.cast(self.lights, C.POINTER(Light)); d.n_lights = len(self.lights)
+        d.fpool = self.fpool.ctypes.data_as(C.POINTER(f32)); d.n_f = self.fpool.size
+        d.ipool = self.ipool.ctypes.data_as(C.POINTER(i32)); d.n_i = self.ipool.size
+        return d
+
+    @property
+    def n_tris(self):
+        return sum(m.ntris for m in self.meshes)
+
+    # ---- blob I/O (same layout as csrc/hpt_blob.cpp) ------------------------------------
+    def save(self, path):
+        h = BlobHeader()
+        h.magic, h.version = HPT_MAGIC, HPT_VERSION
+        h.n_meshes, h.n_quadrics = len(self.meshes), len(self.quadrics)
+        h.n_materials, h.n_lights = len(self.materials), len(self.lights)
+        h.n_f, h.n_i = self.fpool.size, self.ipool.size
+        h.cam, h.rd = self.camera, self.render
+        h.sizeof_mesh, h.sizeof_quadric = C.sizeof(Mesh), C.sizeof(Quadric)
+        h.sizeof_material, h.sizeof_light = C.sizeof(Material), C.sizeof(Light)
+        with _open(path, "wb") as f:
+            f.write(bytes(h))
+            for a in (self.meshes, self.quadrics, self.materials, self.lights):
+                f.write(bytes(a))
+            f.write(self.fpool.tobytes())
+            f.write(self.ipool.tobytes())
+
+    @staticmethod
+    def load(path):
+        with _open(path, "rb") as f:
+            raw = f.read()
+        h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
+        if h.magic != HPT_MAGIC or h.version != HPT_VERSION:
+            raise ValueError(f"{path}: not an HPTS v{HPT_VERSION} blob")
+        if (h.sizeof_mesh, h.sizeof_quadric, h.sizeof_material, h.sizeof_light) != tuple(ABI_SIZES[:4]):
+            raise ValueError(f"{path}: record sizes differ from this build of the ABI")
+        off = C.sizeof(BlobHeader)
+
+        def take(ctype, n):
+            nonlocal off
+            nbytes = C.sizeof(ctype) * n
+            a = (ctype * n).from_buffer_copy(raw[off:off + nbytes])
+            off += nbytes
+            return a
+        s = Scene()
+        s.meshes = take(Mesh, h.n_meshes)
+        s.quadrics = take(Quadric, h.n_quadrics)
+        s.materials = take(Material, h.n_materials)
+        s.lights = take(Light, h.n_lights)
+        s.fpool = np.frombuffer(raw, dtype=np.float32, count=h.n_f, offset=off).copy(); off += 4 * h.n_f
+        s.ipool = np.frombuffer(raw, dtype=np.int32, count=h.n_i, offset=off).copy(); off += 4 * h.n_i
+        s.camera, s.render = h.cam, h.rd
+        return s
+
+
+def _open(path, mode):
+    """Blobs committed as fixtures are gzip-compressed (*.hpts.gz)."""
+    if str(path).endswith(".gz"):
+        import gzip
+        return gzip.open(path, mode)
+    return open(path, mode)
+
+
+def copy_struct(s):
+    return type(s).from_buffer_copy(bytes(s))

@@ -1,0 +1,427 @@
+// hip_renderer.cpp — HipPathRenderer: flattens the pbrt-v2 Scene that the reference's own
+// parser / api.cpp / Create* factories built into the POD descriptors of include/hpt.h and calls
+// the MI355X library.  Built with -fno-access-control so the private members of the reference
+// classes can be READ in place without modifying or copying a single reference source file.
+//
+// What is read, and where it is defined in the reference:
+//   Scene::aggregate (BVHAccel::primitives, accelerators/bvh.h:66-71) -> GeometricPrimitive
+//     {shape, material, areaLight} (core/primitive.h:88-92) -> Triangle{mesh,v} /
+//     TriangleMesh{p,n,uvs,vertexIndex} (shapes/trianglemesh.h:59-68), Sphere, Disk
+//   Materials: MatteMaterial, PlasticMaterial, MeasuredMaterial (materials/*.h) with
+//     ConstantTexture values (textures/constant.h:45-55)
+//   Lights: PointLight, DiffuseAreaLight(+ShapeSet), InfiniteAreaLight(+MIPMap, Distribution2D)
+//   PerspectiveCamera (RasterToCamera, CameraToWorld), ImageFilm (pixel extent, box filter),
+//   LDSampler (nPixelSamples), PathIntegrator (maxDepth)
+// Anything else is outside the hot-path scope and is rejected with Severe().
+#include "stdafx.h"
+#include "hip_renderer.h"
+
+#include "scene.h"
+#include "camera.h"
+#include "film.h"
+#include "sampler.h"
+#include "integrator.h"
+#include "intersection.h"
+#include "light.h"
+#include "parallel.h"
+#include "montecarlo.h"
+#include "mipmap.h"
+#include "reflection.h"
+#include "kdtree.h"
+#include "progressreporter.h"
+#include "accelerators/bvh.h"
+#include "cameras/perspective.h"
+#include "film/image.h"
+#include "filters/box.h"
+#include "integrators/path.h"
+#include "lights/diffuse.h"
+#include "lights/infinite.h"
+#include "lights/point.h"
+#include "materials/matte.h"
+#include "materials/measured.h"
+#include "materials/plastic.h"
+#include "samplers/lowdiscrepancy.h"
+#include "shapes/disk.h"
+#include "shapes/sphere.h"
+#include "shapes/trianglemesh.h"
+#include "textures/constant.h"
+
+#include <map>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hpt.h"
+
+namespace {
+
+void CopyM(const Matrix4x4 &m, float out[16]) { memcpy(out, m.m, 16 * sizeof(float)); }
+
+template <typename T> bool ConstTex(const Reference<Texture<T> > &tex, T *v) {
+    if (!tex.GetPtr()) return false;
+    const ConstantTexture<T> *c = dynamic_cast<const ConstantTexture<T> *>(tex.GetPtr());
+    if (!c) return false;
+    *v = c->value;
+    return true;
+}
+
+struct Flattener {
+    std::vector<hpt_mesh> meshes;
+    std::vector<hpt_quadric> quadrics;
+    std::vector<hpt_material> materials;
+    std::vector<hpt_light> lights;
+    std::vector<float> fpool;
+    std::vector<int32_t> ipool;
+    std::map<const TriangleMesh *, int> meshIndex;
+    std::map<const Shape *, int> quadricIndex;
+    std::map<const Material *, int> materialIndex;
+    std::map<const Light *, int> lightIndex;
+
+    int64_t PushF(const float *p, size_t n) {
+        int64_t off = (int64_t)fpool.size();
+        fpool.insert(fpool.end(), p, p + n);
+        return off;
+    }
+    int64_t PushI(const int *p, size_t n) {
+        int64_t off = (int64_t)ipool.size();
+        ipool.insert(ipool.end(), p, p + n);
+        return off;
+    }
+
+    int AddMaterial(const Material *m) {
+        std::map<const Material *, int>::iterator it = materialIndex.find(m);
+        if (it != materialIndex.end()) return it->second;
+        hpt_material r;
+        memset(&r, 0, sizeof(r));
+        r.kd_split_off = r.kd_bits_off = r.kd_data_off = -1;
+        if (const MatteMaterial *mm = dynamic_cast<const MatteMaterial *>(m)) {
+            Spectrum kd; float sigma;
+            if (mm->bumpMap.GetPtr() || !ConstTex(mm->Kd, &kd) || !ConstTex(mm->sigma, &sigma))
+                Severe("hip renderer: matte material with non-constant textures / bump map "
+                       "is outside the hot-path scope");
+            r.kind = HPT_MAT_MATTE;
+            kd = kd.Clamp();                                   // matte.cpp:53
+            kd.ToRGB(r.kd);
+            r.sigma = Clamp(sigma, 0.f, 90.f);                 // matte.cpp:54
+            if (r.sigma != 0.f)
+                Severe("hip renderer: Oren-Nayar (sigma != 0) is outside the hot-path scope");
+        } else if (const PlasticMaterial *pm = dynamic_cast<const PlasticMaterial *>(m)) {
+            Spectrum kd, ks; float rough;
+            if (pm->bumpMap.GetPtr() || !ConstTex(pm->Kd, &kd) || !ConstTex(pm->Ks, &ks) ||
+                !ConstTex(pm->roughness, &rough))
+                Severe("hip renderer: plastic material with non-constant textures / bump map "
+                       "is outside the hot-path scope");
+            r.kind = HPT_MAT_PLASTIC;
+            kd = kd.Clamp(); kd.ToRGB(r.kd);                   // plastic.cpp:52
+            ks = ks.Clamp(); ks.ToRGB(r.ks);                   // plastic.cpp:57
+            r.roughness = rough;
+        } else if (const MeasuredMaterial *me = dynamic_cast<const MeasuredMaterial *>(m)) {
+            if (me->bumpMap.GetPtr() || !me->thetaPhiData)
+                Severe("hip renderer: only irregular (.brdf) measured materials without bump "
+                       "maps are inside the hot-path scope");
+            r.kind = HPT_MAT_MEASURED_IRREG;
+            const KdTree<IrregIsotropicBRDFSample> *kd = me->thetaPhiData;
+            uint32_t n = kd->nNodes;
+            std::vector<float> split(n), data(6 * (size_t)n);
+            std::vector<int> bits(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                split[i] = kd->nodes[i].splitPos;
+                bits[i] = (int)(kd->nodes[i].splitAxis | (kd->nodes[i].hasLeftChild << 2) |
+                                (kd->nodes[i].rightChild << 3));
+                const IrregIsotropicBRDFSample &s = kd->nodeData[i];
+                float rgb[3];
+                s.v.ToRGB(rgb);
+                data[6 * i + 0] = s.p.x; data[6 * i + 1] = s.p.y; data[6 * i + 2] = s.p.z;
+                data[6 * i + 3] = rgb[0]; data[6 * i + 4] = rgb[1]; data[6 * i + 5] = rgb[2];
+            }
+            r.kd_nnodes = (int)n;
+            r.kd_split_off = PushF(&split[0], n);
+            r.kd_bits_off = PushI(&bits[0], n);
+            r.kd_data_off = PushF(&data[0], 6 * (size_t)n);
+        } else
+            Severe("hip renderer: material type outside the hot-path scope "
+                   "(supported: matte, plastic, measured/.brdf)");
+        int idx = (int)materials.size();
+        materials.push_back(r);
+        materialIndex[m] = idx;
+        return idx;
+    }
+
+    int LightOf(const AreaLight *a) {
+        if (!a) return -1;
+        std::map<const Light *, int>::iterator it = lightIndex.find(a);
+        if (it == lightIndex.end())
+            Severe("hip renderer: primitive refers to an area light that is not in Scene::lights");
+        return it->second;
+    }
+
+    void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp) {
+        const TriangleMesh *mesh = tri->mesh.GetPtr();
+        if (meshIndex.find(mesh) != meshIndex.end()) return;
+        if (mesh->alphaTexture.GetPtr())
+            Severe("hip renderer: alpha-textured meshes are outside the hot-path scope");
+        if (mesh->s)
+            Severe("hip renderer: meshes with explicit tangents \"S\" are outside the hot-path scope");
+        if (gp->areaLight)
+            Severe("hip renderer: triangle-mesh emitters are outside the hot-path scope "
+                   "(sphere / disk emitters are supported)");
+        hpt_mesh r;
+        memset(&r, 0, sizeof(r));
+        r.ntris = mesh->ntris;
+        r.nverts = mesh->nverts;
+        r.p_off = PushF(&mesh->p[0].x, 3 * (size_t)mesh->nverts);
+        r.n_off = mesh->n ? PushF(&mesh->n[0].x, 3 * (size_t)mesh->nverts) : -1;
+        r.uv_off = mesh->uvs ? PushF(mesh->uvs, 2 * (size_t)mesh->nverts) : -1;
+        r.idx_off = PushI(mesh->vertexIndex, 3 * (size_t)mesh->ntris);
+        r.material = AddMaterial(gp->material.GetPtr());
+        r.arealight = -1;
+        r.reverse_orientation = mesh->ReverseOrientation;
+        r.swaps_handedness = mesh->TransformSwapsHandedness;
+        CopyM(mesh->ObjectToWorld->m, r.o2w);
+        CopyM(mesh->ObjectToWorld->mInv, r.o2w_inv);
+        meshIndex[mesh] = (int)meshes.size();
+        meshes.push_back(r);
+    }
+
+    void AddQuadric(const Shape *shape, const GeometricPrimitive *gp) {
+        if (quadricIndex.find(shape) != quadricIndex.end()) return;
+        hpt_quadric q;
+        memset(&q, 0, sizeof(q));
+        if (const Sphere *s = dynamic_cast<const Sphere *>(shape)) {
+            q.kind = HPT_QUADRIC_SPHERE;
+            q.radius = s->radius; q.zmin = s->zmin; q.zmax = s->zmax;
+            q.theta_min = s->thetaMin; q.theta_max = s->thetaMax; q.phi_max = s->phiMax;
+        } else if (const Disk *d = dynamic_cast<const Disk *>(shape)) {
+            q.kind = HPT_QUADRIC_DISK;
+            q.radius = d->radius; q.inner_radius = d->innerRadius; q.height = d->height;
+            q.phi_max = d->phiMax;
+        } else
+            Severe("hip renderer: shape type outside the hot-path scope "
+                   "(supported: trianglemesh, loopsubdiv, sphere, disk)");
+        q.material = AddMaterial(gp->material.GetPtr());
+        q.arealight = LightOf(gp->areaLight);
+        q.reverse_orientation = shape->ReverseOrientation;
+        q.swaps_handedness = shape->TransformSwapsHandedness;
+        CopyM(shape->ObjectToWorld->m, q.o2w);
+        CopyM(shape->ObjectToWorld->mInv, q.o2w_inv);
+        if (memcmp(shape->ObjectToWorld->mInv.m, shape->WorldToObject->m.m, 16 * sizeof(float)))
+            Severe("hip renderer: WorldToObject is not the stored inverse of ObjectToWorld");
+        quadricIndex[shape] = (int)quadrics.size();
+        quadrics.push_back(q);
+    }
+
+    void AddLights(const Scene *scene) {
+        for (uint32_t i = 0; i < scene->lights.size(); ++i) lightIndex[scene->lights[i]] = (int)i;
+        lights.resize(scene->lights.size());
+        for (uint32_t i = 0; i < scene->lights.size(); ++i) {
+            const Light *l = scene->lights[i];
+            hpt_light r;
+            memset(&r, 0, sizeof(r));
+            r.quadric = -1;
+            r.tex_off = r.cond_func_off = r.cond_cdf_off = r.cond_int_off = -1;
+            r.marg_func_off = r.marg_cdf_off = -1;
+            CopyM(l->LightToWorld.m, r.l2w);
+            CopyM(l->LightToWorld.mInv, r.l2w_inv);
+            if (const PointLight *pl = dynamic_cast<const PointLight *>(l)) {
+                r.kind = HPT_LIGHT_POINT;
+                r.pos[0] = pl->lightPos.x; r.pos[1] = pl->lightPos.y; r.pos[2] = pl->lightPos.z;
+                pl->Intensity.ToRGB(r.intensity);
+            } else if (const DiffuseAreaLight *dl = dynamic_cast<const DiffuseAreaLight *>(l)) {
+                r.kind = HPT_LIGHT_DIFFUSE_AREA;
+                dl->Lemit.ToRGB(r.intensity);
+                r.area = dl->area;
+                // quadric index is patched in Finish() once the shapes are known
+            } else if (const InfiniteAreaLight *il = dynamic_cast<const InfiniteAreaLight *>(l)) {
+                r.kind = HPT_LIGHT_INFINITE;
+                const MIPMap<RGBSpectrum> *mm = il->radianceMap;
+                const BlockedArray<RGBSpectrum> &l0 = *mm->pyramid[0];
+                int w = (int)l0.uSize(), h = (int)l0.vSize();
+                r.env_w = w; r.env_h = h;
+                std::vector<float> tex(3 * (size_t)w * h);
+                for (int v = 0; v < h; ++v)
+                    for (int u = 0; u < w; ++u) l0(u, v).ToRGB(&tex[3 * ((size_t)v * w + u)]);
+                r.tex_off = PushF(&tex[0], tex.size());
+                const Distribution2D *d2 = il->distribution;
+                if ((int)d2->pConditionalV.size() != h || d2->pMarginal->count != h)
+                    Severe("hip renderer: unexpected Distribution2D shape");
+                std::vector<float> cf, cc, ci;
+                for (int v = 0; v < h; ++v) {
+                    const Distribution1D *c = d2->pConditionalV[v];
+                    if (c->count != w) Severe("hip renderer: unexpected Distribution1D size");
+                    cf.insert(cf.end(), c->func, c->func + w);
+                    cc.insert(cc.end(), c->cdf, c->cdf + w + 1);
+                    ci.push_back(c->funcInt);
+                }
+                r.cond_func_off = PushF(&cf[0], cf.size());
+                r.cond_cdf_off = PushF(&cc[0], cc.size());
+                r.cond_int_off = PushF(&ci[0], ci.size());
+                r.marg_func_off = PushF(d2->pMarginal->func, h);
+                r.marg_cdf_off = PushF(d2->pMarginal->cdf, h + 1);
+                r.marg_int = d2->pMarginal->funcInt;
+            } else
+                Severe("hip renderer: light type outside the hot-path scope "
+                       "(supported: point, area/diffuse, infinite)");
+            lights[i] = r;
+        }
+    }
+
+    void Flatten(const Scene *scene) {
+        AddLights(scene);
+        const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene->aggregate);
+        if (!bvh) Severe("hip renderer: Accelerator must be \"bvh\" (the default)");
+        for (size_t i = 0; i < bvh->primitives.size(); ++i) {
+            const GeometricPrimitive *gp =
+                dynamic_cast<const GeometricPrimitive *>(bvh->primitives[i].GetPtr());
+            if (!gp)
+                Severe("hip renderer: instanced / animated primitives (TransformedPrimitive) "
+                       "are a later hot-path row (SURVEY.md §8, config 4)");
+            const Shape *shape = gp->shape.GetPtr();
+            if (const Triangle *tri = dynamic_cast<const Triangle *>(shape))
+                AddTriangle(tri, gp);
+            else
+                AddQuadric(shape, gp);
+        }
+        // DiffuseAreaLight -> emitting quadric (the ShapeSet holds the very Shape object of the
+        // GeometricPrimitive: core/api.cpp:1003-1009)
+        for (uint32_t i = 0; i < scene->lights.size(); ++i) {
+            const DiffuseAreaLight *dl = dynamic_cast<const DiffuseAreaLight *>(scene->lights[i]);
+            if (!dl) continue;
+            if (dl->shapeSet->shapes.size() != 1)
+                Severe("hip renderer: area lights over refined shape sets are outside the scope");
+            std::map<const Shape *, int>::iterator it =
+                quadricIndex.find(dl->shapeSet->shapes[0].GetPtr());
+            if (it == quadricIndex.end())
+                Severe("hip renderer: area light shape not found among the scene's quadrics");
+            lights[i].quadric = it->second;
+        }
+    }
+
+    hpt_scene_desc Desc() const {
+        hpt_scene_desc d;
+        memset(&d, 0, sizeof(d));
+        d.meshes = meshes.empty() ? NULL : &meshes[0];        d.n_meshes = (int)meshes.size();
+        d.quadrics = quadrics.empty() ? NULL : &quadrics[0];  d.n_quadrics = (int)quadrics.size();
+        d.materials = materials.empty() ? NULL : &materials[0]; d.n_materials = (int)materials.size();
+        d.lights = lights.empty() ? NULL : &lights[0];        d.n_lights = (int)lights.size();
+        d.fpool = fpool.empty() ? NULL : &fpool[0];           d.n_f = (int64_t)fpool.size();
+        d.ipool = ipool.empty() ? NULL : &ipool[0];           d.n_i = (int64_t)ipool.size();
+        return d;
+    }
+};
+
+} // namespace
+
+HipPathRenderer::HipPathRenderer(Sampler *s, Camera *c, SurfaceIntegrator *si,
+                                 VolumeIntegrator *vi, const ParamSet &params) {
+    sampler = s;
+    camera = c;
+    surfaceIntegrator = si;
+    volumeIntegrator = vi;
+    device = params.FindOneInt("device", 0);
+    seed = (unsigned)params.FindOneInt("seed", 0);
+    std::string sm = params.FindOneString("sampler", "ldhash");
+    if (sm == "ldhash") samplerMode = HPT_SAMPLER_LD_HASH;
+    else if (sm == "mtreplay") samplerMode = HPT_SAMPLER_MT_REPLAY;
+    else { Warning("hip renderer: unknown sampler mode \"%s\"; using ldhash", sm.c_str());
+           samplerMode = HPT_SAMPLER_LD_HASH; }
+    if (const char *e = getenv("HPT_SAMPLER"))
+        samplerMode = !strcmp(e, "mtreplay") ? HPT_SAMPLER_MT_REPLAY : HPT_SAMPLER_LD_HASH;
+    dumpPath = params.FindOneString("dumpscene", "");
+    if (const char *e = getenv("HPT_DUMP_SCENE")) dumpPath = e;
+}
+
+HipPathRenderer::~HipPathRenderer() {
+    delete sampler;
+    delete camera;
+    delete surfaceIntegrator;
+    delete volumeIntegrator;
+}
+
+void HipPathRenderer::Render(const Scene *scene) {
+    // --- what the device path replaces must be exactly what pbrt was asked to run ---------
+    const PerspectiveCamera *pc = dynamic_cast<const PerspectiveCamera *>(camera);
+    if (!pc) Severe("hip renderer: Camera must be \"perspective\"");
+    if (pc->CameraToWorld.actuallyAnimated)
+        Severe("hip renderer: animated cameras are outside the hot-path scope");
+    ImageFilm *film = dynamic_cast<ImageFilm *>(camera->film);
+    if (!film) Severe("hip renderer: Film must be \"image\"");
+    const BoxFilter *box = dynamic_cast<const BoxFilter *>(film->filter);
+    if (!box || box->xWidth != 0.5f || box->yWidth != 0.5f)
+        Severe("hip renderer: PixelFilter must be \"box\" with the default width 0.5 "
+               "(wider filters are a \"next\" row, SURVEY.md §8f-4)");
+    const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
+    if (!lds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\"");
+    const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
+    if (!path) Severe("hip renderer: SurfaceIntegrator must be \"path\"");
+    if (scene->volumeRegion) Severe("hip renderer: participating media are outside the scope");
+
+    Flattener fl;
+    fl.Flatten(scene);
+    hpt_scene_desc desc = fl.Desc();
+
+    hpt_camera cam;
+    memset(&cam, 0, sizeof(cam));
+    CopyM(pc->RasterToCamera.m, cam.raster_to_camera);
+    CopyM(pc->CameraToWorld.startTransform->m, cam.camera_to_world);
+    cam.lens_radius = pc->lensRadius;
+    cam.focal_distance = pc->focalDistance;
+    cam.shutter_open = pc->shutterOpen;
+    cam.shutter_close = pc->shutterClose;
+
+    hpt_render_desc rd;
+    memset(&rd, 0, sizeof(rd));
+    rd.xres = film->xResolution; rd.yres = film->yResolution;
+    rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
+    rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
+    rd.spp = lds->nPixelSamples;
+    rd.maxdepth = path->maxDepth;
+    rd.sampler_mode = samplerMode;
+    rd.seed = seed;
+    // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:298-300)
+    int nPixels = film->xResolution * film->yResolution;
+    rd.ntasks = (int)RoundUpPow2((uint32_t)max(32 * NumSystemCores(), nPixels / (16 * 16)));
+    rd.shard_rank = 0; rd.shard_count = 1;
+
+    if (dumpPath != "") {
+        if (hpt_blob_save(dumpPath.c_str(), &desc, &cam, &rd) != HPT_OK)
+            Severe("hip renderer: %s", hpt_last_error());
+        Info("hip renderer: scene blob written to %s; not rendering", dumpPath.c_str());
+        return;
+    }
+
+    hpt_scene *hs = hpt_scene_create(&desc, device);
+    if (!hs) Severe("hip renderer: %s", hpt_last_error());
+    std::vector<float> xyzw(4 * (size_t)rd.x_count * rd.y_count);
+    hpt_stats st;
+    ProgressReporter reporter(1, "Rendering (HIP)");
+    if (hpt_render(hs, &cam, &rd, &xyzw[0], &st) != HPT_OK)
+        Severe("hip renderer: %s", hpt_last_error());
+    reporter.Update();
+    reporter.Done();
+    hpt_scene_destroy(hs);
+    if (st.bad_samples)
+        Error("hip renderer: %llu camera samples had NaN / negative / infinite luminance and "
+              "were set to black", (unsigned long long)st.bad_samples);
+    Info("hip renderer: %.3f Msamples/s (%.2f ms kernel)",
+         st.camera_samples / (st.kernel_ms * 1e3), st.kernel_ms);
+
+    // Hand the film to ImageFilm so the reference's own WriteImage (film/image.cpp:178) runs.
+    for (int y = 0; y < rd.y_count; ++y)
+        for (int x = 0; x < rd.x_count; ++x) {
+            ImageFilm::Pixel &px = (*film->pixels)(x, y);
+            const float *s = &xyzw[4 * ((size_t)y * rd.x_count + x)];
+            px.Lxyz[0] = s[0]; px.Lxyz[1] = s[1]; px.Lxyz[2] = s[2];
+            px.weightSum = s[3];
+        }
+    camera->film->WriteImage();
+}
+
+Spectrum HipPathRenderer::Li(const Scene *, const RayDifferential &, const Sample *, RNG &,
+                             MemoryArena &, Intersection *, Spectrum *) const {
+    Severe("HipPathRenderer::Li: per-ray host callbacks are not part of the device path");
+    return Spectrum(0.f);
+}
+
+Spectrum HipPathRenderer::Transmittance(const Scene *, const RayDifferential &, const Sample *,
+                                        RNG &, MemoryArena &) const {
+    return Spectrum(1.f);
+}

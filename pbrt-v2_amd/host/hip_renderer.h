@@ -1,0 +1,39 @@
+// hip_renderer.h — the reference-side binding: a pbrt-v2 Renderer plugin that hands the
+// SamplerRenderer + PathIntegrator hot loop to the MI355X library through the C ABI of
+// include/hpt.h.  Compiles against the reference headers where they lie (/root/reference/src);
+// see INTEGRATION.md for the one-branch patch to RenderOptions::MakeRenderer (core/api.cpp:1252).
+//
+// Mirrors SamplerRenderer's interface (renderers/samplerrenderer.h:44-62): same constructor
+// arguments, same ownership (the renderer owns and deletes sampler, camera, both integrators —
+// samplerrenderer.cpp:275-280), same error convention (Error()/Severe(), core/error.h:49-52).
+#ifndef PBRT_RENDERERS_HIPRENDERER_H
+#define PBRT_RENDERERS_HIPRENDERER_H
+
+#include "pbrt.h"
+#include "renderer.h"
+#include "paramset.h"
+
+class HipPathRenderer : public Renderer {
+public:
+    HipPathRenderer(Sampler *s, Camera *c, SurfaceIntegrator *si, VolumeIntegrator *vi,
+                    const ParamSet &params);
+    ~HipPathRenderer();
+    // Renderer interface (core/renderer.h:43-54)
+    void Render(const Scene *scene);
+    Spectrum Li(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng,
+                MemoryArena &arena, Intersection *isect = NULL, Spectrum *T = NULL) const;
+    Spectrum Transmittance(const Scene *scene, const RayDifferential &ray, const Sample *sample,
+                           RNG &rng, MemoryArena &arena) const;
+
+private:
+    Sampler *sampler;
+    Camera *camera;
+    SurfaceIntegrator *surfaceIntegrator;
+    VolumeIntegrator *volumeIntegrator;
+    int device;        // "integer device"  [0]
+    int samplerMode;   // "string sampler"  ["ldhash" | "mtreplay"]
+    unsigned seed;     // "integer seed"    [0]
+    std::string dumpPath; // "string dumpscene" [""] or env HPT_DUMP_SCENE: write blob, do not render
+};
+
+#endif
