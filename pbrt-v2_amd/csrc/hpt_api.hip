@@ -1,0 +1,241 @@
+// hpt_api.hip — implementation of the C ABI in include/hpt.h: scene upload to HBM, the render
+// call that replaces SamplerRenderer::Render (renderers/samplerrenderer.cpp:283-317) and the
+// function-level parity hooks.  HIP runtime only; there is deliberately NO CPU path: without a
+// device every compute entry point fails with HPT_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "hpt_flatten.h"
+#include "hpt_internal.h"
+#include "hpt_kernels.h"
+
+using namespace hpt;
+
+#define HIP_CHECK_RET(expr, ret)                                                            \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            hpt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ret;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+struct hpt_scene {
+    int device;
+    DScene d;             // device pointers
+    std::vector<void *> allocs;
+    hpt_scene_info info;
+    int n_cus;
+};
+
+extern "C" int hpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <typename T> static T *upload(hpt_scene *s, const T *host, size_t n, bool *ok) {
+    if (n == 0) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { *ok = false; return nullptr; }
+    s->allocs.push_back(p);
+    if (hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { *ok = false; return nullptr; }
+    s->info.total_device_bytes += (int64_t)(n * sizeof(T));
+    return (T *)p;
+}
+
+extern "C" void hpt_scene_destroy(hpt_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    delete s;
+}
+
+extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
+    if (hpt_validate_desc(desc) != HPT_OK) return nullptr;
+    int ndev = hpt_device_count();
+    if (ndev <= 0) { hpt_set_error("no HIP device available (hipGetDeviceCount) — the path tracer has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= ndev) { hpt_set_error("device %d out of range (have %d)", device, ndev); return nullptr; }
+    HIP_CHECK_RET(hipSetDevice(device), nullptr);
+    hpt_scene *s = new hpt_scene();
+    s->device = device;
+    memset(&s->d, 0, sizeof(s->d));
+    memset(&s->info, 0, sizeof(s->info));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; hpt_set_error("hipGetDeviceProperties failed"); return nullptr; }
+    s->n_cus = prop.multiProcessorCount;
+
+    FlatScene fs;
+    if (flatten_scene(desc, 4, HPT_STACK_DEPTH - 2, &fs) != HPT_OK) { delete s; return nullptr; }
+    if (fs.max_depth > HPT_STACK_DEPTH) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
+    const int64_t ntris = fs.n_tris;
+    s->info.build_ms = fs.build_ms;
+    s->info.n_tris = ntris; s->info.n_bvh_nodes = (int64_t)fs.nodes.size(); s->info.n_quadrics = desc->n_quadrics;
+    s->info.bvh_bytes = (int64_t)(fs.nodes.size() * sizeof(BvhNode64)); s->info.tri_bytes = 48 * ntris;
+    s->info.bvh_max_depth = fs.max_depth;
+
+    bool ok = true;
+    s->d.nodes = (const f4 *)upload(s, fs.nodes.data(), fs.nodes.size(), &ok);
+    s->d.tris = (const f4 *)upload(s, fs.tri_rec.data(), fs.tri_rec.size(), &ok);
+    s->d.meshes = upload(s, fs.meshes.data(), fs.meshes.size(), &ok);
+    s->d.quadrics = upload(s, desc->quadrics, (size_t)desc->n_quadrics, &ok);
+    s->d.materials = upload(s, desc->materials, (size_t)desc->n_materials, &ok);
+    s->d.lights = upload(s, desc->lights, (size_t)desc->n_lights, &ok);
+    s->d.fpool = upload(s, desc->fpool, (size_t)desc->n_f, &ok);
+    s->d.ipool = upload(s, desc->ipool, (size_t)desc->n_i, &ok);
+    s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
+    s->d.n_nodes = (int32_t)fs.nodes.size();
+    if (!ok) { hpt_set_error("device allocation / upload failed: %s", hipGetErrorString(hipGetLastError())); hpt_scene_destroy(s); return nullptr; }
+    return s;
+}
+
+extern "C" int hpt_scene_get_info(const hpt_scene *s, hpt_scene_info *info) {
+    if (!s || !info) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    *info = s->info;
+    return HPT_OK;
+}
+
+static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
+    if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
+    if (rd->spp <= 0 || (rd->spp & (rd->spp - 1))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42)"); return HPT_E_INVALID; }
+    if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
+    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH) { hpt_set_error("sampler mode %d is not available in this build", rd->sampler_mode); return HPT_E_UNSUPPORTED; }
+    rp->cam = *cam;
+    rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
+    rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
+    rp->seed = rd->seed;
+    rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
+    rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
+    if (rp->shard_rank < 0 || rp->shard_rank >= rp->shard_count) { hpt_set_error("bad shard rank"); return HPT_E_INVALID; }
+    rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
+    int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
+    int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
+    rp->n_items = local * 1024;
+    return HPT_OK;
+}
+
+extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film,
+                                 void *stream_v, hpt_stats *stats) {
+    if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
+    PathKernelArgs a;
+    int rc = fill_params(cam, rd, &a.rp);
+    if (rc != HPT_OK) return rc;
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    hipStream_t stream = (hipStream_t)stream_v;
+    a.sc = s->d;
+    a.film = (float *)d_film;
+    struct Scratch { unsigned long long next_item; WorkCounters wc; };
+    Scratch *d_scr = nullptr;
+    HIP_CHECK_RET(hipMalloc((void **)&d_scr, sizeof(Scratch)), HPT_E_HIP);
+    hipError_t e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
+    a.next_item = &d_scr->next_item;
+    a.counters = &d_scr->wc;
+    int bpc = 0, vgprs = 0;
+    if (e == hipSuccess && path_kernel_occupancy(&bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (bpc < 1) bpc = 1;
+    int grid = s->n_cus * bpc;
+    int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
+    if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+    if (e == hipSuccess) e = launch_path_kernel(a, grid, rd->count_work != 0, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    Scratch h_scr;
+    memset(&h_scr, 0, sizeof(h_scr));
+    if (e == hipSuccess) e = hipMemcpy(&h_scr, d_scr, sizeof(Scratch), hipMemcpyDeviceToHost);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipFree(d_scr);
+    if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->kernel_ms = ms;
+        // samples of this shard: pixels inside the extent x spp (also counted on device when count_work)
+        uint64_t px = 0;
+        int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
+        for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
+            int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
+            int w = rd->x_count - x0; if (w > 32) w = 32;
+            int h = rd->y_count - y0; if (h > 32) h = 32;
+            px += (uint64_t)w * (uint64_t)h;
+        }
+        stats->camera_samples = px * (uint64_t)rd->spp;
+        if (rd->count_work) {
+            stats->camera_samples = h_scr.wc.samples;
+            stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
+            stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris; stats->bad_samples = h_scr.wc.bad;
+        }
+        stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
+        stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs;
+    }
+    return HPT_OK;
+}
+
+extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film_host, hpt_stats *stats) {
+    if (!s || !film_host || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
+    void *d_film = nullptr;
+    HIP_CHECK_RET(hipMalloc(&d_film, bytes), HPT_E_HIP);
+    int rc = hpt_render_device(s, cam, rd, d_film, nullptr, stats);
+    if (rc == HPT_OK && hipMemcpy(film_host, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        hpt_set_error("film download failed"); rc = HPT_E_HIP;
+    }
+    (void)hipFree(d_film);
+    return rc;
+}
+
+// ---- parity hooks -------------------------------------------------------------------------------------
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
+};
+
+extern "C" int hpt_test_intersect(hpt_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim) {
+    if (!s || !rays || !out_hit || !out_prim || n < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    DevBuf<float> d_rays, d_hit; DevBuf<int32_t> d_prim;
+    if (!d_rays.alloc(8 * (size_t)n) || !d_hit.alloc(4 * (size_t)n) || !d_prim.alloc((size_t)n)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
+    HIP_CHECK_RET(hipMemcpy(d_rays.p, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice), HPT_E_HIP);
+    HIP_CHECK_RET(launch_intersect(s->d, d_rays.p, n, anyhit, d_hit.p, d_prim.p, nullptr), HPT_E_HIP);
+    HIP_CHECK_RET(hipDeviceSynchronize(), HPT_E_HIP);
+    HIP_CHECK_RET(hipMemcpy(out_hit, d_hit.p, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost), HPT_E_HIP);
+    HIP_CHECK_RET(hipMemcpy(out_prim, d_prim.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost), HPT_E_HIP);
+    return HPT_OK;
+}
+
+extern "C" int hpt_test_bsdf(hpt_scene *s, int material, const float *in, int64_t n, float *out) {
+    if (!s || !in || !out || n < 0 || material < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    DevBuf<float> d_in, d_out;
+    if (!d_in.alloc(16 * (size_t)n) || !d_out.alloc(12 * (size_t)n)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
+    HIP_CHECK_RET(hipMemcpy(d_in.p, in, sizeof(float) * 16 * (size_t)n, hipMemcpyHostToDevice), HPT_E_HIP);
+    HIP_CHECK_RET(launch_bsdf(s->d, material, d_in.p, n, d_out.p, nullptr), HPT_E_HIP);
+    HIP_CHECK_RET(hipDeviceSynchronize(), HPT_E_HIP);
+    HIP_CHECK_RET(hipMemcpy(out, d_out.p, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost), HPT_E_HIP);
+    return HPT_OK;
+}
+
+extern "C" int hpt_test_sampler(const hpt_render_desc *rd, int x, int y, float *out) {
+    if (!rd || !out) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
+    if (hpt_device_count() <= 0) { hpt_set_error("no HIP device available"); return HPT_E_NODEVICE; }
+    hpt_camera cam; memset(&cam, 0, sizeof(cam));
+    RenderParams rp;
+    int rc = fill_params(&cam, rd, &rp);
+    if (rc != HPT_OK) return rc;
+    DevBuf<float> d_out;
+    if (!d_out.alloc(35 * (size_t)rd->spp)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
+    HIP_CHECK_RET(launch_sampler(rp, x, y, d_out.p, nullptr), HPT_E_HIP);
+    HIP_CHECK_RET(hipDeviceSynchronize(), HPT_E_HIP);
+    HIP_CHECK_RET(hipMemcpy(out, d_out.p, sizeof(float) * 35 * (size_t)rd->spp, hipMemcpyDeviceToHost), HPT_E_HIP);
+    return HPT_OK;
+}

@@ -1,0 +1,898 @@
+// hpt_device.h — device-side building blocks of the MI355X path tracer: pbrt-semantics vector
+// math, the stateless LD sampler, ray/triangle/quadric intersection, BVH2 traversal over 64-byte
+// nodes, shading geometry, BSDFs and lights.
+//
+// Written for gfx950 (hipcc, -ffp-contract=off so float expressions evaluate exactly as written:
+// the reference is compiled without FMA contraction and the parity tests compare against it).
+// The same header also compiles with plain g++ (HPT_HOST_EMU) — that build exists ONLY for
+// tests/hostemu, a development harness that runs these functions lane-by-lane on the CPU to
+// debug them without a GPU.  It is not linked into libhpt.so and is not a fallback.
+//
+// Reference citations (paths relative to the reference's src/): each function names the code
+// whose behaviour it reproduces.
+#ifndef HPT_DEVICE_H
+#define HPT_DEVICE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HPT_FN __device__ __forceinline__
+#define HPT_MFN __device__ __forceinline__
+#define HPT_FN_NOINLINE __device__ __noinline__
+#else
+#define HPT_HOST_EMU 1
+#define HPT_FN static inline
+#define HPT_MFN inline
+#define HPT_FN_NOINLINE static
+#endif
+
+#include "../../include/hpt.h"
+
+namespace hpt {
+
+#define HPT_PI 3.14159265358979323846f       /* core/pbrt.h:190 — a FLOAT literal in pbrt */
+#define HPT_INV_PI 0.31830988618379067154f
+#define HPT_INV_TWOPI 0.15915494309189533577f
+#define HPT_ONE_MINUS_EPS 0x1.fffffep-1f      /* core/montecarlo.h:50 */
+#define HPT_INF __builtin_huge_valf()
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+// ---- core/geometry.h semantics ----------------------------------------------------------
+HPT_FN f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+HPT_FN f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HPT_FN f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HPT_FN f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+HPT_FN f3 operator*(f3 a, float f) { return mk3(a.x * f, a.y * f, a.z * f); }
+HPT_FN f3 vdiv(f3 a, float f) { float inv = 1.f / f; return mk3(a.x * inv, a.y * inv, a.z * inv); } // geometry.h:94-98
+HPT_FN float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HPT_FN float absdot(f3 a, f3 b) { return fabsf(dot(a, b)); }
+HPT_FN f3 cross(f3 a, f3 b) { // geometry.h:475-484: evaluated in DOUBLE
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return mk3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
+}
+HPT_FN float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+HPT_FN float len(f3 a) { return sqrtf(len2(a)); }
+HPT_FN f3 normalize(f3 a) { return vdiv(a, len(a)); }
+HPT_FN float dist2(f3 a, f3 b) { return len2(a - b); }
+HPT_FN float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+HPT_FN float maxf(float a, float b) { return a < b ? b : a; } // std::max
+HPT_FN float minf(float a, float b) { return b < a ? b : a; } // std::min
+HPT_FN float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+HPT_FN void coordinate_system(f3 v1, f3 *v2, f3 *v3) { // geometry.h:508-518
+    if (fabsf(v1.x) > fabsf(v1.y)) {
+        float invLen = 1.f / sqrtf(v1.x * v1.x + v1.z * v1.z);
+        *v2 = mk3(-v1.z * invLen, 0.f, v1.x * invLen);
+    } else {
+        float invLen = 1.f / sqrtf(v1.y * v1.y + v1.z * v1.z);
+        *v2 = mk3(0.f, v1.z * invLen, -v1.y * invLen);
+    }
+    *v3 = cross(v1, *v2);
+}
+HPT_FN float spherical_theta(f3 v) { return acosf(clampf(v.z, -1.f, 1.f)); }
+HPT_FN float spherical_phi(f3 v) { float p = atan2f(v.y, v.x); return (p < 0.f) ? p + 2.f * HPT_PI : p; }
+
+// Transform::operator() (core/transform.h:192-246), m row-major
+HPT_FN f3 xf_point(const float *m, f3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    float xp = m[0] * x + m[1] * y + m[2] * z + m[3];
+    float yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+    float zp = m[8] * x + m[9] * y + m[10] * z + m[11];
+    float wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+    if (wp == 1.f) return mk3(xp, yp, zp);
+    return vdiv(mk3(xp, yp, zp), wp);
+}
+HPT_FN f3 xf_vec(const float *m, f3 v) {
+    float x = v.x, y = v.y, z = v.z;
+    return mk3(m[0] * x + m[1] * y + m[2] * z, m[4] * x + m[5] * y + m[6] * z, m[8] * x + m[9] * y + m[10] * z);
+}
+HPT_FN f3 xf_normal(const float *minv, f3 n) { // transpose of the inverse (transform.h:230-236)
+    float x = n.x, y = n.y, z = n.z;
+    return mk3(minv[0] * x + minv[4] * y + minv[8] * z, minv[1] * x + minv[5] * y + minv[9] * z,
+               minv[2] * x + minv[6] * y + minv[10] * z);
+}
+
+// ---- Spectrum = RGB (core/spectrum.h) ----------------------------------------------------
+HPT_FN f3 S(float v) { return mk3(v, v, v); }
+HPT_FN f3 smul(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HPT_FN f3 sdivf(f3 a, float f) { return mk3(a.x / f, a.y / f, a.z / f); } // true division (spectrum.h:182-189)
+HPT_FN bool sblack(f3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
+HPT_FN float sy(f3 a) { return 0.212671f * a.x + 0.715160f * a.y + 0.072169f * a.z; }
+HPT_FN f3 sclamp0(f3 a) { return mk3(clampf(a.x, 0.f, HPT_INF), clampf(a.y, 0.f, HPT_INF), clampf(a.z, 0.f, HPT_INF)); }
+
+// ---- sampler ------------------------------------------------------------------------------
+// (0,2)-sequence generators: core/montecarlo.h:281-300
+HPT_FN float van_der_corput(uint32_t n, uint32_t scramble) {
+#if defined(__HIPCC__)
+    n = __brev(n);
+#else
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ff) << 8) | ((n & 0xff00ff00) >> 8);
+    n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
+    n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2);
+    n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1);
+#endif
+    n ^= scramble;
+    return minf(((n >> 8) & 0xffffff) / (float)(1 << 24), HPT_ONE_MINUS_EPS);
+}
+HPT_FN float sobol2(uint32_t n, uint32_t scramble) {
+    for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 0x1) scramble ^= v;
+    return minf(((scramble >> 8) & 0xffffff) / (float)(1 << 24), HPT_ONE_MINUS_EPS);
+}
+// HPT_SAMPLER_LD_HASH (mirrored by oracle/hpt_oracle.c ld_hash_sample)
+HPT_FN uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+HPT_FN uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = fmix32(a + 0x9e3779b9u);
+    h = fmix32(h ^ (b + 0x85ebca6bu));
+    h = fmix32(h ^ (c + 0xc2b2ae35u));
+    return h;
+}
+HPT_FN uint32_t perm_pow2(uint32_t i, uint32_t w, uint32_t key) {
+    uint32_t x = i & w;
+    x ^= key & w;          x = (x * 0xe170893du) & w;        x ^= x >> 4;
+    x ^= (key >> 8) & w;   x = (x * 0x0929eb3fu) & w;        x ^= x >> 2;
+    x ^= (key >> 16) & w;  x = (x * ((key >> 3) | 1u)) & w;  x ^= x >> 3;
+    x = (x + (key >> 24)) & w;
+    return x;
+}
+// Sample-array ids: 0=image 1=lens 2=time 3+j = oneD[j] (j<12) 15+j = twoD[j] (j<9);
+// scramble-word ids: image 0,1 lens 2,3 time 4 oneD[j] 5+j twoD[j] 17+2j,18+2j.
+// oneD/twoD indices per path depth d<3 (integrators/path.cpp:41-49):
+//   oneD: 4d light component, 4d+1 light number, 4d+2 bsdf component, 4d+3 path component
+//   twoD: 3d light position,  3d+1 bsdf direction, 3d+2 path direction
+struct LdHash {
+    uint32_t pk;   // hash3(pixelIndex, seed, 'PIXE')
+    uint32_t w;    // spp - 1
+    uint32_t i;    // sample index within the pixel
+    HPT_MFN uint32_t idx(uint32_t arr) const { return perm_pow2(i, w, hash3(pk, arr, 2u)); }
+    HPT_MFN float one(int j) const { return van_der_corput(idx(3u + (uint32_t)j), hash3(pk, 5u + (uint32_t)j, 1u)); }
+    HPT_MFN void two(int j, float *a, float *b) const {
+        uint32_t n = idx(15u + (uint32_t)j);
+        *a = van_der_corput(n, hash3(pk, 17u + 2u * (uint32_t)j, 1u));
+        *b = sobol2(n, hash3(pk, 18u + 2u * (uint32_t)j, 1u));
+    }
+    HPT_MFN void image(float *a, float *b) const {
+        uint32_t n = idx(0u);
+        *a = van_der_corput(n, hash3(pk, 0u, 1u));
+        *b = sobol2(n, hash3(pk, 1u, 1u));
+    }
+    HPT_MFN void lens(float *a, float *b) const {
+        uint32_t n = idx(1u);
+        *a = van_der_corput(n, hash3(pk, 2u, 1u));
+        *b = sobol2(n, hash3(pk, 3u, 1u));
+    }
+    HPT_MFN float time01() const { return van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
+    // draws for bounces >= 3 and Russian roulette: RandomFloat() resolution (core/rng.cpp:59-65)
+    HPT_MFN float draw(uint32_t key, uint32_t counter) const {
+        uint32_t h = fmix32(key + 0x9e3779b9u * counter);
+        return (h & 0xffffff) / (float)(1 << 24);
+    }
+    HPT_MFN uint32_t draw_key() const { return hash3(pk, i, 3u); }
+};
+HPT_FN uint32_t pixel_key(uint32_t pixelIndex, uint32_t seed) { return hash3(pixelIndex, seed, 0x50495845u); }
+
+// ---- device scene ---------------------------------------------------------------------------
+// BVH2 node, 64 bytes = one coalesced 64-B line per visit (both children's boxes inline):
+//   n0 = (c0.min.xyz, c0.max.x)  n1 = (c0.max.yz, c1.min.xy)  n2 = (c1.min.z, c1.max.xyz)
+//   n3 = (bits child0, bits child1, 0, 0)
+// child >= 0: interior node index.  child < 0: leaf, ~child = firstTri | (count-1) << 28.
+// Triangle record, 48 bytes, BVH order: (v0, bits meshId) (v1, bits triInMesh) (v2, 0).
+struct DMesh {
+    int64_t n_off, uv_off, idx_off; // into fpool / ipool (n_off, uv_off: -1 = absent)
+    int32_t prim_base;              // global primitive id of triangle 0
+    int32_t material, arealight, flip; // flip = reverse_orientation ^ swaps_handedness
+    float o2w_inv[12];              // rows 0..2 of ObjectToWorld->mInv (for normals)
+};
+struct DScene {
+    const f4 *nodes;
+    const f4 *tris;
+    const DMesh *meshes;
+    const hpt_quadric *quadrics;
+    const hpt_material *materials;
+    const hpt_light *lights;
+    const float *fpool;
+    const int32_t *ipool;
+    int32_t n_tris, n_quadrics, n_lights, n_nodes;
+};
+
+struct Ray { f3 o, d; float mint, maxt; };
+HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
+struct Hit { float t, b1, b2; int32_t prim; }; // prim: tri slot (BVH order) or n_tris + quadric; -1 miss
+struct DGeom { f3 p, nn, dpdu; };
+
+HPT_FN int32_t as_int(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
+
+// Triangle::Intersect core test (shapes/trianglemesh.cpp:127-160)
+HPT_FN bool tri_test(f3 p1, f3 p2, f3 p3, const Ray &ray, float *t_out, float *b1_out, float *b2_out) {
+    f3 e1 = p2 - p1, e2 = p3 - p1;
+    f3 s1 = cross(ray.d, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.f) return false;
+    float invDivisor = 1.f / divisor;
+    f3 s = ray.o - p1;
+    float b1 = dot(s, s1) * invDivisor;
+    if (b1 < 0.f || b1 > 1.f) return false;
+    f3 s2 = cross(s, e1);
+    float b2 = dot(ray.d, s2) * invDivisor;
+    if (b2 < 0.f || b1 + b2 > 1.f) return false;
+    float t = dot(e2, s2) * invDivisor;
+    if (t < ray.mint || t > ray.maxt) return false;
+    *t_out = t; *b1_out = b1; *b2_out = b2;
+    return true;
+}
+
+// Quadratic (core/pbrt.h:309-323)
+HPT_FN bool quadratic(float A, float B, float C, float *t0, float *t1) {
+    float discrim = B * B - 4.f * A * C;
+    if (discrim < 0.f) return false;
+    float rootDiscrim = sqrtf(discrim);
+    float q;
+    if (B < 0) q = -.5f * (B - rootDiscrim);
+    else q = -.5f * (B + rootDiscrim);
+    *t0 = q / A;
+    *t1 = C / q;
+    if (*t0 > *t1) { float tmp = *t0; *t0 = *t1; *t1 = tmp; }
+    return true;
+}
+HPT_FN void dg_init(DGeom *dg, f3 P, f3 dpdu, f3 dpdv, int flip) { // core/diffgeom.cpp:40-55
+    dg->p = P; dg->dpdu = dpdu;
+    dg->nn = normalize(cross(dpdu, dpdv));
+    if (flip) dg->nn = dg->nn * -1.f;
+}
+// Sphere::Intersect (shapes/sphere.cpp:58-157) / Disk::Intersect (shapes/disk.cpp:56-102);
+// world-space ray in, transformed by WorldToObject (= ObjectToWorld->mInv) as the reference does
+HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, DGeom *dg) {
+    Ray ray;
+    ray.o = xf_point(q.o2w_inv, r.o);
+    ray.d = xf_vec(q.o2w_inv, r.d);
+    ray.mint = r.mint; ray.maxt = r.maxt;
+    int flip = q.reverse_orientation ^ q.swaps_handedness;
+    if (q.kind == HPT_QUADRIC_SPHERE) {
+        float radius = q.radius, phiMax = q.phi_max, zmin = q.zmin, zmax = q.zmax;
+        float A = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
+        float B = 2 * (ray.d.x * ray.o.x + ray.d.y * ray.o.y + ray.d.z * ray.o.z);
+        float C = ray.o.x * ray.o.x + ray.o.y * ray.o.y + ray.o.z * ray.o.z - radius * radius;
+        float t0, t1;
+        if (!quadratic(A, B, C, &t0, &t1)) return false;
+        if (t0 > ray.maxt || t1 < ray.mint) return false;
+        float thit = t0;
+        if (t0 < ray.mint) { thit = t1; if (thit > ray.maxt) return false; }
+        f3 phit = ray_at(ray, thit);
+        if (phit.x == 0.f && phit.y == 0.f) phit.x = 1e-5f * radius;
+        float phi = atan2f(phit.y, phit.x);
+        if (phi < 0.f) phi += 2.f * HPT_PI;
+        if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) {
+            if (thit == t1) return false;
+            if (t1 > ray.maxt) return false;
+            thit = t1;
+            phit = ray_at(ray, thit);
+            if (phit.x == 0.f && phit.y == 0.f) phit.x = 1e-5f * radius;
+            phi = atan2f(phit.y, phit.x);
+            if (phi < 0.f) phi += 2.f * HPT_PI;
+            if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) return false;
+        }
+        if (dg) {
+            float theta = acosf(clampf(phit.z / radius, -1.f, 1.f));
+            float zradius = sqrtf(phit.x * phit.x + phit.y * phit.y);
+            float invzradius = 1.f / zradius;
+            float cosphi = phit.x * invzradius, sinphi = phit.y * invzradius;
+            f3 dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0);
+            f3 dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (q.theta_max - q.theta_min);
+            dg_init(dg, xf_point(q.o2w, phit), xf_vec(q.o2w, dpdu), xf_vec(q.o2w, dpdv), flip);
+        }
+        *tHit = thit;
+        return true;
+    }
+    // disk.  `fabsf(d.z) < 1e-7` compares against the DOUBLE literal in the reference (disk.cpp:63)
+    if ((double)fabsf(ray.d.z) < 1e-7) return false;
+    float thit = (q.height - ray.o.z) / ray.d.z;
+    if (thit < ray.mint || thit > ray.maxt) return false;
+    f3 phit = ray_at(ray, thit);
+    float d2 = phit.x * phit.x + phit.y * phit.y;
+    if (d2 > q.radius * q.radius || d2 < q.inner_radius * q.inner_radius) return false;
+    float phi = atan2f(phit.y, phit.x);
+    if (phi < 0) phi = (float)((double)phi + 2. * (double)HPT_PI); // disk.cpp:75: `2. * M_PI` is double
+    if (phi > q.phi_max) return false;
+    if (dg) {
+        float R = sqrtf(d2);
+        f3 dpdu = mk3(-q.phi_max * phit.y, q.phi_max * phit.x, 0.f);
+        f3 dpdv = mk3(phit.x, phit.y, 0.f) * ((q.radius - q.inner_radius) / R);
+        dg_init(dg, xf_point(q.o2w, phit), xf_vec(q.o2w, dpdu), xf_vec(q.o2w, dpdv), flip);
+    }
+    *tHit = thit;
+    return true;
+}
+HPT_FN float quadric_area(const hpt_quadric &q) {
+    if (q.kind == HPT_QUADRIC_SPHERE) return q.phi_max * q.radius * (q.zmax - q.zmin);
+    return q.phi_max * 0.5f * (q.radius * q.radius - q.inner_radius * q.inner_radius);
+}
+
+// ---- BVH2 traversal --------------------------------------------------------------------------
+// Replaces BVHAccel::Intersect / IntersectP (accelerators/bvh.cpp:403-503): same slab test
+// (bvh.cpp:126-148, strict inequalities, +-inf inverse directions, no NaN guard), near child first
+// by entry distance, far child on a per-lane stack.  `stack` points at this lane's slot 0 and
+// consecutive entries are `stride` ints apart (LDS: stride = block size, so the 64 lanes of a
+// wave hit 64 different banks).
+struct TravCounters { uint32_t nodes, tris; };
+
+HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray &ray, f3 invd,
+                 bool nx, bool ny, bool nz, float *tentry) {
+    float tmin = ((nx ? hix : lox) - ray.o.x) * invd.x;
+    float tmax = ((nx ? lox : hix) - ray.o.x) * invd.x;
+    float tymin = ((ny ? hiy : loy) - ray.o.y) * invd.y;
+    float tymax = ((ny ? loy : hiy) - ray.o.y) * invd.y;
+    bool miss = (tmin > tymax) || (tymin > tmax);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? hiz : loz) - ray.o.z) * invd.z;
+    float tzmax = ((nz ? loz : hiz) - ray.o.z) * invd.z;
+    miss = miss || (tmin > tzmax) || (tzmin > tmax);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    *tentry = tmin;
+    return !miss && (tmin < ray.maxt) && (tmax > ray.mint);
+}
+
+template <bool COUNT>
+HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
+    hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f;
+    // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
+    for (int q = 0; q < sc.n_quadrics; ++q) {
+        float t;
+        if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
+            if (anyhit) { hit->prim = sc.n_tris + q; return true; }
+            hit->prim = sc.n_tris + q; hit->t = t; ray.maxt = t;
+        }
+    }
+    if (sc.n_nodes == 0) return hit->prim >= 0;
+    f3 invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+    bool nx = invd.x < 0, ny = invd.y < 0, nz = invd.z < 0;
+    int sp = 0;
+    int32_t node = 0;
+    while (true) {
+        if (node >= 0) {
+            const f4 *np = sc.nodes + 4 * (int64_t)node;
+            f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) cnt->nodes++;
+            float t0, t1;
+            bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, invd, nx, ny, nz, &t0);
+            bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, invd, nx, ny, nz, &t1);
+            int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                stack[sp * stride] = farc; ++sp;
+                node = nearc;
+                continue;
+            }
+            if (h0) { node = c0; continue; }
+            if (h1) { node = c1; continue; }
+        } else {
+            uint32_t code = (uint32_t)~node;
+            uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
+                f4 a = tp[0], b = tp[1], c = tp[2];
+                if (COUNT) cnt->tris++;
+                float t, b1, b2;
+                if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
+                    hit->prim = (int32_t)(first + k);
+                    if (anyhit) return true;
+                    hit->t = t; hit->b1 = b1; hit->b2 = b2;
+                    ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; node = stack[sp * stride];
+    }
+    return hit->prim >= 0;
+}
+
+// ---- shading geometry + BSDF -------------------------------------------------------------------
+enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
+       BSDF_ALL = 31, BSDF_ALL_NOSPEC = 15 };
+enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3 };
+
+// BSDF value type (replaces the arena-allocated BSDF + BxDF objects of core/reflection.h:150-191)
+struct Bsdf {
+    f3 nn, ng, sn, tn; // shading normal, geometric normal, tangent frame (reflection.cpp:601-609)
+    int n;             // number of BxDFs (<= 2 for the in-scope materials)
+    int kind0, kind1;  // BX_*
+    f3 R0, R1;         // reflectances
+    float exponent;    // Blinn exponent of the microfacet lobe
+    const hpt_material *mat;
+    HPT_MFN int kind(int i) const { return i == 0 ? kind0 : kind1; }
+    HPT_MFN f3 R(int i) const { return i == 0 ? R0 : R1; }
+    HPT_MFN int type(int i) const { return kind(i) == BX_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE) : (BSDF_REFLECTION | BSDF_GLOSSY); }
+    HPT_MFN f3 w2l(f3 v) const { return mk3(dot(v, sn), dot(v, tn), dot(v, nn)); }
+    HPT_MFN f3 l2w(f3 v) const {
+        return mk3(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z, sn.z * v.x + tn.z * v.y + nn.z * v.z);
+    }
+};
+HPT_FN float abs_cos_theta(f3 w) { return fabsf(w.z); }
+HPT_FN float sin_theta2(f3 w) { return maxf(0.f, 1.f - w.z * w.z); }
+HPT_FN float sin_theta(f3 w) { return sqrtf(sin_theta2(w)); }
+HPT_FN bool same_hemisphere(f3 w, f3 wp) { return w.z * wp.z > 0.f; }
+
+HPT_FN void bsdf_frame(Bsdf *b, f3 nn_shading, f3 dpdu_shading, f3 ng) {
+    b->ng = ng; b->nn = nn_shading; b->sn = normalize(dpdu_shading); b->tn = cross(b->nn, b->sn);
+    b->n = 0; b->kind0 = b->kind1 = BX_NONE; b->R0 = b->R1 = S(0.f); b->exponent = 0.f; b->mat = nullptr;
+}
+HPT_FN void bsdf_push(Bsdf *b, int kind, f3 R) {
+    if (b->n == 0) { b->kind0 = kind; b->R0 = R; } else { b->kind1 = kind; b->R1 = R; }
+    b->n++;
+}
+// Material::GetBSDF: materials/matte.cpp:42-63, plastic.cpp:42-66, measured.cpp:194-210
+HPT_FN void bsdf_add_material(Bsdf *b, const hpt_material *m) {
+    b->mat = m;
+    f3 kd = mk3(m->kd[0], m->kd[1], m->kd[2]), ks = mk3(m->ks[0], m->ks[1], m->ks[2]);
+    if (m->kind == HPT_MAT_MATTE) {
+        if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
+    } else if (m->kind == HPT_MAT_PLASTIC) {
+        if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
+        if (!sblack(ks)) {
+            float e = 1.f / m->roughness;
+            if (e > 10000.f || e != e) e = 10000.f; // Blinn ctor (reflection.h:424)
+            b->exponent = e;
+            bsdf_push(b, BX_MICROFACET, ks);
+        }
+    } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
+        bsdf_push(b, BX_IRREG, S(0.f));
+    }
+}
+// FresnelDielectric::Evaluate + FrDiel (reflection.cpp:115-135, 60-67); scalar because eta is scalar
+HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
+    cosi = clampf(cosi, -1.f, 1.f);
+    bool entering = cosi > 0.f;
+    float ei = eta_i, et = eta_t;
+    if (!entering) { float t = ei; ei = et; et = t; }
+    float sint = ei / et * sqrtf(maxf(0.f, 1.f - cosi * cosi));
+    if (sint >= 1.f) return 1.f;
+    float cost = sqrtf(maxf(0.f, 1.f - sint * sint));
+    float ci = fabsf(cosi);
+    float Rparl = ((et * ci) - (ei * cost)) / ((et * ci) + (ei * cost));
+    float Rperp = ((ei * ci) - (et * cost)) / ((ei * ci) + (et * cost));
+    return (Rparl * Rparl + Rperp * Rperp) / 2.f;
+}
+
+// IrregIsotropicBRDF::f (reflection.cpp:247-272): kd-tree radius query with the reference's exact
+// post-order visiting sequence (core/kdtree.h:159-183) so the weighted sums round identically.
+// The recursion is unrolled into an explicit stack of (node, stage) pairs.
+struct IrregProc { f3 v; float sumWeights; int nFound; };
+HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2) {
+    const float *split = sc.fpool + m->kd_split_off;
+    const int32_t *bits = sc.ipool + m->kd_bits_off;
+    const float *data = sc.fpool + m->kd_data_off;
+    const uint32_t nNodes = (uint32_t)m->kd_nnodes;
+    // stage 0: first visit; 1: after first child; 2: after second child -> process node
+    uint32_t stk[40]; // node << 2 | stage ; tree depth <= ceil(log2(nNodes)) + 1
+    int sp = 0;
+    stk[sp++] = 0u << 2;
+    while (sp > 0) {
+        uint32_t e = stk[sp - 1];
+        uint32_t nodeNum = e >> 2, stage = e & 3u;
+        uint32_t b = (uint32_t)bits[nodeNum];
+        int axis = (int)(b & 3u);
+        uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
+        if (axis != 3 && stage < 2) {
+            float pa = comp(p, axis), sp_ = split[nodeNum];
+            float d2 = (pa - sp_) * (pa - sp_);
+            bool leftFirst = pa <= sp_;
+            uint32_t child = 0xffffffffu;
+            if (stage == 0) {
+                if (leftFirst) { if (hasLeft) child = nodeNum + 1; }
+                else { if (right < nNodes) child = right; }
+            } else {
+                if (leftFirst) { if (d2 < maxDist2 && right < nNodes) child = right; }
+                else { if (d2 < maxDist2 && hasLeft) child = nodeNum + 1; }
+            }
+            stk[sp - 1] = (nodeNum << 2) | (stage + 1);
+            if (child != 0xffffffffu) stk[sp++] = child << 2;
+            continue;
+        }
+        --sp;
+        f3 np = mk3(data[6 * nodeNum], data[6 * nodeNum + 1], data[6 * nodeNum + 2]);
+        float d2 = dist2(np, p);
+        if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
+            float weight = expf(-100.f * d2);
+            proc->v = proc->v + mk3(data[6 * nodeNum + 3], data[6 * nodeNum + 4], data[6 * nodeNum + 5]) * weight;
+            proc->sumWeights += weight;
+            ++proc->nFound;
+        }
+    }
+}
+HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {
+    float cosi = wi.z, coso = wo.z;
+    float sini = sin_theta(wi), sino = sin_theta(wo);
+    float phii = spherical_phi(wi), phio = spherical_phi(wo);
+    float dphi = phii - phio;
+    if (dphi < 0.f) dphi += 2.f * HPT_PI;
+    if (dphi > 2.f * HPT_PI) dphi -= 2.f * HPT_PI;
+    if (dphi > HPT_PI) dphi = 2.f * HPT_PI - dphi;
+    f3 mpt = mk3(sini * sino, dphi / HPT_PI, cosi * coso);
+    float lastMaxDist2 = .001f;
+    while (true) {
+        IrregProc proc; proc.v = S(0.f); proc.sumWeights = 0.f; proc.nFound = 0;
+        kd_lookup(sc, m, mpt, &proc, lastMaxDist2);
+        if (proc.nFound > 2 || lastMaxDist2 > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
+        lastMaxDist2 *= 2.f;
+    }
+}
+
+HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi) {
+    int kind = b.kind(i);
+    if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
+    if (kind == BX_MICROFACET) {                                     // :211-222
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+        if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
+        f3 wh = wi + wo;
+        if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return S(0.f);
+        wh = normalize(wh);
+        float cosThetaH = dot(wi, wh);
+        float F = fresnel_dielectric(cosThetaH, 1.5f, 1.f);
+        float D = (b.exponent + 2) * HPT_INV_TWOPI * powf(abs_cos_theta(wh), b.exponent); // Blinn::D
+        float NdotWh = abs_cos_theta(wh), NdotWo = abs_cos_theta(wo), NdotWi = abs_cos_theta(wi);
+        float WOdotWh = absdot(wo, wh);
+        float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+        return sdivf(smul((b.R(i) * D) * G, S(F)), (4.f * cosThetaI * cosThetaO));
+    }
+    return irreg_f(sc, b.mat, wo, wi);
+}
+HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
+    if (b.kind(i) == BX_MICROFACET) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
+        if (!same_hemisphere(wo, wi)) return 0.f;
+        f3 wh = normalize(wo + wi);
+        float costheta = abs_cos_theta(wh);
+        float p = ((b.exponent + 1.f) * powf(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
+        if (dot(wo, wh) <= 0.f) p = 0.f;
+        return p;
+    }
+    return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * HPT_INV_PI : 0.f; // BxDF::Pdf :321-323
+}
+HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { // montecarlo.cpp:306-348
+    float r, theta;
+    float sx = 2 * u1 - 1, sy = 2 * u2 - 1;
+    if (sx == 0.f && sy == 0.f) { *dx = 0.f; *dy = 0.f; return; }
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; if (sy > 0.f) theta = sy / r; else theta = 8.0f + sy / r; }
+        else { r = sy; theta = 2.0f - sx / r; }
+    } else {
+        if (sx <= sy) { r = -sx; theta = 4.0f - sy / r; }
+        else { r = -sy; theta = 6.0f + sx / r; }
+    }
+    theta *= HPT_PI / 4.f;
+    *dx = r * cosf(theta);
+    *dy = r * sinf(theta);
+}
+HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf) {
+    if (b.kind(i) == BX_MICROFACET) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
+        float costheta = powf(u1, 1.f / (b.exponent + 1));
+        float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
+        float phi = u2 * 2.f * HPT_PI;
+        f3 wh = mk3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
+        if (!same_hemisphere(wo, wh)) wh = -wh;
+        *wi = (-wo) + wh * (2.f * dot(wo, wh));
+        float bp = ((b.exponent + 1.f) * powf(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
+        if (dot(wo, wh) <= 0.f) bp = 0.f;
+        *pdf = bp;
+        if (!same_hemisphere(wo, *wi)) return S(0.f);
+        return bxdf_f(sc, b, i, wo, *wi);
+    }
+    f3 w; // BxDF::Sample_f :311-318 (cosine hemisphere)
+    concentric_sample_disk(u1, u2, &w.x, &w.y);
+    w.z = sqrtf(maxf(0.f, 1.f - w.x * w.x - w.y * w.y));
+    if (wo.z < 0.f) w.z *= -1.f;
+    *wi = w;
+    *pdf = bxdf_pdf(b, i, wo, w);
+    return bxdf_f(sc, b, i, wo, w);
+}
+HPT_FN bool bx_match(const Bsdf &b, int i, int flags) { int t = b.type(i); return (t & flags) == t; }
+// BSDF::f (reflection.cpp:612-626)
+HPT_FN f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags) {
+    f3 wi = b.w2l(wiW), wo = b.w2l(woW);
+    if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
+    else flags &= ~BSDF_REFLECTION;
+    f3 f = S(0.f);
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi);
+    return f;
+}
+// BSDF::Pdf (reflection.cpp:583-598)
+HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
+    if (b.n == 0) return 0.f;
+    f3 wo = b.w2l(woW), wi = b.w2l(wiW);
+    float pdf = 0.f; int matching = 0;
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) { ++matching; pdf += bxdf_pdf(b, i, wo, wi); }
+    return matching > 0 ? pdf / matching : 0.f;
+}
+// BSDF::Sample_f (reflection.cpp:522-580)
+HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
+                        int flags, int *sampledType) {
+    int matching = 0;
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) ++matching;
+    if (matching == 0) { *pdf = 0.f; *sampledType = 0; return S(0.f); }
+    int which = (int)floorf(uComp * matching);
+    if (which > matching - 1) which = matching - 1;
+    int sel = -1, count = which;
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
+    f3 wo = b.w2l(woW), wi = S(0.f);
+    *pdf = 0.f;
+    f3 f = bxdf_sample_f(sc, b, sel, wo, &wi, u1, u2, pdf);
+    if (*pdf == 0.f) { *sampledType = 0; return S(0.f); }
+    int stype = b.type(sel);
+    *sampledType = stype;
+    *wiW = b.l2w(wi);
+    if (!(stype & BSDF_SPECULAR) && matching > 1)
+        for (int i = 0; i < b.n; ++i) if (i != sel && bx_match(b, i, flags)) *pdf += bxdf_pdf(b, i, wo, wi);
+    if (matching > 1) *pdf /= matching;
+    if (!(stype & BSDF_SPECULAR)) {
+        f = S(0.f);
+        if (dot(*wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
+        else flags &= ~BSDF_REFLECTION;
+        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi);
+    }
+    return f;
+}
+
+// Hit -> DifferentialGeometry -> shading geometry -> BSDF:
+// Triangle::Intersect tail (trianglemesh.cpp:162-207), DifferentialGeometry ctor (diffgeom.cpp:40-55),
+// Triangle::GetShadingGeometry (trianglemesh.cpp:293-368), BSDF ctor (reflection.cpp:601-609),
+// Material::GetBSDF.  Returns the primitive's area light index (or -1) and rayEpsilon.
+HPT_FN void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
+    if (hit.prim >= sc.n_tris) {
+        const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+        float t;
+        // re-evaluate the accepted hit to build dg: the traversal shrank ray.maxt to hit.t, so the
+        // quadric test returns the same root again
+        quadric_intersect(q, ray, &t, dg);
+        *rayEps = 5e-4f * hit.t;                       // sphere.cpp:155, disk.cpp:100
+        *arealight = q.arealight;
+        bsdf_frame(b, dg->nn, dg->dpdu, dg->nn);       // Shape::GetShadingGeometry: dgShading = dg (shape.h:56-60)
+        bsdf_add_material(b, &sc.materials[q.material]);
+        return;
+    }
+    const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+    f4 a = tp[0], bb = tp[1], c = tp[2];
+    f3 p1 = mk3(a.x, a.y, a.z), p2 = mk3(bb.x, bb.y, bb.z), p3 = mk3(c.x, c.y, c.z);
+    const DMesh &me = sc.meshes[as_int(a.w)];
+    int tri = as_int(bb.w);
+    const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
+    int v0 = idx[0], v1 = idx[1], v2 = idx[2];
+    float uv[3][2];
+    if (me.uv_off >= 0) { // Triangle::GetUVs (trianglemesh.h:86-100)
+        const float *U = sc.fpool + me.uv_off;
+        uv[0][0] = U[2 * v0]; uv[0][1] = U[2 * v0 + 1]; uv[1][0] = U[2 * v1]; uv[1][1] = U[2 * v1 + 1];
+        uv[2][0] = U[2 * v2]; uv[2][1] = U[2 * v2 + 1];
+    } else { uv[0][0] = 0.f; uv[0][1] = 0.f; uv[1][0] = 1.f; uv[1][1] = 0.f; uv[2][0] = 1.f; uv[2][1] = 1.f; }
+    f3 e1 = p2 - p1, e2 = p3 - p1;
+    float du1 = uv[0][0] - uv[2][0], du2 = uv[1][0] - uv[2][0];
+    float dv1 = uv[0][1] - uv[2][1], dv2 = uv[1][1] - uv[2][1];
+    f3 dp1 = p1 - p3, dp2 = p2 - p3;
+    float determinant = du1 * dv2 - dv1 * du2;
+    f3 dpdu, dpdv;
+    if (determinant == 0.f) coordinate_system(normalize(cross(e2, e1)), &dpdu, &dpdv);
+    else {
+        float invdet = 1.f / determinant;
+        dpdu = (dp1 * dv2 - dp2 * dv1) * invdet;
+        dpdv = (dp1 * (-du2) + dp2 * du1) * invdet;
+    }
+    float b1 = hit.b1, b2 = hit.b2;
+    float b0 = 1 - b1 - b2;
+    float tu = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+    float tv = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+    dg_init(dg, ray_at(ray, hit.t), dpdu, dpdv, me.flip);
+    *rayEps = 1e-3f * hit.t;
+    *arealight = me.arealight;
+    f3 ns_nn = dg->nn, ns_dpdu = dg->dpdu;
+    if (me.n_off >= 0) {
+        float A00 = uv[1][0] - uv[0][0], A01 = uv[2][0] - uv[0][0], A10 = uv[1][1] - uv[0][1], A11 = uv[2][1] - uv[0][1];
+        float C0 = tu - uv[0][0], C1 = tv - uv[0][1];
+        float det = A00 * A11 - A01 * A10; // SolveLinearSystem2x2 (core/transform.cpp:39-49)
+        float bb0, bb1, bb2;
+        bool ok = true;
+        if (fabsf(det) < 1e-10f) ok = false;
+        else {
+            bb1 = (A11 * C0 - A01 * C1) / det;
+            bb2 = (A00 * C1 - A10 * C0) / det;
+            if (bb1 != bb1 || bb2 != bb2) ok = false;
+        }
+        if (!ok) bb0 = bb1 = bb2 = 1.f / 3.f;
+        else bb0 = 1.f - bb1 - bb2;
+        const float *N = sc.fpool + me.n_off;
+        f3 n0 = mk3(N[3 * v0], N[3 * v0 + 1], N[3 * v0 + 2]);
+        f3 n1 = mk3(N[3 * v1], N[3 * v1 + 1], N[3 * v1 + 2]);
+        f3 n2 = mk3(N[3 * v2], N[3 * v2 + 1], N[3 * v2 + 2]);
+        f3 nsum = (n0 * bb0 + n1 * bb1) + n2 * bb2;
+        float minv[12];
+        for (int k = 0; k < 12; ++k) minv[k] = me.o2w_inv[k];
+        f3 ns = normalize(xf_normal(minv, nsum));
+        f3 ss = normalize(dg->dpdu);
+        f3 ts = cross(ss, ns);
+        if (len2(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, &ss, &ts);
+        DGeom dgs;
+        dg_init(&dgs, dg->p, ss, ts, me.flip);
+        ns_nn = dgs.nn; ns_dpdu = dgs.dpdu;
+    }
+    bsdf_frame(b, ns_nn, ns_dpdu, dg->nn);
+    bsdf_add_material(b, &sc.materials[me.material]);
+}
+
+// ---- lights ---------------------------------------------------------------------------------------
+HPT_FN f3 area_L(const hpt_light &l, f3 n, f3 w) { // DiffuseAreaLight::L (lights/diffuse.h:51-53)
+    return dot(n, w) > 0.f ? mk3(l.intensity[0], l.intensity[1], l.intensity[2]) : S(0.f);
+}
+HPT_FN int mod_i(int a, int b) { int n = (int)(a / b); a -= n * b; if (a < 0) a += b; return a; }
+HPT_FN f3 env_texel(const DScene &sc, const hpt_light &l, int si, int ti) {
+    si = mod_i(si, l.env_w); ti = mod_i(ti, l.env_h);
+    const float *t = sc.fpool + l.tex_off + 3 * ((int64_t)ti * l.env_w + si);
+    return mk3(t[0], t[1], t[2]);
+}
+HPT_FN f3 env_lookup(const DScene &sc, const hpt_light &l, float s, float t) { // MIPMap::triangle(0,..) mipmap.h:258-269
+    s = s * l.env_w - 0.5f;
+    t = t * l.env_h - 0.5f;
+    int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    float ds = s - s0, dt = t - t0;
+    return ((env_texel(sc, l, s0, t0) * ((1.f - ds) * (1.f - dt)) + env_texel(sc, l, s0, t0 + 1) * ((1.f - ds) * dt)) +
+            env_texel(sc, l, s0 + 1, t0) * (ds * (1.f - dt))) + env_texel(sc, l, s0 + 1, t0 + 1) * (ds * dt);
+}
+HPT_FN f3 light_Le(const DScene &sc, const hpt_light &l, f3 d) { // Light::Le / InfiniteAreaLight::Le (infinite.cpp:117-122)
+    if (l.kind != HPT_LIGHT_INFINITE) return S(0.f);
+    f3 wh = normalize(xf_vec(l.l2w_inv, d));
+    float s = spherical_phi(wh) * HPT_INV_TWOPI;
+    float t = spherical_theta(wh) * HPT_INV_PI;
+    return env_lookup(sc, l, s, t);
+}
+HPT_FN f3 all_lights_Le(const DScene &sc, f3 d) {
+    f3 L = S(0.f);
+    for (int i = 0; i < sc.n_lights; ++i) L = L + light_Le(sc, sc.lights[i], d);
+    return L;
+}
+HPT_FN float dist1d_sample(const float *func, const float *cdf, float funcInt, int count, float u, float *pdf, int *off) {
+    int lo = 0, hi = count + 1; // std::upper_bound(cdf, cdf+count+1, u) (montecarlo.h:82)
+    while (lo < hi) { int mid = (lo + hi) / 2; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
+    int offset = lo - 1; if (offset < 0) offset = 0;
+    if (off) *off = offset;
+    float du = (u - cdf[offset]) / (cdf[offset + 1] - cdf[offset]);
+    if (pdf) *pdf = func[offset] / funcInt;
+    return (offset + du) / count;
+}
+// Sphere::Sample(p,..) (sphere.cpp:236-261), Disk::Sample (disk.cpp:147-156)
+HPT_FN f3 quadric_sample(const hpt_quadric &q, f3 p, float u1, float u2, f3 *ns) {
+    if (q.kind == HPT_QUADRIC_DISK) {
+        f3 pd; concentric_sample_disk(u1, u2, &pd.x, &pd.y);
+        pd.x *= q.radius; pd.y *= q.radius; pd.z = q.height;
+        *ns = normalize(xf_normal(q.o2w_inv, mk3(0, 0, 1)));
+        if (q.reverse_orientation) *ns = *ns * -1.f;
+        return xf_point(q.o2w, pd);
+    }
+    f3 Pcenter = xf_point(q.o2w, mk3(0, 0, 0));
+    f3 wc = normalize(Pcenter - p);
+    f3 wcX, wcY; coordinate_system(wc, &wcX, &wcY);
+    if (dist2(p, Pcenter) - q.radius * q.radius < 1e-4f) { // inside: Sphere::Sample(u1,u2) + UniformSampleSphere
+        float z = 1.f - 2.f * u1;
+        float r = sqrtf(maxf(0.f, 1.f - z * z));
+        float phi = 2.f * HPT_PI * u2;
+        f3 ps = mk3(r * cosf(phi), r * sinf(phi), z) * q.radius;
+        *ns = normalize(xf_normal(q.o2w_inv, ps));
+        if (q.reverse_orientation) *ns = *ns * -1.f;
+        return xf_point(q.o2w, ps);
+    }
+    float sinThetaMax2 = q.radius * q.radius / dist2(p, Pcenter);
+    float cosThetaMax = sqrtf(maxf(0.f, 1.f - sinThetaMax2));
+    float costheta = (1.f - u1) * cosThetaMax + u1 * 1.f; // UniformSampleCone (montecarlo.cpp:413-420)
+    float sintheta = sqrtf(1.f - costheta * costheta);
+    float phi = u2 * 2.f * HPT_PI;
+    f3 dir = (wcX * (cosf(phi) * sintheta) + wcY * (sinf(phi) * sintheta)) + wc * costheta;
+    Ray r; r.o = p; r.d = dir; r.mint = 1e-3f; r.maxt = HPT_INF;
+    float thit;
+    if (!quadric_intersect(q, r, &thit, nullptr)) thit = dot(Pcenter - p, normalize(r.d));
+    f3 ps = ray_at(r, thit);
+    *ns = normalize(ps - Pcenter);
+    if (q.reverse_orientation) *ns = *ns * -1.f;
+    return ps;
+}
+HPT_FN float quadric_pdf(const hpt_quadric &q, f3 p, f3 wi) { // Sphere::Pdf (sphere.cpp:264-274), Shape::Pdf (shape.cpp:86-99)
+    if (q.kind == HPT_QUADRIC_SPHERE) {
+        f3 Pcenter = xf_point(q.o2w, mk3(0, 0, 0));
+        if (!(dist2(p, Pcenter) - q.radius * q.radius < 1e-4f)) {
+            float sinThetaMax2 = q.radius * q.radius / dist2(p, Pcenter);
+            float cosThetaMax = sqrtf(maxf(0.f, 1.f - sinThetaMax2));
+            return 1.f / (2.f * HPT_PI * (1.f - cosThetaMax));
+        }
+    }
+    Ray ray; ray.o = p; ray.d = wi; ray.mint = 1e-3f; ray.maxt = HPT_INF;
+    float thit; DGeom dgl;
+    if (!quadric_intersect(q, ray, &thit, &dgl)) return 0.f;
+    float pdf = dist2(p, ray_at(ray, thit)) / (absdot(dgl.nn, -wi) * quadric_area(q));
+    if (pdf == HPT_INF || pdf == -HPT_INF) pdf = 0.f;
+    return pdf;
+}
+HPT_FN float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
+    if (l.kind == HPT_LIGHT_DIFFUSE_AREA) { // ShapeSet::Pdf (core/light.cpp:157-162), one shape
+        float pdf = 0.f;
+        pdf += l.area * quadric_pdf(sc.quadrics[l.quadric], p, wi);
+        float sumArea = 0.f; sumArea += l.area;
+        return pdf / sumArea;
+    }
+    if (l.kind == HPT_LIGHT_INFINITE) { // infinite.cpp:224-234 + Distribution2D::Pdf (montecarlo.h:153-161)
+        f3 w = xf_vec(l.l2w_inv, wi);
+        float theta = spherical_theta(w), phi = spherical_phi(w);
+        float sintheta = sinf(theta);
+        if (sintheta == 0.f) return 0.f;
+        float u = phi * HPT_INV_TWOPI, v = theta * HPT_INV_PI;
+        int iu = (int)(u * l.env_w); if (iu < 0) iu = 0; if (iu > l.env_w - 1) iu = l.env_w - 1;
+        int iv = (int)(v * l.env_h); if (iv < 0) iv = 0; if (iv > l.env_h - 1) iv = l.env_h - 1;
+        const float *cf = sc.fpool + l.cond_func_off, *ci = sc.fpool + l.cond_int_off, *mf = sc.fpool + l.marg_func_off;
+        float dp;
+        if (ci[iv] * l.marg_int == 0.f) dp = 0.f;
+        else dp = (cf[(int64_t)iv * l.env_w + iu] * mf[iv]) / (ci[iv] * l.marg_int);
+        return dp / (2.f * HPT_PI * HPT_PI * sintheta);
+    }
+    return 0.f;
+}
+// Light::Sample_L(p, pEpsilon, ls, ...) : point.cpp:50-57, diffuse.cpp:69-81, infinite.cpp:195-221.
+// Outputs wi, pdf and the shadow ray of the VisibilityTester (core/light.h:87-96).
+HPT_FN f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow) {
+    if (l.kind == HPT_LIGHT_POINT) {
+        f3 lp = mk3(l.pos[0], l.pos[1], l.pos[2]);
+        *wi = normalize(lp - p);
+        *pdf = 1.f;
+        float d = len(p - lp);
+        shadow->o = p; shadow->d = vdiv(lp - p, d); shadow->mint = pEps; shadow->maxt = d * (1.f - 0.f);
+        return sdivf(mk3(l.intensity[0], l.intensity[1], l.intensity[2]), dist2(lp, p));
+    }
+    if (l.kind == HPT_LIGHT_DIFFUSE_AREA) {
+        const hpt_quadric &q = sc.quadrics[l.quadric];
+        f3 ns; f3 ps = quadric_sample(q, p, u0, u1, &ns);
+        *wi = normalize(ps - p);
+        *pdf = light_pdf(sc, l, p, *wi);
+        float d = len(p - ps);
+        shadow->o = p; shadow->d = vdiv(ps - p, d); shadow->mint = pEps; shadow->maxt = d * (1.f - 1e-3f);
+        return area_L(l, ns, -*wi);
+    }
+    const float *cf = sc.fpool + l.cond_func_off, *cc = sc.fpool + l.cond_cdf_off, *ci = sc.fpool + l.cond_int_off;
+    const float *mf = sc.fpool + l.marg_func_off, *mc = sc.fpool + l.marg_cdf_off;
+    float uv[2], pdfs[2]; int v;
+    uv[1] = dist1d_sample(mf, mc, l.marg_int, l.env_h, u1, &pdfs[1], &v);
+    uv[0] = dist1d_sample(cf + (int64_t)v * l.env_w, cc + (int64_t)v * (l.env_w + 1), ci[v], l.env_w, u0, &pdfs[0], nullptr);
+    float mapPdf = pdfs[0] * pdfs[1];
+    if (mapPdf == 0.f) { *pdf = 0.f; *wi = mk3(0, 0, 1); return S(0.f); }
+    float theta = uv[1] * HPT_PI, phi = uv[0] * 2.f * HPT_PI;
+    float costheta = cosf(theta), sintheta = sinf(theta);
+    float sinphi = sinf(phi), cosphi = cosf(phi);
+    *wi = xf_vec(l.l2w, mk3(sintheta * cosphi, sintheta * sinphi, costheta));
+    *pdf = mapPdf / (2.f * HPT_PI * HPT_PI * sintheta);
+    if (sintheta == 0.f) *pdf = 0.f;
+    shadow->o = p; shadow->d = *wi; shadow->mint = pEps; shadow->maxt = HPT_INF;
+    return env_lookup(sc, l, uv[0], uv[1]);
+}
+HPT_FN float power_heuristic(int nf, float fPdf, int ng, float gPdf) { // montecarlo.h:266-269
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+// ---- camera (cameras/perspective.cpp:81-138) --------------------------------------------------------
+HPT_FN void camera_ray(const hpt_camera &cam, float imageX, float imageY, float lensU, float lensV, Ray *ray) {
+    f3 Pcamera = xf_point(cam.raster_to_camera, mk3(imageX, imageY, 0));
+    f3 dir = normalize(Pcamera);
+    ray->o = mk3(0, 0, 0); ray->d = dir; ray->mint = 0.f; ray->maxt = HPT_INF;
+    if (cam.lens_radius > 0.f) {
+        float lu, lv;
+        concentric_sample_disk(lensU, lensV, &lu, &lv);
+        lu *= cam.lens_radius; lv *= cam.lens_radius;
+        float ft = cam.focal_distance / ray->d.z;
+        f3 Pfocus = ray_at(*ray, ft);
+        ray->o = mk3(lu, lv, 0.f);
+        ray->d = normalize(Pfocus - ray->o);
+    }
+    ray->o = xf_point(cam.camera_to_world, ray->o);
+    ray->d = xf_vec(cam.camera_to_world, ray->d);
+}
+
+} // namespace hpt
+#endif

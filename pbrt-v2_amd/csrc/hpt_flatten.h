@@ -1,0 +1,25 @@
+// hpt_flatten.h — host-side preparation of the device scene: world-space triangle soup -> BVH2
+// (hpt_bvh.cpp) -> 64-byte nodes + 48-byte leaf-ordered triangle records + per-mesh records.
+// Used by hpt_api.hip (which uploads the result to HBM) and by the test-only host emulation.
+#ifndef HPT_FLATTEN_H
+#define HPT_FLATTEN_H
+#include <vector>
+#include "hpt_bvh.h"
+#include "hpt_device.h"
+
+namespace hpt {
+
+struct FlatScene {
+    std::vector<BvhNode64> nodes;
+    std::vector<float> tri_rec;   // 12 floats per triangle, BVH leaf order
+    std::vector<DMesh> meshes;
+    int64_t n_tris = 0;
+    int max_depth = 0;
+    double build_ms = 0.0;
+};
+
+// returns HPT_OK or a negative error code (hpt_last_error() set)
+int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out);
+
+} // namespace hpt
+#endif

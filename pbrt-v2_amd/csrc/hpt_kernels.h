@@ -1,0 +1,28 @@
+// hpt_kernels.h — launcher interface between the C ABI (hpt_api.hip) and the kernels.
+#ifndef HPT_KERNELS_H
+#define HPT_KERNELS_H
+#include <hip/hip_runtime.h>
+#include "hpt_path.h"
+
+#define HPT_BLOCK 256        /* threads per workgroup = 4 wave64 */
+#define HPT_STACK_DEPTH 32   /* LDS traversal stack entries per lane (32 KiB per workgroup) */
+
+namespace hpt {
+
+struct PathKernelArgs {
+    DScene sc;
+    RenderParams rp;
+    float *film;                    // x_count*y_count*4, zeroed before the launch
+    unsigned long long *next_item;  // global work counter, zeroed before the launch
+    WorkCounters *counters;         // only written by the COUNT instantiation
+};
+
+int path_kernel_occupancy(int *blocks_per_cu, int *vgprs);
+hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream);
+hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
+                            int32_t *out_prim, hipStream_t s);
+hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s);
+hipError_t launch_sampler(const RenderParams &rp, int x, int y, float *out, hipStream_t s);
+
+} // namespace hpt
+#endif

@@ -1,0 +1,169 @@
+// hpt_kernels.hip — gfx950 kernels of the path-tracing hot path and their launchers.
+//
+// hpt_path_kernel: ONE persistent-threads launch renders the whole frame.  Grid = (CUs x resident
+// blocks per CU) workgroups of 256 threads = 4 wave64; every wave loops
+//     refill idle lanes (one device-scope atomicAdd per wave, ballot + popcount prefix) ->
+//     one BVH traversal phase for whatever ray each lane has pending (closest- or any-hit) ->
+//     per-lane state machine step (hpt_path.h)
+// until the global work counter is exhausted and all 64 lanes are idle.  Lanes whose path ended
+// are refilled immediately ("path regeneration"), which is this design's form of wavefront
+// compaction: instead of squeezing live rays together between bounces, dead lanes are repopulated
+// in place, so the traversal loop always runs with a full exec mask.
+// Traversal stacks live in LDS, laid out stack[entry][thread] so that the 64 lanes of a wave
+// address 64 consecutive banks (conflict-free ds_read/ds_write_b32).
+// No MFMA anywhere: the workload is divergent pointer chasing, not a contraction.
+#include <hip/hip_runtime.h>
+
+#include "hpt_kernels.h"
+#include "hpt_path.h"
+
+namespace hpt {
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// One atomicAdd per wave hands out consecutive work items to the lanes that need one.
+__device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool need) {
+    unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return -1;
+    int n = __popcll(mask);
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)n);
+    unsigned lo = __shfl((unsigned)(base & 0xffffffffull), leader);
+    unsigned hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    int rank = __popcll(mask & ((1ull << lane_id()) - 1ull));
+    return need ? (int64_t)(base + (unsigned long long)rank) : -1;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(HPT_BLOCK) void hpt_path_kernel(const PathKernelArgs a) {
+    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    int32_t *stack = lds_stack + threadIdx.x;
+    const DScene &sc = a.sc;
+    const RenderParams &rp = a.rp;
+    Lane<LdHashSrc> lane;
+    lane.init();
+    bool exhausted = false;
+    WorkCounters wc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0};
+    for (;;) {
+        // ---- refill: idle lanes pull the next pixel --------------------------------------------
+        for (;;) {
+            bool need = (lane.stage == ST_IDLE) && !exhausted;
+            if (__ballot(need) == 0ull) break;
+            int64_t item = wave_fetch(a.next_item, need);
+            if (need) {
+                if (item >= rp.n_items) exhausted = true;
+                else {
+                    int x, y;
+                    if (item_to_pixel(rp, item, &x, &y)) lane.begin_pixel(rp, x, y);
+                }
+            }
+        }
+        bool active = lane.stage != ST_IDLE;
+        if (__ballot(active) == 0ull) break;
+        // ---- one traversal phase: each lane traces its pending ray --------------------------------
+        Hit hit;
+        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f;
+        if (active) {
+            bool anyhit = lane.stage == ST_SHADOW;
+            if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+            traverse<COUNT>(sc, lane.ray, anyhit, &hit, stack, HPT_BLOCK, &tc);
+        }
+        // ---- state machine step ----------------------------------------------------------------------
+        if (active) lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr);
+    }
+    if (COUNT) {
+        wc.nodes = tc.nodes; wc.tris = tc.tris;
+        atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
+        atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
+        atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
+        atomicAdd((unsigned long long *)&a.counters->nodes, (unsigned long long)wc.nodes);
+        atomicAdd((unsigned long long *)&a.counters->tris, (unsigned long long)wc.tris);
+        atomicAdd((unsigned long long *)&a.counters->bad, (unsigned long long)wc.bad);
+    }
+}
+
+// ---- function-level parity kernels (same device functions, array in / array out) --------------------
+__global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene sc, const float *rays, int64_t n, int anyhit,
+                                                                  float *out_hit, int32_t *out_prim) {
+    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    int64_t i = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 8 * i;
+    Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
+    Hit hit; TravCounters tc = {0, 0};
+    bool h = traverse<false>(sc, ray, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
+    float *o = out_hit + 4 * i;
+    if (anyhit) { out_prim[i] = h ? 0 : -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    if (!h) { out_prim[i] = -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[1] = 0.f; o[2] = 0.f; o[3] = 5e-4f * hit.t; return; }
+    const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+    int mesh = as_int(tp[0].w), tri = as_int(tp[1].w);
+    out_prim[i] = sc.meshes[mesh].prim_base + tri;
+    o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
+}
+
+__global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, int64_t n, float *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *q = in + 16 * i; float *o = out + 12 * i;
+    f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
+    f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
+    Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
+    bsdf_add_material(&b, &sc.materials[material]);
+    f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC);
+    float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
+    f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
+    f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+    o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
+}
+
+__global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.spp) return;
+    LdHashSrc s; s.begin_pixel(rp, x, y); s.begin_sample((uint32_t)i);
+    float *o = out + 35 * i;
+    float a, b;
+    s.image(&a, &b); o[0] = x + a; o[1] = y + b;
+    s.lens(&a, &b); o[2] = a; o[3] = b;
+    { float t = s.h.time01(); o[4] = (1.f - t) * 0.f + t * 1.f; }
+    for (int j = 0; j < 12; ++j) o[5 + j] = s.one(j);
+    for (int j = 0; j < 9; ++j) { s.two(j, &a, &b); o[17 + 2 * j] = a; o[18 + 2 * j] = b; }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------
+int path_kernel_occupancy(int *blocks_per_cu, int *vgprs) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false>, HPT_BLOCK, 0);
+    if (e != hipSuccess) return -1;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)hpt_path_kernel<false>) == hipSuccess) *vgprs = fa.numRegs; else *vgprs = 0;
+    *blocks_per_cu = nb;
+    return 0;
+}
+
+hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL(hpt_path_kernel<true>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL(hpt_path_kernel<false>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {
+    int grid = (int)((n + HPT_BLOCK - 1) / HPT_BLOCK);
+    if (grid > 0) hipLaunchKernelGGL(hpt_intersect_kernel, dim3(grid), dim3(HPT_BLOCK), 0, s, sc, rays, n, anyhit, out_hit, out_prim);
+    return hipGetLastError();
+}
+hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s) {
+    int grid = (int)((n + 63) / 64);
+    if (grid > 0) hipLaunchKernelGGL(hpt_bsdf_kernel, dim3(grid), dim3(64), 0, s, sc, material, in, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_sampler(const RenderParams &rp, int x, int y, float *out, hipStream_t s) {
+    int grid = (rp.spp + 63) / 64;
+    hipLaunchKernelGGL(hpt_sampler_kernel, dim3(grid), dim3(64), 0, s, rp, x, y, out);
+    return hipGetLastError();
+}
+
+} // namespace hpt

@@ -1,0 +1,292 @@
+// hpt_path.h — per-lane path state machine of the persistent-threads wavefront kernel.
+//
+// What it replaces in the reference (one lane == one SamplerRendererTask "thread of control"):
+//   SamplerRendererTask::Run sample loop     renderers/samplerrenderer.cpp:155-259
+//   SamplerRenderer::Li                      renderers/samplerrenderer.cpp:320-342
+//   PathIntegrator::Li                       integrators/path.cpp:52-123
+//   UniformSampleOneLight / EstimateDirect   core/integrator.cpp:82-174
+//   ImageFilm::AddSample (box filter)        film/image.cpp:77-137
+//
+// Control-flow redesign for wave64: every path vertex needs up to three rays — the shadow ray
+// (any-hit), the MIS BSDF-sampled ray (closest-hit) and the continuation ray (closest-hit).  The
+// recursive reference interleaves shading and tracing; here ALL shading of a vertex (BSDF build,
+// light sampling, both BSDF samplings, Russian roulette) happens in one block right after the
+// closest hit, leaving only small "pending ray" records in registers.  The wave then runs ONE
+// traversal loop per iteration in which each lane traces whichever ray it has pending, so the
+// traversal — the part bound by memory latency — always runs with every lane populated.
+// Random-number consumption order is kept identical to the reference (it matters for the
+// MT_REPLAY parity mode): light number, LightSample(3), BSDFSample(3), path BSDFSample(3), RR.
+#ifndef HPT_PATH_H
+#define HPT_PATH_H
+#include "hpt_device.h"
+
+namespace hpt {
+
+enum { ST_IDLE = 0, ST_EXTEND = 1, ST_SHADOW = 2, ST_MIS = 3 };
+
+struct RenderParams {
+    hpt_camera cam;
+    int32_t xres, yres, x_start, x_count, y_start, y_count;
+    int32_t spp, maxdepth;
+    uint32_t seed;
+    int32_t shard_rank, shard_count;
+    int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
+    int64_t n_items;           // work items of this shard (pixels incl. padding)
+};
+
+struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
+
+// ---- film -------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+HPT_FN void film_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+#else
+HPT_FN void film_atomic_add(float *p, float v) { *p += v; }
+#endif
+
+// Work item -> pixel.  Items enumerate this shard's 32x32 super-tiles (round-robin over shards),
+// inside a super-tile 8x8 micro-tiles, inside a micro-tile row-major pixels: 64 consecutive items
+// = one 8x8 pixel block, so the 64 lanes of a wave start on coherent camera rays.
+HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py) {
+    int64_t k = item >> 10;
+    int r = (int)(item & 1023);
+    int64_t st = k * rp.shard_count + rp.shard_rank;
+    if (st >= (int64_t)rp.n_stx * rp.n_sty) return false;
+    int micro = r >> 6, p = r & 63;
+    int x = (int)(st % rp.n_stx) * 32 + (micro & 3) * 8 + (p & 7);
+    int y = (int)(st / rp.n_stx) * 32 + (micro >> 2) * 8 + (p >> 3);
+    if (x >= rp.x_count || y >= rp.y_count) return false;
+    *px = rp.x_start + x; *py = rp.y_start + y;
+    return true;
+}
+
+// ---- lane -----------------------------------------------------------------------------------------
+// Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
+template <class Smp> struct Lane {
+    int stage;
+    // pixel / sample bookkeeping
+    int px, py;
+    uint32_t si;
+    Smp smp;
+    float fX, fY, fZ, fW;   // film accumulators of the lane's own pixel
+    float imgx, imgy;       // CameraSample::imageX/Y of the current sample
+    // path state (PathIntegrator::Li locals)
+    f3 L, beta;
+    int bounce;
+    bool specular;
+    Ray ray;                // the ray to trace in the next traversal phase
+    // pending work of the current vertex
+    f3 p; float eps;        // bsdf->dgShading.p, isect.rayEpsilon
+    f3 Ld;                  // EstimateDirect accumulator
+    f3 LdA;                 // light-sampling term, added if the shadow ray is unoccluded
+    bool has_mis, has_next, spec_next;
+    f3 wi_mis, f_mis; float a_mis, w_mis, pdf_mis; int light_mis;
+    f3 wi_next, beta_next;
+
+    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; fX = fY = fZ = fW = 0.f; }
+
+    // samplerrenderer.cpp:185-206 for one camera sample
+    HPT_MFN void begin_sample(const RenderParams &rp) {
+        smp.begin_sample(si);
+        float a, b;
+        smp.image(&a, &b);
+        imgx = px + a; imgy = py + b;       // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
+        float lu = 0.f, lv = 0.f;
+        if (rp.cam.lens_radius > 0.f) smp.lens(&lu, &lv);
+        camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
+        L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
+        stage = ST_EXTEND;
+    }
+    HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
+        px = x; py = y; si = 0; fX = fY = fZ = fW = 0.f;
+        smp.begin_pixel(rp, x, y);
+        begin_sample(rp);
+    }
+
+    // ImageFilm::AddSample with the box filter (film/image.cpp:77-137) + the radiance sanity
+    // checks of samplerrenderer.cpp:214-228; then advance to the next sample / flush the pixel.
+    HPT_MFN void finish_path(const RenderParams &rp, float *film, WorkCounters *wc) {
+        f3 Ls = L;
+        bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
+        if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
+        if (bad) { Ls = S(0.f); if (wc) wc->bad++; }
+        float dimageX = imgx - 0.5f, dimageY = imgy - 0.5f;
+        int x0 = (int)ceilf(dimageX - 0.5f), x1 = (int)floorf(dimageX + 0.5f);
+        int y0 = (int)ceilf(dimageY - 0.5f), y1 = (int)floorf(dimageY + 0.5f);
+        if (x0 < rp.x_start) x0 = rp.x_start;
+        if (x1 > rp.x_start + rp.x_count - 1) x1 = rp.x_start + rp.x_count - 1;
+        if (y0 < rp.y_start) y0 = rp.y_start;
+        if (y1 > rp.y_start + rp.y_count - 1) y1 = rp.y_start + rp.y_count - 1;
+        float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
+        float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
+        float Z = 0.019334f * Ls.x + 0.119193f * Ls.y + 0.950227f * Ls.z;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                if (x == px && y == py) { fX += X; fY += Y; fZ += Z; fW += 1.f; }
+                else { // a sample on an exact pixel boundary also lands in the neighbour (image.cpp:82-89)
+                    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+                    film_atomic_add(f + 0, X); film_atomic_add(f + 1, Y); film_atomic_add(f + 2, Z); film_atomic_add(f + 3, 1.f);
+                }
+            }
+        if (wc) wc->samples++;
+        ++si;
+        if (si < (uint32_t)rp.spp) { begin_sample(rp); return; }
+        float *f = film + 4 * ((int64_t)(py - rp.y_start) * rp.x_count + (px - rp.x_start));
+        film_atomic_add(f + 0, fX); film_atomic_add(f + 1, fY); film_atomic_add(f + 2, fZ); film_atomic_add(f + 3, fW);
+        stage = ST_IDLE;
+        smp.end_pixel(rp);
+    }
+
+    HPT_MFN void after_mis(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
+        if (sc.n_lights > 0) L = L + smul(beta, Ld * (float)sc.n_lights);  // integrator.cpp:110, path.cpp:71-80
+        if (has_next) {
+            beta = beta_next; specular = spec_next;
+            ray.o = p; ray.d = wi_next; ray.mint = eps; ray.maxt = HPT_INF; // RayDifferential(p, wi, ray, eps) path.cpp:100
+            ++bounce;
+            stage = ST_EXTEND;
+        } else finish_path(rp, film, wc);
+    }
+    HPT_MFN void after_shadow(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
+        if (has_mis) {
+            ray.o = p; ray.d = wi_mis; ray.mint = eps; ray.maxt = HPT_INF; // integrator.cpp:160
+            stage = ST_MIS;
+        } else after_mis(sc, rp, film, wc);
+    }
+
+    // Called with the result of the traversal phase for this lane's pending ray.
+    HPT_MFN void on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc) {
+        if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
+            if (hit.prim < 0) Ld = Ld + LdA;
+            after_shadow(sc, rp, film, wc);
+            return;
+        }
+        if (stage == ST_MIS) {               // integrator.cpp:157-171
+            f3 Li = S(0.f);
+            if (hit.prim >= 0) {
+                if (hit.prim >= sc.n_tris) {
+                    const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+                    if (q.arealight == light_mis) {
+                        DGeom dg; float t;
+                        quadric_intersect(q, ray, &t, &dg);
+                        Li = area_L(sc.lights[light_mis], dg.nn, -wi_mis); // Intersection::Le
+                    }
+                }
+            } else Li = light_Le(sc, sc.lights[light_mis], ray.d);
+            if (!sblack(Li)) Ld = Ld + sdivf((smul(f_mis, Li) * a_mis) * w_mis, pdf_mis);
+            after_mis(sc, rp, film, wc);
+            return;
+        }
+        // ---- ST_EXTEND: closest-hit result of a camera or continuation ray -------------------------
+        if (hit.prim < 0) {
+            if (bounce == 0) L = all_lights_Le(sc, ray.d);                 // samplerrenderer.cpp:335-338
+            else if (specular)                                             // path.cpp:114-116
+                for (int i = 0; i < sc.n_lights; ++i) L = L + smul(beta, light_Le(sc, sc.lights[i], ray.d));
+            finish_path(rp, film, wc);
+            return;
+        }
+        Bsdf bsdf; DGeom dg; int arealight;
+        shade_geometry(sc, ray, hit, &bsdf, &dg, &eps, &arealight);
+        f3 wo = -ray.d;
+        if (bounce == 0 || specular)                                        // path.cpp:63-64
+            if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
+        p = dg.p;
+        f3 n = bsdf.nn;
+        Ld = S(0.f); LdA = S(0.f);
+        bool has_shadow = false;
+        has_mis = false;
+        Ray shadow; shadow.o = p; shadow.d = n; shadow.mint = 0.f; shadow.maxt = 0.f;
+        const bool useArrays = bounce < 3;                                  // SAMPLE_DEPTH (path.h:55)
+        if (sc.n_lights > 0) {                                              // UniformSampleOneLight
+            float ln, ls0, ls1, ls2, bs0, bs1, bs2;
+            if (useArrays) {
+                ln = smp.one(4 * bounce + 1);
+                smp.two(3 * bounce, &ls0, &ls1); ls2 = smp.one(4 * bounce);
+                smp.two(3 * bounce + 1, &bs0, &bs1); bs2 = smp.one(4 * bounce + 2);
+            } else {
+                ln = smp.draw();
+                ls0 = smp.draw(); ls1 = smp.draw(); ls2 = smp.draw();
+                bs0 = smp.draw(); bs1 = smp.draw(); bs2 = smp.draw();
+            }
+            (void)ls2;
+            int lightNum = (int)floorf(ln * sc.n_lights);
+            if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
+            const hpt_light &light = sc.lights[lightNum];
+            const bool isDelta = light.kind == HPT_LIGHT_POINT;
+            // EstimateDirect, light-sampling half (integrator.cpp:123-142)
+            f3 wi; float lightPdf, bsdfPdf;
+            f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow);
+            if (lightPdf > 0.f && !sblack(Li)) {
+                f3 f = bsdf_f(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC);
+                if (!sblack(f)) {
+                    has_shadow = true;
+                    if (isDelta) LdA = smul(f, Li) * (absdot(wi, n) / lightPdf);
+                    else {
+                        bsdfPdf = bsdf_pdf(bsdf, wo, wi, BSDF_ALL_NOSPEC);
+                        float weight = power_heuristic(1, lightPdf, 1, bsdfPdf);
+                        LdA = smul(f, Li) * (absdot(wi, n) * weight / lightPdf);
+                    }
+                }
+            }
+            // BSDF-sampling half (integrator.cpp:145-172)
+            if (!isDelta) {
+                int sampledType;
+                f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType);
+                if (!sblack(f) && bsdfPdf > 0.f) {
+                    float weight = 1.f;
+                    bool ok = true;
+                    if (!(sampledType & BSDF_SPECULAR)) {
+                        lightPdf = light_pdf(sc, light, p, wi);
+                        if (lightPdf == 0.f) ok = false;
+                        else weight = power_heuristic(1, bsdfPdf, 1, lightPdf);
+                    }
+                    if (ok) {
+                        has_mis = true; light_mis = lightNum;
+                        wi_mis = wi; f_mis = f; a_mis = absdot(wi, n); w_mis = weight; pdf_mis = bsdfPdf;
+                    }
+                }
+            }
+        }
+        // continuation (path.cpp:83-110)
+        {
+            float ps0, ps1, ps2;
+            if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
+            else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
+            f3 wi; float pdf; int flags;
+            f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags);
+            has_next = !(sblack(f) || pdf == 0.f);
+            if (has_next) {
+                spec_next = (flags & BSDF_SPECULAR) != 0;
+                beta_next = smul(beta, sdivf(f * absdot(wi, n), pdf));
+                wi_next = wi;
+                if (bounce > 3) {
+                    float continueProbability = minf(.5f, sy(beta_next));
+                    if (smp.draw() > continueProbability) has_next = false;
+                    else beta_next = sdivf(beta_next, continueProbability);
+                }
+                if (bounce == rp.maxdepth) has_next = false;
+            }
+        }
+        if (has_shadow) { ray = shadow; stage = ST_SHADOW; }
+        else after_shadow(sc, rp, film, wc);
+    }
+};
+
+// ---- production sampler adaptor ---------------------------------------------------------------------
+struct LdHashSrc {
+    LdHash h;
+    uint32_t seed_, dkey, dcount;
+    HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
+        uint32_t pixelIndex = (uint32_t)y * (uint32_t)rp.xres + (uint32_t)x;
+        h.pk = pixel_key(pixelIndex, rp.seed);
+        h.w = (uint32_t)rp.spp - 1u;
+    }
+    HPT_MFN void begin_sample(uint32_t i) { h.i = i; dkey = h.draw_key(); dcount = 0; }
+    HPT_MFN void end_pixel(const RenderParams &) {}
+    HPT_MFN float one(int j) const { return h.one(j); }
+    HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
+    HPT_MFN void image(float *a, float *b) const { h.image(a, b); }
+    HPT_MFN void lens(float *a, float *b) const { h.lens(a, b); }
+    HPT_MFN float draw() { return h.draw(dkey, dcount++); }
+};
+
+} // namespace hpt
+#endif

@@ -1,0 +1,141 @@
+"""ctypes binding of libhpt.so — the C ABI of include/hpt.h.
+
+This is the Python face of the same boundary host/hip_renderer.cpp (the pbrt Renderer plugin)
+calls from C++: scene upload, render, parity hooks.  It fails loudly when the library or a HIP
+device is missing — there is no CPU fallback anywhere in the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhpt.so")
+_lib = None
+
+EXPORTS = [
+    "hpt_device_count", "hpt_last_error", "hpt_scene_create", "hpt_scene_destroy",
+    "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_blob_save", "hpt_blob_load",
+    "hpt_blob_scene", "hpt_blob_camera", "hpt_blob_render", "hpt_blob_free",
+    "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
+]
+
+
+class HptError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libhpt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _PKG, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _PKG, "libhpt.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HptError(f"{LIB_PATH} is missing: run `make -C pbrt-v2_amd` (or __graft_entry__.build()); "
+                           "the HIP library is the only implementation of the hot path")
+        L = C.CDLL(LIB_PATH)
+        L.hpt_last_error.restype = C.c_char_p
+        L.hpt_scene_create.restype = C.c_void_p
+        L.hpt_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
+        L.hpt_scene_destroy.argtypes = [C.c_void_p]
+        L.hpt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(abi.SceneInfo)]
+        L.hpt_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc),
+                                 C.c_void_p, C.POINTER(abi.Stats)]
+        L.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc),
+                                        C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.hpt_test_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
+        L.hpt_blob_save.argtypes = [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera),
+                                    C.POINTER(abi.RenderDesc)]
+        L.hpt_abi_sizes.argtypes = [C.c_void_p]
+        sizes = (C.c_int32 * 8)()
+        L.hpt_abi_sizes(sizes)
+        if list(sizes) != abi.ABI_SIZES:
+            raise HptError(f"ABI drift: libhpt.so struct sizes {list(sizes)} != abi.py {abi.ABI_SIZES}")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().hpt_last_error().decode(errors="replace")
+
+
+def device_count():
+    return int(lib().hpt_device_count())
+
+
+def _check(rc):
+    if rc != 0:
+        raise HptError(f"hpt error {rc}: {last_error()}")
+
+
+class DeviceScene:
+    """hpt_scene handle: BVH built, everything resident in the HBM of `device`."""
+
+    def __init__(self, scene, device=0):
+        self.scene = scene
+        d = scene.desc
+        self.h = lib().hpt_scene_create(C.byref(d), device)
+        if not self.h:
+            raise HptError(f"hpt_scene_create failed: {last_error()}")
+
+    def info(self):
+        i = abi.SceneInfo()
+        _check(lib().hpt_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def render(self, cam, rd):
+        """-> (film (H, W, 4) float32 {X,Y,Z,weight}, Stats).  Film copied to host."""
+        film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
+        st = abi.Stats()
+        _check(lib().hpt_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, C.byref(st)))
+        return film, st
+
+    def render_device(self, cam, rd, d_film_ptr, stream=None):
+        """Film stays in HBM at device pointer `d_film_ptr` (e.g. torch tensor .data_ptr())."""
+        st = abi.Stats()
+        _check(lib().hpt_render_device(self.h, C.byref(cam), C.byref(rd), C.c_void_p(d_film_ptr),
+                                       C.c_void_p(stream or 0), C.byref(st)))
+        return st
+
+    def intersect(self, rays, anyhit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros((n, 4), dtype=np.float32)
+        prim = np.zeros(n, dtype=np.int32)
+        _check(lib().hpt_test_intersect(self.h, rays.ctypes.data, n, int(anyhit), hit.ctypes.data,
+                                        prim.ctypes.data))
+        return hit, prim
+
+    def bsdf(self, material, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, 16)
+        out = np.zeros((inp.shape[0], 12), dtype=np.float32)
+        _check(lib().hpt_test_bsdf(self.h, material, inp.ctypes.data, inp.shape[0], out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hpt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sampler(rd, x, y):
+    out = np.zeros((rd.spp, abi.SAMPLE_FLOATS), dtype=np.float32)
+    _check(lib().hpt_test_sampler(C.byref(rd), x, y, out.ctypes.data))
+    return out

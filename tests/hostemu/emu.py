@@ -1,0 +1,76 @@
+"""ctypes binding of tests/hostemu/libhostemu.so (TEST-ONLY CPU emulation of the device code)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+abi = importlib.import_module("pbrt-v2_amd.abi")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+        L = C.CDLL(os.path.join(_HERE, "libhostemu.so"))
+        L.emu_scene_create.restype = C.c_void_p
+        L.emu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
+        L.emu_scene_destroy.argtypes = [C.c_void_p]
+        L.emu_scene_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
+        L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class EmuScene:
+    def __init__(self, scene, max_leaf=4):
+        d = scene.desc
+        self.scene = scene
+        self.h = lib().emu_scene_create(C.byref(d), max_leaf)
+        if not self.h:
+            raise RuntimeError("emu_scene_create failed")
+
+    def info(self):
+        out = np.zeros(3, dtype=np.int64)
+        lib().emu_scene_info(self.h, out.ctypes.data)
+        return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2])}
+
+    def render(self, cam, rd):
+        film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
+        stats = np.zeros(6, dtype=np.uint64)
+        lib().emu_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, stats.ctypes.data)
+        return film, stats
+
+    def intersect(self, rays, anyhit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros((n, 4), dtype=np.float32)
+        prim = np.zeros(n, dtype=np.int32)
+        lib().emu_intersect(self.h, rays.ctypes.data, n, int(anyhit), hit.ctypes.data, prim.ctypes.data)
+        return hit, prim
+
+    def bsdf(self, material, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, 16)
+        out = np.zeros((inp.shape[0], 12), dtype=np.float32)
+        lib().emu_bsdf(self.h, material, inp.ctypes.data, inp.shape[0], out.ctypes.data)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().emu_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def sampler(rd, x, y):
+    out = np.zeros((rd.spp, abi.SAMPLE_FLOATS), dtype=np.float32)
+    lib().emu_sampler(C.byref(rd), x, y, out.ctypes.data)
+    return out

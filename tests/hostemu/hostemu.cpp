@@ -1,0 +1,148 @@
+// hostemu.cpp — TEST-ONLY development harness.  Compiles the device headers of the product
+// (pbrt-v2_amd/csrc/hpt_device.h, hpt_path.h) with plain g++ (HPT_HOST_EMU) and runs the per-lane
+// path state machine one lane at a time on the CPU, over the same flattened scene (BVH2 nodes,
+// 48-byte triangle records) the kernels consume.  Purpose: debug the device logic and check it
+// against the oracle WITHOUT a GPU (the build container has none; GPU minutes are scarce).
+// It is not part of libhpt.so, is never loaded by the product package, and is not a fallback:
+// the C ABI fails with HPT_E_NODEVICE when no HIP device exists.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../pbrt-v2_amd/csrc/hpt_flatten.h"
+#include "../../pbrt-v2_amd/csrc/hpt_path.h"
+
+void hpt_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+
+using namespace hpt;
+
+struct emu_scene {
+    FlatScene fs;
+    std::vector<hpt_quadric> quadrics; std::vector<hpt_material> materials; std::vector<hpt_light> lights;
+    std::vector<float> fpool; std::vector<int32_t> ipool;
+    DScene d;
+};
+
+extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf) {
+    emu_scene *s = new emu_scene();
+    if (flatten_scene(desc, max_leaf, 30, &s->fs) != HPT_OK) { delete s; return nullptr; }
+    s->quadrics.assign(desc->quadrics, desc->quadrics + desc->n_quadrics);
+    s->materials.assign(desc->materials, desc->materials + desc->n_materials);
+    s->lights.assign(desc->lights, desc->lights + desc->n_lights);
+    s->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
+    s->ipool.assign(desc->ipool, desc->ipool + desc->n_i);
+    memset(&s->d, 0, sizeof(s->d));
+    s->d.nodes = (const f4 *)s->fs.nodes.data();
+    s->d.tris = (const f4 *)s->fs.tri_rec.data();
+    s->d.meshes = s->fs.meshes.data();
+    s->d.quadrics = s->quadrics.data(); s->d.materials = s->materials.data(); s->d.lights = s->lights.data();
+    s->d.fpool = s->fpool.data(); s->d.ipool = s->ipool.data();
+    s->d.n_tris = (int32_t)s->fs.n_tris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
+    s->d.n_nodes = (int32_t)s->fs.nodes.size();
+    return s;
+}
+extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
+extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
+    out[0] = s->fs.n_tris; out[1] = (int64_t)s->fs.nodes.size(); out[2] = s->fs.max_depth;
+}
+
+static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
+    rp->cam = *cam;
+    rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
+    rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
+    rp->seed = rd->seed;
+    rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
+    rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
+    rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
+    int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
+    rp->n_items = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
+}
+
+// Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
+extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
+    RenderParams rp; fill_params(cam, rd, &rp);
+    memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
+    WorkCounters total = {0, 0, 0, 0, 0, 0};
+#pragma omp parallel
+    {
+        WorkCounters wc = {0, 0, 0, 0, 0, 0};
+        TravCounters tc = {0, 0};
+        int32_t stack[64];
+        // NOTE: with OpenMP the neighbour-pixel spills race like the device atomics do; the own-pixel
+        // sums are deterministic
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t item = 0; item < rp.n_items; ++item) {
+            int x, y;
+            if (!item_to_pixel(rp, item, &x, &y)) continue;
+            Lane<LdHashSrc> lane; lane.init();
+            lane.begin_pixel(rp, x, y);
+            while (lane.stage != ST_IDLE) {
+                bool anyhit = lane.stage == ST_SHADOW;
+                if (anyhit) wc.shadow++; else wc.closest++;
+                Hit hit;
+                traverse<true>(s->d, lane.ray, anyhit, &hit, stack, 1, &tc);
+                lane.on_hit(s->d, rp, hit, film, &wc);
+            }
+        }
+#pragma omp critical
+        { total.samples += wc.samples; total.closest += wc.closest; total.shadow += wc.shadow; total.nodes += tc.nodes; total.tris += tc.tris; total.bad += wc.bad; }
+    }
+    if (stats) { stats[0] = total.samples; stats[1] = total.closest; stats[2] = total.shadow; stats[3] = total.nodes; stats[4] = total.tris; stats[5] = total.bad; }
+    return 0;
+}
+
+extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim) {
+    const DScene &sc = s->d;
+#pragma omp parallel for
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = rays + 8 * i;
+        Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
+        Hit hit; TravCounters tc = {0, 0}; int32_t stack[64];
+        bool h = traverse<false>(sc, ray, anyhit != 0, &hit, stack, 1, &tc);
+        float *o = out_hit + 4 * i;
+        o[0] = o[1] = o[2] = o[3] = 0.f;
+        if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
+        if (!h) { out_prim[i] = -1; continue; }
+        if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
+        const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+        out_prim[i] = sc.meshes[as_int(tp[0].w)].prim_base + as_int(tp[1].w);
+        o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
+    }
+    return 0;
+}
+
+extern "C" int emu_bsdf(const emu_scene *s, int material, const float *in, int64_t n, float *out) {
+    const DScene &sc = s->d;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *q = in + 16 * i; float *o = out + 12 * i;
+        f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
+        f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
+        Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
+        bsdf_add_material(&b, &sc.materials[material]);
+        f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC);
+        float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
+        f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
+        f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+        o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
+    }
+    return 0;
+}
+
+extern "C" int emu_sampler(const hpt_render_desc *rd, int x, int y, float *out) {
+    hpt_camera cam; memset(&cam, 0, sizeof(cam));
+    RenderParams rp; fill_params(&cam, rd, &rp);
+    for (int i = 0; i < rd->spp; ++i) {
+        LdHashSrc s; s.begin_pixel(rp, x, y); s.begin_sample((uint32_t)i);
+        float *o = out + 35 * i;
+        float a, b;
+        s.image(&a, &b); o[0] = x + a; o[1] = y + b;
+        s.lens(&a, &b); o[2] = a; o[3] = b;
+        { float t = s.h.time01(); o[4] = (1.f - t) * 0.f + t * 1.f; }
+        for (int j = 0; j < 12; ++j) o[5 + j] = s.one(j);
+        for (int j = 0; j < 9; ++j) { s.two(j, &a, &b); o[17 + 2 * j] = a; o[18 + 2 * j] = b; }
+    }
+    return 0;
+}

@@ -1,0 +1,75 @@
+"""The C-ABI library loads, exports every symbol include/hpt.h declares, agrees with the Python
+mirror on struct layouts, round-trips scene blobs, and refuses to compute without a HIP device
+(no CPU fallback).  No compute calls here: runs without a GPU."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.util import ROOT, abi
+
+hpt = importlib.import_module("pbrt-v2_amd.hpt")
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "hpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpt_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = hpt.lib()
+    syms = header_symbols()
+    assert set(hpt.EXPORTS) == set(syms), (sorted(set(syms) ^ set(hpt.EXPORTS)))
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_struct_layouts_match_compiled_library():
+    sizes = (C.c_int32 * 8)()
+    hpt.lib().hpt_abi_sizes(sizes)
+    assert list(sizes) == abi.ABI_SIZES
+
+
+def test_blob_roundtrip_between_c_and_python(cases, tmp_path):
+    s = cases["env"]
+    p = str(tmp_path / "x.hpts")
+    d = s.desc
+    rc = hpt.lib().hpt_blob_save(p.encode(), C.byref(d), C.byref(s.camera), C.byref(s.render))
+    assert rc == 0, hpt.last_error()
+    t = abi.Scene.load(p)
+    assert np.array_equal(t.fpool, s.fpool) and np.array_equal(t.ipool, s.ipool)
+    assert bytes(t.camera) == bytes(s.camera) and bytes(t.render) == bytes(s.render)
+    assert bytes(t.meshes) == bytes(s.meshes) and bytes(t.lights) == bytes(s.lights)
+    p2 = str(tmp_path / "y.hpts.gz")
+    t.save(p2)
+    u = abi.Scene.load(p2)
+    assert np.array_equal(u.fpool, s.fpool) and bytes(u.materials) == bytes(s.materials)
+
+
+def test_invalid_descriptors_are_rejected(cases, tmp_path):
+    s = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "env_soup.hpts.gz"))
+    s.meshes[0].material = 99
+    d = s.desc
+    rc = hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), C.byref(s.camera), C.byref(s.render))
+    assert rc == -2 and "mesh 0" in hpt.last_error()
+    s = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "env_soup.hpts.gz"))
+    s.ipool[5] = 10 ** 6
+    d = s.desc
+    assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -2
+    s = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "env_soup.hpts.gz"))
+    s.materials[0].kind = 77
+    d = s.desc
+    assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -3
+
+
+def test_no_cpu_fallback_without_device(cases):
+    if hpt.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(hpt.HptError, match="no HIP device"):
+        hpt.DeviceScene(cases["env"])
+    with pytest.raises(hpt.HptError):
+        hpt.sampler(cases["env"].render, 0, 0)

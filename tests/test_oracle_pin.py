@@ -1,0 +1,59 @@
+"""The oracle is pinned against the REAL reference: oracle MT_REPLAY renders must equal the images
+oracle/_ref/pbrt (pbrt-v2 built from /root/reference/src) produced for the same scene files,
+stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical."""
+import numpy as np
+import pytest
+
+from tests.util import CASES, abi, load_ref
+import importlib
+
+film = importlib.import_module("pbrt-v2_amd.film")
+from oracle import orc
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_replays_reference_image_bit_exact(cases, name):
+    s = cases[name]
+    o = orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    # one thread: tiles in ascending task order, exactly the order `pbrt --ncores 1` produced the
+    # golden image in, so even the rare samples that spill into a neighbouring tile's pixel
+    # (film/image.cpp:82-89) are summed in the same order
+    f, st = o.render(s.camera, rd, nthreads=1)
+    img = film.xyzw_to_rgb(f)
+    ref = load_ref(name)
+    assert img.shape == ref.shape
+    assert st[0] == rd.x_count * rd.y_count * rd.spp
+    assert st[5] == 0  # no NaN / negative radiance
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
+def test_mt19937_known_answers():
+    # first outputs of MT19937 seeded 5489 (the generator's published test vector) and the
+    # reference's RandomFloat mapping (core/rng.cpp:59-65)
+    v = orc.mt_fill(5489, 5)
+    assert v.tolist() == [3499211612, 581869302, 3890346734, 3586334585, 545404204]
+    v1 = orc.mt_fill(1, 3)
+    assert v1.tolist() == [1791095845, 4282876139, 3093770124]
+
+
+def test_hash_sampler_is_a_stratified_02_sequence(cases):
+    """LD_HASH keeps LDPixelSample's structure: every array is a permutation of a scrambled
+    (0,2)-sequence, so each 1-D array stratifies [0,1) into spp strata and each 2-D array is a
+    (0,2)-net (one point per elementary interval)."""
+    rd = abi.copy_struct(cases["cfg1"].render)
+    rd.spp, rd.seed, rd.sampler_mode = 16, 3, abi.HPT_SAMPLER_LD_HASH
+    for (x, y) in [(0, 0), (5, 9), (255, 255)]:
+        s = orc.sampler(rd, x, y)
+        assert s.shape == (16, abi.SAMPLE_FLOATS)
+        assert np.all((s[:, 0] >= x) & (s[:, 0] <= x + 1) & (s[:, 1] >= y) & (s[:, 1] <= y + 1))
+        for j in range(12):  # 1-D strata
+            assert sorted(np.floor(s[:, 5 + j] * 16).astype(int).tolist()) == list(range(16))
+        for j in range(9):   # 2-D elementary intervals 16x1, 4x4, 1x16
+            a, b = s[:, 17 + 2 * j], s[:, 18 + 2 * j]
+            for (na, nb) in [(16, 1), (4, 4), (1, 16), (8, 2), (2, 8)]:
+                cells = set(zip(np.floor(a * na).astype(int).tolist(), np.floor(b * nb).astype(int).tolist()))
+                assert len(cells) == 16
+    # different pixels / seeds decorrelate
+    assert not np.array_equal(orc.sampler(rd, 1, 1), orc.sampler(rd, 2, 1))

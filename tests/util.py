@@ -1,0 +1,95 @@
+"""Shared test helpers.  `-m "not gpu"`: oracle pin against the golden fixtures, host logic, ABI
+surface, the test-only CPU emulation of the device code.  `-m gpu`: parity tests proper, through
+the C ABI of libhpt.so on cuda:0 (an MI355X)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+abi = importlib.import_module("pbrt-v2_amd.abi")
+
+
+def load_ref(name):
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, name + ".ref.npy.gz"), "rb") as f:
+        return np.load(f)
+
+
+def load_case(name):
+    """-> abi.Scene with the camera / render descriptor the golden image was rendered with."""
+    if name == "cfg1":
+        return abi.Scene.load(os.path.join(GOLDEN, "killeroo_cfg1.hpts.gz"))
+    if name == "k8":
+        s = abi.Scene.load(os.path.join(GOLDEN, "killeroo_cfg1.hpts.gz"))
+        v = np.load(os.path.join(GOLDEN, "k8.view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        return s
+    if name == "b8":
+        return abi.Scene.load(os.path.join(GOLDEN, "bunny_b8.hpts.gz"))
+    if name == "env":
+        return abi.Scene.load(os.path.join(GOLDEN, "env_soup.hpts.gz"))
+    raise KeyError(name)
+
+
+CASES = ["cfg1", "k8", "b8", "env"]
+
+
+def hash_rd(scene, seed=7, spp=None):
+    rd = abi.copy_struct(scene.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_LD_HASH
+    rd.seed = seed
+    if spp:
+        rd.spp = spp
+    return rd
+
+
+def random_rays(scene, n, seed=1):
+    """aggregatetest-style rays (renderers/aggregatetest.cpp:74-89): origins in an expanded world
+    box, random / axis-aligned directions, a share of finite segments."""
+    rng = np.random.default_rng(seed)
+    P = []
+    for m in scene.meshes:
+        P.append(scene.fpool[m.p_off:m.p_off + 3 * m.nverts].reshape(-1, 3))
+    P = np.concatenate(P) if P else np.zeros((1, 3), np.float32)
+    lo, hi = P.min(0), P.max(0)
+    # ignore huge ground quads when sizing the box
+    lo, hi = np.maximum(lo, np.percentile(P, 2, axis=0) - 1), np.minimum(hi, np.percentile(P, 98, axis=0) + 1)
+    ext = hi - lo
+    o = rng.uniform(lo - 0.5 * ext, hi + 0.5 * ext, size=(n, 3))
+    tgt = rng.uniform(lo, hi, size=(n, 3))
+    d = tgt - o
+    axis = rng.integers(0, 8, size=n)
+    for a in range(3):  # some exactly axis-aligned directions (zero components -> inf inverse dirs)
+        sel = axis == a
+        d[sel] = 0
+        d[sel, a] = np.where(rng.random(sel.sum()) < 0.5, 1.0, -1.0) * ext[a]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3], rays[:, 3:6] = o, d
+    rays[:, 6] = np.where(rng.random(n) < 0.3, rng.uniform(0, 0.2, n) * np.linalg.norm(ext), 0.0)
+    rays[:, 7] = np.where(rng.random(n) < 0.3, rng.uniform(0.5, 2.0, n) * np.linalg.norm(ext), np.inf)
+    return rays
+
+
+def bsdf_inputs(n, seed=3):
+    rng = np.random.default_rng(seed)
+
+    def unit(k):
+        v = rng.normal(size=(k, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    inp = np.zeros((n, 16), np.float32)
+    nn = unit(n)
+    inp[:, 0:3], inp[:, 3:6] = unit(n), unit(n)
+    inp[:, 6:9] = rng.random((n, 3)) * 0.999
+    inp[:, 9:12] = nn
+    t = np.cross(nn, unit(n))
+    inp[:, 12:15] = t / np.linalg.norm(t, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
+    inp[:, 15] = np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    return inp
