@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
+#include <vector>
+
 static thread_local char g_err[512] = "";
 
 void hpt_set_error(const char *fmt, ...) {
@@ -92,6 +95,25 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 ma.kd_data_off + 6ll * ma.kd_nnodes > d->n_f) {
                 hpt_set_error("material %d: kd-tree offsets out of range", m);
                 return HPT_E_INVALID;
+            }
+            // the device walks the tree with a 32-entry per-lane stack: bound its depth
+            {
+                const int32_t *bits = d->ipool + ma.kd_bits_off;
+                std::vector<std::pair<uint32_t, int> > todo;
+                std::vector<char> seen((size_t)ma.kd_nnodes, 0);
+                todo.push_back(std::make_pair(0u, 1));
+                int maxDepth = 0;
+                while (!todo.empty()) {
+                    uint32_t n = todo.back().first; int depth = todo.back().second; todo.pop_back();
+                    if (n >= (uint32_t)ma.kd_nnodes || seen[n]) { hpt_set_error("material %d: malformed kd-tree", m); return HPT_E_INVALID; }
+                    seen[n] = 1;
+                    if (depth > maxDepth) maxDepth = depth;
+                    uint32_t b = (uint32_t)bits[n];
+                    if ((b & 3u) == 3u) continue;
+                    if ((b >> 2) & 1u) todo.push_back(std::make_pair(n + 1, depth + 1));
+                    if ((b >> 3) < (uint32_t)ma.kd_nnodes) todo.push_back(std::make_pair(b >> 3, depth + 1));
+                }
+                if (maxDepth > 30) { hpt_set_error("material %d: kd-tree depth %d exceeds the device stack", m, maxDepth); return HPT_E_UNSUPPORTED; }
             }
         } else { hpt_set_error("material %d: unknown kind %d", m, ma.kind); return HPT_E_UNSUPPORTED; }
     }

@@ -464,17 +464,19 @@ HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
 // post-order visiting sequence (core/kdtree.h:159-183) so the weighted sums round identically.
 // The recursion is unrolled into an explicit stack of (node, stage) pairs.
 struct IrregProc { f3 v; float sumWeights; int nFound; };
-HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2) {
+// Scratch stack for the kd-tree walk: the lane's LDS traversal-stack column (free while shading).
+struct LaneStack { int32_t *p; int stride; };
+HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2, LaneStack ls) {
     const float *split = sc.fpool + m->kd_split_off;
     const int32_t *bits = sc.ipool + m->kd_bits_off;
     const float *data = sc.fpool + m->kd_data_off;
     const uint32_t nNodes = (uint32_t)m->kd_nnodes;
     // stage 0: first visit; 1: after first child; 2: after second child -> process node
-    uint32_t stk[40]; // node << 2 | stage ; tree depth <= ceil(log2(nNodes)) + 1
+    // entries: node << 2 | stage ; tree depth <= ceil(log2(nNodes)) + 1 (checked at scene creation)
     int sp = 0;
-    stk[sp++] = 0u << 2;
+    ls.p[0] = 0; sp = 1;
     while (sp > 0) {
-        uint32_t e = stk[sp - 1];
+        uint32_t e = (uint32_t)ls.p[(sp - 1) * ls.stride];
         uint32_t nodeNum = e >> 2, stage = e & 3u;
         uint32_t b = (uint32_t)bits[nodeNum];
         int axis = (int)(b & 3u);
@@ -491,8 +493,8 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
                 if (leftFirst) { if (d2 < maxDist2 && right < nNodes) child = right; }
                 else { if (d2 < maxDist2 && hasLeft) child = nodeNum + 1; }
             }
-            stk[sp - 1] = (nodeNum << 2) | (stage + 1);
-            if (child != 0xffffffffu) stk[sp++] = child << 2;
+            ls.p[(sp - 1) * ls.stride] = (int32_t)((nodeNum << 2) | (stage + 1));
+            if (child != 0xffffffffu) { ls.p[sp * ls.stride] = (int32_t)(child << 2); ++sp; }
             continue;
         }
         --sp;
@@ -506,7 +508,7 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
         }
     }
 }
-HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {
+HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
     float cosi = wi.z, coso = wo.z;
     float sini = sin_theta(wi), sino = sin_theta(wo);
     float phii = spherical_phi(wi), phio = spherical_phi(wo);
@@ -518,13 +520,13 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     float lastMaxDist2 = .001f;
     while (true) {
         IrregProc proc; proc.v = S(0.f); proc.sumWeights = 0.f; proc.nFound = 0;
-        kd_lookup(sc, m, mpt, &proc, lastMaxDist2);
+        kd_lookup(sc, m, mpt, &proc, lastMaxDist2, ls);
         if (proc.nFound > 2 || lastMaxDist2 > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
         lastMaxDist2 *= 2.f;
     }
 }
 
-HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi) {
+HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack ls) {
     int kind = b.kind(i);
     if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
     if (kind == BX_MICROFACET) {                                     // :211-222
@@ -541,7 +543,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi) {
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
         return sdivf(smul((b.R(i) * D) * G, S(F)), (4.f * cosThetaI * cosThetaO));
     }
-    return irreg_f(sc, b.mat, wo, wi);
+    return irreg_f(sc, b.mat, wo, wi, ls);
 }
 HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
     if (b.kind(i) == BX_MICROFACET) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
@@ -569,7 +571,7 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
     *dx = r * cosf(theta);
     *dy = r * sinf(theta);
 }
-HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf) {
+HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, LaneStack ls) {
     if (b.kind(i) == BX_MICROFACET) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
         float costheta = powf(u1, 1.f / (b.exponent + 1));
         float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
@@ -581,7 +583,7 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
         if (dot(wo, wh) <= 0.f) bp = 0.f;
         *pdf = bp;
         if (!same_hemisphere(wo, *wi)) return S(0.f);
-        return bxdf_f(sc, b, i, wo, *wi);
+        return bxdf_f(sc, b, i, wo, *wi, ls);
     }
     f3 w; // BxDF::Sample_f :311-318 (cosine hemisphere)
     concentric_sample_disk(u1, u2, &w.x, &w.y);
@@ -589,16 +591,16 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
     if (wo.z < 0.f) w.z *= -1.f;
     *wi = w;
     *pdf = bxdf_pdf(b, i, wo, w);
-    return bxdf_f(sc, b, i, wo, w);
+    return bxdf_f(sc, b, i, wo, w, ls);
 }
 HPT_FN bool bx_match(const Bsdf &b, int i, int flags) { int t = b.type(i); return (t & flags) == t; }
 // BSDF::f (reflection.cpp:612-626)
-HPT_FN f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags) {
+HPT_FN f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags, LaneStack ls) {
     f3 wi = b.w2l(wiW), wo = b.w2l(woW);
     if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
     else flags &= ~BSDF_REFLECTION;
     f3 f = S(0.f);
-    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi);
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi, ls);
     return f;
 }
 // BSDF::Pdf (reflection.cpp:583-598)
@@ -611,7 +613,7 @@ HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
 }
 // BSDF::Sample_f (reflection.cpp:522-580)
 HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
-                        int flags, int *sampledType) {
+                        int flags, int *sampledType, LaneStack ls) {
     int matching = 0;
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) ++matching;
     if (matching == 0) { *pdf = 0.f; *sampledType = 0; return S(0.f); }
@@ -621,7 +623,7 @@ HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float 
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
     f3 wo = b.w2l(woW), wi = S(0.f);
     *pdf = 0.f;
-    f3 f = bxdf_sample_f(sc, b, sel, wo, &wi, u1, u2, pdf);
+    f3 f = bxdf_sample_f(sc, b, sel, wo, &wi, u1, u2, pdf, ls);
     if (*pdf == 0.f) { *sampledType = 0; return S(0.f); }
     int stype = b.type(sel);
     *sampledType = stype;
@@ -633,7 +635,7 @@ HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float 
         f = S(0.f);
         if (dot(*wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
         else flags &= ~BSDF_REFLECTION;
-        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi);
+        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi, ls);
     }
     return f;
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(HPT_BLOCK) void hpt_path_kernel(const PathKernelArgs a) {
+__global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_path_kernel(const PathKernelArg
             traverse<COUNT>(sc, lane.ray, anyhit, &hit, stack, HPT_BLOCK, &tc);
         }
         // ---- state machine step ----------------------------------------------------------------------
-        if (active) lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr);
+        if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
     }
     if (COUNT) {
         wc.nodes = tc.nodes; wc.tris = tc.tris;
@@ -106,17 +106,19 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
 }
 
 __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, int64_t n, float *out) {
+    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * 64];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    LaneStack ls; ls.p = lds_stack + threadIdx.x; ls.stride = 64;
     const float *q = in + 16 * i; float *o = out + 12 * i;
     f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
     f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
     Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
     bsdf_add_material(&b, &sc.materials[material]);
-    f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC);
+    f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
     float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
     f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-    f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype);
+    f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
     o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
     o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
 }

@@ -153,7 +153,7 @@ template <class Smp> struct Lane {
     }
 
     // Called with the result of the traversal phase for this lane's pending ray.
-    HPT_MFN void on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc) {
+    HPT_MFN void on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
         if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
             if (hit.prim < 0) Ld = Ld + LdA;
             after_shadow(sc, rp, film, wc);
@@ -215,7 +215,7 @@ template <class Smp> struct Lane {
             f3 wi; float lightPdf, bsdfPdf;
             f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow);
             if (lightPdf > 0.f && !sblack(Li)) {
-                f3 f = bsdf_f(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC);
+                f3 f = bsdf_f(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
                 if (!sblack(f)) {
                     has_shadow = true;
                     if (isDelta) LdA = smul(f, Li) * (absdot(wi, n) / lightPdf);
@@ -229,7 +229,7 @@ template <class Smp> struct Lane {
             // BSDF-sampling half (integrator.cpp:145-172)
             if (!isDelta) {
                 int sampledType;
-                f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType);
+                f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType, ls);
                 if (!sblack(f) && bsdfPdf > 0.f) {
                     float weight = 1.f;
                     bool ok = true;
@@ -251,7 +251,7 @@ template <class Smp> struct Lane {
             if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
             else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
             f3 wi; float pdf; int flags;
-            f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags);
+            f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, ls);
             has_next = !(sblack(f) || pdf == 0.f);
             if (has_next) {
                 spec_next = (flags & BSDF_SPECULAR) != 0;

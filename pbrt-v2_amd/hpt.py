@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libhpt.so")
+LIB_PATH = os.environ.get("HPT_LIB") or os.path.join(_PKG, "libhpt.so")  # HPT_LIB: A/B kernel variants
 _lib = None
 
 EXPORTS = [

@@ -83,7 +83,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
                 traverse<true>(s->d, lane.ray, anyhit, &hit, stack, 1, &tc);
-                lane.on_hit(s->d, rp, hit, film, &wc);
+                { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit(s->d, rp, hit, film, &wc, ls); }
             }
         }
 #pragma omp critical
@@ -121,10 +121,11 @@ extern "C" int emu_bsdf(const emu_scene *s, int material, const float *in, int64
         f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
         Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
         bsdf_add_material(&b, &sc.materials[material]);
-        f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC);
+        int32_t stk[64]; LaneStack ls; ls.p = stk; ls.stride = 1;
+        f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
         float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
         f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-        f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype);
+        f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
         o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
         o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
     }
