@@ -68,7 +68,6 @@ template <class Smp> struct Lane {
     uint32_t si;
     Smp smp;
     float fX, fY, fZ, fW;   // film accumulators of the lane's own pixel
-    float imgx, imgy;       // CameraSample::imageX/Y of the current sample
     // path state (PathIntegrator::Li locals)
     f3 L, beta;
     int bounce;
@@ -76,10 +75,11 @@ template <class Smp> struct Lane {
     Ray ray;                // the ray to trace in the next traversal phase
     // pending work of the current vertex
     f3 p; float eps;        // bsdf->dgShading.p, isect.rayEpsilon
-    f3 Ld;                  // EstimateDirect accumulator
-    f3 LdA;                 // light-sampling term, added if the shadow ray is unoccluded
+    f3 Ld;                  // EstimateDirect accumulator; holds the light-sampling term while its
+                            // shadow ray is in flight (zeroed again if the ray is occluded)
     bool has_mis, has_next, spec_next;
-    f3 wi_mis, f_mis; float a_mis, w_mis, pdf_mis; int light_mis;
+    f3 wi_mis, C_mis;       // BSDF-sampling term f*Li*|wi.n|*w/pdf, evaluated for the radiance the ray
+    int light_mis;          // would see if it reaches light_mis; added when the MIS ray confirms it
     f3 wi_next, beta_next;
 
     HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; fX = fY = fZ = fW = 0.f; }
@@ -89,7 +89,7 @@ template <class Smp> struct Lane {
         smp.begin_sample(si);
         float a, b;
         smp.image(&a, &b);
-        imgx = px + a; imgy = py + b;       // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
+        float imgx = px + a, imgy = py + b; // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
         float lu = 0.f, lv = 0.f;
         if (rp.cam.lens_radius > 0.f) smp.lens(&lu, &lv);
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
@@ -109,6 +109,9 @@ template <class Smp> struct Lane {
         bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
         if (bad) { Ls = S(0.f); if (wc) wc->bad++; }
+        float ia, ib;
+        smp.image(&ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
+        float imgx = px + ia, imgy = py + ib;
         float dimageX = imgx - 0.5f, dimageY = imgy - 0.5f;
         int x0 = (int)ceilf(dimageX - 0.5f), x1 = (int)floorf(dimageX + 0.5f);
         int y0 = (int)ceilf(dimageY - 0.5f), y1 = (int)floorf(dimageY + 0.5f);
@@ -155,23 +158,23 @@ template <class Smp> struct Lane {
     // Called with the result of the traversal phase for this lane's pending ray.
     HPT_MFN void on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
         if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
-            if (hit.prim < 0) Ld = Ld + LdA;
+            if (hit.prim >= 0) Ld = S(0.f);
             after_shadow(sc, rp, film, wc);
             return;
         }
         if (stage == ST_MIS) {               // integrator.cpp:157-171
-            f3 Li = S(0.f);
+            bool sees = false;               // does the ray see light_mis with non-black radiance?
             if (hit.prim >= 0) {
                 if (hit.prim >= sc.n_tris) {
                     const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
                     if (q.arealight == light_mis) {
                         DGeom dg; float t;
                         quadric_intersect(q, ray, &t, &dg);
-                        Li = area_L(sc.lights[light_mis], dg.nn, -wi_mis); // Intersection::Le
+                        sees = dot(dg.nn, -wi_mis) > 0.f;       // Intersection::Le -> DiffuseAreaLight::L
                     }
                 }
-            } else Li = light_Le(sc, sc.lights[light_mis], ray.d);
-            if (!sblack(Li)) Ld = Ld + sdivf((smul(f_mis, Li) * a_mis) * w_mis, pdf_mis);
+            } else sees = sc.lights[light_mis].kind == HPT_LIGHT_INFINITE; // light->Le(ray), integrator.cpp:166
+            if (sees) Ld = Ld + C_mis;
             after_mis(sc, rp, film, wc);
             return;
         }
@@ -190,7 +193,7 @@ template <class Smp> struct Lane {
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
         p = dg.p;
         f3 n = bsdf.nn;
-        Ld = S(0.f); LdA = S(0.f);
+        Ld = S(0.f);
         bool has_shadow = false;
         has_mis = false;
         Ray shadow; shadow.o = p; shadow.d = n; shadow.mint = 0.f; shadow.maxt = 0.f;
@@ -218,11 +221,11 @@ template <class Smp> struct Lane {
                 f3 f = bsdf_f(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
                 if (!sblack(f)) {
                     has_shadow = true;
-                    if (isDelta) LdA = smul(f, Li) * (absdot(wi, n) / lightPdf);
+                    if (isDelta) Ld = smul(f, Li) * (absdot(wi, n) / lightPdf);
                     else {
                         bsdfPdf = bsdf_pdf(bsdf, wo, wi, BSDF_ALL_NOSPEC);
                         float weight = power_heuristic(1, lightPdf, 1, bsdfPdf);
-                        LdA = smul(f, Li) * (absdot(wi, n) * weight / lightPdf);
+                        Ld = smul(f, Li) * (absdot(wi, n) * weight / lightPdf);
                     }
                 }
             }
@@ -239,8 +242,14 @@ template <class Smp> struct Lane {
                         else weight = power_heuristic(1, bsdfPdf, 1, lightPdf);
                     }
                     if (ok) {
-                        has_mis = true; light_mis = lightNum;
-                        wi_mis = wi; f_mis = f; a_mis = absdot(wi, n); w_mis = weight; pdf_mis = bsdfPdf;
+                        // radiance the ray carries IF it reaches the light unoccluded: Lemit for an area
+                        // light (facing test at the hit), the environment lookup for an infinite one
+                        f3 Lic = light.kind == HPT_LIGHT_INFINITE ? light_Le(sc, light, wi)
+                                                                  : mk3(light.intensity[0], light.intensity[1], light.intensity[2]);
+                        if (!sblack(Lic)) {
+                            has_mis = true; light_mis = lightNum; wi_mis = wi;
+                            C_mis = sdivf((smul(f, Lic) * absdot(wi, n)) * weight, bsdfPdf); // integrator.cpp:169
+                        }
                     }
                 }
             }
@@ -273,19 +282,19 @@ template <class Smp> struct Lane {
 // ---- production sampler adaptor ---------------------------------------------------------------------
 struct LdHashSrc {
     LdHash h;
-    uint32_t seed_, dkey, dcount;
+    uint32_t dcount;
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
         uint32_t pixelIndex = (uint32_t)y * (uint32_t)rp.xres + (uint32_t)x;
         h.pk = pixel_key(pixelIndex, rp.seed);
         h.w = (uint32_t)rp.spp - 1u;
     }
-    HPT_MFN void begin_sample(uint32_t i) { h.i = i; dkey = h.draw_key(); dcount = 0; }
+    HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; }
     HPT_MFN void end_pixel(const RenderParams &) {}
     HPT_MFN float one(int j) const { return h.one(j); }
     HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
     HPT_MFN void image(float *a, float *b) const { h.image(a, b); }
     HPT_MFN void lens(float *a, float *b) const { h.lens(a, b); }
-    HPT_MFN float draw() { return h.draw(dkey, dcount++); }
+    HPT_MFN float draw() { return h.draw(h.draw_key(), dcount++); }
 };
 
 } // namespace hpt
