@@ -7,7 +7,7 @@
 #define HPT_BLOCK 256        /* threads per workgroup = 4 wave64 */
 #define HPT_STACK_DEPTH 32   /* LDS traversal stack entries per lane (32 KiB per workgroup) */
 #ifndef HPT_MIN_WAVES
-#define HPT_MIN_WAVES 2    /* __launch_bounds__ 2nd arg: min waves per SIMD the register allocator must allow */
+#define HPT_MIN_WAVES 4    /* __launch_bounds__ 2nd arg: waves per SIMD the register allocator must allow (A/B in profiles/r01_ab.md) */
 #endif
 
 namespace hpt {

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Turn one gpurun_out/prof_<workload>_<time>/ directory (scripts/gpu_profile.sh) into the tracked
+evidence under profiles/: the rocprofv3 kernel-stats rows, the PMC values of the path kernel, the
+derived figures bench.py and DESIGN.md quote, and profiles/hbm_traffic_<workload>.json.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB,
+collected in separate --pmc passes; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. it
+reads HALF the bytes of wide (16 B/lane) loads — which is what this kernel issues for BVH nodes and
+triangle records — so the read side is doubled.  WRITE_SIZE is used as reported (uncalibrated)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]          # e.g. gpurun_out/prof_bunny_234126  r01_bunny_w2
+root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+KERNEL = "hpt_path_kernel"
+
+stats_rows = []
+for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
+    stats_rows = list(csv.DictReader(open(f)))
+pmc = collections.OrderedDict()
+meta = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if KERNEL not in r["Kernel_Name"]:
+                continue
+            pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                      "Accum_VGPR_Count", "SGPR_Count")}
+            meta["duration_ns_under_pmc"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+pmc = {k: sum(v) / len(v) for k, v in pmc.items()}     # per launch
+
+k = next((r for r in stats_rows if KERNEL in r["Name"]), None)
+derived = {}
+if k:
+    derived["kernel_avg_ms"] = float(k["AverageNs"]) / 1e6
+    derived["kernel_calls"] = int(k["Calls"])
+    derived["kernel_pct_of_gpu_time"] = float(k["Percentage"])
+if "FETCH_SIZE" in pmc:
+    derived["hbm_read_bytes_per_launch"] = pmc["FETCH_SIZE"] * 1024 * 2
+if "WRITE_SIZE" in pmc:
+    derived["hbm_write_bytes_per_launch"] = pmc["WRITE_SIZE"] * 1024
+if "hbm_read_bytes_per_launch" in derived and "hbm_write_bytes_per_launch" in derived:
+    derived["hbm_bytes_per_launch"] = derived["hbm_read_bytes_per_launch"] + derived["hbm_write_bytes_per_launch"]
+if "TCC_HIT_sum" in pmc:
+    derived["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+if "SQ_WAVE_CYCLES" in pmc:
+    wc = pmc["SQ_WAVE_CYCLES"]
+    for name in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+        if name in pmc:
+            derived[name + "_over_WAVE_CYCLES"] = pmc[name] / wc
+    if "SQ_BUSY_CYCLES" in pmc and "SQ_WAVES" in pmc:
+        derived["waves_launched"] = pmc["SQ_WAVES"]
+if "SQ_INSTS_VALU" in pmc:
+    derived["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
+
+doc = {"source": os.path.basename(src.rstrip("/")), "kernel": KERNEL, "dispatch": meta, "pmc_per_launch": pmc,
+       "derived": derived, "kernel_stats_csv": stats_rows[:4]}
+json.dump(doc, open(os.path.join(out_dir, tag + ".json"), "w"), indent=1)
+with open(os.path.join(out_dir, tag + ".md"), "w") as f:
+    f.write("# rocprofv3 summary `%s` (from %s)\n\n" % (tag, doc["source"]))
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...` then one\n"
+            "`rocprofv3 --kernel-trace --pmc <counters>` run per counter group (scripts/gpu_profile.sh).\n\n")
+    f.write("## kernel stats (rocprofv3 --stats)\n\n| Name | Calls | AverageNs | Percentage |\n|---|---|---|---|\n")
+    for r in stats_rows[:4]:
+        f.write("| %s | %s | %s | %s |\n" % (r["Name"][:70], r["Calls"], r["AverageNs"], r["Percentage"]))
+    f.write("\n## dispatch\n\n%s\n\n## PMC (per launch of %s)\n\n| counter | value |\n|---|---|\n" % (json.dumps(meta), KERNEL))
+    for kk, v in pmc.items():
+        f.write("| %s | %.6g |\n" % (kk, v))
+    f.write("\n## derived\n\n| figure | value |\n|---|---|\n")
+    for kk, v in derived.items():
+        f.write("| %s | %.6g |\n" % (kk, v))
+if len(sys.argv) > 3 and "hbm_bytes_per_launch" in derived:
+    json.dump({"bytes_per_launch": derived["hbm_bytes_per_launch"], "read_bytes": derived["hbm_read_bytes_per_launch"],
+               "write_bytes": derived["hbm_write_bytes_per_launch"], "source": "profiles/%s.json" % tag,
+               "note": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-load correction) + WRITE_SIZE KiB x1024"},
+              open(os.path.join(out_dir, "hbm_traffic_%s.json" % sys.argv[3]), "w"), indent=1)
+print(open(os.path.join(out_dir, tag + ".md")).read())
