@@ -10,6 +10,7 @@
 #include "hpt_flatten.h"
 #include "hpt_internal.h"
 #include "hpt_kernels.h"
+#include "hpt_replay.h"
 
 using namespace hpt;
 
@@ -101,7 +102,11 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
     if (rd->spp <= 0 || (rd->spp & (rd->spp - 1))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
-    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH) { hpt_set_error("sampler mode %d is not available in this build", rd->sampler_mode); return HPT_E_UNSUPPORTED; }
+    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
+    if (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY) {
+        if (rd->ntasks <= 0 || (rd->ntasks & (rd->ntasks - 1))) { hpt_set_error("MT_REPLAY needs ntasks = the reference's nTasks (a power of two, samplerrenderer.cpp:298-300)"); return HPT_E_INVALID; }
+        if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
+    }
     rp->cam = *cam;
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
@@ -139,11 +144,20 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+    const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
+    ReplayArgs ra; memset(&ra, 0, sizeof(ra));
+    if (replay && e == hipSuccess) {
+        ra.ntasks = rd->ntasks;
+        ra.nlanes = ((int64_t)rd->ntasks + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK;
+        e = hipMalloc((void **)&ra.mt, sizeof(uint32_t) * HPT_MT_N * (size_t)ra.nlanes);
+        if (e == hipSuccess) e = hipMalloc((void **)&ra.buf, sizeof(float) * HPT_REPLAY_FLOATS_PER_SAMPLE * (size_t)rd->spp * (size_t)ra.nlanes);
+        grid = (int)(ra.nlanes / HPT_BLOCK);
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
-    if (e == hipSuccess) e = launch_path_kernel(a, grid, rd->count_work != 0, stream);
+    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(a, grid, rd->count_work != 0, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     float ms = 0.f;
@@ -154,6 +168,8 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipFree(d_scr);
+    if (ra.mt) (void)hipFree(ra.mt);
+    if (ra.buf) (void)hipFree(ra.buf);
     if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -168,7 +184,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
             px += (uint64_t)w * (uint64_t)h;
         }
         stats->camera_samples = px * (uint64_t)rd->spp;
-        if (rd->count_work) {
+        if (rd->count_work || replay) {
             stats->camera_samples = h_scr.wc.samples;
             stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
             stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris; stats->bad_samples = h_scr.wc.bad;

@@ -20,8 +20,16 @@ struct PathKernelArgs {
     WorkCounters *counters;         // only written by the COUNT instantiation
 };
 
+struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
+    uint32_t *mt;              // [624][nlanes]
+    float *buf;                // [37 * spp][nlanes]
+    int64_t nlanes;            // ntasks rounded up to a multiple of HPT_BLOCK
+    int32_t ntasks;
+};
+
 int path_kernel_occupancy(int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream);
+hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
                             int32_t *out_prim, hipStream_t s);
 hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s);

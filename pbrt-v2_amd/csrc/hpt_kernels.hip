@@ -16,6 +16,7 @@
 
 #include "hpt_kernels.h"
 #include "hpt_path.h"
+#include "hpt_replay.h"
 
 namespace hpt {
 
@@ -85,6 +86,51 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
     }
 }
 
+// ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------
+__global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelArgs a, const ReplayArgs ra) {
+    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    int32_t *stack = lds_stack + threadIdx.x;
+    const DScene &sc = a.sc;
+    const RenderParams &rp = a.rp;
+    const int64_t gid = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
+    Lane<MtReplaySrc> lane;
+    lane.init();
+    lane.smp.mt = ra.mt + gid; lane.smp.buf = ra.buf + gid; lane.smp.stride = ra.nlanes; lane.smp.mti = HPT_MT_N; lane.smp.n = (uint32_t)rp.spp; lane.smp.i = 0;
+    TileWalk tw; tw.started = false; tw.x0 = tw.x1 = tw.y0 = tw.y1 = tw.x = tw.y = 0;
+    bool exhausted = gid >= ra.ntasks;
+    if (!exhausted) {
+        compute_sub_window(rp.x_start, rp.x_start + rp.x_count, rp.y_start, rp.y_start + rp.y_count, (int)gid, ra.ntasks,
+                           &tw.x0, &tw.x1, &tw.y0, &tw.y1);
+        lane.smp.seed((uint32_t)gid);                       // RNG rng(taskNum), samplerrenderer.cpp:168
+    }
+    WorkCounters wc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0};
+    for (;;) {
+        if (lane.stage == ST_IDLE && !exhausted) {
+            int x, y;
+            if (tw.next(&x, &y)) lane.begin_pixel(rp, x, y); else exhausted = true;
+        }
+        bool active = lane.stage != ST_IDLE;
+        if (__ballot(active) == 0ull) break;
+        Hit hit;
+        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f;
+        if (active) {
+            bool anyhit = lane.stage == ST_SHADOW;
+            if (anyhit) wc.shadow++; else wc.closest++;
+            traverse<true>(sc, lane.ray, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+            lane.on_hit(sc, rp, hit, a.film, &wc, ls);
+        }
+    }
+    wc.nodes = tc.nodes; wc.tris = tc.tris;
+    atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
+    atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
+    atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
+    atomicAdd((unsigned long long *)&a.counters->nodes, (unsigned long long)wc.nodes);
+    atomicAdd((unsigned long long *)&a.counters->tris, (unsigned long long)wc.tris);
+    atomicAdd((unsigned long long *)&a.counters->bad, (unsigned long long)wc.bad);
+}
+
 // ---- function-level parity kernels (same device functions, array in / array out) --------------------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene sc, const float *rays, int64_t n, int anyhit,
                                                                   float *out_hit, int32_t *out_prim) {
@@ -150,6 +196,11 @@ int path_kernel_occupancy(int *blocks_per_cu, int *vgprs) {
 hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
     if (count) hipLaunchKernelGGL(hpt_path_kernel<true>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
     else hipLaunchKernelGGL(hpt_path_kernel<false>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {
+    int grid = (int)(ra.nlanes / HPT_BLOCK);
+    hipLaunchKernelGGL(hpt_replay_kernel, dim3(grid), dim3(HPT_BLOCK), 0, stream, a, ra);
     return hipGetLastError();
 }
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {

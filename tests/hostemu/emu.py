@@ -21,6 +21,7 @@ def lib():
         L.emu_scene_destroy.argtypes = [C.c_void_p]
         L.emu_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
+        L.emu_render_replay.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -44,7 +45,8 @@ class EmuScene:
     def render(self, cam, rd):
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
-        lib().emu_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, stats.ctypes.data)
+        fn = lib().emu_render_replay if rd.sampler_mode == abi.HPT_SAMPLER_MT_REPLAY else lib().emu_render
+        fn(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, stats.ctypes.data)
         return film, stats
 
     def intersect(self, rays, anyhit=False):

@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import CASES, abi, bsdf_inputs, hash_rd, random_rays
+from tests.util import CASES, abi, bsdf_inputs, hash_rd, load_ref, random_rays
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc
@@ -92,3 +92,20 @@ def test_shards_partition_the_image(cases, pairs):
             acc += f
         assert wsum.max() == 1 and wsum.min() == 1          # every pixel owned by exactly one shard
         assert np.allclose(acc, full, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_replay_mode_reproduces_reference_image(cases, pairs, name):
+    """The device state machine + MT_REPLAY sampler source (hpt_replay.h), emulated on the CPU,
+    against the image the REFERENCE BINARY rendered (golden fixture).  Same libm, same stream:
+    identical except where the different BVH resolves an exact tie / box-edge graze differently."""
+    s = cases[name]
+    _, e = pairs[name]
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = e.render(s.camera, rd)
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp
+    differing = (np.abs(img - ref).max(axis=2) > 0).mean()
+    assert differing < 1e-3, differing
+    assert film.rmse(img, ref) < 1e-3

@@ -93,3 +93,25 @@ def bsdf_inputs(n, seed=3):
     inp[:, 12:15] = t / np.linalg.norm(t, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
     inp[:, 15] = np.where(rng.random(n) < 0.1, -1.0, 1.0)
     return inp
+
+
+def sub_windows(rd):
+    """Sampler::ComputeSubWindow (core/sampler.cpp:55-74) for every task: list of (x0, x1, y0, y1)
+    relative to the film extent."""
+    f32 = np.float32
+    xs, xe, ys, ye = rd.x_start, rd.x_start + rd.x_count, rd.y_start, rd.y_start + rd.y_count
+    dx, dy = xe - xs, ye - ys
+    nx, ny = rd.ntasks, 1
+    while (nx & 1) == 0 and 2 * dx * ny < dy * nx:
+        nx >>= 1
+        ny <<= 1
+    out = []
+    for num in range(rd.ntasks):
+        xo, yo = num % nx, num // nx
+        tx0, tx1 = f32(xo) / f32(nx), f32(xo + 1) / f32(nx)
+        ty0, ty1 = f32(yo) / f32(ny), f32(yo + 1) / f32(ny)
+        lerp = lambda t, a, b: f32(f32(f32(1) - t) * f32(a)) + f32(t * f32(b))
+        x0, x1 = int(np.floor(lerp(tx0, xs, xe))), int(np.floor(lerp(tx1, xs, xe)))
+        y0, y1 = int(np.floor(lerp(ty0, ys, ye))), int(np.floor(lerp(ty1, ys, ye)))
+        out.append((x0 - xs, x1 - xs, y0 - ys, y1 - ys))
+    return out
