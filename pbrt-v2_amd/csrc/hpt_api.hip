@@ -4,6 +4,7 @@
 // device every compute entry point fails with HPT_E_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -69,7 +70,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->n_cus = prop.multiProcessorCount;
 
     FlatScene fs;
-    if (flatten_scene(desc, 4, HPT_STACK_DEPTH - 2, &fs) != HPT_OK) { delete s; return nullptr; }
+    int maxLeaf = 4;
+    if (const char *e = getenv("HPT_BVH_MAXLEAF")) maxLeaf = atoi(e);   // tuning knob (default 4, range 1..8)
+    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs) != HPT_OK) { delete s; return nullptr; }
     if (fs.max_depth > HPT_STACK_DEPTH) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
     const int64_t ntris = fs.n_tris;
     s->info.build_ms = fs.build_ms;
@@ -82,9 +85,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.tris = (const f4 *)upload(s, fs.tri_rec.data(), fs.tri_rec.size(), &ok);
     s->d.meshes = upload(s, fs.meshes.data(), fs.meshes.size(), &ok);
     s->d.quadrics = upload(s, desc->quadrics, (size_t)desc->n_quadrics, &ok);
-    s->d.materials = upload(s, desc->materials, (size_t)desc->n_materials, &ok);
+    s->d.materials = upload(s, fs.materials.data(), fs.materials.size(), &ok);
     s->d.lights = upload(s, desc->lights, (size_t)desc->n_lights, &ok);
-    s->d.fpool = upload(s, desc->fpool, (size_t)desc->n_f, &ok);
+    s->d.fpool = upload(s, fs.fpool.data(), fs.fpool.size(), &ok);
     s->d.ipool = upload(s, desc->ipool, (size_t)desc->n_i, &ok);
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();

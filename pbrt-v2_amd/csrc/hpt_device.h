@@ -337,6 +337,12 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
     return !miss && (tmin < ray.maxt) && (tmax > ray.mint);
 }
 
+#ifndef HPT_TRAV
+#define HPT_TRAV 1   /* loop shape: 0 = node XOR leaf per iteration, 1 = node then leaf per iteration ("if-if"),
+                        2 = descend to a leaf, then test it ("while-while"); A/B in profiles/ */
+#endif
+#define HPT_TRAV_EMPTY ((int32_t)0x80000000)
+
 template <bool COUNT>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f;
@@ -349,47 +355,66 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t 
         }
     }
     if (sc.n_nodes == 0) return hit->prim >= 0;
-    f3 invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-    bool nx = invd.x < 0, ny = invd.y < 0, nz = invd.z < 0;
+    const f3 invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+    const bool nx = invd.x < 0, ny = invd.y < 0, nz = invd.z < 0;
     int sp = 0;
     int32_t node = 0;
-    while (true) {
-        if (node >= 0) {
-            const f4 *np = sc.nodes + 4 * (int64_t)node;
-            f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT) cnt->nodes++;
-            float t0, t1;
-            bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, invd, nx, ny, nz, &t0);
-            bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, invd, nx, ny, nz, &t1);
-            int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
-            if (h0 && h1) {
-                bool swap = t1 < t0;
-                int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                stack[sp * stride] = farc; ++sp;
-                node = nearc;
-                continue;
-            }
-            if (h0) { node = c0; continue; }
-            if (h1) { node = c1; continue; }
-        } else {
-            uint32_t code = (uint32_t)~node;
-            uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
-                f4 a = tp[0], b = tp[1], c = tp[2];
-                if (COUNT) cnt->tris++;
-                float t, b1, b2;
-                if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
-                    hit->prim = (int32_t)(first + k);
-                    if (anyhit) return true;
-                    hit->t = t; hit->b1 = b1; hit->b2 = b2;
-                    ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
-                }
-            }
-        }
-        if (sp == 0) break;
-        --sp; node = stack[sp * stride];
+    // interior step: one 64-byte node fetch, two slab tests, near child first, far child stacked
+#define HPT_NODE_STEP()                                                                              \
+    do {                                                                                             \
+        const f4 *np = sc.nodes + 4 * (int64_t)node;                                                 \
+        f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];                                           \
+        if (COUNT) cnt->nodes++;                                                                     \
+        float t0, t1;                                                                                \
+        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, invd, nx, ny, nz, &t0);              \
+        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, invd, nx, ny, nz, &t1);              \
+        int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);                                                \
+        if (h0 && h1) {                                                                              \
+            bool swap = t1 < t0;                                                                     \
+            stack[sp * stride] = swap ? c0 : c1; ++sp;                                               \
+            node = swap ? c1 : c0;                                                                   \
+        } else if (h0) node = c0;                                                                    \
+        else if (h1) node = c1;                                                                      \
+        else if (sp > 0) { --sp; node = stack[sp * stride]; }                                        \
+        else node = HPT_TRAV_EMPTY;                                                                  \
+    } while (0)
+    // leaf step: <= 8 pre-gathered 48-byte triangle records; then pop
+#define HPT_LEAF_STEP()                                                                              \
+    do {                                                                                             \
+        uint32_t code = (uint32_t)~node;                                                             \
+        uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;                              \
+        for (uint32_t k = 0; k < count; ++k) {                                                       \
+            const f4 *tp = sc.tris + 3 * (int64_t)(first + k);                                       \
+            f4 a = tp[0], b = tp[1], c = tp[2];                                                      \
+            if (COUNT) cnt->tris++;                                                                  \
+            float t, b1, b2;                                                                         \
+            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) { \
+                hit->prim = (int32_t)(first + k);                                                    \
+                if (anyhit) return true;                                                             \
+                hit->t = t; hit->b1 = b1; hit->b2 = b2;                                              \
+                ray.maxt = t; /* GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174) */ \
+            }                                                                                        \
+        }                                                                                            \
+        if (sp > 0) { --sp; node = stack[sp * stride]; } else node = HPT_TRAV_EMPTY;                 \
+    } while (0)
+#if HPT_TRAV == 0
+    while (node != HPT_TRAV_EMPTY) {
+        if (node >= 0) HPT_NODE_STEP();
+        else HPT_LEAF_STEP();
     }
+#elif HPT_TRAV == 1
+    while (node != HPT_TRAV_EMPTY) {
+        if (node >= 0) HPT_NODE_STEP();
+        if (node < 0 && node != HPT_TRAV_EMPTY) HPT_LEAF_STEP();
+    }
+#else
+    while (node != HPT_TRAV_EMPTY) {
+        while (node >= 0) HPT_NODE_STEP();
+        if (node != HPT_TRAV_EMPTY) HPT_LEAF_STEP();
+    }
+#endif
+#undef HPT_NODE_STEP
+#undef HPT_LEAF_STEP
     return hit->prim >= 0;
 }
 
@@ -467,22 +492,22 @@ struct IrregProc { f3 v; float sumWeights; int nFound; };
 // Scratch stack for the kd-tree walk: the lane's LDS traversal-stack column (free while shading).
 struct LaneStack { int32_t *p; int stride; };
 HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2, LaneStack ls) {
-    const float *split = sc.fpool + m->kd_split_off;
-    const int32_t *bits = sc.ipool + m->kd_bits_off;
-    const float *data = sc.fpool + m->kd_data_off;
+    // packed node: {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
+    const f4 *nodes = (const f4 *)(sc.fpool + m->kd_data_off);
     const uint32_t nNodes = (uint32_t)m->kd_nnodes;
     // stage 0: first visit; 1: after first child; 2: after second child -> process node
-    // entries: node << 2 | stage ; tree depth <= ceil(log2(nNodes)) + 1 (checked at scene creation)
+    // entries: node << 2 | stage ; tree depth <= 30 (checked at scene creation)
     int sp = 0;
     ls.p[0] = 0; sp = 1;
     while (sp > 0) {
         uint32_t e = (uint32_t)ls.p[(sp - 1) * ls.stride];
         uint32_t nodeNum = e >> 2, stage = e & 3u;
-        uint32_t b = (uint32_t)bits[nodeNum];
+        f4 n0 = nodes[2 * (int64_t)nodeNum];
+        uint32_t b = (uint32_t)as_int(n0.y);
         int axis = (int)(b & 3u);
         uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
         if (axis != 3 && stage < 2) {
-            float pa = comp(p, axis), sp_ = split[nodeNum];
+            float pa = comp(p, axis), sp_ = n0.x;
             float d2 = (pa - sp_) * (pa - sp_);
             bool leftFirst = pa <= sp_;
             uint32_t child = 0xffffffffu;
@@ -498,11 +523,12 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
             continue;
         }
         --sp;
-        f3 np = mk3(data[6 * nodeNum], data[6 * nodeNum + 1], data[6 * nodeNum + 2]);
+        f4 n1 = nodes[2 * (int64_t)nodeNum + 1];
+        f3 np = mk3(n0.z, n0.w, n1.x);
         float d2 = dist2(np, p);
         if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
             float weight = expf(-100.f * d2);
-            proc->v = proc->v + mk3(data[6 * nodeNum + 3], data[6 * nodeNum + 4], data[6 * nodeNum + 5]) * weight;
+            proc->v = proc->v + mk3(n1.y, n1.z, n1.w) * weight;
             proc->sumWeights += weight;
             ++proc->nFound;
         }

@@ -12,7 +12,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     auto t0 = std::chrono::steady_clock::now();
     int64_t ntris = 0;
     for (int m = 0; m < desc->n_meshes; ++m) ntris += desc->meshes[m].ntris;
-    if (ntris >= (1ll << 28)) { hpt_set_error("too many triangles (%lld)", (long long)ntris); return HPT_E_UNSUPPORTED; }
+    if (ntris >= (1ll << 28) - 16) { hpt_set_error("too many triangles (%lld)", (long long)ntris); return HPT_E_UNSUPPORTED; }
     // world-space triangle soup (the reference transforms vertices at mesh construction,
     // shapes/trianglemesh.cpp:70-71, so P is already in world space)
     std::vector<BvhInputTri> in((size_t)ntris);
@@ -47,6 +47,23 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[src].v[k][0]; r[4 * k + 1] = in[src].v[k][1]; r[4 * k + 2] = in[src].v[k][2]; }
         memcpy(&r[3], &tri_mesh[src], 4);
         memcpy(&r[7], &tri_idx[src], 4);
+    }
+    // ---- measured-BRDF kd-trees -> packed 32-byte nodes ---------------------------------------
+    out->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
+    out->materials.assign(desc->materials, desc->materials + desc->n_materials);
+    for (int m = 0; m < desc->n_materials; ++m) {
+        hpt_material &ma = out->materials[(size_t)m];
+        if (ma.kind != HPT_MAT_MEASURED_IRREG) continue;
+        while (out->fpool.size() % 8) out->fpool.push_back(0.f);
+        int64_t base = (int64_t)out->fpool.size();
+        const float *split = desc->fpool + ma.kd_split_off, *data = desc->fpool + ma.kd_data_off;
+        const int32_t *bits = desc->ipool + ma.kd_bits_off;
+        for (int i = 0; i < ma.kd_nnodes; ++i) {
+            float bf; memcpy(&bf, &bits[i], 4);
+            out->fpool.push_back(split[i]); out->fpool.push_back(bf);
+            for (int k = 0; k < 6; ++k) out->fpool.push_back(data[6 * i + k]);
+        }
+        ma.kd_data_off = base; ma.kd_split_off = HPT_KD_PACKED; ma.kd_bits_off = HPT_KD_PACKED;
     }
     out->nodes.swap(bvh.nodes);
     out->n_tris = ntris;

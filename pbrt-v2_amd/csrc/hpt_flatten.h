@@ -9,10 +9,18 @@
 
 namespace hpt {
 
+#define HPT_KD_PACKED (-2)
+
 struct FlatScene {
     std::vector<BvhNode64> nodes;
     std::vector<float> tri_rec;   // 12 floats per triangle, BVH leaf order
     std::vector<DMesh> meshes;
+    // device copies of the float pool and the material table: measured-BRDF kd-trees are re-packed
+    // into 32-byte node records {splitPos, bits, p.xyz, v.rgb} appended to the pool (one sector per
+    // node visit instead of three scattered loads); materials[i].kd_data_off then points at the
+    // packed records (in floats, a multiple of 8) and kd_split_off == HPT_KD_PACKED marks the form
+    std::vector<float> fpool;
+    std::vector<hpt_material> materials;
     int64_t n_tris = 0;
     int max_depth = 0;
     double build_ms = 0.0;

@@ -30,9 +30,9 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     emu_scene *s = new emu_scene();
     if (flatten_scene(desc, max_leaf, 30, &s->fs) != HPT_OK) { delete s; return nullptr; }
     s->quadrics.assign(desc->quadrics, desc->quadrics + desc->n_quadrics);
-    s->materials.assign(desc->materials, desc->materials + desc->n_materials);
+    s->materials = s->fs.materials;
     s->lights.assign(desc->lights, desc->lights + desc->n_lights);
-    s->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
+    s->fpool = s->fs.fpool;
     s->ipool.assign(desc->ipool, desc->ipool + desc->n_i);
     memset(&s->d, 0, sizeof(s->d));
     s->d.nodes = (const f4 *)s->fs.nodes.data();
