@@ -120,7 +120,12 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
-    rp->n_items = local * 1024;
+    // a pixel's samples are split into items of `chunk` samples: keeps items small next to the job
+    // (short tail, even load when a shard owns few pixels); <= 64 spp is one item, summed in order
+    rp->chunk = rd->spp < 64 ? rd->spp : 64;
+    if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
+    rp->items_per_pass = local * 1024;
+    rp->n_items = rp->items_per_pass * (rd->spp / rp->chunk);
     return HPT_OK;
 }
 

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
             if (need) {
                 if (item >= rp.n_items) exhausted = true;
                 else {
-                    int x, y;
-                    if (item_to_pixel(rp, item, &x, &y)) lane.begin_pixel(rp, x, y);
+                    int x, y; uint32_t s0;
+                    if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
                 }
             }
         }

@@ -31,7 +31,9 @@ struct RenderParams {
     uint32_t seed;
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
-    int64_t n_items;           // work items of this shard (pixels incl. padding)
+    int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
+    int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
+    int64_t n_items;           // items_per_pass x (spp / chunk)
 };
 
 struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
@@ -46,7 +48,12 @@ HPT_FN void film_atomic_add(float *p, float v) { *p += v; }
 // Work item -> pixel.  Items enumerate this shard's 32x32 super-tiles (round-robin over shards),
 // inside a super-tile 8x8 micro-tiles, inside a micro-tile row-major pixels: 64 consecutive items
 // = one 8x8 pixel block, so the 64 lanes of a wave start on coherent camera rays.
-HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py) {
+HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py, uint32_t *s0) {
+    // sample chunks are the slowest-varying index: the frame is swept spp/chunk times, so items stay
+    // small next to the whole job (short tail) however few pixels a shard owns
+    int64_t pass = item / rp.items_per_pass;
+    item -= pass * rp.items_per_pass;
+    *s0 = (uint32_t)pass * (uint32_t)rp.chunk;
     int64_t k = item >> 10;
     int r = (int)(item & 1023);
     int64_t st = k * rp.shard_count + rp.shard_rank;
@@ -65,7 +72,7 @@ template <class Smp> struct Lane {
     int stage;
     // pixel / sample bookkeeping
     int px, py;
-    uint32_t si;
+    uint32_t si, s_end;     // current sample, end of this item's sample range
     Smp smp;
     float fX, fY, fZ, fW;   // film accumulators of the lane's own pixel
     // path state (PathIntegrator::Li locals)
@@ -96,8 +103,8 @@ template <class Smp> struct Lane {
         L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
         stage = ST_EXTEND;
     }
-    HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
-        px = x; py = y; si = 0; fX = fY = fZ = fW = 0.f;
+    HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y, uint32_t s0 = 0, uint32_t n = 0) {
+        px = x; py = y; si = s0; s_end = s0 + (n ? n : (uint32_t)rp.spp); fX = fY = fZ = fW = 0.f;
         smp.begin_pixel(rp, x, y);
         begin_sample(rp);
     }
@@ -132,7 +139,7 @@ template <class Smp> struct Lane {
             }
         if (wc) wc->samples++;
         ++si;
-        if (si < (uint32_t)rp.spp) { begin_sample(rp); return; }
+        if (si < s_end) { begin_sample(rp); return; }
         float *f = film + 4 * ((int64_t)(py - rp.y_start) * rp.x_count + (px - rp.x_start));
         film_atomic_add(f + 0, fX); film_atomic_add(f + 1, fY); film_atomic_add(f + 2, fZ); film_atomic_add(f + 3, fW);
         stage = ST_IDLE;

@@ -58,7 +58,9 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
-    rp->n_items = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
+    rp->chunk = rd->spp < 64 ? rd->spp : 64;
+    rp->items_per_pass = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
+    rp->n_items = rp->items_per_pass * (rd->spp / rp->chunk);
 }
 
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
@@ -75,10 +77,10 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
         // sums are deterministic
 #pragma omp for schedule(dynamic, 64)
         for (int64_t item = 0; item < rp.n_items; ++item) {
-            int x, y;
-            if (!item_to_pixel(rp, item, &x, &y)) continue;
+            int x, y; uint32_t s0;
+            if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
             Lane<LdHashSrc> lane; lane.init();
-            lane.begin_pixel(rp, x, y);
+            lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;

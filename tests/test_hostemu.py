@@ -109,3 +109,17 @@ def test_replay_mode_reproduces_reference_image(cases, pairs, name):
     differing = (np.abs(img - ref).max(axis=2) > 0).mean()
     assert differing < 1e-3, differing
     assert film.rmse(img, ref) < 1e-3
+
+
+def test_sample_chunking_above_64_spp(cases, pairs):
+    """spp > 64 splits a pixel into several work items (64 samples each) that flush separately:
+    same samples, sums regrouped."""
+    s = cases["env"]
+    o, e = pairs["env"]
+    rd = hash_rd(s, seed=9, spp=256)
+    rd.x_count, rd.y_count, rd.xres, rd.yres = 40, 24, s.render.xres, s.render.yres
+    fo, so = o.render(s.camera, rd)
+    fe, se = e.render(s.camera, rd)
+    assert so[0] == se[0] == 40 * 24 * 256
+    assert np.array_equal(fo[..., 3], fe[..., 3])
+    assert np.allclose(fo, fe, rtol=2e-6, atol=1e-6)
