@@ -122,4 +122,4 @@ def test_sample_chunking_above_64_spp(cases, pairs):
     fe, se = e.render(s.camera, rd)
     assert so[0] == se[0] == 40 * 24 * 256
     assert np.array_equal(fo[..., 3], fe[..., 3])
-    assert np.allclose(fo, fe, rtol=2e-6, atol=1e-6)
+    assert np.allclose(fo, fe, rtol=1e-5, atol=1e-5)
