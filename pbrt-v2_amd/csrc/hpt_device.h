@@ -32,6 +32,29 @@
 
 namespace hpt {
 
+// experiment switches: outline (noinline) the big cold shading blocks to cut code size / register peaks
+#if defined(__HIPCC__)
+#ifdef HPT_NI_SHADE
+#define HPT_FN_SHADE __device__ __noinline__
+#else
+#define HPT_FN_SHADE HPT_FN
+#endif
+#ifdef HPT_NI_LIGHT
+#define HPT_FN_LIGHT __device__ __noinline__
+#else
+#define HPT_FN_LIGHT HPT_FN
+#endif
+#ifdef HPT_NI_BSDF
+#define HPT_FN_BSDF __device__ __noinline__
+#else
+#define HPT_FN_BSDF HPT_FN
+#endif
+#else
+#define HPT_FN_SHADE HPT_FN
+#define HPT_FN_LIGHT HPT_FN
+#define HPT_FN_BSDF HPT_FN
+#endif
+
 #define HPT_PI 3.14159265358979323846f       /* core/pbrt.h:190 — a FLOAT literal in pbrt */
 #define HPT_INV_PI 0.31830988618379067154f
 #define HPT_INV_TWOPI 0.15915494309189533577f
@@ -621,7 +644,7 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
 }
 HPT_FN bool bx_match(const Bsdf &b, int i, int flags) { int t = b.type(i); return (t & flags) == t; }
 // BSDF::f (reflection.cpp:612-626)
-HPT_FN f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags, LaneStack ls) {
+HPT_FN_BSDF f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags, LaneStack ls) {
     f3 wi = b.w2l(wiW), wo = b.w2l(woW);
     if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
     else flags &= ~BSDF_REFLECTION;
@@ -638,7 +661,7 @@ HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
     return matching > 0 ? pdf / matching : 0.f;
 }
 // BSDF::Sample_f (reflection.cpp:522-580)
-HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
+HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
                         int flags, int *sampledType, LaneStack ls) {
     int matching = 0;
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) ++matching;
@@ -670,7 +693,7 @@ HPT_FN f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float 
 // Triangle::Intersect tail (trianglemesh.cpp:162-207), DifferentialGeometry ctor (diffgeom.cpp:40-55),
 // Triangle::GetShadingGeometry (trianglemesh.cpp:293-368), BSDF ctor (reflection.cpp:601-609),
 // Material::GetBSDF.  Returns the primitive's area light index (or -1) and rayEpsilon.
-HPT_FN void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
+HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
     if (hit.prim >= sc.n_tris) {
         const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
         float t;
@@ -840,7 +863,7 @@ HPT_FN float quadric_pdf(const hpt_quadric &q, f3 p, f3 wi) { // Sphere::Pdf (sp
     if (pdf == HPT_INF || pdf == -HPT_INF) pdf = 0.f;
     return pdf;
 }
-HPT_FN float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
+HPT_FN_LIGHT float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
     if (l.kind == HPT_LIGHT_DIFFUSE_AREA) { // ShapeSet::Pdf (core/light.cpp:157-162), one shape
         float pdf = 0.f;
         pdf += l.area * quadric_pdf(sc.quadrics[l.quadric], p, wi);
@@ -865,7 +888,7 @@ HPT_FN float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
 }
 // Light::Sample_L(p, pEpsilon, ls, ...) : point.cpp:50-57, diffuse.cpp:69-81, infinite.cpp:195-221.
 // Outputs wi, pdf and the shadow ray of the VisibilityTester (core/light.h:87-96).
-HPT_FN f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow) {
+HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow) {
     if (l.kind == HPT_LIGHT_POINT) {
         f3 lp = mk3(l.pos[0], l.pos[1], l.pos[2]);
         *wi = normalize(lp - p);

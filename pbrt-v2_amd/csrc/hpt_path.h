@@ -203,7 +203,9 @@ template <class Smp> struct Lane {
         Ld = S(0.f);
         bool has_shadow = false;
         has_mis = false;
-        Ray shadow; shadow.o = p; shadow.d = n; shadow.mint = 0.f; shadow.maxt = 0.f;
+        // the incoming ray is dead from here on (wo, p, eps are taken): its registers receive the
+        // shadow ray directly
+        Ray &shadow = ray;
         const bool useArrays = bounce < 3;                                  // SAMPLE_DEPTH (path.h:55)
         if (sc.n_lights > 0) {                                              // UniformSampleOneLight
             float ln, ls0, ls1, ls2, bs0, bs1, bs2;
@@ -281,7 +283,7 @@ template <class Smp> struct Lane {
                 if (bounce == rp.maxdepth) has_next = false;
             }
         }
-        if (has_shadow) { ray = shadow; stage = ST_SHADOW; }
+        if (has_shadow) stage = ST_SHADOW;
         else after_shadow(sc, rp, film, wc);
     }
 };
