@@ -96,7 +96,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 hpt_set_error("material %d: kd-tree offsets out of range", m);
                 return HPT_E_INVALID;
             }
-            // the device walks the tree with a 32-entry per-lane stack: bound its depth
+            // the device walks the tree with a 26-entry per-lane stack: bound its depth
             {
                 const int32_t *bits = d->ipool + ma.kd_bits_off;
                 std::vector<std::pair<uint32_t, int> > todo;
@@ -113,7 +113,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                     if ((b >> 2) & 1u) todo.push_back(std::make_pair(n + 1, depth + 1));
                     if ((b >> 3) < (uint32_t)ma.kd_nnodes) todo.push_back(std::make_pair(b >> 3, depth + 1));
                 }
-                if (maxDepth > 30) { hpt_set_error("material %d: kd-tree depth %d exceeds the device stack", m, maxDepth); return HPT_E_UNSUPPORTED; }
+                if (maxDepth > 24) { hpt_set_error("material %d: kd-tree depth %d exceeds the device stack", m, maxDepth); return HPT_E_UNSUPPORTED; }
             }
         } else { hpt_set_error("material %d: unknown kind %d", m, ma.kind); return HPT_E_UNSUPPORTED; }
     }

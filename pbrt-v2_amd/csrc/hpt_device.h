@@ -360,84 +360,89 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
     return !miss && (tmin < ray.maxt) && (tmax > ray.mint);
 }
 
-#ifndef HPT_TRAV
-#define HPT_TRAV 1   /* loop shape: 0 = node XOR leaf per iteration, 1 = node then leaf per iteration ("if-if"),
-                        2 = descend to a leaf, then test it ("while-while"); A/B in profiles/ */
-#endif
 #define HPT_TRAV_EMPTY ((int32_t)0x80000000)
 
-template <bool COUNT>
-HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
-    hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f;
+// Resumable traversal: the state of one ray's walk.  trav_begin() runs the quadric pre-test and
+// positions the walk at the root; trav_step() advances it by one interior-node step followed, if
+// that reached a leaf, by the leaf's triangle tests ("if-if" loop shape: measured best on gfx950
+// against node-XOR-leaf and while-while, profiles/r01_ab.md).  done() when node == HPT_TRAV_EMPTY.
+struct TravState {
+    Ray ray;
+    f3 invd;
+    bool nx, ny, nz, anyhit;
+    int32_t node;
+    int sp;
+    Hit hit;
+    HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
+};
+
+HPT_FN void trav_begin(const DScene &sc, TravState &ts, const Ray &ray, bool anyhit) {
+    ts.ray = ray; ts.anyhit = anyhit;
+    ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f;
+    ts.sp = 0; ts.node = 0;
     // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
     for (int q = 0; q < sc.n_quadrics; ++q) {
         float t;
-        if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
-            if (anyhit) { hit->prim = sc.n_tris + q; return true; }
-            hit->prim = sc.n_tris + q; hit->t = t; ray.maxt = t;
+        if (quadric_intersect(sc.quadrics[q], ts.ray, &t, nullptr)) {
+            ts.hit.prim = sc.n_tris + q;
+            if (anyhit) { ts.node = HPT_TRAV_EMPTY; break; }
+            ts.hit.t = t; ts.ray.maxt = t;
         }
     }
-    if (sc.n_nodes == 0) return hit->prim >= 0;
-    const f3 invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-    const bool nx = invd.x < 0, ny = invd.y < 0, nz = invd.z < 0;
-    int sp = 0;
-    int32_t node = 0;
-    // interior step: one 64-byte node fetch, two slab tests, near child first, far child stacked
-#define HPT_NODE_STEP()                                                                              \
-    do {                                                                                             \
-        const f4 *np = sc.nodes + 4 * (int64_t)node;                                                 \
-        f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];                                           \
-        if (COUNT) cnt->nodes++;                                                                     \
-        float t0, t1;                                                                                \
-        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, invd, nx, ny, nz, &t0);              \
-        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, invd, nx, ny, nz, &t1);              \
-        int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);                                                \
-        if (h0 && h1) {                                                                              \
-            bool swap = t1 < t0;                                                                     \
-            stack[sp * stride] = swap ? c0 : c1; ++sp;                                               \
-            node = swap ? c1 : c0;                                                                   \
-        } else if (h0) node = c0;                                                                    \
-        else if (h1) node = c1;                                                                      \
-        else if (sp > 0) { --sp; node = stack[sp * stride]; }                                        \
-        else node = HPT_TRAV_EMPTY;                                                                  \
-    } while (0)
-    // leaf step: <= 8 pre-gathered 48-byte triangle records; then pop
-#define HPT_LEAF_STEP()                                                                              \
-    do {                                                                                             \
-        uint32_t code = (uint32_t)~node;                                                             \
-        uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;                              \
-        for (uint32_t k = 0; k < count; ++k) {                                                       \
-            const f4 *tp = sc.tris + 3 * (int64_t)(first + k);                                       \
-            f4 a = tp[0], b = tp[1], c = tp[2];                                                      \
-            if (COUNT) cnt->tris++;                                                                  \
-            float t, b1, b2;                                                                         \
-            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) { \
-                hit->prim = (int32_t)(first + k);                                                    \
-                if (anyhit) return true;                                                             \
-                hit->t = t; hit->b1 = b1; hit->b2 = b2;                                              \
-                ray.maxt = t; /* GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174) */ \
-            }                                                                                        \
-        }                                                                                            \
-        if (sp > 0) { --sp; node = stack[sp * stride]; } else node = HPT_TRAV_EMPTY;                 \
-    } while (0)
-#if HPT_TRAV == 0
-    while (node != HPT_TRAV_EMPTY) {
-        if (node >= 0) HPT_NODE_STEP();
-        else HPT_LEAF_STEP();
+    if (sc.n_nodes == 0) ts.node = HPT_TRAV_EMPTY;
+    ts.invd = mk3(1.f / ts.ray.d.x, 1.f / ts.ray.d.y, 1.f / ts.ray.d.z);
+    ts.nx = ts.invd.x < 0; ts.ny = ts.invd.y < 0; ts.nz = ts.invd.z < 0;
+}
+
+template <bool COUNT>
+HPT_FN void trav_step(const DScene &sc, TravState &ts, int32_t *stack, int stride, TravCounters *cnt) {
+    if (ts.node >= 0) { // interior: one 64-byte node fetch, two slab tests, near child first, far child stacked
+        const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
+        f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (COUNT) cnt->nodes++;
+        float t0, t1;
+        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ts.ray, ts.invd, ts.nx, ts.ny, ts.nz, &t0);
+        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ts.ray, ts.invd, ts.nx, ts.ny, ts.nz, &t1);
+        int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
+        if (h0 && h1) {
+            bool swap = t1 < t0;
+            stack[ts.sp * stride] = swap ? c0 : c1; ++ts.sp;
+            ts.node = swap ? c1 : c0;
+        } else if (h0) ts.node = c0;
+        else if (h1) ts.node = c1;
+        else if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
+        else ts.node = HPT_TRAV_EMPTY;
     }
-#elif HPT_TRAV == 1
-    while (node != HPT_TRAV_EMPTY) {
-        if (node >= 0) HPT_NODE_STEP();
-        if (node < 0 && node != HPT_TRAV_EMPTY) HPT_LEAF_STEP();
+    if (ts.node < 0 && ts.node != HPT_TRAV_EMPTY) { // leaf: <= 8 pre-gathered 48-byte triangle records, then pop
+        uint32_t code = (uint32_t)~ts.node;
+        uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+        bool stop = false;
+        for (uint32_t k = 0; k < count; ++k) {
+            const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
+            f4 a = tp[0], b = tp[1], c = tp[2];
+            if (COUNT) cnt->tris++;
+            float t, b1, b2;
+            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ts.ray, &t, &b1, &b2)) {
+                ts.hit.prim = (int32_t)(first + k);
+                if (ts.anyhit) { stop = true; break; }
+                ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
+                ts.ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
+            }
+        }
+        if (stop) ts.node = HPT_TRAV_EMPTY;
+        else if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
+        else ts.node = HPT_TRAV_EMPTY;
     }
-#else
-    while (node != HPT_TRAV_EMPTY) {
-        while (node >= 0) HPT_NODE_STEP();
-        if (node != HPT_TRAV_EMPTY) HPT_LEAF_STEP();
-    }
-#endif
-#undef HPT_NODE_STEP
-#undef HPT_LEAF_STEP
+}
+
+// One ray, start to finish, on this lane.  `ray.maxt` is shrunk to the hit distance like the reference does.
+template <bool COUNT>
+HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
+    TravState ts;
+    trav_begin(sc, ts, ray, anyhit);
+    while (!ts.done()) trav_step<COUNT>(sc, ts, stack, stride, cnt);
+    ray.maxt = ts.ray.maxt;
+    *hit = ts.hit;
     return hit->prim >= 0;
 }
 

@@ -5,7 +5,15 @@
 #include "hpt_path.h"
 
 #define HPT_BLOCK 256        /* threads per workgroup = 4 wave64 */
-#define HPT_STACK_DEPTH 32   /* LDS traversal stack entries per lane (32 KiB per workgroup) */
+#define HPT_STACK_DEPTH 26   /* LDS traversal stack entries per lane (26 KiB per workgroup); with the 13 KiB ray
+                                pool that is 39 KiB -> 4 workgroups (16 waves) per CU in 160 KiB of LDS.
+                                The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2. */
+#ifndef HPT_POOL
+#define HPT_POOL 1           /* 1: block-level ray pool + dynamic fetch in the traversal phase; 0: one ray per lane */
+#endif
+#ifndef HPT_FETCH_MIN
+#define HPT_FETCH_MIN 16     /* refill idle lanes from the pool once this many lanes of the wave are idle */
+#endif
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4    /* __launch_bounds__ 2nd arg: waves per SIMD the register allocator must allow (A/B in profiles/r01_ab.md) */
 #endif

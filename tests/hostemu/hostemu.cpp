@@ -28,7 +28,7 @@ struct emu_scene {
 
 extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf) {
     emu_scene *s = new emu_scene();
-    if (flatten_scene(desc, max_leaf, 30, &s->fs) != HPT_OK) { delete s; return nullptr; }
+    if (flatten_scene(desc, max_leaf, 24, &s->fs) != HPT_OK) { delete s; return nullptr; }
     s->quadrics.assign(desc->quadrics, desc->quadrics + desc->n_quadrics);
     s->materials = s->fs.materials;
     s->lights.assign(desc->lights, desc->lights + desc->n_lights);

@@ -48,7 +48,7 @@ def test_intersect_matches_oracle(cases, pairs, name):
 def test_bvh_depth_is_bounded(pairs):
     for n, (_, e) in pairs.items():
         info = e.info()
-        assert info["max_depth"] <= 30 and info["n_nodes"] > 0
+        assert info["max_depth"] <= 25 and info["n_nodes"] > 0
 
 
 @pytest.mark.parametrize("name,material", [("cfg1", 1), ("cfg1", 2), ("cfg1", 3), ("b8", 1), ("env", 0)])
