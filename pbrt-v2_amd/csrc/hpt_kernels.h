@@ -9,7 +9,11 @@
                                 pool that is 39 KiB -> 4 workgroups (16 waves) per CU in 160 KiB of LDS.
                                 The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2. */
 #ifndef HPT_POOL
-#define HPT_POOL 1           /* 1: block-level ray pool + dynamic fetch in the traversal phase; 0: one ray per lane */
+#define HPT_POOL 0           /* 0: each lane traces its own pending ray (default).  1: workgroup ray pool in LDS with
+                                dynamic fetch (a lane whose ray is done takes another lane's ray instead of idling).
+                                Measured SLOWER on gfx950 (killeroo 348 vs 483, bunny 97 vs 124, soup 131 vs 181
+                                Msamples/s, profiles/r01_ab.md): two workgroup barriers per phase, +80 B/lane of
+                                spills and LDS round trips cost more than the idle lanes they recover. */
 #endif
 #ifndef HPT_FETCH_MIN
 #define HPT_FETCH_MIN 16     /* refill idle lanes from the pool once this many lanes of the wave are idle */
