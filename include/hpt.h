@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 2
+#define HPT_VERSION 3
 
 enum {
     HPT_OK = 0,
@@ -69,9 +69,28 @@ typedef struct hpt_mesh {
     int32_t arealight;           /* index into lights, or -1 */
     int32_t reverse_orientation; /* Shape::ReverseOrientation */
     int32_t swaps_handedness;    /* Shape::TransformSwapsHandedness */
+    int32_t instance;            /* index into instances, or -1: mesh lives directly in the world */
+    int32_t pad;
     float o2w[16];               /* ObjectToWorld->m    */
     float o2w_inv[16];           /* ObjectToWorld->mInv */
 } hpt_mesh;
+
+/* One animated instance: TransformedPrimitive(BVHAccel(refined shape), AnimatedTransform)
+ * (core/primitive.h:104-125, created by pbrtShape for an animated CTM, core/api.cpp:1012-1044).
+ * Its meshes are built with identity ObjectToWorld (api.cpp:1019-1021), i.e. their P are in the
+ * instance's own space; rays reach them through WorldToPrimitive interpolated at the ray's time
+ * (AnimatedTransform::Interpolate, core/transform.cpp:371-396). */
+typedef struct hpt_instance {
+    int32_t actually_animated;   /* AnimatedTransform::actuallyAnimated               */
+    int32_t pad;
+    float start_time, end_time;  /* RenderOptions::transformStartTime / EndTime       */
+    float bounds[6];             /* TransformedPrimitive::WorldBound() (MotionBounds) */
+    float T[2][3];               /* AnimatedTransform::Decompose of start / end       */
+    float R[2][4];               /* quaternion (v.xyz, w)                             */
+    float S[2][16];
+    float w2p_m[2][16];          /* start / end WorldToPrimitive ->m                  */
+    float w2p_minv[2][16];       /*                               ->mInv              */
+} hpt_instance;
 
 /* Sphere (shapes/sphere.cpp:40-49) or Disk (shapes/disk.cpp:40-47). */
 typedef struct hpt_quadric {
@@ -129,6 +148,7 @@ typedef struct hpt_scene_desc {
     const hpt_quadric *quadrics;   int32_t n_quadrics;
     const hpt_material *materials; int32_t n_materials;
     const hpt_light *lights;       int32_t n_lights;   /* order = Scene::lights */
+    const hpt_instance *instances; int32_t n_instances;
     const float *fpool;            int64_t n_f;
     const int32_t *ipool;          int64_t n_i;
 } hpt_scene_desc;

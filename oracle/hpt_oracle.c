@@ -90,6 +90,113 @@ static inline v3 xf_normal(const float *minv, v3 n) { /* transform.h:230-236: tr
              minv[2] * x + minv[6] * y + minv[10] * z);
 }
 
+
+/* ---- 4x4 matrices, quaternions, AnimatedTransform (core/transform.{h,cpp}, core/quaternion.cpp) ---- */
+typedef struct { float m[16]; } mat4;
+static mat4 m4_identity(void) { mat4 r; memset(&r, 0, sizeof(r)); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f; return r; }
+static mat4 m4_mul(const mat4 *a, const mat4 *b) { /* Matrix4x4::Mul transform.h:83-92 */
+    mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[4 * i + j] = a->m[4 * i + 0] * b->m[0 + j] + a->m[4 * i + 1] * b->m[4 + j] +
+                             a->m[4 * i + 2] * b->m[8 + j] + a->m[4 * i + 3] * b->m[12 + j];
+    return r;
+}
+static mat4 m4_transpose(const mat4 *a) { mat4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = a->m[4 * j + i]; return r; }
+static mat4 m4_inverse(const mat4 *in) { /* Inverse(Matrix4x4) transform.cpp:76-135 (Gauss-Jordan, full pivoting) */
+    int indxc[4], indxr[4];
+    int ipiv[4] = {0, 0, 0, 0};
+    float minv[4][4];
+    memcpy(minv, in->m, 16 * sizeof(float));
+    for (int i = 0; i < 4; i++) {
+        int irow = -1, icol = -1;
+        float big = 0.;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] != 1) {
+                for (int k = 0; k < 4; k++) {
+                    if (ipiv[k] == 0) {
+                        if (fabsf(minv[j][k]) >= big) { big = (float)fabsf(minv[j][k]); irow = j; icol = k; }
+                    }
+                }
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol) for (int k = 0; k < 4; ++k) { float t = minv[irow][k]; minv[irow][k] = minv[icol][k]; minv[icol][k] = t; }
+        indxr[i] = irow; indxc[i] = icol;
+        float pivinv = 1.f / minv[icol][icol];
+        minv[icol][icol] = 1.f;
+        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j != icol) {
+                float save = minv[j][icol];
+                minv[j][icol] = 0;
+                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
+            }
+        }
+    }
+    for (int j = 3; j >= 0; j--) {
+        if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) { float t = minv[k][indxr[j]]; minv[k][indxr[j]] = minv[k][indxc[j]]; minv[k][indxc[j]] = t; }
+    }
+    mat4 r; memcpy(r.m, minv, 16 * sizeof(float));
+    return r;
+}
+static int m4_is_identity(const mat4 *a) { /* Transform::IsIdentity transform.h:138-147 */
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (a->m[4 * i + j] != (i == j ? 1.f : 0.f)) return 0;
+    return 1;
+}
+typedef struct { mat4 m, minv; } xform;
+typedef struct { v3 v; float w; } quat;
+static inline float qdot(quat a, quat b) { return dot(a.v, b.v) + a.w * b.w; }          /* quaternion.h:104-106 */
+static inline quat qscale(quat q, float f) { quat r; r.v = vmul(q.v, f); r.w = q.w * f; return r; }
+static inline quat qadd(quat a, quat b) { quat r; r.v = vadd(a.v, b.v); r.w = a.w + b.w; return r; }
+static inline quat qsub(quat a, quat b) { quat r; r.v = vsub(a.v, b.v); r.w = a.w - b.w; return r; }
+static inline quat qnormalize(quat q) { float f = sqrtf(qdot(q, q)); quat r; r.v = vdiv(q.v, f); r.w = q.w / f; return r; } /* :109-111; v /= f is inv-multiply, w /= f divides */
+static quat slerp(float t, quat q1, quat q2) { /* quaternion.cpp:95-107 */
+    float cosTheta = qdot(q1, q2);
+    if (cosTheta > .9995f) return qnormalize(qadd(qscale(q1, 1.f - t), qscale(q2, t)));
+    float theta = acosf(clampf(cosTheta, -1.f, 1.f));
+    float thetap = theta * t;
+    quat qperp = qnormalize(qsub(q2, qscale(q1, cosTheta)));
+    return qadd(qscale(q1, cosf(thetap)), qscale(qperp, sinf(thetap)));
+}
+static xform quat_to_transform(quat q) { /* Quaternion::ToTransform quaternion.cpp:39-59 */
+    float xx = q.v.x * q.v.x, yy = q.v.y * q.v.y, zz = q.v.z * q.v.z;
+    float xy = q.v.x * q.v.y, xz = q.v.x * q.v.z, yz = q.v.y * q.v.z;
+    float wx = q.v.x * q.w, wy = q.v.y * q.w, wz = q.v.z * q.w;
+    mat4 m = m4_identity();
+    m.m[0] = 1.f - 2.f * (yy + zz); m.m[1] = 2.f * (xy + wz);       m.m[2] = 2.f * (xz - wy);
+    m.m[4] = 2.f * (xy - wz);       m.m[5] = 1.f - 2.f * (xx + zz); m.m[6] = 2.f * (yz + wx);
+    m.m[8] = 2.f * (xz + wy);       m.m[9] = 2.f * (yz - wx);       m.m[10] = 1.f - 2.f * (xx + yy);
+    xform r; r.m = m4_transpose(&m); r.minv = m;
+    return r;
+}
+static xform xf_mul(const xform *a, const xform *b) { /* Transform::operator* transform.cpp:286-290 */
+    xform r; r.m = m4_mul(&a->m, &b->m); r.minv = m4_mul(&b->minv, &a->minv);
+    return r;
+}
+/* AnimatedTransform::Interpolate (core/transform.cpp:371-396) */
+static xform anim_interpolate(const hpt_instance *in, float time) {
+    xform r;
+    if (!in->actually_animated || time <= in->start_time) { memcpy(r.m.m, in->w2p_m[0], 64); memcpy(r.minv.m, in->w2p_minv[0], 64); return r; }
+    if (time >= in->end_time) { memcpy(r.m.m, in->w2p_m[1], 64); memcpy(r.minv.m, in->w2p_minv[1], 64); return r; }
+    float dt = (time - in->start_time) / (in->end_time - in->start_time);
+    v3 T0 = V(in->T[0][0], in->T[0][1], in->T[0][2]), T1 = V(in->T[1][0], in->T[1][1], in->T[1][2]);
+    v3 trans = vadd(vmul(T0, 1.f - dt), vmul(T1, dt));
+    quat q0 = {V(in->R[0][0], in->R[0][1], in->R[0][2]), in->R[0][3]}, q1 = {V(in->R[1][0], in->R[1][1], in->R[1][2]), in->R[1][3]};
+    quat rotate = slerp(dt, q0, q1);
+    mat4 scale = m4_identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            scale.m[4 * i + j] = (1.f - dt) * in->S[0][4 * i + j] + dt * in->S[1][4 * i + j];
+    xform A; A.m = m4_identity(); A.minv = m4_identity();  /* Translate(trans) transform.cpp:145-155 */
+    A.m.m[3] = trans.x; A.m.m[7] = trans.y; A.m.m[11] = trans.z;
+    A.minv.m[3] = -trans.x; A.minv.m[7] = -trans.y; A.minv.m[11] = -trans.z;
+    xform B = quat_to_transform(rotate);
+    xform C; C.m = scale; C.minv = m4_inverse(&scale);      /* Transform(const Matrix4x4&) transform.h:111-113 */
+    xform AB = xf_mul(&A, &B);
+    return xf_mul(&AB, &C);
+}
+
 /* ---- Spectrum = RGBSpectrum (pbrt.h:156, core/spectrum.h) -------------------------------- */
 static inline rgb S(float v) { rgb r = {{v, v, v}}; return r; }
 static inline rgb sadd(rgb a, rgb b) { rgb r = {{a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]}}; return r; }
@@ -292,15 +399,15 @@ typedef struct { /* LinearBVHNode, accelerators/bvh.cpp:113-123 */
     uint8_t nprims, axis, pad[2];
 } lnode;
 
+typedef struct { int32_t *ordered; lnode *nodes; int64_t nnodes; } bvh_t;
 struct orc_scene {
     hpt_scene_desc d; /* deep copy */
-    int64_t ntris;
+    int64_t ntris;            /* prim ids: [0,ntris) triangles of ALL meshes, then quadrics, then instances */
     int64_t *mesh_base;       /* first global prim id of each mesh */
     int32_t *prim_mesh;       /* per triangle prim: mesh */
-    int64_t nprims;           /* ntris + n_quadrics */
-    int32_t *ordered;         /* BVH-ordered primitive ids */
-    lnode *nodes;
-    int64_t nnodes;
+    int64_t nprims;           /* ntris + n_quadrics + n_instances */
+    bvh_t top;                /* Scene::aggregate */
+    bvh_t *inst;              /* TransformedPrimitive::primitive of each instance */
 };
 
 typedef struct { v3 o, d; float mint, maxt, time; int depth; } ray_t;
@@ -315,7 +422,7 @@ static void dg_init(dgeom *dg, v3 P, v3 dpdu, v3 dpdv, float u, float v, int fli
     if (flip) dg->nn = vmul(dg->nn, -1.f);
 }
 
-typedef struct { dgeom dg; int64_t prim; float rayEpsilon; float t, b1, b2; } isect_t;
+typedef struct { dgeom dg; int64_t prim; float rayEpsilon; float t, b1, b2; int inst; mat4 w2p_m; } isect_t;
 
 static void tri_verts(const orc_scene *s, int64_t prim, const hpt_mesh **mo, int *vi, v3 *p1, v3 *p2, v3 *p3) {
     int m = s->prim_mesh[prim];
@@ -479,23 +586,56 @@ static bbox quadric_world_bound(const hpt_quadric *q) { /* Shape::WorldBound -> 
     return b;
 }
 
-/* GeometricPrimitive::Intersect (core/primitive.cpp:163-176): shrinks ray.maxt on hit */
+static int bvh_intersect(const orc_scene *s, const bvh_t *bvh, ray_t *ray, isect_t *is, int anyhit, uint64_t *st);
+/* GeometricPrimitive::Intersect (core/primitive.cpp:163-176): shrinks ray.maxt on hit;
+ * TransformedPrimitive::Intersect (core/primitive.cpp:95-119) for instance prims */
 static int prim_intersect(const orc_scene *s, int64_t prim, ray_t *ray, isect_t *is, uint64_t *st) {
     if (prim < s->ntris) {
         if (!tri_intersect(s, prim, ray, is, 1, st)) return 0;
         ray->maxt = is->t;
+        is->inst = -1;
         return 1;
     }
-    float thit, eps;
-    if (!quadric_intersect(&s->d.quadrics[prim - s->ntris], ray, &thit, &eps, &is->dg)) return 0;
-    is->prim = prim; is->t = thit; is->rayEpsilon = eps; is->b1 = is->b2 = 0.f;
-    ray->maxt = thit;
+    if (prim < s->ntris + s->d.n_quadrics) {
+        float thit, eps;
+        if (!quadric_intersect(&s->d.quadrics[prim - s->ntris], ray, &thit, &eps, &is->dg)) return 0;
+        is->prim = prim; is->t = thit; is->rayEpsilon = eps; is->b1 = is->b2 = 0.f; is->inst = -1;
+        ray->maxt = thit;
+        return 1;
+    }
+    int k = (int)(prim - s->ntris - s->d.n_quadrics);
+    xform w2p = anim_interpolate(&s->d.instances[k], ray->time);
+    ray_t r2 = *ray;                               /* Ray ray = w2p(r) transform.h:237-243 */
+    r2.o = xf_point(w2p.m.m, ray->o);
+    r2.d = xf_vec(w2p.m.m, ray->d);
+    if (!bvh_intersect(s, &s->inst[k], &r2, is, 0, st)) return 0;
+    ray->maxt = r2.maxt;
+    is->inst = k;
+    is->w2p_m = w2p.m;       /* isect->WorldToObject = identity * w2p ; ObjectToWorld = Inverse(...) */
+    if (!m4_is_identity(&w2p.m)) {
+        /* PrimitiveToWorld = Inverse(w2p): m = w2p.mInv, mInv = w2p.m */
+        is->dg.p = xf_point(w2p.minv.m, is->dg.p);
+        is->dg.nn = normalize(xf_normal(w2p.m.m, is->dg.nn));
+        is->dg.dpdu = xf_vec(w2p.minv.m, is->dg.dpdu);
+        is->dg.dpdv = xf_vec(w2p.minv.m, is->dg.dpdv);
+    }
     return 1;
 }
 static int prim_intersect_p(const orc_scene *s, int64_t prim, const ray_t *ray, uint64_t *st) {
     if (prim < s->ntris) { isect_t tmp; return tri_intersect(s, prim, ray, &tmp, 0, st); }
-    float thit, eps;
-    return quadric_intersect(&s->d.quadrics[prim - s->ntris], ray, &thit, &eps, NULL);
+    if (prim < s->ntris + s->d.n_quadrics) {
+        float thit, eps;
+        return quadric_intersect(&s->d.quadrics[prim - s->ntris], ray, &thit, &eps, NULL);
+    }
+    /* TransformedPrimitive::IntersectP (primitive.cpp:122-124) via AnimatedTransform::operator()(Ray)
+     * (transform.cpp:416-427): same boundary handling as Interpolate */
+    int k = (int)(prim - s->ntris - s->d.n_quadrics);
+    xform w2p = anim_interpolate(&s->d.instances[k], ray->time);
+    ray_t r2 = *ray;
+    r2.o = xf_point(w2p.m.m, ray->o);
+    r2.d = xf_vec(w2p.m.m, ray->d);
+    isect_t tmp;
+    return bvh_intersect(s, &s->inst[k], &r2, &tmp, 1, st);
 }
 
 /* ---- BVH build (accelerators/bvh.cpp:153-395, SAH, maxPrimsInNode = 4) ------------------- */
@@ -604,40 +744,62 @@ orc_scene *orc_scene_create(const hpt_scene_desc *desc) {
 #define DUP(field, n, T) do { if ((n) > 0) { T *p_ = (T *)malloc(sizeof(T) * (size_t)(n)); memcpy(p_, desc->field, sizeof(T) * (size_t)(n)); s->d.field = p_; } else s->d.field = NULL; } while (0)
     DUP(meshes, desc->n_meshes, hpt_mesh); DUP(quadrics, desc->n_quadrics, hpt_quadric);
     DUP(materials, desc->n_materials, hpt_material); DUP(lights, desc->n_lights, hpt_light);
+    DUP(instances, desc->n_instances, hpt_instance);
     DUP(fpool, desc->n_f, float); DUP(ipool, desc->n_i, int32_t);
 #undef DUP
     s->mesh_base = (int64_t *)calloc((size_t)desc->n_meshes + 1, sizeof(int64_t));
     for (int m = 0; m < desc->n_meshes; ++m) { s->mesh_base[m] = s->ntris; s->ntris += desc->meshes[m].ntris; }
-    s->nprims = s->ntris + desc->n_quadrics;
+    s->nprims = s->ntris + desc->n_quadrics + desc->n_instances;
     s->prim_mesh = (int32_t *)malloc(sizeof(int32_t) * (size_t)(s->ntris + 1));
     for (int m = 0; m < desc->n_meshes; ++m)
         for (int64_t t = 0; t < desc->meshes[m].ntris; ++t) s->prim_mesh[s->mesh_base[m] + t] = m;
+    s->inst = (bvh_t *)calloc((size_t)desc->n_instances + 1, sizeof(bvh_t));
     if (s->nprims == 0) return s;
-    binfo *bd = (binfo *)malloc(sizeof(binfo) * (size_t)s->nprims);
-    for (int64_t p = 0; p < s->nprims; ++p) {
-        bbox b;
-        if (p < s->ntris) {
+    /* one BVH per instance over its own triangles, then the top level over world triangles,
+     * quadrics and instances (bounded by their MotionBounds) */
+    for (int k = -1 + 0; k < desc->n_instances + 1; ++k) {
+        int which = (k == desc->n_instances) ? -1 : k;   /* instances first, top level (-1) last */
+        if (k == -1) continue;
+        binfo *bd = (binfo *)malloc(sizeof(binfo) * (size_t)s->nprims);
+        int64_t n = 0;
+        for (int64_t p = 0; p < s->ntris; ++p) {
+            if (s->d.meshes[s->prim_mesh[p]].instance != which) continue;
             const hpt_mesh *me; int vi[3]; v3 p1, p2, p3;
             tri_verts(s, p, &me, vi, &p1, &p2, &p3);
-            b = bbox_union_p(bbox_union_p(bbox_union_p(bbox_empty(), p1), p2), p3);
-        } else b = quadric_world_bound(&s->d.quadrics[p - s->ntris]);
-        bd[p].prim = (int32_t)p; bd[p].bounds = b;
-        bd[p].centroid = vadd(vmul(b.pmin, .5f), vmul(b.pmax, .5f)); /* bvh.cpp:47 */
+            bd[n].prim = (int32_t)p;
+            bd[n].bounds = bbox_union_p(bbox_union_p(bbox_union_p(bbox_empty(), p1), p2), p3);
+            ++n;
+        }
+        if (which == -1) {
+            for (int q = 0; q < desc->n_quadrics; ++q) { bd[n].prim = (int32_t)(s->ntris + q); bd[n].bounds = quadric_world_bound(&s->d.quadrics[q]); ++n; }
+            for (int i = 0; i < desc->n_instances; ++i) {
+                const float *bb = s->d.instances[i].bounds;
+                bd[n].prim = (int32_t)(s->ntris + desc->n_quadrics + i);
+                bd[n].bounds.pmin = V(bb[0], bb[1], bb[2]); bd[n].bounds.pmax = V(bb[3], bb[4], bb[5]);
+                ++n;
+            }
+        }
+        for (int64_t i = 0; i < n; ++i)
+            bd[i].centroid = vadd(vmul(bd[i].bounds.pmin, .5f), vmul(bd[i].bounds.pmax, .5f)); /* bvh.cpp:47 */
+        bvh_t *out = which == -1 ? &s->top : &s->inst[which];
+        if (n > 0) {
+            bctx c; c.s = s; c.bd = bd; c.ordered = (int32_t *)malloc(sizeof(int32_t) * (size_t)n); c.nordered = 0; c.total = 0;
+            bnode *root = bvh_build(&c, 0, n);
+            out->ordered = c.ordered; out->nnodes = c.total;
+            out->nodes = (lnode *)calloc((size_t)c.total, sizeof(lnode));
+            uint32_t off = 0;
+            bvh_flatten(out->nodes, root, &off);
+        }
+        free(bd);
     }
-    bctx c; c.s = s; c.bd = bd; c.ordered = (int32_t *)malloc(sizeof(int32_t) * (size_t)s->nprims); c.nordered = 0; c.total = 0;
-    bnode *root = bvh_build(&c, 0, s->nprims);
-    s->ordered = c.ordered; s->nnodes = c.total;
-    s->nodes = (lnode *)calloc((size_t)c.total, sizeof(lnode));
-    uint32_t off = 0;
-    bvh_flatten(s->nodes, root, &off);
-    free(bd);
     return s;
 }
 void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
+    for (int k = 0; k < s->d.n_instances; ++k) { free(s->inst[k].ordered); free(s->inst[k].nodes); }
     free((void *)s->d.meshes); free((void *)s->d.quadrics); free((void *)s->d.materials); free((void *)s->d.lights);
-    free((void *)s->d.fpool); free((void *)s->d.ipool);
-    free(s->mesh_base); free(s->prim_mesh); free(s->ordered); free(s->nodes); free(s);
+    free((void *)s->d.instances); free((void *)s->d.fpool); free((void *)s->d.ipool);
+    free(s->mesh_base); free(s->prim_mesh); free(s->top.ordered); free(s->top.nodes); free(s->inst); free(s);
 }
 
 /* slab test (accelerators/bvh.cpp:126-148) */
@@ -658,20 +820,19 @@ static inline int box_hit(const bbox *b, const ray_t *ray, v3 invDir, const uint
     return (tmin < ray->maxt) && (tmax > ray->mint);
 }
 /* BVHAccel::Intersect (bvh.cpp:403-454) / IntersectP (:457-503) */
-static int scene_intersect(const orc_scene *s, ray_t *ray, isect_t *is, int anyhit, uint64_t *st) {
-    if (!s->nodes) return 0;
-    if (st) st[anyhit ? 2 : 1]++;
+static int bvh_intersect(const orc_scene *s, const bvh_t *bvh, ray_t *ray, isect_t *is, int anyhit, uint64_t *st) {
+    if (!bvh->nodes) return 0;
     int hit = 0;
     v3 invDir = V(1.f / ray->d.x, 1.f / ray->d.y, 1.f / ray->d.z);
     uint32_t neg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
     uint32_t todoOffset = 0, nodeNum = 0, todo[64];
     while (1) {
-        const lnode *node = &s->nodes[nodeNum];
+        const lnode *node = &bvh->nodes[nodeNum];
         if (st) st[3]++;
         if (box_hit(&node->bounds, ray, invDir, neg)) {
             if (node->nprims > 0) {
                 for (uint32_t i = 0; i < node->nprims; ++i) {
-                    int64_t prim = s->ordered[node->offset + i];
+                    int64_t prim = bvh->ordered[node->offset + i];
                     if (anyhit) { if (prim_intersect_p(s, prim, ray, st)) return 1; }
                     else if (prim_intersect(s, prim, ray, is, st)) hit = 1;
                 }
@@ -687,6 +848,10 @@ static int scene_intersect(const orc_scene *s, ray_t *ray, isect_t *is, int anyh
         }
     }
     return hit;
+}
+static int scene_intersect(const orc_scene *s, ray_t *ray, isect_t *is, int anyhit, uint64_t *st) { /* Scene::Intersect/IntersectP core/scene.h:50-61 */
+    if (st) st[anyhit ? 2 : 1]++;
+    return bvh_intersect(s, &s->top, ray, is, anyhit, st);
 }
 
 /* ---- BSDF (core/reflection.cpp) ---------------------------------------------------------- */
@@ -933,7 +1098,8 @@ static void get_bsdf(const orc_scene *s, const isect_t *is, bsdf_t *b) {
             /* b[0]*n0 + b[1]*n1 + b[2]*n2 : Normal operator*(float f, Normal) = (f*x..), left-to-right + */
             v3 nsum = vadd(vadd(V(bb[0] * n0.x, bb[0] * n0.y, bb[0] * n0.z), V(bb[1] * n1.x, bb[1] * n1.y, bb[1] * n1.z)),
                            V(bb[2] * n2.x, bb[2] * n2.y, bb[2] * n2.z));
-            v3 ns = normalize(xf_normal(me->o2w_inv, nsum));
+            /* obj2world = isect.ObjectToWorld: for an instance hit its mInv is w2p.m (primitive.cpp:104-107) */
+            v3 ns = normalize(xf_normal(is->inst >= 0 ? is->w2p_m.m : me->o2w_inv, nsum));
             v3 ss = normalize(dg->dpdu);
             v3 ts = cross(ss, ns);
             if (vlen2(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 2
+HPT_VERSION = 3
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG = 1, 2, 3
@@ -25,7 +25,14 @@ class Mesh(C.Structure):
     _fields_ = [("p_off", i64), ("n_off", i64), ("uv_off", i64), ("idx_off", i64),
                 ("ntris", i32), ("nverts", i32), ("material", i32), ("arealight", i32),
                 ("reverse_orientation", i32), ("swaps_handedness", i32),
+                ("instance", i32), ("pad", i32),
                 ("o2w", M16), ("o2w_inv", M16)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("actually_animated", i32), ("pad", i32), ("start_time", f32), ("end_time", f32),
+                ("bounds", f32 * 6), ("T", (f32 * 3) * 2), ("R", (f32 * 4) * 2), ("S", M16 * 2),
+                ("w2p_m", M16 * 2), ("w2p_minv", M16 * 2)]
 
 
 class Quadric(C.Structure):
@@ -55,6 +62,7 @@ class SceneDesc(C.Structure):
                 ("quadrics", C.POINTER(Quadric)), ("n_quadrics", i32),
                 ("materials", C.POINTER(Material)), ("n_materials", i32),
                 ("lights", C.POINTER(Light)), ("n_lights", i32),
+                ("instances", C.POINTER(Instance)), ("n_instances", i32),
                 ("fpool", C.POINTER(f32)), ("n_f", i64),
                 ("ipool", C.POINTER(i32)), ("n_i", i64)]
 
@@ -87,14 +95,16 @@ class SceneInfo(C.Structure):
 
 class BlobHeader(C.Structure):
     _fields_ = [("magic", u32), ("version", u32), ("n_meshes", i32), ("n_quadrics", i32),
-                ("n_materials", i32), ("n_lights", i32), ("n_f", i64), ("n_i", i64),
+                ("n_materials", i32), ("n_lights", i32), ("n_instances", i32), ("pad", i32),
+                ("n_f", i64), ("n_i", i64),
                 ("cam", Camera), ("rd", RenderDesc),
                 ("sizeof_mesh", u32), ("sizeof_quadric", u32), ("sizeof_material", u32),
-                ("sizeof_light", u32)]
+                ("sizeof_light", u32), ("sizeof_instance", u32), ("pad2", u32)]
 
 
 ABI_SIZES = [C.sizeof(Mesh), C.sizeof(Quadric), C.sizeof(Material), C.sizeof(Light),
-             C.sizeof(Camera), C.sizeof(RenderDesc), C.sizeof(Stats), C.sizeof(BlobHeader)]
+             C.sizeof(Camera), C.sizeof(RenderDesc), C.sizeof(Stats), C.sizeof(BlobHeader),
+             C.sizeof(Instance)]
 
 
 def _arr(ctype, n):
@@ -106,7 +116,7 @@ class Scene:
     camera and the render defaults it was dumped with.  `.desc` is the hpt_scene_desc view."""
 
     def __init__(self, meshes=(), quadrics=(), materials=(), lights=(), fpool=None, ipool=None,
-                 camera=None, render=None):
+                 camera=None, render=None, instances=()):
         self.meshes = _arr(Mesh, len(meshes))
         for i, m in enumerate(meshes):
             self.meshes[i] = m
@@ -119,6 +129,9 @@ class Scene:
         self.lights = _arr(Light, len(lights))
         for i, l in enumerate(lights):
             self.lights[i] = l
+        self.instances = _arr(Instance, len(instances))
+        for i, l in enumerate(instances):
+            self.instances[i] = l
         self.fpool = np.ascontiguousarray(fpool if fpool is not None else np.zeros(0), dtype=np.float32)
         self.ipool = np.ascontiguousarray(ipool if ipool is not None else np.zeros(0), dtype=np.int32)
         self.camera = camera if camera is not None else Camera()
@@ -131,6 +144,7 @@ class Scene:
         d.quadrics = C.cast(self.quadrics, C.POINTER(Quadric)); d.n_quadrics = len(self.quadrics)
         d.materials = C.cast(self.materials, C.POINTER(Material)); d.n_materials = len(self.materials)
         d.lights = C.cast(self.lights, C.POINTER(Light)); d.n_lights = len(self.lights)
+        d.instances = C.cast(self.instances, C.POINTER(Instance)); d.n_instances = len(self.instances)
         d.fpool = self.fpool.ctypes.data_as(C.POINTER(f32)); d.n_f = self.fpool.size
         d.ipool = self.ipool.ctypes.data_as(C.POINTER(i32)); d.n_i = self.ipool.size
         return d
@@ -145,13 +159,15 @@ class Scene:
         h.magic, h.version = HPT_MAGIC, HPT_VERSION
         h.n_meshes, h.n_quadrics = len(self.meshes), len(self.quadrics)
         h.n_materials, h.n_lights = len(self.materials), len(self.lights)
+        h.n_instances = len(self.instances)
+        h.sizeof_instance = C.sizeof(Instance)
         h.n_f, h.n_i = self.fpool.size, self.ipool.size
         h.cam, h.rd = self.camera, self.render
         h.sizeof_mesh, h.sizeof_quadric = C.sizeof(Mesh), C.sizeof(Quadric)
         h.sizeof_material, h.sizeof_light = C.sizeof(Material), C.sizeof(Light)
         with _open(path, "wb") as f:
             f.write(bytes(h))
-            for a in (self.meshes, self.quadrics, self.materials, self.lights):
+            for a in (self.meshes, self.quadrics, self.materials, self.lights, self.instances):
                 f.write(bytes(a))
             f.write(self.fpool.tobytes())
             f.write(self.ipool.tobytes())
@@ -163,7 +179,8 @@ class Scene:
         h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
         if h.magic != HPT_MAGIC or h.version != HPT_VERSION:
             raise ValueError(f"{path}: not an HPTS v{HPT_VERSION} blob")
-        if (h.sizeof_mesh, h.sizeof_quadric, h.sizeof_material, h.sizeof_light) != tuple(ABI_SIZES[:4]):
+        if (h.sizeof_mesh, h.sizeof_quadric, h.sizeof_material, h.sizeof_light, h.sizeof_instance) != \
+                tuple(ABI_SIZES[:4]) + (C.sizeof(Instance),):
             raise ValueError(f"{path}: record sizes differ from this build of the ABI")
         off = C.sizeof(BlobHeader)
 
@@ -178,6 +195,7 @@ class Scene:
         s.quadrics = take(Quadric, h.n_quadrics)
         s.materials = take(Material, h.n_materials)
         s.lights = take(Light, h.n_lights)
+        s.instances = take(Instance, h.n_instances)
         s.fpool = np.frombuffer(raw, dtype=np.float32, count=h.n_f, offset=off).copy(); off += 4 * h.n_f
         s.ipool = np.frombuffer(raw, dtype=np.int32, count=h.n_i, offset=off).copy(); off += 4 * h.n_i
         s.camera, s.render = h.cam, h.rd

@@ -89,6 +89,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.lights = upload(s, desc->lights, (size_t)desc->n_lights, &ok);
     s->d.fpool = upload(s, fs.fpool.data(), fs.fpool.size(), &ok);
     s->d.ipool = upload(s, desc->ipool, (size_t)desc->n_i, &ok);
+    s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
+    s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
+    s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
     if (!ok) { hpt_set_error("device allocation / upload failed: %s", hipGetErrorString(hipGetLastError())); hpt_scene_destroy(s); return nullptr; }
@@ -114,6 +117,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
+    rp->has_motion = 0;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     if (rp->shard_rank < 0 || rp->shard_rank >= rp->shard_count) { hpt_set_error("bad shard rank"); return HPT_E_INVALID; }
@@ -138,6 +142,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     hipStream_t stream = (hipStream_t)stream_v;
     a.sc = s->d;
+    a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
     a.film = (float *)d_film;
     struct Scratch { unsigned long long next_item; WorkCounters wc; };
     Scratch *d_scr = nullptr;

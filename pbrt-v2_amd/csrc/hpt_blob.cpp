@@ -27,11 +27,11 @@ extern "C" const char *hpt_last_error(void) { return g_err; }
 
 struct hpt_blob_header {
     uint32_t magic, version;
-    int32_t n_meshes, n_quadrics, n_materials, n_lights;
+    int32_t n_meshes, n_quadrics, n_materials, n_lights, n_instances, pad;
     int64_t n_f, n_i;
     hpt_camera cam;
     hpt_render_desc rd;
-    uint32_t sizeof_mesh, sizeof_quadric, sizeof_material, sizeof_light;
+    uint32_t sizeof_mesh, sizeof_quadric, sizeof_material, sizeof_light, sizeof_instance, pad2;
 };
 
 struct hpt_blob {
@@ -40,7 +40,7 @@ struct hpt_blob {
     void *storage;
 };
 
-extern "C" void hpt_abi_sizes(int32_t out[8]) {
+extern "C" void hpt_abi_sizes(int32_t out[9]) {
     out[0] = (int32_t)sizeof(hpt_mesh);
     out[1] = (int32_t)sizeof(hpt_quadric);
     out[2] = (int32_t)sizeof(hpt_material);
@@ -49,19 +49,21 @@ extern "C" void hpt_abi_sizes(int32_t out[8]) {
     out[5] = (int32_t)sizeof(hpt_render_desc);
     out[6] = (int32_t)sizeof(hpt_stats);
     out[7] = (int32_t)sizeof(hpt_blob_header);
+    out[8] = (int32_t)sizeof(hpt_instance);
 }
 
 int hpt_validate_desc(const hpt_scene_desc *d) {
     if (!d) { hpt_set_error("null scene descriptor"); return HPT_E_INVALID; }
-    if (d->n_meshes < 0 || d->n_quadrics < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_f < 0 ||
-        d->n_i < 0) { hpt_set_error("negative count in scene descriptor"); return HPT_E_INVALID; }
+    if (d->n_meshes < 0 || d->n_quadrics < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_instances < 0 ||
+        d->n_f < 0 || d->n_i < 0) { hpt_set_error("negative count in scene descriptor"); return HPT_E_INVALID; }
     for (int m = 0; m < d->n_meshes; ++m) {
         const hpt_mesh &me = d->meshes[m];
         if (me.ntris < 0 || me.nverts < 0 || me.p_off < 0 || me.idx_off < 0 ||
             me.p_off + 3ll * me.nverts > d->n_f || me.idx_off + 3ll * me.ntris > d->n_i ||
             (me.n_off >= 0 && me.n_off + 3ll * me.nverts > d->n_f) ||
             (me.uv_off >= 0 && me.uv_off + 2ll * me.nverts > d->n_f) ||
-            me.material < 0 || me.material >= d->n_materials || me.arealight >= d->n_lights) {
+            me.material < 0 || me.material >= d->n_materials || me.arealight >= d->n_lights ||
+            me.instance < -1 || me.instance >= d->n_instances) {
             hpt_set_error("mesh %d: offsets/indices out of range", m);
             return HPT_E_INVALID;
         }
@@ -150,15 +152,17 @@ extern "C" int hpt_blob_save(const char *path, const hpt_scene_desc *d, const hp
     memset(&h, 0, sizeof(h));
     h.magic = HPT_MAGIC; h.version = HPT_VERSION;
     h.n_meshes = d->n_meshes; h.n_quadrics = d->n_quadrics; h.n_materials = d->n_materials;
-    h.n_lights = d->n_lights; h.n_f = d->n_f; h.n_i = d->n_i;
+    h.n_lights = d->n_lights; h.n_instances = d->n_instances; h.n_f = d->n_f; h.n_i = d->n_i;
     if (cam) h.cam = *cam;
     if (rd) h.rd = *rd;
     h.sizeof_mesh = sizeof(hpt_mesh); h.sizeof_quadric = sizeof(hpt_quadric);
     h.sizeof_material = sizeof(hpt_material); h.sizeof_light = sizeof(hpt_light);
+    h.sizeof_instance = sizeof(hpt_instance);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
 #define W(ptr, n, T) if ((n) > 0) ok = ok && fwrite(ptr, sizeof(T), (size_t)(n), f) == (size_t)(n)
     W(d->meshes, d->n_meshes, hpt_mesh); W(d->quadrics, d->n_quadrics, hpt_quadric);
     W(d->materials, d->n_materials, hpt_material); W(d->lights, d->n_lights, hpt_light);
+    W(d->instances, d->n_instances, hpt_instance);
     W(d->fpool, d->n_f, float); W(d->ipool, d->n_i, int32_t);
 #undef W
     ok = (fclose(f) == 0) && ok;
@@ -172,13 +176,15 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     hpt_blob *b = (hpt_blob *)calloc(1, sizeof(hpt_blob));
     if (fread(&b->h, sizeof(b->h), 1, f) != 1 || b->h.magic != HPT_MAGIC || b->h.version != HPT_VERSION ||
         b->h.sizeof_mesh != sizeof(hpt_mesh) || b->h.sizeof_quadric != sizeof(hpt_quadric) ||
-        b->h.sizeof_material != sizeof(hpt_material) || b->h.sizeof_light != sizeof(hpt_light)) {
+        b->h.sizeof_material != sizeof(hpt_material) || b->h.sizeof_light != sizeof(hpt_light) ||
+        b->h.sizeof_instance != sizeof(hpt_instance)) {
         hpt_set_error("%s: not an HPTS v%d blob", path, HPT_VERSION);
         fclose(f); free(b); return NULL;
     }
     const hpt_blob_header &h = b->h;
     size_t bytes = sizeof(hpt_mesh) * (size_t)h.n_meshes + sizeof(hpt_quadric) * (size_t)h.n_quadrics +
                    sizeof(hpt_material) * (size_t)h.n_materials + sizeof(hpt_light) * (size_t)h.n_lights +
+                   sizeof(hpt_instance) * (size_t)h.n_instances +
                    sizeof(float) * (size_t)h.n_f + sizeof(int32_t) * (size_t)h.n_i;
     b->storage = malloc(bytes ? bytes : 1);
     if (fread(b->storage, 1, bytes, f) != bytes) {
@@ -191,10 +197,11 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     b->desc.quadrics = (const hpt_quadric *)p;     p += sizeof(hpt_quadric) * (size_t)h.n_quadrics;
     b->desc.materials = (const hpt_material *)p;   p += sizeof(hpt_material) * (size_t)h.n_materials;
     b->desc.lights = (const hpt_light *)p;         p += sizeof(hpt_light) * (size_t)h.n_lights;
+    b->desc.instances = (const hpt_instance *)p;   p += sizeof(hpt_instance) * (size_t)h.n_instances;
     b->desc.fpool = (const float *)p;              p += sizeof(float) * (size_t)h.n_f;
     b->desc.ipool = (const int32_t *)p;
     b->desc.n_meshes = h.n_meshes; b->desc.n_quadrics = h.n_quadrics; b->desc.n_materials = h.n_materials;
-    b->desc.n_lights = h.n_lights; b->desc.n_f = h.n_f; b->desc.n_i = h.n_i;
+    b->desc.n_lights = h.n_lights; b->desc.n_instances = h.n_instances; b->desc.n_f = h.n_f; b->desc.n_i = h.n_i;
     if (hpt_validate_desc(&b->desc) != HPT_OK) { free(b->storage); free(b); return NULL; }
     return b;
 }

@@ -208,6 +208,7 @@ struct DMesh {
     int64_t n_off, uv_off, idx_off; // into fpool / ipool (n_off, uv_off: -1 = absent)
     int32_t prim_base;              // global primitive id of triangle 0
     int32_t material, arealight, flip; // flip = reverse_orientation ^ swaps_handedness
+    int32_t instance, pad;          // animated instance the mesh belongs to, or -1
     float o2w_inv[12];              // rows 0..2 of ObjectToWorld->mInv (for normals)
 };
 struct DScene {
@@ -219,12 +220,14 @@ struct DScene {
     const hpt_light *lights;
     const float *fpool;
     const int32_t *ipool;
-    int32_t n_tris, n_quadrics, n_lights, n_nodes;
+    const hpt_instance *instances;  // animated instances (TransformedPrimitive), tested after the world BVH
+    const int32_t *inst_root;       // root node of each instance's own BVH (-1: empty)
+    int32_t n_tris, n_quadrics, n_lights, n_nodes, n_instances, world_root;
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
 HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
-struct Hit { float t, b1, b2; int32_t prim; }; // prim: tri slot (BVH order) or n_tris + quadric; -1 miss
+struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or n_tris + quadric; -1 miss; inst: animated instance or -1
 struct DGeom { f3 p, nn, dpdu; };
 
 HPT_FN int32_t as_int(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
@@ -334,6 +337,118 @@ HPT_FN float quadric_area(const hpt_quadric &q) {
     return q.phi_max * 0.5f * (q.radius * q.radius - q.inner_radius * q.inner_radius);
 }
 
+// ---- AnimatedTransform::Interpolate on the device (core/transform.cpp:371-396) ---------------------
+// Per ray and per instance visit the reference rebuilds WorldToPrimitive at the ray's time: lerp of the
+// translation, slerp of the rotation (core/quaternion.cpp:95-107), lerp of the scale, then
+// Translate * Rotate * Scale with the scale's inverse by Gauss-Jordan (transform.cpp:76-135).  Kept
+// operation for operation so instance hits agree with the reference bit for bit.
+struct M4 { float m[16]; };
+struct Xf { M4 m, minv; };
+HPT_FN M4 m4_identity() { M4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.f : 0.f; return r; }
+HPT_FN M4 m4_mul(const M4 &a, const M4 &b) {
+    M4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[4 * i + j] = a.m[4 * i + 0] * b.m[0 + j] + a.m[4 * i + 1] * b.m[4 + j] + a.m[4 * i + 2] * b.m[8 + j] + a.m[4 * i + 3] * b.m[12 + j];
+    return r;
+}
+HPT_FN M4 m4_transpose(const M4 &a) { M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = a.m[4 * j + i]; return r; }
+HPT_FN_NOINLINE M4 m4_inverse(const M4 &in) {
+    int indxc[4], indxr[4];
+    int ipiv[4] = {0, 0, 0, 0};
+    float minv[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) minv[i][j] = in.m[4 * i + j];
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        float big = 0.f;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] != 1) {
+                for (int k = 0; k < 4; k++) {
+                    if (ipiv[k] == 0) {
+                        if (fabsf(minv[j][k]) >= big) { big = fabsf(minv[j][k]); irow = j; icol = k; }
+                    }
+                }
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol) for (int k = 0; k < 4; ++k) { float t = minv[irow][k]; minv[irow][k] = minv[icol][k]; minv[icol][k] = t; }
+        indxr[i] = irow; indxc[i] = icol;
+        float pivinv = 1.f / minv[icol][icol];
+        minv[icol][icol] = 1.f;
+        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j != icol) {
+                float save = minv[j][icol];
+                minv[j][icol] = 0;
+                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
+            }
+        }
+    }
+    for (int j = 3; j >= 0; j--) {
+        if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) { float t = minv[k][indxr[j]]; minv[k][indxr[j]] = minv[k][indxc[j]]; minv[k][indxc[j]] = t; }
+    }
+    M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = minv[i][j];
+    return r;
+}
+HPT_FN bool m4_is_identity(const M4 &a) {
+    bool id = true;
+    for (int i = 0; i < 16; ++i) id = id && (a.m[i] == ((i % 5 == 0) ? 1.f : 0.f));
+    return id;
+}
+struct Quat { f3 v; float w; };
+HPT_FN float qdot(Quat a, Quat b) { return dot(a.v, b.v) + a.w * b.w; }
+HPT_FN Quat qscale(Quat q, float f) { Quat r; r.v = q.v * f; r.w = q.w * f; return r; }
+HPT_FN Quat qadd(Quat a, Quat b) { Quat r; r.v = a.v + b.v; r.w = a.w + b.w; return r; }
+HPT_FN Quat qsub(Quat a, Quat b) { Quat r; r.v = a.v - b.v; r.w = a.w - b.w; return r; }
+HPT_FN Quat qnormalize(Quat q) { float f = sqrtf(qdot(q, q)); Quat r; r.v = vdiv(q.v, f); r.w = q.w / f; return r; }
+HPT_FN Quat slerp(float t, Quat q1, Quat q2) {
+    float cosTheta = qdot(q1, q2);
+    if (cosTheta > .9995f) return qnormalize(qadd(qscale(q1, 1.f - t), qscale(q2, t)));
+    float theta = acosf(clampf(cosTheta, -1.f, 1.f));
+    float thetap = theta * t;
+    Quat qperp = qnormalize(qsub(q2, qscale(q1, cosTheta)));
+    return qadd(qscale(q1, cosf(thetap)), qscale(qperp, sinf(thetap)));
+}
+// want_inverse = false skips the inverse half (only .m is needed to carry a ray into the instance)
+HPT_FN_NOINLINE Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse) {
+    Xf r;
+    if (!in.actually_animated || time <= in.start_time) {
+        for (int i = 0; i < 16; ++i) { r.m.m[i] = in.w2p_m[0][i]; r.minv.m[i] = in.w2p_minv[0][i]; }
+        return r;
+    }
+    if (time >= in.end_time) {
+        for (int i = 0; i < 16; ++i) { r.m.m[i] = in.w2p_m[1][i]; r.minv.m[i] = in.w2p_minv[1][i]; }
+        return r;
+    }
+    float dt = (time - in.start_time) / (in.end_time - in.start_time);
+    f3 trans = mk3(in.T[0][0], in.T[0][1], in.T[0][2]) * (1.f - dt) + mk3(in.T[1][0], in.T[1][1], in.T[1][2]) * dt;
+    Quat q0, q1;
+    q0.v = mk3(in.R[0][0], in.R[0][1], in.R[0][2]); q0.w = in.R[0][3];
+    q1.v = mk3(in.R[1][0], in.R[1][1], in.R[1][2]); q1.w = in.R[1][3];
+    Quat q = slerp(dt, q0, q1);
+    M4 scale = m4_identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            scale.m[4 * i + j] = (1.f - dt) * in.S[0][4 * i + j] + dt * in.S[1][4 * i + j];
+    M4 Tm = m4_identity();
+    Tm.m[3] = trans.x; Tm.m[7] = trans.y; Tm.m[11] = trans.z;
+    float xx = q.v.x * q.v.x, yy = q.v.y * q.v.y, zz = q.v.z * q.v.z;    // Quaternion::ToTransform quaternion.cpp:39-59
+    float xy = q.v.x * q.v.y, xz = q.v.x * q.v.z, yz = q.v.y * q.v.z;
+    float wx = q.v.x * q.w, wy = q.v.y * q.w, wz = q.v.z * q.w;
+    M4 mq = m4_identity();
+    mq.m[0] = 1.f - 2.f * (yy + zz); mq.m[1] = 2.f * (xy + wz);       mq.m[2] = 2.f * (xz - wy);
+    mq.m[4] = 2.f * (xy - wz);       mq.m[5] = 1.f - 2.f * (xx + zz); mq.m[6] = 2.f * (yz + wx);
+    mq.m[8] = 2.f * (xz + wy);       mq.m[9] = 2.f * (yz - wx);       mq.m[10] = 1.f - 2.f * (xx + yy);
+    M4 Rm = m4_transpose(mq);
+    r.m = m4_mul(m4_mul(Tm, Rm), scale);                                  // (Translate * Rotate) * Scale, transform.cpp:286-290
+    if (want_inverse) {
+        M4 Tinv = m4_identity();
+        Tinv.m[3] = -trans.x; Tinv.m[7] = -trans.y; Tinv.m[11] = -trans.z;
+        r.minv = m4_mul(m4_inverse(scale), m4_mul(mq, Tinv));
+    } else r.minv = r.m;
+    return r;
+}
+
 // ---- BVH2 traversal --------------------------------------------------------------------------
 // Replaces BVHAccel::Intersect / IntersectP (accelerators/bvh.cpp:403-503): same slab test
 // (bvh.cpp:126-148, strict inequalities, +-inf inverse directions, no NaN guard), near child first
@@ -376,12 +491,12 @@ struct TravState {
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
-HPT_FN void trav_begin(const DScene &sc, TravState &ts, const Ray &ray, bool anyhit) {
+HPT_FN void trav_begin(const DScene &sc, TravState &ts, const Ray &ray, bool anyhit, int32_t root, bool world) {
     ts.ray = ray; ts.anyhit = anyhit;
-    ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f;
-    ts.sp = 0; ts.node = 0;
+    ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
+    ts.sp = 0; ts.node = root;
     // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
-    for (int q = 0; q < sc.n_quadrics; ++q) {
+    for (int q = 0; world && q < sc.n_quadrics; ++q) {
         float t;
         if (quadric_intersect(sc.quadrics[q], ts.ray, &t, nullptr)) {
             ts.hit.prim = sc.n_tris + q;
@@ -389,7 +504,7 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, const Ray &ray, bool any
             ts.hit.t = t; ts.ray.maxt = t;
         }
     }
-    if (sc.n_nodes == 0) ts.node = HPT_TRAV_EMPTY;
+    if (root < 0) ts.node = HPT_TRAV_EMPTY;
     ts.invd = mk3(1.f / ts.ray.d.x, 1.f / ts.ray.d.y, 1.f / ts.ray.d.z);
     ts.nx = ts.invd.x < 0; ts.ny = ts.invd.y < 0; ts.nz = ts.invd.z < 0;
 }
@@ -435,14 +550,34 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, int32_t *stack, int strid
     }
 }
 
-// One ray, start to finish, on this lane.  `ray.maxt` is shrunk to the hit distance like the reference does.
+// One ray, start to finish, on this lane: the world BVH (+ quadrics), then every animated instance
+// whose motion bounds the ray crosses (TransformedPrimitive::Intersect / IntersectP,
+// core/primitive.cpp:95-124): WorldToPrimitive interpolated at the ray's time carries the ray into the
+// instance's own BVH.  `ray.maxt` is shrunk to the hit distance like the reference does.
 template <bool COUNT>
-HPT_FN bool traverse(const DScene &sc, Ray &ray, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
+HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
     TravState ts;
-    trav_begin(sc, ts, ray, anyhit);
+    trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
     while (!ts.done()) trav_step<COUNT>(sc, ts, stack, stride, cnt);
     ray.maxt = ts.ray.maxt;
     *hit = ts.hit;
+    if (anyhit && hit->prim >= 0) return true;
+    for (int k = 0; k < sc.n_instances; ++k) {
+        const hpt_instance &in = sc.instances[k];
+        float tentry;
+        if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, ts.nx, ts.ny, ts.nz, &tentry)) continue;
+        Xf w2p = anim_interpolate(in, time, false);
+        Ray r2;
+        r2.o = xf_point(w2p.m.m, ray.o); r2.d = xf_vec(w2p.m.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
+        TravState t2;
+        trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
+        while (!t2.done()) trav_step<COUNT>(sc, t2, stack, stride, cnt);
+        if (t2.hit.prim >= 0) {
+            *hit = t2.hit; hit->inst = k;
+            ray.maxt = t2.ray.maxt;
+            if (anyhit) return true;
+        }
+    }
     return hit->prim >= 0;
 }
 
@@ -698,7 +833,8 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
 // Triangle::Intersect tail (trianglemesh.cpp:162-207), DifferentialGeometry ctor (diffgeom.cpp:40-55),
 // Triangle::GetShadingGeometry (trianglemesh.cpp:293-368), BSDF ctor (reflection.cpp:601-609),
 // Material::GetBSDF.  Returns the primitive's area light index (or -1) and rayEpsilon.
-HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
+HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
+    Ray ray = wray;
     if (hit.prim >= sc.n_tris) {
         const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
         float t;
@@ -716,6 +852,14 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hi
     f3 p1 = mk3(a.x, a.y, a.z), p2 = mk3(bb.x, bb.y, bb.z), p3 = mk3(c.x, c.y, c.z);
     const DMesh &me = sc.meshes[as_int(a.w)];
     int tri = as_int(bb.w);
+    // hit inside an animated instance: redo the geometry in the instance's space with the transformed
+    // ray, then carry p / nn / dpdu back to the world (core/primitive.cpp:104-117)
+    Xf w2p;
+    const bool inInstance = hit.inst >= 0;
+    if (inInstance) {
+        w2p = anim_interpolate(sc.instances[hit.inst], time, true);
+        ray.o = xf_point(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);
+    }
     const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
     int v0 = idx[0], v1 = idx[1], v2 = idx[2];
     float uv[3][2];
@@ -741,6 +885,11 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hi
     float tu = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     float tv = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
     dg_init(dg, ray_at(ray, hit.t), dpdu, dpdv, me.flip);
+    if (inInstance && !m4_is_identity(w2p.m)) {   // PrimitiveToWorld = Inverse(w2p): m = w2p.mInv, mInv = w2p.m
+        dg->p = xf_point(w2p.minv.m, dg->p);
+        dg->nn = normalize(xf_normal(w2p.m.m, dg->nn));
+        dg->dpdu = xf_vec(w2p.minv.m, dg->dpdu);
+    }
     *rayEps = 1e-3f * hit.t;
     *arealight = me.arealight;
     f3 ns_nn = dg->nn, ns_dpdu = dg->dpdu;
@@ -763,8 +912,9 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &ray, const Hit &hi
         f3 n1 = mk3(N[3 * v1], N[3 * v1 + 1], N[3 * v1 + 2]);
         f3 n2 = mk3(N[3 * v2], N[3 * v2 + 1], N[3 * v2 + 2]);
         f3 nsum = (n0 * bb0 + n1 * bb1) + n2 * bb2;
+        // obj2world = isect.ObjectToWorld; for an instance hit its mInv is w2p.m (primitive.cpp:104-107)
         float minv[12];
-        for (int k = 0; k < 12; ++k) minv[k] = me.o2w_inv[k];
+        for (int k = 0; k < 12; ++k) minv[k] = inInstance ? w2p.m.m[k] : me.o2w_inv[k];
         f3 ns = normalize(xf_normal(minv, nsum));
         f3 ss = normalize(dg->dpdu);
         f3 ts = cross(ss, ns);

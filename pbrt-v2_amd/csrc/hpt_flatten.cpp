@@ -25,6 +25,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         dm.n_off = me.n_off; dm.uv_off = me.uv_off; dm.idx_off = me.idx_off;
         dm.prim_base = (int32_t)base; dm.material = me.material; dm.arealight = me.arealight;
         dm.flip = me.reverse_orientation ^ me.swaps_handedness;
+        dm.instance = me.instance; dm.pad = 0;
         for (int k = 0; k < 12; ++k) dm.o2w_inv[k] = me.o2w_inv[k];
         const float *P = desc->fpool + me.p_off;
         const int32_t *idx = desc->ipool + me.idx_off;
@@ -38,15 +39,48 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         }
         base += me.ntris;
     }
-    BvhResult bvh;
-    build_bvh(in.data(), in.size(), max_leaf, max_depth, &bvh);
+    // One BVH for the triangles that live directly in the world and one per animated instance (its
+    // triangles are in the instance's own space), all in the same node / triangle arrays.
     out->tri_rec.assign(12 * (size_t)ntris, 0.f);
-    for (size_t i = 0; i < (size_t)ntris; ++i) {
-        uint32_t src = bvh.order[i];
-        float *r = &out->tri_rec[12 * i];
-        for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[src].v[k][0]; r[4 * k + 1] = in[src].v[k][1]; r[4 * k + 2] = in[src].v[k][2]; }
-        memcpy(&r[3], &tri_mesh[src], 4);
-        memcpy(&r[7], &tri_idx[src], 4);
+    out->nodes.clear();
+    out->inst_root.assign((size_t)desc->n_instances, -1);
+    out->world_root = -1;
+    out->max_depth = 0;
+    size_t tri_base = 0;
+    for (int g = -1; g < desc->n_instances; ++g) {
+        std::vector<BvhInputTri> sub;
+        std::vector<uint32_t> src;
+        for (int m = 0; m < desc->n_meshes; ++m) {
+            if (desc->meshes[m].instance != g) continue;
+            int64_t mb = out->meshes[(size_t)m].prim_base;
+            for (int t = 0; t < desc->meshes[m].ntris; ++t) { sub.push_back(in[(size_t)(mb + t)]); src.push_back((uint32_t)(mb + t)); }
+        }
+        if (sub.empty()) continue;
+        BvhResult bvh;
+        build_bvh(sub.data(), sub.size(), max_leaf, max_depth, &bvh);
+        const int32_t node_base = (int32_t)out->nodes.size();
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            BvhNode64 nd = bvh.nodes[i];
+            for (int c = 0; c < 2; ++c) {
+                if (nd.child[c] >= 0) nd.child[c] += node_base;
+                else {
+                    uint32_t code = (uint32_t)~nd.child[c];
+                    uint32_t first = (code & 0x0fffffffu) + (uint32_t)tri_base;
+                    nd.child[c] = (int32_t)~(first | (code & 0xf0000000u));
+                }
+            }
+            out->nodes.push_back(nd);
+        }
+        for (size_t i = 0; i < sub.size(); ++i) {
+            uint32_t s0 = src[bvh.order[i]];
+            float *r = &out->tri_rec[12 * (tri_base + i)];
+            for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[s0].v[k][0]; r[4 * k + 1] = in[s0].v[k][1]; r[4 * k + 2] = in[s0].v[k][2]; }
+            memcpy(&r[3], &tri_mesh[s0], 4);
+            memcpy(&r[7], &tri_idx[s0], 4);
+        }
+        if (g < 0) out->world_root = node_base; else out->inst_root[(size_t)g] = node_base;
+        if (bvh.max_depth > out->max_depth) out->max_depth = bvh.max_depth;
+        tri_base += sub.size();
     }
     // ---- measured-BRDF kd-trees -> packed 32-byte nodes ---------------------------------------
     out->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
@@ -65,9 +99,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         }
         ma.kd_data_off = base; ma.kd_split_off = HPT_KD_PACKED; ma.kd_bits_off = HPT_KD_PACKED;
     }
-    out->nodes.swap(bvh.nodes);
     out->n_tris = ntris;
-    out->max_depth = bvh.max_depth;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HPT_OK;
 }

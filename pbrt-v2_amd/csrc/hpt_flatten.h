@@ -15,6 +15,8 @@ struct FlatScene {
     std::vector<BvhNode64> nodes;
     std::vector<float> tri_rec;   // 12 floats per triangle, BVH leaf order
     std::vector<DMesh> meshes;
+    std::vector<int32_t> inst_root;   // root node of each animated instance's BVH (-1 = no triangles)
+    int32_t world_root = -1;          // root node of the world BVH (-1 = no world triangles)
     // device copies of the float pool and the material table: measured-BRDF kd-trees are re-packed
     // into 32-byte node records {splitPos, bits, p.xyz, v.rgb} appended to the pool (one sector per
     // node visit instead of three scattered loads); materials[i].kd_data_off then points at the

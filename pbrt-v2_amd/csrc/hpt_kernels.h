@@ -5,19 +5,10 @@
 #include "hpt_path.h"
 
 #define HPT_BLOCK 256        /* threads per workgroup = 4 wave64 */
-#define HPT_STACK_DEPTH 26   /* LDS traversal stack entries per lane (26 KiB per workgroup); with the 13 KiB ray
-                                pool that is 39 KiB -> 4 workgroups (16 waves) per CU in 160 KiB of LDS.
-                                The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2. */
-#ifndef HPT_POOL
-#define HPT_POOL 0           /* 0: each lane traces its own pending ray (default).  1: workgroup ray pool in LDS with
-                                dynamic fetch (a lane whose ray is done takes another lane's ray instead of idling).
-                                Measured SLOWER on gfx950 (killeroo 348 vs 483, bunny 97 vs 124, soup 131 vs 181
-                                Msamples/s, profiles/r01_ab.md): two workgroup barriers per phase, +80 B/lane of
-                                spills and LDS round trips cost more than the idle lanes they recover. */
-#endif
-#ifndef HPT_FETCH_MIN
-#define HPT_FETCH_MIN 16     /* refill idle lanes from the pool once this many lanes of the wave are idle */
-#endif
+#define HPT_STACK_DEPTH 26   /* LDS traversal stack entries per lane (26 KiB per workgroup, up to 6 workgroups per CU
+                                in 160 KiB of LDS).  The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2.
+                                (A workgroup-level ray pool with dynamic fetch was tried here and measured slower:
+                                profiles/r01_ab.md, second A/B.) */
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4    /* __launch_bounds__ 2nd arg: waves per SIMD the register allocator must allow (A/B in profiles/r01_ab.md) */
 #endif

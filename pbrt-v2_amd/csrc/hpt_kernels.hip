@@ -37,32 +37,12 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
     return need ? (int64_t)(base + (unsigned long long)rank) : -1;
 }
 
-// Wave-aggregated fetch from a workgroup-local (LDS) counter.
-__device__ __forceinline__ int wave_fetch_lds(int *counter, bool need) {
-    unsigned long long mask = __ballot(need);
-    if (mask == 0ull) return 0x7fffffff;
-    int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane_id() == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader);
-    return need ? base + __popcll(mask & ((1ull << lane_id()) - 1ull)) : 0x7fffffff;
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
     int32_t *stack = lds_stack + threadIdx.x;
-#if HPT_POOL
-    // Workgroup ray pool (SoA, one slot per thread): rows 0..7 = o.xyz d.xyz mint maxt (maxt comes
-    // back shrunk to the hit distance), rows 8..11 = the hit {t, b1, b2, prim}.  The lane's own ray
-    // lives here during the traversal phase, not in registers.
-    __shared__ float pool[12][HPT_BLOCK];
-    __shared__ int32_t pool_kind[HPT_BLOCK];   // 0 no ray, 1 closest-hit, 2 any-hit
-    __shared__ int pool_next;
-#endif
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
-    const int tid = threadIdx.x;
     Lane<LdHashSrc> lane;
     lane.init();
     bool exhausted = false;
@@ -84,76 +64,14 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
         }
         const bool active = lane.stage != ST_IDLE;
         Hit hit;
-        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f;
-#if HPT_POOL
-        // ---- publish this lane's pending ray to the workgroup pool ---------------------------------
-        if (tid == 0) pool_next = 0;
-        pool_kind[tid] = active ? (lane.stage == ST_SHADOW ? 2 : 1) : 0;
-        if (active) {
-            if (COUNT) { if (lane.stage == ST_SHADOW) wc.shadow++; else wc.closest++; }
-            pool[0][tid] = lane.ray.o.x; pool[1][tid] = lane.ray.o.y; pool[2][tid] = lane.ray.o.z;
-            pool[3][tid] = lane.ray.d.x; pool[4][tid] = lane.ray.d.y; pool[5][tid] = lane.ray.d.z;
-            pool[6][tid] = lane.ray.mint; pool[7][tid] = lane.ray.maxt;
-        }
-        if (!__syncthreads_or(active ? 1 : 0)) break;
-        // ---- traversal phase with dynamic fetch: a lane whose ray is finished takes the next ray of
-        //      the pool instead of idling until the longest ray of the wave is done -----------------------
-        {
-            TravState ts;
-            ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false;
-            int slot = -1;
-            bool drained = false;
-            for (;;) {
-                const bool need = ts.done() && !drained;
-                const unsigned long long needm = __ballot(need);
-                const unsigned long long busym = __ballot(!ts.done());
-                if (needm != 0ull && (__popcll(needm) >= HPT_FETCH_MIN || busym == 0ull)) {
-                    if (need && slot >= 0) {   // hand the finished ray's result back to its owner
-                        pool[8][slot] = ts.hit.t; pool[9][slot] = ts.hit.b1; pool[10][slot] = ts.hit.b2;
-                        pool[11][slot] = __int_as_float(ts.hit.prim); pool[7][slot] = ts.ray.maxt;
-                        slot = -1;
-                    }
-                    int idx = wave_fetch_lds(&pool_next, need);
-                    if (need) {
-                        if (idx >= HPT_BLOCK) drained = true;
-                        else {
-                            int kind = pool_kind[idx];
-                            if (kind) {
-                                Ray r;
-                                r.o = mk3(pool[0][idx], pool[1][idx], pool[2][idx]);
-                                r.d = mk3(pool[3][idx], pool[4][idx], pool[5][idx]);
-                                r.mint = pool[6][idx]; r.maxt = pool[7][idx];
-                                trav_begin(sc, ts, r, kind == 2);
-                                slot = idx;
-                            }
-                        }
-                    }
-                    continue;
-                }
-                if (busym == 0ull) break;     // nothing running and nobody may fetch: every lane drained
-                if (!ts.done()) trav_step<COUNT>(sc, ts, stack, HPT_BLOCK, &tc);
-            }
-            if (slot >= 0) {
-                pool[8][slot] = ts.hit.t; pool[9][slot] = ts.hit.b1; pool[10][slot] = ts.hit.b2;
-                pool[11][slot] = __int_as_float(ts.hit.prim); pool[7][slot] = ts.ray.maxt;
-            }
-        }
-        __syncthreads();
-        if (active) {
-            hit.t = pool[8][tid]; hit.b1 = pool[9][tid]; hit.b2 = pool[10][tid]; hit.prim = __float_as_int(pool[11][tid]);
-            lane.ray.o = mk3(pool[0][tid], pool[1][tid], pool[2][tid]);
-            lane.ray.d = mk3(pool[3][tid], pool[4][tid], pool[5][tid]);
-            lane.ray.mint = pool[6][tid]; lane.ray.maxt = pool[7][tid];
-        }
-#else
+        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
         // ---- one traversal phase: each lane traces its own pending ray ------------------------------
         if (active) {
             bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse<COUNT>(sc, lane.ray, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            traverse<COUNT>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
         }
-#endif
         // ---- state machine step ----------------------------------------------------------------------
         if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
     }
@@ -195,11 +113,11 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
         bool active = lane.stage != ST_IDLE;
         if (__ballot(active) == 0ull) break;
         Hit hit;
-        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f;
+        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (active) {
             bool anyhit = lane.stage == ST_SHADOW;
             if (anyhit) wc.shadow++; else wc.closest++;
-            traverse<true>(sc, lane.ray, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            traverse<true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
             LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
             lane.on_hit(sc, rp, hit, a.film, &wc, ls);
         }
@@ -222,7 +140,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
     const float *r = rays + 8 * i;
     Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
     Hit hit; TravCounters tc = {0, 0};
-    bool h = traverse<false>(sc, ray, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
+    bool h = traverse<false>(sc, ray, 0.f, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
     float *o = out_hit + 4 * i;
     if (anyhit) { out_prim[i] = h ? 0 : -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
     if (!h) { out_prim[i] = -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }

@@ -31,6 +31,7 @@ struct RenderParams {
     uint32_t seed;
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
+    int32_t has_motion;        // scene has animated instances: rays carry a time sample
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
     int64_t n_items;           // items_per_pass x (spp / chunk)
@@ -80,6 +81,7 @@ template <class Smp> struct Lane {
     int bounce;
     bool specular;
     Ray ray;                // the ray to trace in the next traversal phase
+    float time;             // CameraSample::time; every ray of the path inherits it (geometry.h:329-332)
     // pending work of the current vertex
     f3 p; float eps;        // bsdf->dgShading.p, isect.rayEpsilon
     f3 Ld;                  // EstimateDirect accumulator; holds the light-sampling term while its
@@ -100,6 +102,8 @@ template <class Smp> struct Lane {
         float lu = 0.f, lv = 0.f;
         if (rp.cam.lens_radius > 0.f) smp.lens(&lu, &lv);
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
+        time = 0.f;
+        if (rp.has_motion) { float t = smp.time01(); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
         L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
         stage = ST_EXTEND;
     }
@@ -194,7 +198,7 @@ template <class Smp> struct Lane {
             return;
         }
         Bsdf bsdf; DGeom dg; int arealight;
-        shade_geometry(sc, ray, hit, &bsdf, &dg, &eps, &arealight);
+        shade_geometry(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
         if (bounce == 0 || specular)                                        // path.cpp:63-64
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
@@ -303,6 +307,7 @@ struct LdHashSrc {
     HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
     HPT_MFN void image(float *a, float *b) const { h.image(a, b); }
     HPT_MFN void lens(float *a, float *b) const { h.lens(a, b); }
+    HPT_MFN float time01() const { return h.time01(); }
     HPT_MFN float draw() { return h.draw(h.draw_key(), dcount++); }
 };
 

@@ -120,6 +120,7 @@ struct MtReplaySrc {
     HPT_MFN void two(int j, float *a, float *b) { *a = at(off_2d(j) + 2 * i); *b = at(off_2d(j) + 2 * i + 1); }
     HPT_MFN void image(float *a, float *b) { *a = at(2 * i); *b = at(2 * i + 1); }
     HPT_MFN void lens(float *a, float *b) { *a = at(2u * n + 2 * i); *b = at(2u * n + 2 * i + 1); }
+    HPT_MFN float time01() { return at(4u * n + i); }
     HPT_MFN float draw() { return (next_uint() & 0xffffff) / (float)(1 << 24); } // RandomFloat (rng.cpp:59-65)
 };
 

@@ -44,6 +44,8 @@
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
+#include "primitive.h"
+#include "quaternion.h"
 #include "textures/constant.h"
 
 #include <map>
@@ -69,6 +71,7 @@ struct Flattener {
     std::vector<hpt_quadric> quadrics;
     std::vector<hpt_material> materials;
     std::vector<hpt_light> lights;
+    std::vector<hpt_instance> instances;
     std::vector<float> fpool;
     std::vector<int32_t> ipool;
     std::map<const TriangleMesh *, int> meshIndex;
@@ -154,7 +157,7 @@ struct Flattener {
         return it->second;
     }
 
-    void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp) {
+    void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp, int instance = -1) {
         const TriangleMesh *mesh = tri->mesh.GetPtr();
         if (meshIndex.find(mesh) != meshIndex.end()) return;
         if (mesh->alphaTexture.GetPtr())
@@ -174,6 +177,7 @@ struct Flattener {
         r.idx_off = PushI(mesh->vertexIndex, 3 * (size_t)mesh->ntris);
         r.material = AddMaterial(gp->material.GetPtr());
         r.arealight = -1;
+        r.instance = instance;
         r.reverse_orientation = mesh->ReverseOrientation;
         r.swaps_handedness = mesh->TransformSwapsHandedness;
         CopyM(mesh->ObjectToWorld->m, r.o2w);
@@ -207,6 +211,40 @@ struct Flattener {
             Severe("hip renderer: WorldToObject is not the stored inverse of ObjectToWorld");
         quadricIndex[shape] = (int)quadrics.size();
         quadrics.push_back(q);
+    }
+
+    // TransformedPrimitive over BVHAccel(refined shape) (core/api.cpp:1012-1044)
+    void AddInstance(const TransformedPrimitive *tp) {
+        const AnimatedTransform &at = tp->WorldToPrimitive;
+        hpt_instance r;
+        memset(&r, 0, sizeof(r));
+        r.actually_animated = at.actuallyAnimated;
+        r.start_time = at.startTime; r.end_time = at.endTime;
+        BBox wb = tp->WorldBound();
+        r.bounds[0] = wb.pMin.x; r.bounds[1] = wb.pMin.y; r.bounds[2] = wb.pMin.z;
+        r.bounds[3] = wb.pMax.x; r.bounds[4] = wb.pMax.y; r.bounds[5] = wb.pMax.z;
+        for (int k = 0; k < 2; ++k) {
+            r.T[k][0] = at.T[k].x; r.T[k][1] = at.T[k].y; r.T[k][2] = at.T[k].z;
+            r.R[k][0] = at.R[k].v.x; r.R[k][1] = at.R[k].v.y; r.R[k][2] = at.R[k].v.z; r.R[k][3] = at.R[k].w;
+            CopyM(at.S[k], r.S[k]);
+            const Transform *t = k == 0 ? at.startTransform : at.endTransform;
+            CopyM(t->m, r.w2p_m[k]); CopyM(t->mInv, r.w2p_minv[k]);
+        }
+        int idx = (int)instances.size();
+        instances.push_back(r);
+        std::vector<const Primitive *> todo;
+        todo.push_back(tp->primitive.GetPtr());
+        while (!todo.empty()) {
+            const Primitive *p = todo.back(); todo.pop_back();
+            if (const BVHAccel *b = dynamic_cast<const BVHAccel *>(p)) {
+                for (size_t i = 0; i < b->primitives.size(); ++i) todo.push_back(b->primitives[i].GetPtr());
+            } else if (const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(p)) {
+                const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.GetPtr());
+                if (!tri) Severe("hip renderer: animated instances of non-triangle shapes are outside the hot-path scope");
+                AddTriangle(tri, gp, idx);
+            } else
+                Severe("hip renderer: nested instances are outside the hot-path scope");
+        }
     }
 
     void AddLights(const Scene *scene) {
@@ -269,11 +307,14 @@ struct Flattener {
         const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene->aggregate);
         if (!bvh) Severe("hip renderer: Accelerator must be \"bvh\" (the default)");
         for (size_t i = 0; i < bvh->primitives.size(); ++i) {
+            if (const TransformedPrimitive *tp =
+                    dynamic_cast<const TransformedPrimitive *>(bvh->primitives[i].GetPtr())) {
+                AddInstance(tp);
+                continue;
+            }
             const GeometricPrimitive *gp =
                 dynamic_cast<const GeometricPrimitive *>(bvh->primitives[i].GetPtr());
-            if (!gp)
-                Severe("hip renderer: instanced / animated primitives (TransformedPrimitive) "
-                       "are a later hot-path row (SURVEY.md §8, config 4)");
+            if (!gp) Severe("hip renderer: primitive type outside the hot-path scope");
             const Shape *shape = gp->shape.GetPtr();
             if (const Triangle *tri = dynamic_cast<const Triangle *>(shape))
                 AddTriangle(tri, gp);
@@ -302,6 +343,7 @@ struct Flattener {
         d.quadrics = quadrics.empty() ? NULL : &quadrics[0];  d.n_quadrics = (int)quadrics.size();
         d.materials = materials.empty() ? NULL : &materials[0]; d.n_materials = (int)materials.size();
         d.lights = lights.empty() ? NULL : &lights[0];        d.n_lights = (int)lights.size();
+        d.instances = instances.empty() ? NULL : &instances[0]; d.n_instances = (int)instances.size();
         d.fpool = fpool.empty() ? NULL : &fpool[0];           d.n_f = (int64_t)fpool.size();
         d.ipool = ipool.empty() ? NULL : &ipool[0];           d.n_i = (int64_t)ipool.size();
         return d;

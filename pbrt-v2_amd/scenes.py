@@ -149,7 +149,7 @@ def synthetic_soup(n_tris=1_000_000, xres=1920, yres=1080, spp=256, maxdepth=8, 
     mesh = abi.Mesh()
     mesh.p_off, mesh.n_off, mesh.uv_off, mesh.idx_off = 0, -1, -1, 0
     mesh.ntris, mesh.nverts = n_tris, 3 * n_tris
-    mesh.material, mesh.arealight = 0, -1
+    mesh.material, mesh.arealight, mesh.instance = 0, -1, -1
     mesh.reverse_orientation = mesh.swaps_handedness = 0
     mesh.o2w, mesh.o2w_inv = _m16(np.eye(4)), _m16(np.eye(4))
     light = constant_infinite_light([1.0, 1.0, 1.0], fpool_parts)

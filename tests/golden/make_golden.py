@@ -16,6 +16,7 @@ Cases
   cfg1   BASELINE.json configs[0]: killeroo-simple 256x256, 4 spp, path maxdepth 3
   k8     killeroo-simple 200x120, 16 spp, maxdepth 8   (Russian roulette + rng draws, bounces>=3)
   b8     bunny 240x135, 8 spp, maxdepth 8              (measured BRDF kd-tree, point + disk lights)
+  anim   anim-killeroos-moving 200x120, 8 spp, maxdepth 5 (animated instances, motion blur)
   env    2000 random triangles + constant infinite light 160x90, 8 spp, maxdepth 5
          (InfiniteAreaLight Sample_L / Pdf / Le, MIS ray escaping to the environment)
 k8 shares cfg1's geometry: only its camera + render descriptor are stored (k8.view.npz).
@@ -47,7 +48,10 @@ def sub(text, xres, yres, spp, maxdepth, out_pfm):
     import re
     text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
     text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
-    text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_pfm, text)
+    if '"string filename"' in text:
+        text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_pfm, text)
+    else:
+        text = re.sub(r'Film "image"', 'Film "image" "string filename" "%s"' % out_pfm, text, count=1)
     text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
     text = text.replace('SurfaceIntegrator "directlighting"', 'SurfaceIntegrator "path" "integer maxdepth" [%d]' % maxdepth)
     text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
@@ -99,6 +103,11 @@ def main():
         b = run_case("b8", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
                      .replace('"brdfs/', '"%s/brdfs/' % REF), tmp)
         b.save(os.path.join(HERE, "bunny_b8.hpts.gz"))
+        # anim: BASELINE.json configs[3] feature set — two animated instances (TransformedPrimitive over
+        # object-space BVHs, motion blur through the LD time sample)
+        anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
+        a = run_case("anim", sub(anim, 200, 120, 8, 5, os.path.join(tmp, "anim_ref.pfm")), tmp)
+        a.save(os.path.join(HERE, "anim_killeroos.hpts.gz"))
         # bench workloads (BASELINE.json configs[1] and the north-star target scene) at 1920x1080
         dump_view("killeroo_1080p", sub(kill, 1920, 1080, 64, 8, os.path.join(tmp, "x.pfm")), tmp, s)
         head1080 = head.replace("[240]", "[1920]").replace("[135]", "[1080]").replace("[8]\nSurface", "[64]\nSurface")

@@ -22,7 +22,7 @@ using namespace hpt;
 struct emu_scene {
     FlatScene fs;
     std::vector<hpt_quadric> quadrics; std::vector<hpt_material> materials; std::vector<hpt_light> lights;
-    std::vector<float> fpool; std::vector<int32_t> ipool;
+    std::vector<float> fpool; std::vector<int32_t> ipool; std::vector<hpt_instance> instances;
     DScene d;
 };
 
@@ -42,6 +42,9 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.fpool = s->fpool.data(); s->d.ipool = s->ipool.data();
     s->d.n_tris = (int32_t)s->fs.n_tris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)s->fs.nodes.size();
+    s->instances.assign(desc->instances, desc->instances + desc->n_instances);
+    s->d.instances = s->instances.data(); s->d.inst_root = s->fs.inst_root.data();
+    s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
     return s;
 }
 extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
@@ -54,6 +57,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
+    rp->has_motion = 0;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
@@ -66,6 +70,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
 extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
+    rp.has_motion = s->d.n_instances > 0;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
     WorkCounters total = {0, 0, 0, 0, 0, 0};
 #pragma omp parallel
@@ -85,7 +90,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true>(s->d, lane.ray, anyhit, &hit, stack, 1, &tc);
+                traverse<true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit(s->d, rp, hit, film, &wc, ls); }
             }
         }
@@ -100,6 +105,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
 // the order `pbrt --ncores 1` (and the golden images) use.
 extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
+    rp.has_motion = s->d.n_instances > 0;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
@@ -120,7 +126,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true>(s->d, lane.ray, anyhit, &hit, stack, 1, &tc);
+                traverse<true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 LaneStack ls; ls.p = stack; ls.stride = 1;
                 lane.on_hit(s->d, rp, hit, film, &wc, ls);
             }
@@ -137,7 +143,7 @@ extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, i
         const float *r = rays + 8 * i;
         Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
         Hit hit; TravCounters tc = {0, 0}; int32_t stack[64];
-        bool h = traverse<false>(sc, ray, anyhit != 0, &hit, stack, 1, &tc);
+        bool h = traverse<false>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
         float *o = out_hit + 4 * i;
         o[0] = o[1] = o[2] = o[3] = 0.f;
         if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
