@@ -13,6 +13,7 @@ samples / max-over-ranks wall time.
 Workloads (all 1920x1080, path maxdepth 8, lowdiscrepancy-structured sampler, box filter):
   bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 453 prims, measured BRDF), 64 spp/GPU
   killeroo north-star target scene: scenes/killeroo-simple.pbrt (66 533 prims), 64 spp/GPU
+  anim     BASELINE.json configs[3] scene: scenes/anim-killeroos-moving.pbrt (2 animated instances), 64 spp/GPU
   soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 16 spp/GPU here
 Geometry comes from the committed blobs (dumped from the reference's own parser by
 host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does not exist on the
@@ -37,19 +38,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # algorithmic traversal bytes per camera sample of the REFERENCE algorithm
 # (32 B x BVH nodes visited + 48 B x triangles tested, measured on the instrumented reference)
-ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0}
+ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def load_workload(name, spp):
-    if name in ("bunny", "killeroo"):
-        blob = {"bunny": "bunny_b8.hpts.gz", "killeroo": "killeroo_cfg1.hpts.gz"}[name]
+    if name in ("bunny", "killeroo", "anim"):
+        blob = {"bunny": "bunny_b8.hpts.gz", "killeroo": "killeroo_cfg1.hpts.gz", "anim": "anim_killeroos.hpts.gz"}[name]
         s = abi.Scene.load(os.path.join(GOLDEN, blob))
         v = np.load(os.path.join(GOLDEN, name + "_1080p.view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.render.spp = spp or 64
-        desc = "scenes/%s.pbrt" % {"bunny": "bunny", "killeroo": "killeroo-simple"}[name]
+        desc = "scenes/%s.pbrt" % {"bunny": "bunny", "killeroo": "killeroo-simple", "anim": "anim-killeroos-moving"}[name]
     elif name == "soup":
         s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or 16, maxdepth=8)
         desc = "synthetic 1M random triangles + 1 env light (seed 0x5EED0001)"

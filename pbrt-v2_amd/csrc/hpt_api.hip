@@ -152,7 +152,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.next_item = &d_scr->next_item;
     a.counters = &d_scr->wc;
     int bpc = 0, vgprs = 0;
-    if (e == hipSuccess && path_kernel_occupancy(&bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && path_kernel_occupancy(s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;

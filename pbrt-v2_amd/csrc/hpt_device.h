@@ -554,7 +554,7 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, int32_t *stack, int strid
 // whose motion bounds the ray crosses (TransformedPrimitive::Intersect / IntersectP,
 // core/primitive.cpp:95-124): WorldToPrimitive interpolated at the ray's time carries the ray into the
 // instance's own BVH.  `ray.maxt` is shrunk to the hit distance like the reference does.
-template <bool COUNT>
+template <bool COUNT, bool INST>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
     TravState ts;
     trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
@@ -562,7 +562,7 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
     ray.maxt = ts.ray.maxt;
     *hit = ts.hit;
     if (anyhit && hit->prim >= 0) return true;
-    for (int k = 0; k < sc.n_instances; ++k) {
+    if (INST) for (int k = 0; k < sc.n_instances; ++k) {
         const hpt_instance &in = sc.instances[k];
         float tentry;
         if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, ts.nx, ts.ny, ts.nz, &tentry)) continue;
@@ -833,6 +833,7 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
 // Triangle::Intersect tail (trianglemesh.cpp:162-207), DifferentialGeometry ctor (diffgeom.cpp:40-55),
 // Triangle::GetShadingGeometry (trianglemesh.cpp:293-368), BSDF ctor (reflection.cpp:601-609),
 // Material::GetBSDF.  Returns the primitive's area light index (or -1) and rayEpsilon.
+template <bool INST>
 HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
     Ray ray = wray;
     if (hit.prim >= sc.n_tris) {
@@ -855,7 +856,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     // hit inside an animated instance: redo the geometry in the instance's space with the transformed
     // ray, then carry p / nn / dpdu back to the world (core/primitive.cpp:104-117)
     Xf w2p;
-    const bool inInstance = hit.inst >= 0;
+    const bool inInstance = INST && hit.inst >= 0;
     if (inInstance) {
         w2p = anim_interpolate(sc.instances[hit.inst], time, true);
         ray.o = xf_point(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);

@@ -37,13 +37,13 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
     return need ? (int64_t)(base + (unsigned long long)rank) : -1;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool INST>
 __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
-    Lane<LdHashSrc> lane;
+    Lane<LdHashSrc, INST> lane;
     lane.init();
     bool exhausted = false;
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
         if (active) {
             bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse<COUNT>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
         }
         // ---- state machine step ----------------------------------------------------------------------
         if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
     const int64_t gid = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
-    Lane<MtReplaySrc> lane;
+    Lane<MtReplaySrc, true> lane;
     lane.init();
     lane.smp.mt = ra.mt + gid; lane.smp.buf = ra.buf + gid; lane.smp.stride = ra.nlanes; lane.smp.mti = HPT_MT_N; lane.smp.n = (uint32_t)rp.spp; lane.smp.i = 0;
     TileWalk tw; tw.started = false; tw.x0 = tw.x1 = tw.y0 = tw.y1 = tw.x = tw.y = 0;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
         if (active) {
             bool anyhit = lane.stage == ST_SHADOW;
             if (anyhit) wc.shadow++; else wc.closest++;
-            traverse<true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            traverse<true, true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
             LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
             lane.on_hit(sc, rp, hit, a.film, &wc, ls);
         }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
     const float *r = rays + 8 * i;
     Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
     Hit hit; TravCounters tc = {0, 0};
-    bool h = traverse<false>(sc, ray, 0.f, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
+    bool h = traverse<false, true>(sc, ray, 0.f, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
     float *o = out_hit + 4 * i;
     if (anyhit) { out_prim[i] = h ? 0 : -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
     if (!h) { out_prim[i] = -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
@@ -183,19 +183,24 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
-int path_kernel_occupancy(int *blocks_per_cu, int *vgprs) {
+int path_kernel_occupancy(bool inst, int *blocks_per_cu, int *vgprs) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false>, HPT_BLOCK, 0);
+    hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, true>, HPT_BLOCK, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, false>, HPT_BLOCK, 0);
     if (e != hipSuccess) return -1;
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void *)hpt_path_kernel<false>) == hipSuccess) *vgprs = fa.numRegs; else *vgprs = 0;
+    const void *fn = inst ? (const void *)hpt_path_kernel<false, true> : (const void *)hpt_path_kernel<false, false>;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) *vgprs = fa.numRegs; else *vgprs = 0;
     *blocks_per_cu = nb;
     return 0;
 }
 
 hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
-    if (count) hipLaunchKernelGGL(hpt_path_kernel<true>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL(hpt_path_kernel<false>, dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    const bool inst = a.sc.n_instances > 0;
+    if (count && inst) hipLaunchKernelGGL((hpt_path_kernel<true, true>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, false>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    else if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((hpt_path_kernel<false, false>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {

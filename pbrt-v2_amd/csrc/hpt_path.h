@@ -69,7 +69,8 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
 
 // ---- lane -----------------------------------------------------------------------------------------
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
-template <class Smp> struct Lane {
+// INST: compile the animated-instance code in (scenes without instances use the leaner INST=false kernel).
+template <class Smp, bool INST> struct Lane {
     int stage;
     // pixel / sample bookkeeping
     int px, py;
@@ -103,7 +104,7 @@ template <class Smp> struct Lane {
         if (rp.cam.lens_radius > 0.f) smp.lens(&lu, &lv);
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
         time = 0.f;
-        if (rp.has_motion) { float t = smp.time01(); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
+        if (INST && rp.has_motion) { float t = smp.time01(); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
         L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
         stage = ST_EXTEND;
     }
@@ -198,7 +199,7 @@ template <class Smp> struct Lane {
             return;
         }
         Bsdf bsdf; DGeom dg; int arealight;
-        shade_geometry(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
+        shade_geometry<INST>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
         if (bounce == 0 || specular)                                        // path.cpp:63-64
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));

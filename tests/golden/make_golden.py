@@ -108,6 +108,7 @@ def main():
         anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
         a = run_case("anim", sub(anim, 200, 120, 8, 5, os.path.join(tmp, "anim_ref.pfm")), tmp)
         a.save(os.path.join(HERE, "anim_killeroos.hpts.gz"))
+        dump_view("anim_1080p", sub(anim, 1920, 1080, 128, 8, os.path.join(tmp, "x.pfm")), tmp, a)
         # bench workloads (BASELINE.json configs[1] and the north-star target scene) at 1920x1080
         dump_view("killeroo_1080p", sub(kill, 1920, 1080, 64, 8, os.path.join(tmp, "x.pfm")), tmp, s)
         head1080 = head.replace("[240]", "[1920]").replace("[135]", "[1080]").replace("[8]\nSurface", "[64]\nSurface")

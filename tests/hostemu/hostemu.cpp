@@ -84,13 +84,13 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
             if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashSrc> lane; lane.init();
+            Lane<LdHashSrc, true> lane; lane.init();
             lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit(s->d, rp, hit, film, &wc, ls); }
             }
         }
@@ -113,7 +113,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
     std::vector<float> buf((size_t)HPT_REPLAY_FLOATS_PER_SAMPLE * rd->spp);
     int32_t stack[64];
     for (int task = 0; task < rd->ntasks; ++task) {
-        Lane<MtReplaySrc> lane; lane.init();
+        Lane<MtReplaySrc, true> lane; lane.init();
         lane.smp.mt = mt.data(); lane.smp.buf = buf.data(); lane.smp.stride = 1; lane.smp.n = (uint32_t)rd->spp; lane.smp.i = 0;
         TileWalk tw; tw.started = false;
         compute_sub_window(rp.x_start, rp.x_start + rp.x_count, rp.y_start, rp.y_start + rp.y_count, task, rd->ntasks,
@@ -126,7 +126,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 LaneStack ls; ls.p = stack; ls.stride = 1;
                 lane.on_hit(s->d, rp, hit, film, &wc, ls);
             }
@@ -143,7 +143,7 @@ extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, i
         const float *r = rays + 8 * i;
         Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
         Hit hit; TravCounters tc = {0, 0}; int32_t stack[64];
-        bool h = traverse<false>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
+        bool h = traverse<false, true>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
         float *o = out_hit + 4 * i;
         o[0] = o[1] = o[2] = o[3] = 0.f;
         if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }

@@ -42,7 +42,7 @@ def test_sampler_bit_identical(cases):
     assert np.array_equal(orc.sampler(rd, 9, 9), hpt.sampler(rd, 9, 9))
 
 
-@pytest.mark.parametrize("name", ["cfg1", "b8", "env"])
+@pytest.mark.parametrize("name", ["cfg1", "b8", "env", "anim"])
 def test_intersect_matches_oracle(cases, dev, ora, name):
     rays = random_rays(cases[name], 200000, seed=5)
     ho, po = ora[name].intersect(rays)

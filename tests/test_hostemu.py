@@ -27,7 +27,7 @@ def test_sampler_bit_identical(cases):
         assert np.array_equal(orc.sampler(rd, x, y), emu.sampler(rd, x, y))
 
 
-@pytest.mark.parametrize("name", ["cfg1", "b8", "env"])
+@pytest.mark.parametrize("name", ["cfg1", "b8", "env", "anim"])
 def test_intersect_matches_oracle(cases, pairs, name):
     o, e = pairs[name]
     rays = random_rays(cases[name], 20000, seed=5)
