@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 3
+#define HPT_VERSION 4
 
 enum {
     HPT_OK = 0,
@@ -48,8 +48,9 @@ enum {
 /* Shape kinds other than triangles.  shapes/sphere.cpp, shapes/disk.cpp */
 enum { HPT_QUADRIC_SPHERE = 1, HPT_QUADRIC_DISK = 2 };
 
-/* Material kinds: materials/matte.cpp:42, plastic.cpp:42, measured.cpp:194 (IrregIsotropicBRDF) */
-enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3 };
+/* Material kinds: materials/matte.cpp:42, plastic.cpp:42, measured.cpp:194 (IrregIsotropicBRDF),
+ * metal.cpp:51 (Microfacet + FresnelConductor + Blinn), substrate.cpp:42 (FresnelBlend + Anisotropic) */
+enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_MAT_METAL = 4, HPT_MAT_SUBSTRATE = 5 };
 
 /* Light kinds: lights/point.cpp:50, lights/diffuse.cpp:69, lights/infinite.cpp:68 */
 enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3 };
@@ -123,6 +124,9 @@ typedef struct hpt_material {
     int64_t kd_split_off, kd_bits_off, kd_data_off;
     int32_t kd_nnodes;
     int32_t pad;
+    float eta[3], k[3]; /* metal: conductor index / absorption as RGB (SPDs are converted at load, spectrum.h:428);
+                           roughness above = Blinn roughness                                                  */
+    float nu, nv;       /* substrate: uroughness, vroughness (Anisotropic exponents 1/nu, 1/nv); kd, ks above */
 } hpt_material;
 
 typedef struct hpt_light {

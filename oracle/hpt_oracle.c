@@ -856,8 +856,9 @@ static int scene_intersect(const orc_scene *s, ray_t *ray, isect_t *is, int anyh
 
 /* ---- BSDF (core/reflection.cpp) ---------------------------------------------------------- */
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };
-enum { BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3 };
-typedef struct { int kind, type; rgb R; float exponent; const hpt_material *mat; } bxdf_t;
+enum { BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFACET_COND = 4, BX_FRESNELBLEND = 5 };
+/* R: reflectance (Rd for FresnelBlend); R2: k for the conductor / Rs for FresnelBlend; eta in R for the conductor */
+typedef struct { int kind, type; rgb R; float exponent; const hpt_material *mat; rgb R2; float ey; } bxdf_t;
 typedef struct { v3 nn, ng, sn, tn; int n; bxdf_t bx[2]; v3 p; } bsdf_t;
 
 static inline float cos_theta(v3 w) { return w.z; }
@@ -889,6 +890,24 @@ static void bsdf_add_material(bsdf_t *b, const hpt_material *m) {
         }
     } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
         bxdf_t x = {BX_IRREG, BSDF_REFLECTION | BSDF_GLOSSY, S(0.f), 0.f, m}; b->bx[b->n++] = x; /* reflection.h:464-466 */
+    } else if (m->kind == HPT_MAT_METAL) { /* metal.cpp:51-68: Microfacet(1., FresnelConductor(eta,k), Blinn(1/rough)) */
+        float e = 1.f / m->roughness;
+        if (e > 10000.f || isnan(e)) e = 10000.f;
+        bxdf_t x; memset(&x, 0, sizeof(x));
+        x.kind = BX_MICROFACET_COND; x.type = BSDF_REFLECTION | BSDF_GLOSSY; x.exponent = e; x.mat = m;
+        x.R.c[0] = m->eta[0]; x.R.c[1] = m->eta[1]; x.R.c[2] = m->eta[2];
+        x.R2.c[0] = m->k[0]; x.R2.c[1] = m->k[1]; x.R2.c[2] = m->k[2];
+        b->bx[b->n++] = x;
+    } else if (m->kind == HPT_MAT_SUBSTRATE) { /* substrate.cpp:42-58: FresnelBlend(d, s, Anisotropic(1/u, 1/v)) */
+        if (!sblack(kd) || !sblack(ks)) {
+            bxdf_t x; memset(&x, 0, sizeof(x));
+            x.kind = BX_FRESNELBLEND; x.type = BSDF_REFLECTION | BSDF_GLOSSY; x.mat = m; x.R = kd; x.R2 = ks;
+            float ex = 1.f / m->nu, ey = 1.f / m->nv;           /* Anisotropic ctor reflection.h:439-443 */
+            if (ex > 10000.f || isnan(ex)) ex = 10000.f;
+            if (ey > 10000.f || isnan(ey)) ey = 10000.f;
+            x.exponent = ex; x.ey = ey;
+            b->bx[b->n++] = x;
+        }
     }
 }
 /* FresnelDielectric::Evaluate(1.5, 1) (reflection.cpp:115-135) + FrDiel (:60-67); scalar: all
@@ -953,6 +972,58 @@ static rgb irreg_f(const orc_scene *s, const hpt_material *m, v3 wo, v3 wi) { /*
         lastMaxDist2 *= 2.f;
     }
 }
+/* FrCond (reflection.cpp:70-79) via FresnelConductor::Evaluate (:110-112) */
+static rgb fr_cond(float cosi, rgb eta, rgb k) {
+    cosi = fabsf(cosi);
+    rgb r;
+    for (int c = 0; c < 3; ++c) {
+        float e = eta.c[c], kk = k.c[c];
+        float tmp = (e * e + kk * kk) * cosi * cosi;
+        float Rparl2 = (tmp - (2.f * e * cosi) + 1) / (tmp + (2.f * e * cosi) + 1);
+        float tmp_f = e * e + kk * kk;
+        float Rperp2 = (tmp_f - (2.f * e * cosi) + cosi * cosi) / (tmp_f + (2.f * e * cosi) + cosi * cosi);
+        r.c[c] = (Rparl2 + Rperp2) / 2.f;
+    }
+    return r;
+}
+/* Anisotropic::D / Pdf / Sample_f (reflection.h:444-451, reflection.cpp:377-443) */
+static float aniso_D(float ex, float ey, v3 wh) {
+    float costhetah = abs_cos_theta(wh);
+    float d = 1.f - costhetah * costhetah;
+    if (d == 0.f) return 0.f;
+    float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / d;
+    return sqrtf((ex + 2.f) * (ey + 2.f)) * INV_TWOPI_F * powf(costhetah, e);
+}
+static float aniso_pdf_wh(float ex, float ey, v3 wo, v3 wh) {
+    float costhetah = abs_cos_theta(wh);
+    float ds = 1.f - costhetah * costhetah;
+    float p = 0.f;
+    if (ds > 0.f && dot(wo, wh) > 0.f) {
+        float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / ds;
+        float d = sqrtf((ex + 1.f) * (ey + 1.f)) * INV_TWOPI_F * powf(costhetah, e);
+        p = d / (4.f * dot(wo, wh));
+    }
+    return p;
+}
+static void aniso_first_quadrant(float ex, float ey, float u1, float u2, float *phi, float *costheta) {
+    if (ex == ey) *phi = PI_F * u1 * 0.5f;
+    else *phi = atanf(sqrtf((ex + 1.f) / (ey + 1.f)) * tanf(PI_F * u1 * 0.5f));
+    float cosphi = cosf(*phi), sinphi = sinf(*phi);
+    *costheta = powf(u2, 1.f / (ex * cosphi * cosphi + ey * sinphi * sinphi + 1));
+}
+static void aniso_sample(float ex, float ey, v3 wo, v3 *wi, float u1, float u2, float *pdf) {
+    float phi, costheta;
+    if (u1 < .25f) aniso_first_quadrant(ex, ey, 4.f * u1, u2, &phi, &costheta);
+    else if (u1 < .5f) { u1 = 4.f * (.5f - u1); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi = PI_F - phi; }
+    else if (u1 < .75f) { u1 = 4.f * (u1 - .5f); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi += PI_F; }
+    else { u1 = 4.f * (1.f - u1); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi = 2.f * PI_F - phi; }
+    float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
+    v3 wh = V(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
+    if (!same_hemisphere(wo, wh)) wh = vneg(wh);
+    *wi = vadd(vneg(wo), vmul(wh, 2.f * dot(wo, wh)));
+    *pdf = aniso_pdf_wh(ex, ey, wo, wh);
+}
+static void concentric_sample_disk(float u1, float u2, float *dx, float *dy);
 static rgb bxdf_f(const orc_scene *s, const bxdf_t *x, v3 wo, v3 wi) {
     if (x->kind == BX_LAMBERT) return sscale(x->R, INV_PI_F);                 /* reflection.cpp:173-175 */
     if (x->kind == BX_MICROFACET) {                                           /* :211-222 */
@@ -969,6 +1040,32 @@ static rgb bxdf_f(const orc_scene *s, const bxdf_t *x, v3 wo, v3 wi) {
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh))); /* :403-410 */
         return sdivf(smul(sscale(sscale(x->R, D), G), S(F)), (4.f * cosThetaI * cosThetaO));
     }
+    if (x->kind == BX_MICROFACET_COND) { /* Microfacet::f with FresnelConductor, R = 1 (reflection.cpp:211-222) */
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+        if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
+        v3 wh = vadd(wi, wo);
+        if (wh.x == 0. && wh.y == 0. && wh.z == 0.) return S(0.f);
+        wh = normalize(wh);
+        float cosThetaH = dot(wi, wh);
+        rgb F = fr_cond(cosThetaH, x->R, x->R2);
+        float D = (x->exponent + 2) * INV_TWOPI_F * powf(abs_cos_theta(wh), x->exponent);
+        float NdotWh = abs_cos_theta(wh), NdotWo = abs_cos_theta(wo), NdotWi = abs_cos_theta(wi);
+        float WOdotWh = absdot(wo, wh);
+        float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+        return sdivf(smul(sscale(sscale(S(1.f), D), G), F), (4.f * cosThetaI * cosThetaO));
+    }
+    if (x->kind == BX_FRESNELBLEND) { /* FresnelBlend::f (reflection.cpp:232-244) */
+        rgb one_minus_rs = {{1.f - x->R2.c[0], 1.f - x->R2.c[1], 1.f - x->R2.c[2]}};
+        rgb diffuse = sscale(sscale(smul(sscale(x->R, (28.f / (23.f * PI_F))), one_minus_rs),
+                                    (1.f - powf(1.f - .5f * abs_cos_theta(wi), 5))), (1.f - powf(1.f - .5f * abs_cos_theta(wo), 5)));
+        v3 wh = vadd(wi, wo);
+        if (wh.x == 0. && wh.y == 0. && wh.z == 0.) return S(0.f);
+        wh = normalize(wh);
+        float sc = aniso_D(x->exponent, x->ey, wh) / (4.f * absdot(wi, wh) * maxf(abs_cos_theta(wi), abs_cos_theta(wo)));
+        float pw = powf(1 - dot(wi, wh), 5.f);
+        rgb schlick = sadd(x->R2, sscale(one_minus_rs, pw));   /* SchlickFresnel reflection.h:468-470 */
+        return sadd(diffuse, sscale(schlick, sc));
+    }
     return irreg_f(s, x->mat, wo, wi);
 }
 static float blinn_pdf(float exponent, v3 wo, v3 wi) { /* reflection.cpp:366-374 */
@@ -979,7 +1076,11 @@ static float blinn_pdf(float exponent, v3 wo, v3 wi) { /* reflection.cpp:366-374
     return p;
 }
 static float bxdf_pdf(const bxdf_t *x, v3 wo, v3 wi) {
-    if (x->kind == BX_MICROFACET) { if (!same_hemisphere(wo, wi)) return 0.f; return blinn_pdf(x->exponent, wo, wi); } /* :340-343 */
+    if (x->kind == BX_FRESNELBLEND) { /* FresnelBlend::Pdf (reflection.cpp:465-468) */
+        if (!same_hemisphere(wo, wi)) return 0.f;
+        return .5f * (abs_cos_theta(wi) * INV_PI_F + aniso_pdf_wh(x->exponent, x->ey, wo, normalize(vadd(wo, wi))));
+    }
+    if (x->kind == BX_MICROFACET || x->kind == BX_MICROFACET_COND) { if (!same_hemisphere(wo, wi)) return 0.f; return blinn_pdf(x->exponent, wo, wi); } /* :340-343 */
     return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * INV_PI_F : 0.f;                                                /* :321-323 */
 }
 static void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /* montecarlo.cpp:306-348 */
@@ -998,7 +1099,22 @@ static void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
     *dy = r * sinf(theta);
 }
 static rgb bxdf_sample_f(const orc_scene *s, const bxdf_t *x, v3 wo, v3 *wi, float u1, float u2, float *pdf) {
-    if (x->kind == BX_MICROFACET) { /* Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363 */
+    if (x->kind == BX_FRESNELBLEND) { /* FresnelBlend::Sample_f (reflection.cpp:446-462) */
+        if (u1 < .5) {
+            u1 = 2.f * u1;
+            v3 w; concentric_sample_disk(u1, u2, &w.x, &w.y);
+            w.z = sqrtf(maxf(0.f, 1.f - w.x * w.x - w.y * w.y));
+            if (wo.z < 0.) w.z *= -1.f;
+            *wi = w;
+        } else {
+            u1 = 2.f * (u1 - .5f);
+            aniso_sample(x->exponent, x->ey, wo, wi, u1, u2, pdf);
+            if (!same_hemisphere(wo, *wi)) return S(0.f);
+        }
+        *pdf = bxdf_pdf(x, wo, *wi);
+        return bxdf_f(s, x, wo, *wi);
+    }
+    if (x->kind == BX_MICROFACET || x->kind == BX_MICROFACET_COND) { /* Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363 */
         float costheta = powf(u1, 1.f / (x->exponent + 1));
         float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
         float phi = u2 * 2.f * PI_F;

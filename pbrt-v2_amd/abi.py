@@ -9,10 +9,10 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 3
+HPT_VERSION = 4
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
-HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG = 1, 2, 3
+HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY = 0, 1
 SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs
@@ -46,7 +46,8 @@ class Quadric(C.Structure):
 class Material(C.Structure):
     _fields_ = [("kind", i32), ("kd", f32 * 3), ("sigma", f32), ("ks", f32 * 3),
                 ("roughness", f32), ("kd_split_off", i64), ("kd_bits_off", i64),
-                ("kd_data_off", i64), ("kd_nnodes", i32), ("pad", i32)]
+                ("kd_data_off", i64), ("kd_nnodes", i32), ("pad", i32),
+                ("eta", f32 * 3), ("k", f32 * 3), ("nu", f32), ("nv", f32)]
 
 
 class Light(C.Structure):

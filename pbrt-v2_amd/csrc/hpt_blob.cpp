@@ -90,7 +90,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
         const hpt_material &ma = d->materials[m];
         if (ma.kind == HPT_MAT_MATTE) {
             if (ma.sigma != 0.f) { hpt_set_error("material %d: Oren-Nayar (sigma != 0) unsupported", m); return HPT_E_UNSUPPORTED; }
-        } else if (ma.kind == HPT_MAT_PLASTIC) {
+        } else if (ma.kind == HPT_MAT_PLASTIC || ma.kind == HPT_MAT_METAL || ma.kind == HPT_MAT_SUBSTRATE) {
         } else if (ma.kind == HPT_MAT_MEASURED_IRREG) {
             if (ma.kd_nnodes <= 0 || ma.kd_split_off < 0 || ma.kd_bits_off < 0 || ma.kd_data_off < 0 ||
                 ma.kd_split_off + ma.kd_nnodes > d->n_f || ma.kd_bits_off + ma.kd_nnodes > d->n_i ||

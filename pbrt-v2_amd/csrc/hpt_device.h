@@ -584,15 +584,17 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
 // ---- shading geometry + BSDF -------------------------------------------------------------------
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31, BSDF_ALL_NOSPEC = 15 };
-enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3 };
+enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFACET_COND = 4, BX_FRESNELBLEND = 5 };
 
 // BSDF value type (replaces the arena-allocated BSDF + BxDF objects of core/reflection.h:150-191)
 struct Bsdf {
     f3 nn, ng, sn, tn; // shading normal, geometric normal, tangent frame (reflection.cpp:601-609)
     int n;             // number of BxDFs (<= 2 for the in-scope materials)
     int kind0, kind1;  // BX_*
-    f3 R0, R1;         // reflectances
-    float exponent;    // Blinn exponent of the microfacet lobe
+    f3 R0, R1;         // reflectances; single-lobe materials reuse the pair: metal R0 = eta, R1 = k;
+                       // substrate R0 = Rd, R1 = Rs
+    float exponent;    // Blinn exponent of the microfacet lobe / Anisotropic ex
+    float ey;          // Anisotropic ey
     const hpt_material *mat;
     HPT_MFN int kind(int i) const { return i == 0 ? kind0 : kind1; }
     HPT_MFN f3 R(int i) const { return i == 0 ? R0 : R1; }
@@ -609,7 +611,7 @@ HPT_FN bool same_hemisphere(f3 w, f3 wp) { return w.z * wp.z > 0.f; }
 
 HPT_FN void bsdf_frame(Bsdf *b, f3 nn_shading, f3 dpdu_shading, f3 ng) {
     b->ng = ng; b->nn = nn_shading; b->sn = normalize(dpdu_shading); b->tn = cross(b->nn, b->sn);
-    b->n = 0; b->kind0 = b->kind1 = BX_NONE; b->R0 = b->R1 = S(0.f); b->exponent = 0.f; b->mat = nullptr;
+    b->n = 0; b->kind0 = b->kind1 = BX_NONE; b->R0 = b->R1 = S(0.f); b->exponent = 0.f; b->ey = 0.f; b->mat = nullptr;
 }
 HPT_FN void bsdf_push(Bsdf *b, int kind, f3 R) {
     if (b->n == 0) { b->kind0 = kind; b->R0 = R; } else { b->kind1 = kind; b->R1 = R; }
@@ -631,6 +633,21 @@ HPT_FN void bsdf_add_material(Bsdf *b, const hpt_material *m) {
         }
     } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
         bsdf_push(b, BX_IRREG, S(0.f));
+    } else if (m->kind == HPT_MAT_METAL) {        // metal.cpp:51-68: Microfacet(1., FresnelConductor(eta, k), Blinn(1/rough))
+        float e = 1.f / m->roughness;
+        if (e > 10000.f || e != e) e = 10000.f;
+        b->exponent = e;
+        bsdf_push(b, BX_MICROFACET_COND, mk3(m->eta[0], m->eta[1], m->eta[2]));
+        b->R1 = mk3(m->k[0], m->k[1], m->k[2]);
+    } else if (m->kind == HPT_MAT_SUBSTRATE) {    // substrate.cpp:42-58: FresnelBlend(d, s, Anisotropic(1/u, 1/v))
+        if (!sblack(kd) || !sblack(ks)) {
+            float ex = 1.f / m->nu, ey = 1.f / m->nv;
+            if (ex > 10000.f || ex != ex) ex = 10000.f;   // Anisotropic ctor (reflection.h:439-443)
+            if (ey > 10000.f || ey != ey) ey = 10000.f;
+            b->exponent = ex; b->ey = ey;
+            bsdf_push(b, BX_FRESNELBLEND, kd);
+            b->R1 = ks;
+        }
     }
 }
 // FresnelDielectric::Evaluate + FrDiel (reflection.cpp:115-135, 60-67); scalar because eta is scalar
@@ -715,6 +732,52 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     }
 }
 
+// FrCond (reflection.cpp:70-79) through FresnelConductor::Evaluate (:110-112), per RGB channel
+HPT_FN float fr_cond1(float cosi, float e, float kk) {
+    float tmp = (e * e + kk * kk) * cosi * cosi;
+    float Rparl2 = (tmp - (2.f * e * cosi) + 1) / (tmp + (2.f * e * cosi) + 1);
+    float tmp_f = e * e + kk * kk;
+    float Rperp2 = (tmp_f - (2.f * e * cosi) + cosi * cosi) / (tmp_f + (2.f * e * cosi) + cosi * cosi);
+    return (Rparl2 + Rperp2) / 2.f;
+}
+// Anisotropic microfacet distribution (reflection.h:444-451, reflection.cpp:377-443)
+HPT_FN float aniso_D(float ex, float ey, f3 wh) {
+    float costhetah = abs_cos_theta(wh);
+    float d = 1.f - costhetah * costhetah;
+    if (d == 0.f) return 0.f;
+    float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / d;
+    return sqrtf((ex + 2.f) * (ey + 2.f)) * HPT_INV_TWOPI * powf(costhetah, e);
+}
+HPT_FN float aniso_pdf_wh(float ex, float ey, f3 wo, f3 wh) {
+    float costhetah = abs_cos_theta(wh);
+    float ds = 1.f - costhetah * costhetah;
+    float p = 0.f;
+    if (ds > 0.f && dot(wo, wh) > 0.f) {
+        float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / ds;
+        float d = sqrtf((ex + 1.f) * (ey + 1.f)) * HPT_INV_TWOPI * powf(costhetah, e);
+        p = d / (4.f * dot(wo, wh));
+    }
+    return p;
+}
+HPT_FN void aniso_first_quadrant(float ex, float ey, float u1, float u2, float *phi, float *costheta) {
+    if (ex == ey) *phi = HPT_PI * u1 * 0.5f;
+    else *phi = atanf(sqrtf((ex + 1.f) / (ey + 1.f)) * tanf(HPT_PI * u1 * 0.5f));
+    float cosphi = cosf(*phi), sinphi = sinf(*phi);
+    *costheta = powf(u2, 1.f / (ex * cosphi * cosphi + ey * sinphi * sinphi + 1));
+}
+HPT_FN void aniso_sample(float ex, float ey, f3 wo, f3 *wi, float u1, float u2, float *pdf) {
+    float phi, costheta;
+    if (u1 < .25f) aniso_first_quadrant(ex, ey, 4.f * u1, u2, &phi, &costheta);
+    else if (u1 < .5f) { u1 = 4.f * (.5f - u1); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi = HPT_PI - phi; }
+    else if (u1 < .75f) { u1 = 4.f * (u1 - .5f); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi += HPT_PI; }
+    else { u1 = 4.f * (1.f - u1); aniso_first_quadrant(ex, ey, u1, u2, &phi, &costheta); phi = 2.f * HPT_PI - phi; }
+    float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
+    f3 wh = mk3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
+    if (!same_hemisphere(wo, wh)) wh = -wh;
+    *wi = (-wo) + wh * (2.f * dot(wo, wh));
+    *pdf = aniso_pdf_wh(ex, ey, wo, wh);
+}
+HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy);
 HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack ls) {
     int kind = b.kind(i);
     if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
@@ -732,10 +795,41 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
         return sdivf(smul((b.R(i) * D) * G, S(F)), (4.f * cosThetaI * cosThetaO));
     }
+    if (kind == BX_MICROFACET_COND) {                                // Microfacet::f, R = 1, FresnelConductor
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+        if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
+        f3 wh = wi + wo;
+        if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return S(0.f);
+        wh = normalize(wh);
+        float ci = fabsf(dot(wi, wh));
+        f3 F = mk3(fr_cond1(ci, b.R0.x, b.R1.x), fr_cond1(ci, b.R0.y, b.R1.y), fr_cond1(ci, b.R0.z, b.R1.z));
+        float D = (b.exponent + 2) * HPT_INV_TWOPI * powf(abs_cos_theta(wh), b.exponent);
+        float NdotWh = abs_cos_theta(wh), NdotWo = abs_cos_theta(wo), NdotWi = abs_cos_theta(wi);
+        float WOdotWh = absdot(wo, wh);
+        float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+        return sdivf(smul((S(1.f) * D) * G, F), (4.f * cosThetaI * cosThetaO));
+    }
+    if (kind == BX_FRESNELBLEND) {                                   // FresnelBlend::f (reflection.cpp:232-244)
+        f3 Rd = b.R0, Rs = b.R1;
+        f3 one_minus_rs = mk3(1.f - Rs.x, 1.f - Rs.y, 1.f - Rs.z);
+        f3 diffuse = (smul(Rd * (28.f / (23.f * HPT_PI)), one_minus_rs) * (1.f - powf(1.f - .5f * abs_cos_theta(wi), 5.f))) *
+                     (1.f - powf(1.f - .5f * abs_cos_theta(wo), 5.f));
+        f3 wh = wi + wo;
+        if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return S(0.f);
+        wh = normalize(wh);
+        float sc_ = aniso_D(b.exponent, b.ey, wh) / (4.f * absdot(wi, wh) * maxf(abs_cos_theta(wi), abs_cos_theta(wo)));
+        float pw = powf(1 - dot(wi, wh), 5.f);
+        f3 schlick = Rs + one_minus_rs * pw;                         // SchlickFresnel (reflection.h:468-470)
+        return diffuse + schlick * sc_;
+    }
     return irreg_f(sc, b.mat, wo, wi, ls);
 }
 HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
-    if (b.kind(i) == BX_MICROFACET) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
+    if (b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Pdf (reflection.cpp:465-468)
+        if (!same_hemisphere(wo, wi)) return 0.f;
+        return .5f * (abs_cos_theta(wi) * HPT_INV_PI + aniso_pdf_wh(b.exponent, b.ey, wo, normalize(wo + wi)));
+    }
+    if (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
         if (!same_hemisphere(wo, wi)) return 0.f;
         f3 wh = normalize(wo + wi);
         float costheta = abs_cos_theta(wh);
@@ -761,7 +855,22 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
     *dy = r * sinf(theta);
 }
 HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, LaneStack ls) {
-    if (b.kind(i) == BX_MICROFACET) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
+    if (b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Sample_f (reflection.cpp:446-462)
+        if (u1 < .5f) {
+            u1 = 2.f * u1;
+            f3 w; concentric_sample_disk(u1, u2, &w.x, &w.y);
+            w.z = sqrtf(maxf(0.f, 1.f - w.x * w.x - w.y * w.y));
+            if (wo.z < 0.f) w.z *= -1.f;
+            *wi = w;
+        } else {
+            u1 = 2.f * (u1 - .5f);
+            aniso_sample(b.exponent, b.ey, wo, wi, u1, u2, pdf);
+            if (!same_hemisphere(wo, *wi)) return S(0.f);
+        }
+        *pdf = bxdf_pdf(b, i, wo, *wi);
+        return bxdf_f(sc, b, i, wo, *wi, ls);
+    }
+    if (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
         float costheta = powf(u1, 1.f / (b.exponent + 1));
         float sintheta = sqrtf(maxf(0.f, 1.f - costheta * costheta));
         float phi = u2 * 2.f * HPT_PI;

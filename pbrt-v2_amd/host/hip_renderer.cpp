@@ -39,6 +39,8 @@
 #include "lights/point.h"
 #include "materials/matte.h"
 #include "materials/measured.h"
+#include "materials/metal.h"
+#include "materials/substrate.h"
 #include "materials/plastic.h"
 #include "samplers/lowdiscrepancy.h"
 #include "shapes/disk.h"
@@ -140,9 +142,25 @@ struct Flattener {
             r.kd_split_off = PushF(&split[0], n);
             r.kd_bits_off = PushI(&bits[0], n);
             r.kd_data_off = PushF(&data[0], 6 * (size_t)n);
+        } else if (const MetalMaterial *mt = dynamic_cast<const MetalMaterial *>(m)) {
+            Spectrum eta, k; float rough;
+            if (mt->bumpMap.GetPtr() || !ConstTex(mt->eta, &eta) || !ConstTex(mt->k, &k) || !ConstTex(mt->roughness, &rough))
+                Severe("hip renderer: metal material with non-constant textures / bump map is outside the hot-path scope");
+            r.kind = HPT_MAT_METAL;
+            eta.ToRGB(r.eta); k.ToRGB(r.k);                    // metal.cpp:64-65 (no Clamp)
+            r.roughness = rough;
+        } else if (const SubstrateMaterial *sm = dynamic_cast<const SubstrateMaterial *>(m)) {
+            Spectrum kd, ks; float nu, nv;
+            if (sm->bumpMap.GetPtr() || !ConstTex(sm->Kd, &kd) || !ConstTex(sm->Ks, &ks) || !ConstTex(sm->nu, &nu) ||
+                !ConstTex(sm->nv, &nv))
+                Severe("hip renderer: substrate material with non-constant textures / bump map is outside the hot-path scope");
+            r.kind = HPT_MAT_SUBSTRATE;
+            kd = kd.Clamp(); kd.ToRGB(r.kd);                   // substrate.cpp:50-51
+            ks = ks.Clamp(); ks.ToRGB(r.ks);
+            r.nu = nu; r.nv = nv;
         } else
             Severe("hip renderer: material type outside the hot-path scope "
-                   "(supported: matte, plastic, measured/.brdf)");
+                   "(supported: matte, plastic, measured/.brdf, metal, substrate)");
         int idx = (int)materials.size();
         materials.push_back(r);
         materialIndex[m] = idx;

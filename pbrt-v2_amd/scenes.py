@@ -134,6 +134,61 @@ def matte(kd):
     return m
 
 
+def metal(eta, k, roughness):
+    m = abi.Material()
+    m.kind, m.roughness = abi.HPT_MAT_METAL, roughness
+    for i in range(3):
+        m.eta[i], m.k[i] = float(eta[i]), float(k[i])
+    m.kd_split_off = m.kd_bits_off = m.kd_data_off = -1
+    return m
+
+
+def substrate(kd, ks, nu, nv):
+    m = abi.Material()
+    m.kind, m.nu, m.nv = abi.HPT_MAT_SUBSTRATE, nu, nv
+    for i in range(3):
+        m.kd[i], m.ks[i] = float(kd[i]), float(ks[i])
+    m.kd_split_off = m.kd_bits_off = m.kd_data_off = -1
+    return m
+
+
+def materials_soup(n_tris=3000, xres=160, yres=90, spp=8, maxdepth=5, seed=7):
+    """Small test scene for the config-5 BxDFs: three interleaved triangle soups with a copper-like
+    metal (Microfacet + FresnelConductor + Blinn), an anisotropic substrate (FresnelBlend +
+    Anisotropic, uroughness != vroughness) and an isotropic substrate, under a constant infinite
+    light plus a point light."""
+    base = synthetic_soup(n_tris=n_tris, xres=xres, yres=yres, spp=spp, maxdepth=maxdepth, seed=seed, extent=0.1)
+    P = base.fpool[:9 * n_tris].copy()
+    cuts = [0, n_tris // 3, 2 * n_tris // 3, n_tris]
+    mats = [metal([0.2, 0.92, 1.1], [3.9, 2.45, 2.14], 0.05), substrate([0.3, 0.4, 0.5], [0.4, 0.3, 0.2], 0.05, 0.2),
+            substrate([0.5, 0.5, 0.5], [0.5, 0.5, 0.5], 0.1, 0.1)]
+    meshes, idx_parts = [], []
+    for i in range(3):
+        nt = cuts[i + 1] - cuts[i]
+        me = abi.Mesh()
+        me.p_off, me.n_off, me.uv_off = 9 * cuts[i], -1, -1
+        me.idx_off = 3 * cuts[i]
+        me.ntris, me.nverts = nt, 3 * nt
+        me.material, me.arealight, me.instance = i, -1, -1
+        me.o2w, me.o2w_inv = _m16(np.eye(4)), _m16(np.eye(4))
+        meshes.append(me)
+        idx_parts.append(np.arange(3 * nt, dtype=np.int32))
+    fparts = [P]
+    env = constant_infinite_light([0.6, 0.7, 0.9], fparts)
+    pt = abi.Light()
+    pt.kind, pt.quadric = abi.HPT_LIGHT_POINT, -1
+    for i, v in enumerate([0.0, 2.5, 3.0]):
+        pt.pos[i] = v
+    for i in range(3):
+        pt.intensity[i] = 6.0
+    l2w = np.eye(4); l2w[:3, 3] = [0.0, 2.5, 3.0]
+    pt.l2w, pt.l2w_inv = _m16(l2w), _m16(np.linalg.inv(l2w))
+    s = abi.Scene(meshes=meshes, materials=mats, lights=[env, pt], fpool=np.concatenate(fparts),
+                  ipool=np.concatenate(idx_parts), camera=base.camera, render=base.render)
+    s.meta = base.meta
+    return s
+
+
 def synthetic_soup(n_tris=1_000_000, xres=1920, yres=1080, spp=256, maxdepth=8, seed=SYNTH_SEED,
                    extent=0.01):
     """BASELINE.json configs[2] / SURVEY.md §8d: n_tris random triangles, vertex i of triangle k =
@@ -194,6 +249,12 @@ def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres
         if m.kind == abi.HPT_MAT_PLASTIC:
             return ['Material "plastic" "color Kd" [%s] "color Ks" [%s] "float roughness" [%.9g]'
                     % (_fmt(list(m.kd)), _fmt(list(m.ks)), m.roughness)]
+        if m.kind == abi.HPT_MAT_METAL:
+            return ['Material "metal" "color eta" [%s] "color k" [%s] "float roughness" [%.9g]'
+                    % (_fmt(list(m.eta)), _fmt(list(m.k)), m.roughness)]
+        if m.kind == abi.HPT_MAT_SUBSTRATE:
+            return ['Material "substrate" "color Kd" [%s] "color Ks" [%s] "float uroughness" [%.9g] "float vroughness" [%.9g]'
+                    % (_fmt(list(m.kd)), _fmt(list(m.ks)), m.nu, m.nv)]
         raise ValueError("export_pbrt: material kind %d not exportable" % m.kind)
 
     for li, l in enumerate(scene.lights):

@@ -17,6 +17,8 @@ Cases
   k8     killeroo-simple 200x120, 16 spp, maxdepth 8   (Russian roulette + rng draws, bounces>=3)
   b8     bunny 240x135, 8 spp, maxdepth 8              (measured BRDF kd-tree, point + disk lights)
   anim   anim-killeroos-moving 200x120, 8 spp, maxdepth 5 (animated instances, motion blur)
+  ms     3000 random triangles with metal / anisotropic substrate / isotropic substrate, point +
+         infinite light, 160x90, 8 spp, maxdepth 5
   env    2000 random triangles + constant infinite light 160x90, 8 spp, maxdepth 5
          (InfiniteAreaLight Sample_L / Pdf / Le, MIS ray escaping to the environment)
 k8 shares cfg1's geometry: only its camera + render descriptor are stored (k8.view.npz).
@@ -120,6 +122,15 @@ def main():
         scenes.export_pbrt(syn, env_pbrt, os.path.join(tmp, "env_ref.pfm"))
         e = run_case("env", open(env_pbrt).read(), tmp)
         e.save(os.path.join(HERE, "env_soup.hpts.gz"))
+        # ms: config-5 BxDFs with constant parameters — metal (FresnelConductor + Blinn microfacet) and
+        # substrate (FresnelBlend + Anisotropic), point + constant infinite light
+        msyn = scenes.materials_soup()
+        ms_pbrt = os.path.join(tmp, "ms.pbrt")
+        scenes.export_pbrt(msyn, ms_pbrt, os.path.join(tmp, "ms_ref.pfm"))
+        ms = run_case("ms", open(ms_pbrt).read(), tmp)
+        ms.save(os.path.join(HERE, "ms_soup.hpts.gz"))
+        for a_, b_ in zip(ms.materials, msyn.materials):
+            assert bytes(a_) == bytes(b_), "material records differ from what the reference parsed"
         # cross-check scenes.py's own light tables / camera against what the reference built
         le, ls = e.lights[0], syn.lights[0]
         for a in ("tex_off", "cond_func_off", "cond_cdf_off", "cond_int_off", "marg_func_off", "marg_cdf_off"):

@@ -71,7 +71,7 @@ def test_intersect_edge_cases(cases, dev, ora):
     assert (pd[:48] == -1).all()
 
 
-@pytest.mark.parametrize("name,material", [("cfg1", 1), ("cfg1", 2), ("cfg1", 3), ("b8", 1), ("env", 0)])
+@pytest.mark.parametrize("name,material", [("cfg1", 1), ("cfg1", 2), ("cfg1", 3), ("b8", 1), ("env", 0), ("ms", 0), ("ms", 1), ("ms", 2)])
 def test_bsdf_matches_oracle(cases, dev, ora, name, material):
     inp = bsdf_inputs(4000 if name != "b8" else 800)
     a, b = ora[name].bsdf(material, inp), dev[name].bsdf(material, inp)

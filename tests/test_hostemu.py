@@ -51,7 +51,7 @@ def test_bvh_depth_is_bounded(pairs):
         assert info["max_depth"] <= 25 and info["n_nodes"] > 0
 
 
-@pytest.mark.parametrize("name,material", [("cfg1", 1), ("cfg1", 2), ("cfg1", 3), ("b8", 1), ("env", 0)])
+@pytest.mark.parametrize("name,material", [("cfg1", 1), ("cfg1", 2), ("cfg1", 3), ("b8", 1), ("env", 0), ("ms", 0), ("ms", 1), ("ms", 2)])
 def test_bsdf_bit_identical(cases, pairs, name, material):
     o, e = pairs[name]
     inp = bsdf_inputs(4000 if name != "b8" else 800)

@@ -35,12 +35,14 @@ def load_case(name):
         return abi.Scene.load(os.path.join(GOLDEN, "bunny_b8.hpts.gz"))
     if name == "anim":
         return abi.Scene.load(os.path.join(GOLDEN, "anim_killeroos.hpts.gz"))
+    if name == "ms":
+        return abi.Scene.load(os.path.join(GOLDEN, "ms_soup.hpts.gz"))
     if name == "env":
         return abi.Scene.load(os.path.join(GOLDEN, "env_soup.hpts.gz"))
     raise KeyError(name)
 
 
-CASES = ["cfg1", "k8", "b8", "env", "anim"]
+CASES = ["cfg1", "k8", "b8", "env", "anim", "ms"]
 
 
 def hash_rd(scene, seed=7, spp=None):
