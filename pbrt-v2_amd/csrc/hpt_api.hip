@@ -26,6 +26,7 @@ using namespace hpt;
 
 struct hpt_scene {
     int device;
+    int mats;             // MATS_* bits of the BxDF families the scene's materials need
     DScene d;             // device pointers
     std::vector<void *> allocs;
     hpt_scene_info info;
@@ -92,6 +93,12 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
+    s->mats = 0;
+    for (int m = 0; m < desc->n_materials; ++m) {
+        int k = desc->materials[m].kind;
+        s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
+                 : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
+    }
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
     if (!ok) { hpt_set_error("device allocation / upload failed: %s", hipGetErrorString(hipGetLastError())); hpt_scene_destroy(s); return nullptr; }
@@ -152,7 +159,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.next_item = &d_scr->next_item;
     a.counters = &d_scr->wc;
     int bpc = 0, vgprs = 0;
-    if (e == hipSuccess && path_kernel_occupancy(s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && path_kernel_occupancy(s->mats, s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
@@ -170,7 +177,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
-    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(a, grid, rd->count_work != 0, stream);
+    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     float ms = 0.f;

@@ -586,6 +586,11 @@ enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY
        BSDF_ALL = 31, BSDF_ALL_NOSPEC = 15 };
 enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFACET_COND = 4, BX_FRESNELBLEND = 5 };
 
+// Material feature bits: the path kernel is instantiated per set of BxDF families a scene can need,
+// so a scene of matte + plastic surfaces does not carry the registers and code of the measured-BRDF
+// kd-tree walk, the conductor Fresnel or the anisotropic substrate (hpt_kernels_*.hip).
+enum { MATS_PLASTIC = 1, MATS_MEASURED = 2, MATS_METAL = 4, MATS_SUBSTRATE = 8, MATS_ALL = 15 };
+
 // BSDF value type (replaces the arena-allocated BSDF + BxDF objects of core/reflection.h:150-191)
 struct Bsdf {
     f3 nn, ng, sn, tn; // shading normal, geometric normal, tangent frame (reflection.cpp:601-609)
@@ -618,12 +623,13 @@ HPT_FN void bsdf_push(Bsdf *b, int kind, f3 R) {
     b->n++;
 }
 // Material::GetBSDF: materials/matte.cpp:42-63, plastic.cpp:42-66, measured.cpp:194-210
+template <int MATS>
 HPT_FN void bsdf_add_material(Bsdf *b, const hpt_material *m) {
     b->mat = m;
     f3 kd = mk3(m->kd[0], m->kd[1], m->kd[2]), ks = mk3(m->ks[0], m->ks[1], m->ks[2]);
     if (m->kind == HPT_MAT_MATTE) {
         if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
-    } else if (m->kind == HPT_MAT_PLASTIC) {
+    } else if ((MATS & MATS_PLASTIC) && m->kind == HPT_MAT_PLASTIC) {
         if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
         if (!sblack(ks)) {
             float e = 1.f / m->roughness;
@@ -631,15 +637,15 @@ HPT_FN void bsdf_add_material(Bsdf *b, const hpt_material *m) {
             b->exponent = e;
             bsdf_push(b, BX_MICROFACET, ks);
         }
-    } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
+    } else if ((MATS & MATS_MEASURED) && m->kind == HPT_MAT_MEASURED_IRREG) {
         bsdf_push(b, BX_IRREG, S(0.f));
-    } else if (m->kind == HPT_MAT_METAL) {        // metal.cpp:51-68: Microfacet(1., FresnelConductor(eta, k), Blinn(1/rough))
+    } else if ((MATS & MATS_METAL) && m->kind == HPT_MAT_METAL) {        // metal.cpp:51-68: Microfacet(1., FresnelConductor(eta, k), Blinn(1/rough))
         float e = 1.f / m->roughness;
         if (e > 10000.f || e != e) e = 10000.f;
         b->exponent = e;
         bsdf_push(b, BX_MICROFACET_COND, mk3(m->eta[0], m->eta[1], m->eta[2]));
         b->R1 = mk3(m->k[0], m->k[1], m->k[2]);
-    } else if (m->kind == HPT_MAT_SUBSTRATE) {    // substrate.cpp:42-58: FresnelBlend(d, s, Anisotropic(1/u, 1/v))
+    } else if ((MATS & MATS_SUBSTRATE) && m->kind == HPT_MAT_SUBSTRATE) {    // substrate.cpp:42-58: FresnelBlend(d, s, Anisotropic(1/u, 1/v))
         if (!sblack(kd) || !sblack(ks)) {
             float ex = 1.f / m->nu, ey = 1.f / m->nv;
             if (ex > 10000.f || ex != ex) ex = 10000.f;   // Anisotropic ctor (reflection.h:439-443)
@@ -778,10 +784,11 @@ HPT_FN void aniso_sample(float ex, float ey, f3 wo, f3 *wi, float u1, float u2, 
     *pdf = aniso_pdf_wh(ex, ey, wo, wh);
 }
 HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy);
+template <int MATS>
 HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack ls) {
     int kind = b.kind(i);
     if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
-    if (kind == BX_MICROFACET) {                                     // :211-222
+    if ((MATS & MATS_PLASTIC) && kind == BX_MICROFACET) {            // :211-222
         float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
         if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
         f3 wh = wi + wo;
@@ -795,7 +802,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
         return sdivf(smul((b.R(i) * D) * G, S(F)), (4.f * cosThetaI * cosThetaO));
     }
-    if (kind == BX_MICROFACET_COND) {                                // Microfacet::f, R = 1, FresnelConductor
+    if ((MATS & MATS_METAL) && kind == BX_MICROFACET_COND) {                                // Microfacet::f, R = 1, FresnelConductor
         float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
         if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
         f3 wh = wi + wo;
@@ -809,7 +816,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
         return sdivf(smul((S(1.f) * D) * G, F), (4.f * cosThetaI * cosThetaO));
     }
-    if (kind == BX_FRESNELBLEND) {                                   // FresnelBlend::f (reflection.cpp:232-244)
+    if ((MATS & MATS_SUBSTRATE) && kind == BX_FRESNELBLEND) {        // FresnelBlend::f (reflection.cpp:232-244)
         f3 Rd = b.R0, Rs = b.R1;
         f3 one_minus_rs = mk3(1.f - Rs.x, 1.f - Rs.y, 1.f - Rs.z);
         f3 diffuse = (smul(Rd * (28.f / (23.f * HPT_PI)), one_minus_rs) * (1.f - powf(1.f - .5f * abs_cos_theta(wi), 5.f))) *
@@ -822,14 +829,16 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         f3 schlick = Rs + one_minus_rs * pw;                         // SchlickFresnel (reflection.h:468-470)
         return diffuse + schlick * sc_;
     }
-    return irreg_f(sc, b.mat, wo, wi, ls);
+    if (MATS & MATS_MEASURED) return irreg_f(sc, b.mat, wo, wi, ls);
+    return S(0.f);
 }
+template <int MATS>
 HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
-    if (b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Pdf (reflection.cpp:465-468)
+    if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Pdf (reflection.cpp:465-468)
         if (!same_hemisphere(wo, wi)) return 0.f;
         return .5f * (abs_cos_theta(wi) * HPT_INV_PI + aniso_pdf_wh(b.exponent, b.ey, wo, normalize(wo + wi)));
     }
-    if (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
+    if ((MATS & (MATS_PLASTIC | MATS_METAL)) && (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND)) { // Microfacet::Pdf :340-343 + Blinn::Pdf :366-374
         if (!same_hemisphere(wo, wi)) return 0.f;
         f3 wh = normalize(wo + wi);
         float costheta = abs_cos_theta(wh);
@@ -854,8 +863,9 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
     *dx = r * cosf(theta);
     *dy = r * sinf(theta);
 }
+template <int MATS>
 HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, LaneStack ls) {
-    if (b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Sample_f (reflection.cpp:446-462)
+    if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Sample_f (reflection.cpp:446-462)
         if (u1 < .5f) {
             u1 = 2.f * u1;
             f3 w; concentric_sample_disk(u1, u2, &w.x, &w.y);
@@ -867,8 +877,8 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
             aniso_sample(b.exponent, b.ey, wo, wi, u1, u2, pdf);
             if (!same_hemisphere(wo, *wi)) return S(0.f);
         }
-        *pdf = bxdf_pdf(b, i, wo, *wi);
-        return bxdf_f(sc, b, i, wo, *wi, ls);
+        *pdf = bxdf_pdf<MATS>(b, i, wo, *wi);
+        return bxdf_f<MATS>(sc, b, i, wo, *wi, ls);
     }
     if (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
         float costheta = powf(u1, 1.f / (b.exponent + 1));
@@ -881,35 +891,38 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
         if (dot(wo, wh) <= 0.f) bp = 0.f;
         *pdf = bp;
         if (!same_hemisphere(wo, *wi)) return S(0.f);
-        return bxdf_f(sc, b, i, wo, *wi, ls);
+        return bxdf_f<MATS>(sc, b, i, wo, *wi, ls);
     }
     f3 w; // BxDF::Sample_f :311-318 (cosine hemisphere)
     concentric_sample_disk(u1, u2, &w.x, &w.y);
     w.z = sqrtf(maxf(0.f, 1.f - w.x * w.x - w.y * w.y));
     if (wo.z < 0.f) w.z *= -1.f;
     *wi = w;
-    *pdf = bxdf_pdf(b, i, wo, w);
-    return bxdf_f(sc, b, i, wo, w, ls);
+    *pdf = bxdf_pdf<MATS>(b, i, wo, w);
+    return bxdf_f<MATS>(sc, b, i, wo, w, ls);
 }
 HPT_FN bool bx_match(const Bsdf &b, int i, int flags) { int t = b.type(i); return (t & flags) == t; }
 // BSDF::f (reflection.cpp:612-626)
+template <int MATS>
 HPT_FN_BSDF f3 bsdf_f(const DScene &sc, const Bsdf &b, f3 woW, f3 wiW, int flags, LaneStack ls) {
     f3 wi = b.w2l(wiW), wo = b.w2l(woW);
     if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
     else flags &= ~BSDF_REFLECTION;
     f3 f = S(0.f);
-    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi, ls);
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f<MATS>(sc, b, i, wo, wi, ls);
     return f;
 }
 // BSDF::Pdf (reflection.cpp:583-598)
+template <int MATS>
 HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
     if (b.n == 0) return 0.f;
     f3 wo = b.w2l(woW), wi = b.w2l(wiW);
     float pdf = 0.f; int matching = 0;
-    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) { ++matching; pdf += bxdf_pdf(b, i, wo, wi); }
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) { ++matching; pdf += bxdf_pdf<MATS>(b, i, wo, wi); }
     return matching > 0 ? pdf / matching : 0.f;
 }
 // BSDF::Sample_f (reflection.cpp:522-580)
+template <int MATS>
 HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
                         int flags, int *sampledType, LaneStack ls) {
     int matching = 0;
@@ -921,19 +934,19 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
     f3 wo = b.w2l(woW), wi = S(0.f);
     *pdf = 0.f;
-    f3 f = bxdf_sample_f(sc, b, sel, wo, &wi, u1, u2, pdf, ls);
+    f3 f = bxdf_sample_f<MATS>(sc, b, sel, wo, &wi, u1, u2, pdf, ls);
     if (*pdf == 0.f) { *sampledType = 0; return S(0.f); }
     int stype = b.type(sel);
     *sampledType = stype;
     *wiW = b.l2w(wi);
     if (!(stype & BSDF_SPECULAR) && matching > 1)
-        for (int i = 0; i < b.n; ++i) if (i != sel && bx_match(b, i, flags)) *pdf += bxdf_pdf(b, i, wo, wi);
+        for (int i = 0; i < b.n; ++i) if (i != sel && bx_match(b, i, flags)) *pdf += bxdf_pdf<MATS>(b, i, wo, wi);
     if (matching > 1) *pdf /= matching;
     if (!(stype & BSDF_SPECULAR)) {
         f = S(0.f);
         if (dot(*wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
         else flags &= ~BSDF_REFLECTION;
-        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f(sc, b, i, wo, wi, ls);
+        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f<MATS>(sc, b, i, wo, wi, ls);
     }
     return f;
 }
@@ -942,7 +955,7 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
 // Triangle::Intersect tail (trianglemesh.cpp:162-207), DifferentialGeometry ctor (diffgeom.cpp:40-55),
 // Triangle::GetShadingGeometry (trianglemesh.cpp:293-368), BSDF ctor (reflection.cpp:601-609),
 // Material::GetBSDF.  Returns the primitive's area light index (or -1) and rayEpsilon.
-template <bool INST>
+template <bool INST, int MATS>
 HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
     Ray ray = wray;
     if (hit.prim >= sc.n_tris) {
@@ -954,7 +967,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
         *rayEps = 5e-4f * hit.t;                       // sphere.cpp:155, disk.cpp:100
         *arealight = q.arealight;
         bsdf_frame(b, dg->nn, dg->dpdu, dg->nn);       // Shape::GetShadingGeometry: dgShading = dg (shape.h:56-60)
-        bsdf_add_material(b, &sc.materials[q.material]);
+        bsdf_add_material<MATS>(b, &sc.materials[q.material]);
         return;
     }
     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
@@ -1035,7 +1048,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
         ns_nn = dgs.nn; ns_dpdu = dgs.dpdu;
     }
     bsdf_frame(b, ns_nn, ns_dpdu, dg->nn);
-    bsdf_add_material(b, &sc.materials[me.material]);
+    bsdf_add_material<MATS>(b, &sc.materials[me.material]);
 }
 
 // ---- lights ---------------------------------------------------------------------------------------

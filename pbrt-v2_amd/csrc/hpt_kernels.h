@@ -30,8 +30,8 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
-int path_kernel_occupancy(bool inst, int *blocks_per_cu, int *vgprs);
-hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream);
+int path_kernel_occupancy(int mats, bool inst, int *blocks_per_cu, int *vgprs);
+hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
                             int32_t *out_prim, hipStream_t s);

@@ -1,4 +1,5 @@
-// hpt_kernels.hip — gfx950 kernels of the path-tracing hot path and their launchers.
+// hpt_kernels.hip — replay / parity kernels and the dispatch of the path kernel over its per-material-set
+// instantiations (hpt_kernels_{basic,measured,all}.hip; kernel template in hpt_kernels_impl.h).
 //
 // hpt_path_kernel: ONE persistent-threads launch renders the whole frame.  Grid = (CUs x resident
 // blocks per CU) workgroups of 256 threads = 4 wave64; every wave loops
@@ -14,77 +15,10 @@
 // No MFMA anywhere: the workload is divergent pointer chasing, not a contraction.
 #include <hip/hip_runtime.h>
 
-#include "hpt_kernels.h"
-#include "hpt_path.h"
+#include "hpt_kernels_impl.h"
 #include "hpt_replay.h"
 
 namespace hpt {
-
-__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
-
-// One atomicAdd per wave hands out consecutive work items to the lanes that need one.
-__device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool need) {
-    unsigned long long mask = __ballot(need);
-    if (mask == 0ull) return -1;
-    int n = __popcll(mask);
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)n);
-    unsigned lo = __shfl((unsigned)(base & 0xffffffffull), leader);
-    unsigned hi = __shfl((unsigned)(base >> 32), leader);
-    base = ((unsigned long long)hi << 32) | lo;
-    int rank = __popcll(mask & ((1ull << lane_id()) - 1ull));
-    return need ? (int64_t)(base + (unsigned long long)rank) : -1;
-}
-
-template <bool COUNT, bool INST>
-__global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
-    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
-    int32_t *stack = lds_stack + threadIdx.x;
-    const DScene &sc = a.sc;
-    const RenderParams &rp = a.rp;
-    Lane<LdHashSrc, INST> lane;
-    lane.init();
-    bool exhausted = false;
-    WorkCounters wc = {0, 0, 0, 0, 0, 0};
-    TravCounters tc = {0, 0};
-    for (;;) {
-        // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
-        for (;;) {
-            bool need = (lane.stage == ST_IDLE) && !exhausted;
-            if (__ballot(need) == 0ull) break;
-            int64_t item = wave_fetch(a.next_item, need);
-            if (need) {
-                if (item >= rp.n_items) exhausted = true;
-                else {
-                    int x, y; uint32_t s0;
-                    if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
-                }
-            }
-        }
-        const bool active = lane.stage != ST_IDLE;
-        Hit hit;
-        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
-        if (__ballot(active) == 0ull) break;
-        // ---- one traversal phase: each lane traces its own pending ray ------------------------------
-        if (active) {
-            bool anyhit = lane.stage == ST_SHADOW;
-            if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-        }
-        // ---- state machine step ----------------------------------------------------------------------
-        if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
-    }
-    if (COUNT) {
-        wc.nodes = tc.nodes; wc.tris = tc.tris;
-        atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
-        atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
-        atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
-        atomicAdd((unsigned long long *)&a.counters->nodes, (unsigned long long)wc.nodes);
-        atomicAdd((unsigned long long *)&a.counters->tris, (unsigned long long)wc.tris);
-        atomicAdd((unsigned long long *)&a.counters->bad, (unsigned long long)wc.bad);
-    }
-}
 
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelArgs a, const ReplayArgs ra) {
@@ -93,7 +27,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
     const int64_t gid = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
-    Lane<MtReplaySrc, true> lane;
+    Lane<MtReplaySrc, true, MATS_ALL> lane;
     lane.init();
     lane.smp.mt = ra.mt + gid; lane.smp.buf = ra.buf + gid; lane.smp.stride = ra.nlanes; lane.smp.mti = HPT_MT_N; lane.smp.n = (uint32_t)rp.spp; lane.smp.i = 0;
     TileWalk tw; tw.started = false; tw.x0 = tw.x1 = tw.y0 = tw.y1 = tw.x = tw.y = 0;
@@ -160,11 +94,11 @@ __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, 
     f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
     f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
     Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
-    bsdf_add_material(&b, &sc.materials[material]);
-    f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
-    float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
+    bsdf_add_material<MATS_ALL>(&b, &sc.materials[material]);
+    f3 f = bsdf_f<MATS_ALL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
+    float pdf = bsdf_pdf<MATS_ALL>(b, wo, wi, BSDF_ALL_NOSPEC);
     f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-    f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
+    f3 sf = bsdf_sample_f<MATS_ALL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
     o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
     o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
 }
@@ -183,25 +117,32 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
-int path_kernel_occupancy(bool inst, int *blocks_per_cu, int *vgprs) {
-    int nb = 0;
-    hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, true>, HPT_BLOCK, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, false>, HPT_BLOCK, 0);
-    if (e != hipSuccess) return -1;
-    hipFuncAttributes fa;
-    const void *fn = inst ? (const void *)hpt_path_kernel<false, true> : (const void *)hpt_path_kernel<false, false>;
-    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) *vgprs = fa.numRegs; else *vgprs = 0;
-    *blocks_per_cu = nb;
-    return 0;
-}
+hipError_t launch_path_basic(const PathKernelArgs &, int, bool, hipStream_t);
+hipError_t launch_path_measured(const PathKernelArgs &, int, bool, hipStream_t);
+hipError_t launch_path_all(const PathKernelArgs &, int, bool, hipStream_t);
+int occupancy_basic(bool, int *, int *);
+int occupancy_measured(bool, int *, int *);
+int occupancy_all(bool, int *, int *);
 
-hipError_t launch_path_kernel(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
-    const bool inst = a.sc.n_instances > 0;
-    if (count && inst) hipLaunchKernelGGL((hpt_path_kernel<true, true>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
-    else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, false>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
-    else if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((hpt_path_kernel<false, false>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);
-    return hipGetLastError();
+// smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
+static int pick_variant(int mats) {
+    if ((mats & ~MATS_PLASTIC) == 0) return 0;
+    if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
+    return 2;
+}
+int path_kernel_occupancy(int mats, bool inst, int *blocks_per_cu, int *vgprs) {
+    switch (pick_variant(mats)) {
+        case 0: return occupancy_basic(inst, blocks_per_cu, vgprs);
+        case 1: return occupancy_measured(inst, blocks_per_cu, vgprs);
+        default: return occupancy_all(inst, blocks_per_cu, vgprs);
+    }
+}
+hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
+    switch (pick_variant(mats)) {
+        case 0: return launch_path_basic(a, grid_blocks, count, stream);
+        case 1: return launch_path_measured(a, grid_blocks, count, stream);
+        default: return launch_path_all(a, grid_blocks, count, stream);
+    }
 }
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {
     int grid = (int)(ra.nlanes / HPT_BLOCK);

@@ -1,0 +1,117 @@
+// hpt_kernels_impl.h — the persistent-threads path kernel template and the per-material-set launcher
+// macro.  Included by hpt_kernels_{basic,measured,all}.hip, each of which instantiates the kernel for
+// one set of BxDF families (MATS_* bits) so that a scene only pays — in registers, spills and
+// instruction-cache footprint — for the material code it can actually reach.
+//
+// hpt_path_kernel: ONE persistent-threads launch renders the whole frame.  Grid = (CUs x resident
+// blocks per CU) workgroups of 256 threads = 4 wave64; every wave loops
+//     refill idle lanes (one device-scope atomicAdd per wave, ballot + popcount prefix) ->
+//     one BVH traversal phase for whatever ray each lane has pending (closest- or any-hit) ->
+//     per-lane state machine step (hpt_path.h)
+// until the global work counter is exhausted and all 64 lanes are idle.  Lanes whose path ended
+// are refilled immediately ("path regeneration"), which is this design's form of wavefront
+// compaction: instead of squeezing live rays together between bounces, dead lanes are repopulated
+// in place, so the traversal loop always runs with a full exec mask.
+// Traversal stacks live in LDS, laid out stack[entry][thread] so that the 64 lanes of a wave
+// address 64 consecutive banks (conflict-free ds_read/ds_write_b32).
+// No MFMA anywhere: the workload is divergent pointer chasing, not a contraction.
+#ifndef HPT_KERNELS_IMPL_H
+#define HPT_KERNELS_IMPL_H
+#include <hip/hip_runtime.h>
+
+#include "hpt_kernels.h"
+#include "hpt_path.h"
+
+namespace hpt {
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// One atomicAdd per wave hands out consecutive work items to the lanes that need one.
+__device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool need) {
+    unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return -1;
+    int n = __popcll(mask);
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)n);
+    unsigned lo = __shfl((unsigned)(base & 0xffffffffull), leader);
+    unsigned hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    int rank = __popcll(mask & ((1ull << lane_id()) - 1ull));
+    return need ? (int64_t)(base + (unsigned long long)rank) : -1;
+}
+
+template <bool COUNT, bool INST, int MATS>
+__global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
+    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    int32_t *stack = lds_stack + threadIdx.x;
+    const DScene &sc = a.sc;
+    const RenderParams &rp = a.rp;
+    Lane<LdHashSrc, INST, MATS> lane;
+    lane.init();
+    bool exhausted = false;
+    WorkCounters wc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0};
+    for (;;) {
+        // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
+        for (;;) {
+            bool need = (lane.stage == ST_IDLE) && !exhausted;
+            if (__ballot(need) == 0ull) break;
+            int64_t item = wave_fetch(a.next_item, need);
+            if (need) {
+                if (item >= rp.n_items) exhausted = true;
+                else {
+                    int x, y; uint32_t s0;
+                    if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
+                }
+            }
+        }
+        const bool active = lane.stage != ST_IDLE;
+        Hit hit;
+        hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
+        if (__ballot(active) == 0ull) break;
+        // ---- one traversal phase: each lane traces its own pending ray ------------------------------
+        if (active) {
+            bool anyhit = lane.stage == ST_SHADOW;
+            if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+            traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+        }
+        // ---- state machine step ----------------------------------------------------------------------
+        if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
+    }
+    if (COUNT) {
+        wc.nodes = tc.nodes; wc.tris = tc.tris;
+        atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
+        atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
+        atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
+        atomicAdd((unsigned long long *)&a.counters->nodes, (unsigned long long)wc.nodes);
+        atomicAdd((unsigned long long *)&a.counters->tris, (unsigned long long)wc.tris);
+        atomicAdd((unsigned long long *)&a.counters->bad, (unsigned long long)wc.bad);
+    }
+}
+
+
+// Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.
+#define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS)                                                                        \
+    hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {      \
+        const bool inst = a.sc.n_instances > 0;                                                                     \
+        if (count && inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);   \
+        else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);    \
+        else if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);     \
+        else hipLaunchKernelGGL((hpt_path_kernel<false, false, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);              \
+        return hipGetLastError();                                                                                   \
+    }                                                                                                               \
+    int occupancy_##NAME(bool inst, int *blocks_per_cu, int *vgprs) {                                               \
+        int nb = 0;                                                                                                 \
+        hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, true, MATS>, HPT_BLOCK, 0)     \
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, false, MATS>, HPT_BLOCK, 0);   \
+        if (e != hipSuccess) return -1;                                                                             \
+        hipFuncAttributes fa;                                                                                       \
+        const void *fn = inst ? (const void *)hpt_path_kernel<false, true, MATS> : (const void *)hpt_path_kernel<false, false, MATS>; \
+        *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0;                                      \
+        *blocks_per_cu = nb;                                                                                        \
+        return 0;                                                                                                   \
+    }
+
+} // namespace hpt
+#endif

@@ -69,8 +69,9 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
 
 // ---- lane -----------------------------------------------------------------------------------------
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
+// MATS: BxDF families compiled in (MATS_* bits, hpt_device.h).
 // INST: compile the animated-instance code in (scenes without instances use the leaner INST=false kernel).
-template <class Smp, bool INST> struct Lane {
+template <class Smp, bool INST, int MATS> struct Lane {
     int stage;
     // pixel / sample bookkeeping
     int px, py;
@@ -199,7 +200,7 @@ template <class Smp, bool INST> struct Lane {
             return;
         }
         Bsdf bsdf; DGeom dg; int arealight;
-        shade_geometry<INST>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
+        shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
         if (bounce == 0 || specular)                                        // path.cpp:63-64
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
@@ -232,12 +233,12 @@ template <class Smp, bool INST> struct Lane {
             f3 wi; float lightPdf, bsdfPdf;
             f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow);
             if (lightPdf > 0.f && !sblack(Li)) {
-                f3 f = bsdf_f(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
+                f3 f = bsdf_f<MATS>(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
                 if (!sblack(f)) {
                     has_shadow = true;
                     if (isDelta) Ld = smul(f, Li) * (absdot(wi, n) / lightPdf);
                     else {
-                        bsdfPdf = bsdf_pdf(bsdf, wo, wi, BSDF_ALL_NOSPEC);
+                        bsdfPdf = bsdf_pdf<MATS>(bsdf, wo, wi, BSDF_ALL_NOSPEC);
                         float weight = power_heuristic(1, lightPdf, 1, bsdfPdf);
                         Ld = smul(f, Li) * (absdot(wi, n) * weight / lightPdf);
                     }
@@ -246,7 +247,7 @@ template <class Smp, bool INST> struct Lane {
             // BSDF-sampling half (integrator.cpp:145-172)
             if (!isDelta) {
                 int sampledType;
-                f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType, ls);
+                f3 f = bsdf_sample_f<MATS>(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType, ls);
                 if (!sblack(f) && bsdfPdf > 0.f) {
                     float weight = 1.f;
                     bool ok = true;
@@ -274,7 +275,7 @@ template <class Smp, bool INST> struct Lane {
             if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
             else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
             f3 wi; float pdf; int flags;
-            f3 f = bsdf_sample_f(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, ls);
+            f3 f = bsdf_sample_f<MATS>(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, ls);
             has_next = !(sblack(f) || pdf == 0.f);
             if (has_next) {
                 spec_next = (flags & BSDF_SPECULAR) != 0;

@@ -84,7 +84,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
             if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashSrc, true> lane; lane.init();
+            Lane<LdHashSrc, true, MATS_ALL> lane; lane.init();
             lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 bool anyhit = lane.stage == ST_SHADOW;
@@ -113,7 +113,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
     std::vector<float> buf((size_t)HPT_REPLAY_FLOATS_PER_SAMPLE * rd->spp);
     int32_t stack[64];
     for (int task = 0; task < rd->ntasks; ++task) {
-        Lane<MtReplaySrc, true> lane; lane.init();
+        Lane<MtReplaySrc, true, MATS_ALL> lane; lane.init();
         lane.smp.mt = mt.data(); lane.smp.buf = buf.data(); lane.smp.stride = 1; lane.smp.n = (uint32_t)rd->spp; lane.smp.i = 0;
         TileWalk tw; tw.started = false;
         compute_sub_window(rp.x_start, rp.x_start + rp.x_count, rp.y_start, rp.y_start + rp.y_count, task, rd->ntasks,
@@ -163,12 +163,12 @@ extern "C" int emu_bsdf(const emu_scene *s, int material, const float *in, int64
         f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
         f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
         Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
-        bsdf_add_material(&b, &sc.materials[material]);
+        bsdf_add_material<MATS_ALL>(&b, &sc.materials[material]);
         int32_t stk[64]; LaneStack ls; ls.p = stk; ls.stride = 1;
-        f3 f = bsdf_f(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
-        float pdf = bsdf_pdf(b, wo, wi, BSDF_ALL_NOSPEC);
+        f3 f = bsdf_f<MATS_ALL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
+        float pdf = bsdf_pdf<MATS_ALL>(b, wo, wi, BSDF_ALL_NOSPEC);
         f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-        f3 sf = bsdf_sample_f(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
+        f3 sf = bsdf_sample_f<MATS_ALL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
         o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
         o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
     }
