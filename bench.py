@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="bunny")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (power of two)")
+    ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
     args = ap.parse_args()
@@ -130,6 +131,7 @@ def main():
     rd.spp = spp_per_gpu * world                     # weak scaling: per-rank samples fixed
     rd.shard_rank, rd.shard_count = rank, world
     rd.count_work = 1 if args.count_work else 0
+    rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.HPT_PIPELINE_PERSISTENT
     t0 = time.time()
     dev = hpt.DeviceScene(scene, local)
     setup_s = time.time() - t0
@@ -181,7 +183,7 @@ def main():
                        "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile gather" % world,
                        "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
                        "scene_bytes_in_hbm": int(info.total_device_bytes)},
-            "kernel": {"name": "hpt_path_kernel", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
+            "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
                        "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
                        "samples_per_launch": int(per_launch_samples)},
             "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "scene_create_total_s": round(setup_s, 3)},

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 4
+#define HPT_VERSION 5
 
 enum {
     HPT_OK = 0,
@@ -177,6 +177,13 @@ typedef struct hpt_camera {
  *                          One lane per tile, serial inside the tile: slow, bit-for-bit sequence. */
 enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1 };
 
+/* Kernel organisation of the same path state machine:
+ *  HPT_PIPELINE_PERSISTENT : one persistent-threads launch per frame, path state in registers,
+ *                            dead lanes regenerated in place;
+ *  HPT_PIPELINE_WAVEFRONT  : advance / trace kernels over a pool of paths in HBM, active rays
+ *                            compacted into a dense queue between the two (ballot + popcount). */
+enum { HPT_PIPELINE_PERSISTENT = 0, HPT_PIPELINE_WAVEFRONT = 1 };
+
 typedef struct hpt_render_desc {
     int32_t xres, yres;               /* Film::xResolution, yResolution                  */
     int32_t x_start, x_count;         /* ImageFilm::xPixelStart/xPixelCount (crop window) */
@@ -188,6 +195,8 @@ typedef struct hpt_render_desc {
     int32_t ntasks;                   /* MT_REPLAY: nTasks of samplerrenderer.cpp:298-300 */
     int32_t shard_rank, shard_count;  /* pixel-tile shard of this device (0,1 = all)      */
     int32_t count_work;               /* 1: fill the traversal counters of hpt_stats      */
+    int32_t pipeline;                 /* HPT_PIPELINE_*                                   */
+    int32_t pad;
 } hpt_render_desc;
 
 typedef struct hpt_stats {

@@ -9,12 +9,13 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 4
+HPT_VERSION = 5
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY = 0, 1
+HPT_PIPELINE_PERSISTENT, HPT_PIPELINE_WAVEFRONT = 0, 1
 SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs
 
 f32, i32, i64, u32, u64 = C.c_float, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
@@ -78,7 +79,8 @@ class RenderDesc(C.Structure):
     _fields_ = [("xres", i32), ("yres", i32), ("x_start", i32), ("x_count", i32),
                 ("y_start", i32), ("y_count", i32), ("spp", i32), ("maxdepth", i32),
                 ("sampler_mode", i32), ("seed", u32), ("ntasks", i32),
-                ("shard_rank", i32), ("shard_count", i32), ("count_work", i32)]
+                ("shard_rank", i32), ("shard_count", i32), ("count_work", i32),
+                ("pipeline", i32), ("pad", i32)]
 
 
 class Stats(C.Structure):

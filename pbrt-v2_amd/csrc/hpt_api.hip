@@ -12,6 +12,7 @@
 #include "hpt_internal.h"
 #include "hpt_kernels.h"
 #include "hpt_replay.h"
+#include "hpt_wavefront.h"
 
 using namespace hpt;
 
@@ -140,6 +141,68 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     return HPT_OK;
 }
 
+// ---- HPT_PIPELINE_WAVEFRONT driver: advance / trace kernel pairs until the ray queue runs dry ------
+static int render_wavefront(hpt_scene *s, PathKernelArgs &pa, const hpt_render_desc *rd, hipStream_t stream, hpt_stats *stats,
+                            unsigned long long *d_next_item, WorkCounters *d_wc, float *ms_out, int *grid_out, int *vgprs_out, int *bpc_out) {
+    WfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sc = pa.sc; a.rp = pa.rp; a.film = pa.film; a.next_item = d_next_item; a.counters = d_wc;
+    int64_t P = 1 << 19;                                             // 512 Ki path slots ~ 210 MB of state + rays
+    if (const char *e = getenv("HPT_WF_PATHS")) { long v = atol(e); if (v >= HPT_BLOCK) P = v; }
+    int64_t cap = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK;
+    if (P > cap) P = cap;
+    P = (P + HPT_BLOCK - 1) / HPT_BLOCK * HPT_BLOCK;
+    a.P = P;
+    hipError_t e = hipMalloc((void **)&a.state, sizeof(float4) * 10 * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.rays, sizeof(float4) * 2 * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.hits, sizeof(float4) * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.hit_inst, sizeof(int) * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.queue, sizeof(int) * (size_t)P);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.qcount, sizeof(int) * 4);
+    a.qhead = a.qcount ? a.qcount + 2 : nullptr;
+    if (e == hipSuccess) e = hipMemsetAsync(a.state, 0, sizeof(float4) * 10 * (size_t)P, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a.qcount, 0, sizeof(int) * 4, stream);
+    int bpc = 1, vgprs = 0;
+    if (e == hipSuccess && wf_trace_occupancy(s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (bpc < 1) bpc = 1;
+    int grid = s->n_cus * bpc;
+    int *h_q = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h_q, sizeof(int) * 4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+    const bool count = rd->count_work != 0;
+    long iters = 0;
+    const int check_every = 16;
+    while (e == hipSuccess) {
+        bool done = false;
+        for (int k = 0; k < check_every && e == hipSuccess; ++k, ++iters) {
+            a.parity = (int)(iters & 1);
+            e = wf_launch_advance(s->mats, a, count, stream);
+            if (e == hipSuccess) e = wf_launch_trace(a, grid, count, stream);
+        }
+        // the queue length of the last advance tells whether anything is still in flight
+        if (e == hipSuccess) e = hipMemcpyAsync(h_q, a.qcount, sizeof(int) * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e == hipSuccess && h_q[(iters - 1) & 1] == 0) done = true;
+        if (done) break;
+        if (iters > 100000000L) { e = hipErrorUnknown; break; }
+    }
+    if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (h_q) (void)hipHostFree(h_q);
+    for (void *p : {(void *)a.state, (void *)a.rays, (void *)a.hits, (void *)a.hit_inst, (void *)a.queue, (void *)a.qcount}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) { hpt_set_error("wavefront render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    *ms_out = ms; *grid_out = grid; *vgprs_out = vgprs; *bpc_out = bpc;
+    (void)stats;
+    return HPT_OK;
+}
+
 extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film,
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
@@ -165,6 +228,36 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
+    if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
+        float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
+        int wrc = render_wavefront(s, a, rd, stream, stats, &d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
+        Scratch h_scr2; memset(&h_scr2, 0, sizeof(h_scr2));
+        if (wrc == HPT_OK && hipMemcpy(&h_scr2, d_scr, sizeof(Scratch), hipMemcpyDeviceToHost) != hipSuccess) wrc = HPT_E_HIP;
+        (void)hipFree(d_scr);
+        if (wrc != HPT_OK) return wrc;
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->kernel_ms = wms;
+            stats->camera_samples = (uint64_t)rd->x_count * rd->y_count * rd->spp;
+            if (rd->shard_count > 1) {
+                uint64_t px = 0; int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
+                for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
+                    int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
+                    int w = rd->x_count - x0; if (w > 32) w = 32;
+                    int h = rd->y_count - y0; if (h > 32) h = 32;
+                    px += (uint64_t)w * (uint64_t)h;
+                }
+                stats->camera_samples = px * (uint64_t)rd->spp;
+            }
+            if (rd->count_work) {
+                stats->camera_samples = h_scr2.wc.samples; stats->closest_rays = h_scr2.wc.closest; stats->shadow_rays = h_scr2.wc.shadow;
+                stats->nodes_visited = h_scr2.wc.nodes; stats->tris_tested = h_scr2.wc.tris; stats->bad_samples = h_scr2.wc.bad;
+            }
+            stats->grid_blocks = (uint32_t)wgrid; stats->block_threads = HPT_BLOCK;
+            stats->resident_waves = (uint32_t)(wbpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)wvg;
+        }
+        return HPT_OK;
+    }
     ReplayArgs ra; memset(&ra, 0, sizeof(ra));
     if (replay && e == hipSuccess) {
         ra.ntasks = rd->ntasks;

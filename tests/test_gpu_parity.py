@@ -139,6 +139,37 @@ def test_replay_mode_reproduces_the_reference_binary_image(cases, dev, name):
     assert abs(float(img.mean()) / float(ref.mean()) - 1) < 0.02
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_wavefront_pipeline_equals_persistent(cases, dev, ora, name):
+    """HPT_PIPELINE_WAVEFRONT (advance / trace kernels, path state in HBM, compacted ray queue) runs
+    the same state machine as the persistent megakernel: same film, same work."""
+    s = cases[name]
+    rd = hash_rd(s, seed=5)
+    rd.count_work = 1
+    fp, sp = dev[name].render(s.camera, rd)
+    rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT
+    fw, sw = dev[name].render(s.camera, rd)
+    assert sw.camera_samples == sp.camera_samples and sw.bad_samples == 0
+    assert sw.closest_rays == sp.closest_rays and sw.shadow_rays == sp.shadow_rays
+    assert sw.nodes_visited == sp.nodes_visited and sw.tris_tested == sp.tris_tested
+    assert np.array_equal(fp[..., 3], fw[..., 3])
+    assert np.allclose(fp, fw, rtol=1e-6, atol=1e-6)     # identical up to the order of the rare boundary spills
+    fo, _ = ora[name].render(s.camera, rd)
+    assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fw)) < 1e-3
+
+
+def test_wavefront_pipeline_full_size():
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    s = scenes.synthetic_soup(n_tris=50000, spp=128, maxdepth=8, xres=640, yres=360)
+    d = hpt.DeviceScene(s)
+    rd = s.render
+    fp, _ = d.render(s.camera, rd)
+    rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT
+    fw, st = d.render(s.camera, rd)
+    assert st.camera_samples == 640 * 360 * 128
+    assert np.allclose(fp, fw, rtol=1e-5, atol=1e-5)
+
+
 def test_render_is_deterministic_and_seed_sensitive(cases, dev):
     s = cases["k8"]
     rd = hash_rd(s, seed=1, spp=4)
