@@ -482,7 +482,6 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
 // that reached a leaf, by the leaf's triangle tests ("if-if" loop shape: measured best on gfx950
 // against node-XOR-leaf and while-while, profiles/r01_ab.md).  done() when node == HPT_TRAV_EMPTY.
 struct TravState {
-    Ray ray;
     f3 invd;
     bool nx, ny, nz, anyhit;
     int32_t node;
@@ -491,33 +490,33 @@ struct TravState {
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
-HPT_FN void trav_begin(const DScene &sc, TravState &ts, const Ray &ray, bool anyhit, int32_t root, bool world) {
-    ts.ray = ray; ts.anyhit = anyhit;
+HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world) {
+    ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
     // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
     for (int q = 0; world && q < sc.n_quadrics; ++q) {
         float t;
-        if (quadric_intersect(sc.quadrics[q], ts.ray, &t, nullptr)) {
+        if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
             ts.hit.prim = sc.n_tris + q;
             if (anyhit) { ts.node = HPT_TRAV_EMPTY; break; }
-            ts.hit.t = t; ts.ray.maxt = t;
+            ts.hit.t = t; ray.maxt = t;
         }
     }
     if (root < 0) ts.node = HPT_TRAV_EMPTY;
-    ts.invd = mk3(1.f / ts.ray.d.x, 1.f / ts.ray.d.y, 1.f / ts.ray.d.z);
+    ts.invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
     ts.nx = ts.invd.x < 0; ts.ny = ts.invd.y < 0; ts.nz = ts.invd.z < 0;
 }
 
 template <bool COUNT>
-HPT_FN void trav_step(const DScene &sc, TravState &ts, int32_t *stack, int stride, TravCounters *cnt) {
+HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
     if (ts.node >= 0) { // interior: one 64-byte node fetch, two slab tests, near child first, far child stacked
         const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
         f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
         if (COUNT) cnt->nodes++;
         float t0, t1;
-        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ts.ray, ts.invd, ts.nx, ts.ny, ts.nz, &t0);
-        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ts.ray, ts.invd, ts.nx, ts.ny, ts.nz, &t1);
+        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, ts.nx, ts.ny, ts.nz, &t0);
+        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, ts.nx, ts.ny, ts.nz, &t1);
         int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
         if (h0 && h1) {
             bool swap = t1 < t0;
@@ -537,11 +536,11 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, int32_t *stack, int strid
             f4 a = tp[0], b = tp[1], c = tp[2];
             if (COUNT) cnt->tris++;
             float t, b1, b2;
-            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ts.ray, &t, &b1, &b2)) {
+            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
                 ts.hit.prim = (int32_t)(first + k);
                 if (ts.anyhit) { stop = true; break; }
                 ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
-                ts.ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
+                ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
             }
         }
         if (stop) ts.node = HPT_TRAV_EMPTY;
@@ -558,8 +557,7 @@ template <bool COUNT, bool INST>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
     TravState ts;
     trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
-    while (!ts.done()) trav_step<COUNT>(sc, ts, stack, stride, cnt);
-    ray.maxt = ts.ray.maxt;
+    while (!ts.done()) trav_step<COUNT>(sc, ts, ray, stack, stride, cnt);
     *hit = ts.hit;
     if (anyhit && hit->prim >= 0) return true;
     if (INST) for (int k = 0; k < sc.n_instances; ++k) {
@@ -571,10 +569,10 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         r2.o = xf_point(w2p.m.m, ray.o); r2.d = xf_vec(w2p.m.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
         trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
-        while (!t2.done()) trav_step<COUNT>(sc, t2, stack, stride, cnt);
+        while (!t2.done()) trav_step<COUNT>(sc, t2, r2, stack, stride, cnt);
         if (t2.hit.prim >= 0) {
             *hit = t2.hit; hit->inst = k;
-            ray.maxt = t2.ray.maxt;
+            ray.maxt = r2.maxt;
             if (anyhit) return true;
         }
     }

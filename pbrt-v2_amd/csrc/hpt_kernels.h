@@ -9,6 +9,9 @@
                                 in 160 KiB of LDS).  The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2.
                                 (A workgroup-level ray pool with dynamic fetch was tried here and measured slower:
                                 profiles/r01_ab.md, second A/B.) */
+#ifndef HPT_EARLY_EXIT
+#define HPT_EARLY_EXIT 32    /* leave the traversal loop once fewer lanes than this are still walking (0 = never) */
+#endif
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4    /* __launch_bounds__ 2nd arg: waves per SIMD the register allocator must allow (A/B in profiles/r01_ab.md) */
 #endif

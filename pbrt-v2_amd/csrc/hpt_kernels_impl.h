@@ -50,6 +50,9 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
     Lane<LdHashSrc, INST, MATS> lane;
     lane.init();
     bool exhausted = false;
+    TravState ts;                  // this lane's walk, resumable across iterations (see the traversal phase)
+    ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false;
+    bool tracing = false;
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
     for (;;) {
@@ -70,14 +73,43 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
-        // ---- one traversal phase: each lane traces its own pending ray ------------------------------
-        if (active) {
-            bool anyhit = lane.stage == ST_SHADOW;
-            if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+        if (INST) {
+            // ---- one traversal phase: each lane traces its own pending ray to completion (two-level walk) ----
+            if (active) {
+                bool anyhit = lane.stage == ST_SHADOW;
+                if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+                traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+            }
+        } else {
+            // ---- traversal phase with early exit --------------------------------------------------------
+            // Ray lengths inside a wave differ by an order of magnitude; waiting for the longest ray leaves
+            // most lanes idle (measured SIMD utilisation of the walk ~12 %).  So the walk is resumable: once
+            // fewer than HPT_EARLY_EXIT lanes are still walking and at least one lane has finished, the wave
+            // leaves the loop, the finished lanes shade and start their next ray, and the unfinished lanes
+            // simply continue in the next round (their node / stack pointer stay in registers, their stack in
+            // their LDS column).
+            if (active && !tracing) {
+                bool anyhit = lane.stage == ST_SHADOW;
+                if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+                trav_begin(sc, ts, lane.ray, anyhit, sc.world_root, true);
+                tracing = true;
+            }
+            for (;;) {
+                const bool busy = tracing && !ts.done();
+                const unsigned long long bm = __ballot(busy);
+                if (bm == 0ull) break;
+                if (HPT_EARLY_EXIT > 0 && __popcll(bm) < HPT_EARLY_EXIT && __ballot(tracing && !busy) != 0ull) break;
+                if (busy) trav_step<COUNT>(sc, ts, lane.ray, stack, HPT_BLOCK, &tc);
+            }
+            if (tracing && ts.done()) {
+                tracing = false;
+                hit = ts.hit;
+                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+            }
         }
-        // ---- state machine step ----------------------------------------------------------------------
-        if (active) { LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK; lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls); }
     }
     if (COUNT) {
         wc.nodes = tc.nodes; wc.tris = tc.tris;
