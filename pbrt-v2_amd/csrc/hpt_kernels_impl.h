@@ -73,8 +73,8 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
-        if (INST) {
-            // ---- one traversal phase: each lane traces its own pending ray to completion (two-level walk) ----
+        if (INST || HPT_EARLY_EXIT == 0) {
+            // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (active) {
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
