@@ -134,6 +134,10 @@ def main():
     rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.HPT_PIPELINE_PERSISTENT
     t0 = time.time()
     dev = hpt.DeviceScene(scene, local)
+    t1 = time.time()
+    if args.pipeline == "persistent" and not args.count_work:
+        dev.tune(scene.camera, rd)                   # scene preparation: BVH build + kernel-configuration probe
+    tune_s = time.time() - t1
     setup_s = time.time() - t0
     info = dev.info()
     film = torch.zeros((rd.y_count, rd.x_count, 4), dtype=torch.float32, device="cuda")
@@ -185,8 +189,9 @@ def main():
                        "scene_bytes_in_hbm": int(info.total_device_bytes)},
             "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
                        "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
+                       "tune_cfg": "%d (%s)" % (last.tune_cfg, ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD"][last.tune_cfg]),
                        "samples_per_launch": int(per_launch_samples)},
-            "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "scene_create_total_s": round(setup_s, 3)},
+            "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
             "film_mean_Y": round(img_mean, 5),
         }
         bps = ALGO_BYTES_PER_SAMPLE.get(args.workload)

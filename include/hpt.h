@@ -207,6 +207,9 @@ typedef struct hpt_stats {
     uint64_t tris_tested;      /* 48-byte triangle records fetched                          */
     uint64_t bad_samples;      /* NaN / negative / inf radiance zeroed (samplerrenderer.cpp:214-228) */
     uint32_t resident_waves, grid_blocks, block_threads, vgprs;
+    uint32_t tune_cfg;         /* kernel configuration that ran: 0 = 4 waves/SIMD, 1 = 4 waves + early-exit
+                                * traversal, 2 = 3 waves/SIMD; picked per scene by a probe render, HPT_TUNE pins it */
+    uint32_t pad;
 } hpt_stats;
 
 typedef struct hpt_scene_info {
@@ -236,6 +239,12 @@ int hpt_render(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *r
                float *film_xyzw_host, hpt_stats *stats);
 int hpt_render_device(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd,
                       void *d_film_xyzw, void *stream, hpt_stats *stats);
+
+/* Pick the kernel configuration for this scene now (part of scene preparation, like the BVH build):
+ * times each configuration on a probe render of the image centre.  Returns the configuration
+ * (>= 0, also reported as hpt_stats.tune_cfg) or a negative HPT_E_*.  Optional: the first large
+ * hpt_render* of an untuned scene does the same; HPT_TUNE=<cfg> in the environment pins it. */
+int hpt_scene_tune(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd);
 
 /* ---- scene blob (serialised hpt_scene_desc + camera + render defaults); host only ------ */
 typedef struct hpt_blob hpt_blob;

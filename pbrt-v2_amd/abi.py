@@ -87,7 +87,8 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("camera_samples", u64), ("closest_rays", u64),
                 ("shadow_rays", u64), ("nodes_visited", u64), ("tris_tested", u64),
                 ("bad_samples", u64), ("resident_waves", u32), ("grid_blocks", u32),
-                ("block_threads", u32), ("vgprs", u32)]
+                ("block_threads", u32), ("vgprs", u32),
+                ("tune_cfg", u32), ("pad", u32)]
 
 
 class SceneInfo(C.Structure):

@@ -4,6 +4,7 @@
 // device every compute entry point fails with HPT_E_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,6 +33,7 @@ struct hpt_scene {
     std::vector<void *> allocs;
     hpt_scene_info info;
     int n_cus;
+    int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
 };
 
 extern "C" int hpt_device_count(void) {
@@ -65,6 +67,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     HIP_CHECK_RET(hipSetDevice(device), nullptr);
     hpt_scene *s = new hpt_scene();
     s->device = device;
+    s->tune_cfg = -1;
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
     hipDeviceProp_t prop;
@@ -203,6 +206,67 @@ static int render_wavefront(hpt_scene *s, PathKernelArgs &pa, const hpt_render_d
     return HPT_OK;
 }
 
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
+};
+
+// ---- kernel configuration: which (waves/SIMD, early-exit) build of the path kernel runs this scene ------------
+// Which one is fastest is a property of the scene (how deep its rays go, whether its BVH stays in L2, how heavy
+// its shading is: profiles/r01_ab.md), so the first large render of a scene times every configuration on a probe:
+// the centre of the image at <= 16 spp, in work items of 4 samples so that lanes regenerate like in the real job.
+// HPT_TUNE=<cfg> pins the choice.  Every configuration computes the same image (same code, different scheduling).
+static int tune_forced() {
+    if (const char *e = getenv("HPT_TUNE")) { int c = atoi(e); if (c >= 0 && c < HPT_N_TUNE_CFG) return c; }
+    return -1;
+}
+static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, PathKernelArgs a, void *d_scr, size_t scr_bytes,
+                           hipStream_t stream) {
+    hpt_render_desc prd = *rd;
+    prd.x_count = rd->x_count < 640 ? rd->x_count : 640;
+    prd.y_count = rd->y_count < 360 ? rd->y_count : 360;
+    prd.x_start = rd->x_start + (rd->x_count - prd.x_count) / 2;
+    prd.y_start = rd->y_start + (rd->y_count - prd.y_count) / 2;
+    prd.spp = rd->spp < 16 ? rd->spp : 16;
+    prd.shard_rank = 0; prd.shard_count = 1; prd.count_work = 0;
+    if (fill_params(cam, &prd, &a.rp) != HPT_OK) return hipErrorInvalidValue;
+    a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
+    if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * (prd.spp / 4); }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    float best = 0.f;
+    int best_cfg = 0;
+    const bool inst = s->d.n_instances > 0;
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
+        if (inst && cfg == 1) continue;                       // early exit is not compiled for instanced scenes
+        int bpc = 0, vg = 0;
+        if (path_kernel_occupancy(s->mats, inst, cfg, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
+        if (bpc < 1) bpc = 1;
+        int grid = s->n_cus * bpc;
+        int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
+        if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+        float t = 0.f;
+        for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) { // first launch also pays the code-object load
+            e = hipMemsetAsync(d_scr, 0, scr_bytes, stream);
+            if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+            if (e == hipSuccess) e = launch_path_kernel(s->mats, a, grid, false, cfg, stream);
+            if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ev1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+            if (rep == 0 || ms < t) t = ms;
+        }
+        if (getenv("HPT_TUNE_VERBOSE")) fprintf(stderr, "hpt autotune: cfg %d  %.3f ms\n", cfg, t);
+        if (cfg == 0 || t < best) { best = t; best_cfg = cfg; }
+    }
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (e == hipSuccess) s->tune_cfg = best_cfg;
+    return e;
+}
+
 extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film,
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
@@ -217,17 +281,27 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     struct Scratch { unsigned long long next_item; WorkCounters wc; };
     Scratch *d_scr = nullptr;
     HIP_CHECK_RET(hipMalloc((void **)&d_scr, sizeof(Scratch)), HPT_E_HIP);
-    hipError_t e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     a.next_item = &d_scr->next_item;
     a.counters = &d_scr->wc;
+    const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
+    hipError_t e = hipSuccess;
+    // configuration: pinned by HPT_TUNE, else tuned once per scene by the first job big enough to amortise the probe
+    int cfg = tune_forced();
+    if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
+        if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
+            e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
+        cfg = s->tune_cfg;
+    }
+    if (cfg < 0) cfg = 0;
+    if (rd->count_work) cfg = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     int bpc = 0, vgprs = 0;
-    if (e == hipSuccess && path_kernel_occupancy(s->mats, s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && path_kernel_occupancy(s->mats, s->d.n_instances > 0, cfg, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
-    const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
         float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
         int wrc = render_wavefront(s, a, rd, stream, stats, &d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
@@ -270,7 +344,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
-    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, stream);
+    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     float ms = 0.f;
@@ -304,8 +378,26 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         }
         stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
         stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs;
+        stats->tune_cfg = replay ? 0u : (uint32_t)cfg;
     }
     return HPT_OK;
+}
+
+extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
+    if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    PathKernelArgs a;
+    int rc = fill_params(cam, rd, &a.rp);
+    if (rc != HPT_OK) return rc;
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    a.sc = s->d;
+    struct Scratch { unsigned long long next_item; WorkCounters wc; };
+    DevBuf<Scratch> scr;
+    DevBuf<float> filmbuf;
+    if (!scr.alloc(1) || !filmbuf.alloc((size_t)4 * 640 * 360)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
+    a.next_item = &scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p;
+    hipError_t e = autotune(s, cam, rd, a, scr.p, sizeof(Scratch), nullptr);
+    if (e != hipSuccess) { hpt_set_error("autotune failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    return s->tune_cfg;
 }
 
 extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film_host, hpt_stats *stats) {
@@ -323,12 +415,6 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
 }
 
 // ---- parity hooks -------------------------------------------------------------------------------------
-template <typename T> struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
-};
-
 extern "C" int hpt_test_intersect(hpt_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim) {
     if (!s || !rays || !out_hit || !out_prim || n < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);

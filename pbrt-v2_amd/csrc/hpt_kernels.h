@@ -9,13 +9,6 @@
                                 in 160 KiB of LDS).  The BVH builder bounds the tree depth to HPT_STACK_DEPTH - 2.
                                 (A workgroup-level ray pool with dynamic fetch was tried here and measured slower:
                                 profiles/r01_ab.md, second A/B.) */
-#ifndef HPT_EARLY_EXIT
-#define HPT_EARLY_EXIT 32    /* leave the traversal loop once fewer lanes than this are still walking (0 = never) */
-#endif
-#ifndef HPT_MIN_WAVES
-#define HPT_MIN_WAVES 4    /* __launch_bounds__ 2nd arg: waves per SIMD the register allocator must allow (A/B in profiles/r01_ab.md) */
-#endif
-
 namespace hpt {
 
 struct PathKernelArgs {
@@ -33,8 +26,9 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
-int path_kernel_occupancy(int mats, bool inst, int *blocks_per_cu, int *vgprs);
-hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream);
+#define HPT_N_TUNE_CFG 3   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves} — hpt_kernels_impl.h */
+int path_kernel_occupancy(int mats, bool inst, int cfg, int *blocks_per_cu, int *vgprs);
+hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
                             int32_t *out_prim, hipStream_t s);

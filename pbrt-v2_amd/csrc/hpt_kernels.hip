@@ -117,12 +117,12 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
-hipError_t launch_path_basic(const PathKernelArgs &, int, bool, hipStream_t);
-hipError_t launch_path_measured(const PathKernelArgs &, int, bool, hipStream_t);
-hipError_t launch_path_all(const PathKernelArgs &, int, bool, hipStream_t);
-int occupancy_basic(bool, int *, int *);
-int occupancy_measured(bool, int *, int *);
-int occupancy_all(bool, int *, int *);
+hipError_t launch_path_basic(const PathKernelArgs &, int, bool, int, hipStream_t);
+hipError_t launch_path_measured(const PathKernelArgs &, int, bool, int, hipStream_t);
+hipError_t launch_path_all(const PathKernelArgs &, int, bool, int, hipStream_t);
+int occupancy_basic(bool, int, int *, int *);
+int occupancy_measured(bool, int, int *, int *);
+int occupancy_all(bool, int, int *, int *);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
 static int pick_variant(int mats) {
@@ -130,18 +130,18 @@ static int pick_variant(int mats) {
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
     return 2;
 }
-int path_kernel_occupancy(int mats, bool inst, int *blocks_per_cu, int *vgprs) {
+int path_kernel_occupancy(int mats, bool inst, int cfg, int *blocks_per_cu, int *vgprs) {
     switch (pick_variant(mats)) {
-        case 0: return occupancy_basic(inst, blocks_per_cu, vgprs);
-        case 1: return occupancy_measured(inst, blocks_per_cu, vgprs);
-        default: return occupancy_all(inst, blocks_per_cu, vgprs);
+        case 0: return occupancy_basic(inst, cfg, blocks_per_cu, vgprs);
+        case 1: return occupancy_measured(inst, cfg, blocks_per_cu, vgprs);
+        default: return occupancy_all(inst, cfg, blocks_per_cu, vgprs);
     }
 }
-hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {
+hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {
     switch (pick_variant(mats)) {
-        case 0: return launch_path_basic(a, grid_blocks, count, stream);
-        case 1: return launch_path_measured(a, grid_blocks, count, stream);
-        default: return launch_path_all(a, grid_blocks, count, stream);
+        case 0: return launch_path_basic(a, grid_blocks, count, cfg, stream);
+        case 1: return launch_path_measured(a, grid_blocks, count, cfg, stream);
+        default: return launch_path_all(a, grid_blocks, count, cfg, stream);
     }
 }
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {

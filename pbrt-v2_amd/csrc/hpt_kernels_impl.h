@@ -41,8 +41,12 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
     return need ? (int64_t)(base + (unsigned long long)rank) : -1;
 }
 
-template <bool COUNT, bool INST, int MATS>
-__global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(const PathKernelArgs a) {
+// WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
+// (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
+// scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
+// exit — so the library carries a few configurations and times them on a probe render (hpt_api.hip, autotune).
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE>
+__global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
-        if (INST || HPT_EARLY_EXIT == 0) {
+        if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (active) {
                 bool anyhit = lane.stage == ST_SHADOW;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
             // ---- traversal phase with early exit --------------------------------------------------------
             // Ray lengths inside a wave differ by an order of magnitude; waiting for the longest ray leaves
             // most lanes idle (measured SIMD utilisation of the walk ~12 %).  So the walk is resumable: once
-            // fewer than HPT_EARLY_EXIT lanes are still walking and at least one lane has finished, the wave
+            // fewer than EE lanes are still walking and at least one lane has finished, the wave
             // leaves the loop, the finished lanes shade and start their next ray, and the unfinished lanes
             // simply continue in the next round (their node / stack pointer stay in registers, their stack in
             // their LDS column).
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
                 const bool busy = tracing && !ts.done();
                 const unsigned long long bm = __ballot(busy);
                 if (bm == 0ull) break;
-                if (HPT_EARLY_EXIT > 0 && __popcll(bm) < HPT_EARLY_EXIT && __ballot(tracing && !busy) != 0ull) break;
+                if (EE > 0 && __popcll(bm) < EE && __ballot(tracing && !busy) != 0ull) break;
                 if (busy) trav_step<COUNT>(sc, ts, lane.ray, stack, HPT_BLOCK, &tc);
             }
             if (tracing && ts.done()) {
@@ -123,23 +127,43 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_MIN_WAVES) void hpt_path_kernel(cons
 }
 
 
-// Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.
+// Tuning configurations (index = hpt_stats.tune_cfg): {waves/SIMD, early-exit threshold}
+#define HPT_N_CFG 3
+#define HPT_CFG_WAVES(c) ((c) == 2 ? 3 : 4)
+#define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
+
+// Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
+// build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
 #define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS)                                                                        \
-    hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid_blocks, bool count, hipStream_t stream) {      \
-        const bool inst = a.sc.n_instances > 0;                                                                     \
-        if (count && inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);   \
-        else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);    \
-        else if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);     \
-        else hipLaunchKernelGGL((hpt_path_kernel<false, false, MATS>), dim3(grid_blocks), dim3(HPT_BLOCK), 0, stream, a);              \
+    template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, bool inst, hipStream_t s) { \
+        if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true, MATS, HPT_CFG_WAVES(CFG), 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);             \
+        else hipLaunchKernelGGL((hpt_path_kernel<false, false, MATS, HPT_CFG_WAVES(CFG), HPT_CFG_EE(CFG)>), dim3(grid), dim3(HPT_BLOCK), 0, s, a); \
         return hipGetLastError();                                                                                   \
     }                                                                                                               \
-    int occupancy_##NAME(bool inst, int *blocks_per_cu, int *vgprs) {                                               \
+    hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
+        const bool inst = a.sc.n_instances > 0;                                                                     \
+        if (count) {                                                                                                \
+            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);  \
+            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
+            return hipGetLastError();                                                                               \
+        }                                                                                                           \
+        if (inst && cfg == 1) cfg = 0;                                                                              \
+        switch (cfg) {                                                                                              \
+            case 1: return launch_cfg_##NAME<1>(a, grid, inst, s);                                                  \
+            case 2: return launch_cfg_##NAME<2>(a, grid, inst, s);                                                  \
+            default: return launch_cfg_##NAME<0>(a, grid, inst, s);                                                 \
+        }                                                                                                           \
+    }                                                                                                               \
+    template <int CFG> static const void *fn_cfg_##NAME(bool inst) {                                                \
+        return inst ? (const void *)hpt_path_kernel<false, true, MATS, HPT_CFG_WAVES(CFG), 0>                       \
+                    : (const void *)hpt_path_kernel<false, false, MATS, HPT_CFG_WAVES(CFG), HPT_CFG_EE(CFG)>;       \
+    }                                                                                                               \
+    int occupancy_##NAME(bool inst, int cfg, int *blocks_per_cu, int *vgprs) {                                      \
+        if (inst && cfg == 1) cfg = 0;                                                                              \
+        const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : fn_cfg_##NAME<0>(inst); \
         int nb = 0;                                                                                                 \
-        hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, true, MATS>, HPT_BLOCK, 0)     \
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpt_path_kernel<false, false, MATS>, HPT_BLOCK, 0);   \
-        if (e != hipSuccess) return -1;                                                                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, 0) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \
-        const void *fn = inst ? (const void *)hpt_path_kernel<false, true, MATS> : (const void *)hpt_path_kernel<false, false, MATS>; \
         *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0;                                      \
         *blocks_per_cu = nb;                                                                                        \
         return 0;                                                                                                   \

@@ -18,7 +18,7 @@ _lib = None
 
 EXPORTS = [
     "hpt_device_count", "hpt_last_error", "hpt_scene_create", "hpt_scene_destroy",
-    "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_blob_save", "hpt_blob_load",
+    "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_scene_tune", "hpt_blob_save", "hpt_blob_load",
     "hpt_blob_scene", "hpt_blob_camera", "hpt_blob_render", "hpt_blob_free",
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
 ]
@@ -52,6 +52,7 @@ def lib():
                                  C.c_void_p, C.POINTER(abi.Stats)]
         L.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc),
                                         C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.hpt_scene_tune.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc)]
         L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.hpt_test_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -93,6 +94,13 @@ class DeviceScene:
         i = abi.SceneInfo()
         _check(lib().hpt_scene_get_info(self.h, C.byref(i)))
         return i
+
+    def tune(self, cam, rd):
+        """Pick the kernel configuration for this scene now (else the first large render does)."""
+        rc = lib().hpt_scene_tune(self.h, C.byref(cam), C.byref(rd))
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def render(self, cam, rd):
         """-> (film (H, W, 4) float32 {X,Y,Z,weight}, Stats).  Film copied to host."""

@@ -158,6 +158,44 @@ def test_wavefront_pipeline_equals_persistent(cases, dev, ora, name):
     assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fw)) < 1e-3
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_kernel_configurations_render_the_same_film(cases, dev, name, monkeypatch):
+    """The tuning configurations of the path kernel (waves/SIMD, early-exit traversal) differ in
+    scheduling only: pinned one after the other with HPT_TUNE they must produce the same film."""
+    s = cases[name]
+    rd = hash_rd(s, seed=9)
+    films = []
+    for cfg in range(3):
+        monkeypatch.setenv("HPT_TUNE", str(cfg))
+        f, st = dev[name].render(s.camera, rd)
+        assert st.tune_cfg == cfg and st.bad_samples == 0
+        films.append(f)
+    for f in films[1:]:
+        assert np.array_equal(films[0][..., 3], f[..., 3])
+        assert np.allclose(films[0], f, rtol=1e-6, atol=1e-6)   # order of the rare boundary spills
+
+
+def test_autotune_probes_once_per_scene(monkeypatch):
+    """A job big enough to amortise the probe picks a configuration and later renders reuse it;
+    the probe leaves nothing behind in the film."""
+    monkeypatch.delenv("HPT_TUNE", raising=False)
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    s = scenes.synthetic_soup(n_tris=50000, spp=64, maxdepth=8, xres=1024, yres=576)
+    d = hpt.DeviceScene(s)
+    small = abi.copy_struct(s.render)
+    small.spp = 4
+    _, st0 = d.render(s.camera, small)                  # too small to tune: configuration 0
+    assert st0.tune_cfg == 0
+    f1, st1 = d.render(s.camera, s.render)              # tunes
+    f2, st2 = d.render(s.camera, s.render)
+    assert 0 <= st1.tune_cfg < 3 and st2.tune_cfg == st1.tune_cfg
+    assert st1.camera_samples == 1024 * 576 * 64
+    assert np.array_equal(f1[..., 3], f2[..., 3]) and np.allclose(f1, f2, rtol=1e-6, atol=1e-6)
+    monkeypatch.setenv("HPT_TUNE", "0")
+    f0, _ = d.render(s.camera, s.render)
+    assert np.allclose(f0, f1, rtol=1e-6, atol=1e-6)
+
+
 def test_wavefront_pipeline_full_size():
     scenes = importlib.import_module("pbrt-v2_amd.scenes")
     s = scenes.synthetic_soup(n_tris=50000, spp=128, maxdepth=8, xres=640, yres=360)
