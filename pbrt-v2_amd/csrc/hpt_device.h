@@ -672,15 +672,25 @@ HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
 // IrregIsotropicBRDF::f (reflection.cpp:247-272): kd-tree radius query with the reference's exact
 // post-order visiting sequence (core/kdtree.h:159-183) so the weighted sums round identically.
 // The recursion is unrolled into an explicit stack of (node, stage) pairs.
-struct IrregProc { f3 v; float sumWeights; int nFound; };
+//
+// The reference grows the radius .001, .002, ... until a pass finds more than two samples and returns
+// the sums of THAT pass (3.1 passes and 98 node visits per lookup on bunny.pbrt's BRDF).  The result
+// only depends on the final radius r_k, k = min{k : #(d2 < r_k) > 2}, and a pass at any radius visits
+// the samples in the same relative order (the order is a function of the query point alone; the radius
+// only prunes).  So the device starts at a guessed level g (a 16^3 table of the level at cell centres,
+// built at scene creation: hpt_flatten.cpp), tracks the third-smallest d2 of the pass, and sums for
+// r_g and r_(g-1) at once: k == g or g-1 ends after ONE pass with bit-identical sums, k < g-1 takes one
+// more (smaller) pass at r_k, k > g continues upwards like the reference (1.3 passes, 61 visits).
+struct IrregProc { f3 v; float sumWeights; f3 v2; float sumWeights2; float r2; float m1, m2, m3; };
 // Scratch stack for the kd-tree walk: the lane's LDS traversal-stack column (free while shading).
 struct LaneStack { int32_t *p; int stride; };
+#define HPT_KD_GRID 16
 HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2, LaneStack ls) {
     // packed node: {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
     const f4 *nodes = (const f4 *)(sc.fpool + m->kd_data_off);
     const uint32_t nNodes = (uint32_t)m->kd_nnodes;
     // stage 0: first visit; 1: after first child; 2: after second child -> process node
-    // entries: node << 2 | stage ; tree depth <= 30 (checked at scene creation)
+    // entries: node << 2 | stage ; tree depth <= 24 (checked at scene creation)
     int sp = 0;
     ls.p[0] = 0; sp = 1;
     while (sp > 0) {
@@ -689,22 +699,26 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
         f4 n0 = nodes[2 * (int64_t)nodeNum];
         uint32_t b = (uint32_t)as_int(n0.y);
         int axis = (int)(b & 3u);
-        uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
         if (axis != 3 && stage < 2) {
+            uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
             float pa = comp(p, axis), sp_ = n0.x;
             float d2 = (pa - sp_) * (pa - sp_);
             bool leftFirst = pa <= sp_;
+            bool hasRight = right < nNodes;
             uint32_t child = 0xffffffffu;
-            if (stage == 0) {
-                if (leftFirst) { if (hasLeft) child = nodeNum + 1; }
-                else { if (right < nNodes) child = right; }
-            } else {
-                if (leftFirst) { if (d2 < maxDist2 && right < nNodes) child = right; }
-                else { if (d2 < maxDist2 && hasLeft) child = nodeNum + 1; }
+            if (stage == 0) {                            // first child, else straight on to the second
+                if (leftFirst ? hasLeft != 0u : hasRight) child = leftFirst ? nodeNum + 1 : right;
+                stage = 1;
             }
-            ls.p[(sp - 1) * ls.stride] = (int32_t)((nodeNum << 2) | (stage + 1));
-            if (child != 0xffffffffu) { ls.p[sp * ls.stride] = (int32_t)(child << 2); ++sp; }
-            continue;
+            if (child == 0xffffffffu) {                  // stage 1: the far child, if the slab reaches it
+                if (d2 < maxDist2 && (leftFirst ? hasRight : hasLeft != 0u)) child = leftFirst ? right : nodeNum + 1;
+                stage = 2;
+            }
+            if (child != 0xffffffffu) {
+                ls.p[(sp - 1) * ls.stride] = (int32_t)((nodeNum << 2) | stage);
+                ls.p[sp * ls.stride] = (int32_t)(child << 2); ++sp;
+                continue;
+            }
         }
         --sp;
         f4 n1 = nodes[2 * (int64_t)nodeNum + 1];
@@ -712,11 +726,20 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
         float d2 = dist2(np, p);
         if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
             float weight = expf(-100.f * d2);
-            proc->v = proc->v + mk3(n1.y, n1.z, n1.w) * weight;
+            f3 wv = mk3(n1.y, n1.z, n1.w) * weight;
+            proc->v = proc->v + wv;
             proc->sumWeights += weight;
-            ++proc->nFound;
+            if (d2 < proc->r2) { proc->v2 = proc->v2 + wv; proc->sumWeights2 += weight; }
+            if (d2 < proc->m3) {                         // keep the three smallest distances, m1 <= m2 <= m3
+                if (d2 < proc->m2) { proc->m3 = proc->m2; if (d2 < proc->m1) { proc->m2 = proc->m1; proc->m1 = d2; } else proc->m2 = d2; }
+                else proc->m3 = d2;
+            }
         }
     }
+}
+HPT_FN void irreg_proc_reset(IrregProc *pr, float r2) {
+    pr->v = S(0.f); pr->sumWeights = 0.f; pr->v2 = S(0.f); pr->sumWeights2 = 0.f; pr->r2 = r2;
+    pr->m1 = pr->m2 = pr->m3 = HPT_INF;
 }
 HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
     float cosi = wi.z, coso = wo.z;
@@ -727,12 +750,30 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     if (dphi > 2.f * HPT_PI) dphi -= 2.f * HPT_PI;
     if (dphi > HPT_PI) dphi = 2.f * HPT_PI - dphi;
     f3 mpt = mk3(sini * sino, dphi / HPT_PI, cosi * coso);
-    float lastMaxDist2 = .001f;
+    // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
+    int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
+    gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
+    gy = gy < 0 ? 0 : gy > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gy;
+    gz = gz < 0 ? 0 : gz > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gz;
+    int cell = (gz * HPT_KD_GRID + gy) * HPT_KD_GRID + gx;
+    int level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
+    float r = .001f;
+    for (int i = 0; i < level; ++i) r *= 2.f;            // the reference's lastMaxDist2 after `level` doublings
     while (true) {
-        IrregProc proc; proc.v = S(0.f); proc.sumWeights = 0.f; proc.nFound = 0;
-        kd_lookup(sc, m, mpt, &proc, lastMaxDist2, ls);
-        if (proc.nFound > 2 || lastMaxDist2 > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
-        lastMaxDist2 *= 2.f;
+        IrregProc proc;
+        irreg_proc_reset(&proc, level > 0 ? r * .5f : 0.f);
+        kd_lookup(sc, m, mpt, &proc, r, ls);
+        if (proc.m3 < r) {                               // more than two samples inside r: the reference stopped at k <= level
+            int k = level; float rk = r;
+            while (k > 0 && proc.m3 < rk * .5f) { --k; rk *= .5f; }
+            if (k == level) return sdivf(sclamp0(proc.v), proc.sumWeights);
+            if (k == level - 1) return sdivf(sclamp0(proc.v2), proc.sumWeights2);
+            irreg_proc_reset(&proc, 0.f);
+            kd_lookup(sc, m, mpt, &proc, rk, ls);
+            return sdivf(sclamp0(proc.v), proc.sumWeights);
+        }
+        if (r > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
+        r *= 2.f; ++level;
     }
 }
 

@@ -8,6 +8,25 @@
 
 namespace hpt {
 
+// number of kd-tree samples within sqrt(r2) of q, counting stops at `enough` (same pruning rule as
+// KdTree::privateLookup, core/kdtree.h:159-183); host helper for the starting-level table below
+static int kd_count_within(const float *split, const int32_t *bits, const float *data, uint32_t n_nodes, uint32_t node,
+                           const float q[3], float r2, int enough) {
+    uint32_t b = (uint32_t)bits[node];
+    int axis = (int)(b & 3u), found = 0;
+    if (axis != 3) {
+        uint32_t left = ((b >> 2) & 1u) ? node + 1 : n_nodes, right = b >> 3;
+        float d = q[axis] - split[node];
+        uint32_t near_c = d <= 0.f ? left : right, far_c = d <= 0.f ? right : left;
+        if (near_c < n_nodes) found += kd_count_within(split, bits, data, n_nodes, near_c, q, r2, enough);
+        if (found < enough && d * d < r2 && far_c < n_nodes) found += kd_count_within(split, bits, data, n_nodes, far_c, q, r2, enough - found);
+    }
+    const float *p = data + 6 * (size_t)node;
+    float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    if (dx * dx + dy * dy + dz * dz < r2) ++found;
+    return found;
+}
+
 int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out) {
     auto t0 = std::chrono::steady_clock::now();
     int64_t ntris = 0;
@@ -97,7 +116,20 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             out->fpool.push_back(split[i]); out->fpool.push_back(bf);
             for (int k = 0; k < 6; ++k) out->fpool.push_back(data[6 * i + k]);
         }
-        ma.kd_data_off = base; ma.kd_split_off = HPT_KD_PACKED; ma.kd_bits_off = HPT_KD_PACKED;
+        // starting-level table for irreg_f (hpt_device.h): the level k at which the reference's growing-radius
+        // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 16^3 grid over
+        // (sin*sin, dphi/pi, cos*cos) in [0,1] x [0,1] x [-1,1]; one byte per cell, four to a pool word
+        const int G = 16;
+        std::vector<uint8_t> lev((size_t)G * G * G);
+        for (int z = 0; z < G; ++z) for (int y = 0; y < G; ++y) for (int x = 0; x < G; ++x) {
+            float q[3] = {(x + .5f) / G, (y + .5f) / G, -1.f + 2.f * (z + .5f) / G};
+            float r = .001f; int k = 0;
+            while (kd_count_within(split, bits, data, (uint32_t)ma.kd_nnodes, 0u, q, r, 3) <= 2 && !(r > 1.5f)) { r *= 2.f; ++k; }
+            lev[((size_t)z * G + y) * G + x] = (uint8_t)k;
+        }
+        int64_t gbase = (int64_t)out->fpool.size();
+        for (size_t i = 0; i < lev.size(); i += 4) { float w; memcpy(&w, &lev[i], 4); out->fpool.push_back(w); }
+        ma.kd_data_off = base; ma.kd_split_off = HPT_KD_PACKED; ma.kd_bits_off = gbase;
     }
     out->n_tris = ntris;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
