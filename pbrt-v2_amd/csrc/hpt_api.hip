@@ -385,6 +385,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 
 extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    if (tune_forced() >= 0) return tune_forced();
     PathKernelArgs a;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;

@@ -26,7 +26,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
-#define HPT_N_TUNE_CFG 3   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves} — hpt_kernels_impl.h */
+#define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step} — hpt_kernels_impl.h */
 int path_kernel_occupancy(int mats, bool inst, int cfg, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);

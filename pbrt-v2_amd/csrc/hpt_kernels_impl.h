@@ -45,7 +45,14 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
 // scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
 // exit — so the library carries a few configurations and times them on a probe render (hpt_api.hip, autotune).
-template <bool COUNT, bool INST, int MATS, int WAVES, int EE>
+//
+// PHASED: the wave walks the three ray kinds of a path vertex in lock step — extension rays, then shadow rays,
+// then MIS rays — and a lane only traces (and then advances its state machine) in the phase of its own stage.
+// Free-running lanes (PHASED = false) always have a ray in flight, but sit in different stages, so the heavy
+// block behind an extension hit (BSDF set-up, light sampling, three BSDF evaluations — kd-tree queries for a
+// measured BRDF) runs with about a third of the lanes (measured VALU lane utilisation 7-12 %).  In lock step
+// every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
     int32_t *stack = lds_stack + threadIdx.x;
@@ -59,6 +66,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     bool tracing = false;
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
+    int phase = ST_EXTEND;         // wave-uniform (PHASED only)
     for (;;) {
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
         for (;;) {
@@ -77,7 +85,18 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
-        if (INST || EE == 0) {
+        if (PHASED) {
+            // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for ---------
+            while (__ballot(lane.stage == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+            if (lane.stage == phase) {
+                bool anyhit = phase == ST_SHADOW;
+                if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+                traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+            }
+            phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+        } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (active) {
                 bool anyhit = lane.stage == ST_SHADOW;
@@ -127,40 +146,44 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 }
 
 
-// Tuning configurations (index = hpt_stats.tune_cfg): {waves/SIMD, early-exit threshold}
-#define HPT_N_CFG 3
-#define HPT_CFG_WAVES(c) ((c) == 2 ? 3 : 4)
+// Tuning configurations (index = hpt_stats.tune_cfg): {waves/SIMD, early-exit threshold, lock-step phases}
+#define HPT_N_CFG 5
+#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? 3 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
+#define HPT_CFG_PHASED(c) ((c) >= 3)
+#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C)>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
 #define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS)                                                                        \
     template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, bool inst, hipStream_t s) { \
-        if (inst) hipLaunchKernelGGL((hpt_path_kernel<false, true, MATS, HPT_CFG_WAVES(CFG), 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);             \
-        else hipLaunchKernelGGL((hpt_path_kernel<false, false, MATS, HPT_CFG_WAVES(CFG), HPT_CFG_EE(CFG)>), dim3(grid), dim3(HPT_BLOCK), 0, s, a); \
+        if (inst) hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, true, CFG)), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
+        else hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, false, CFG)), dim3(grid), dim3(HPT_BLOCK), 0, s, a);          \
         return hipGetLastError();                                                                                   \
     }                                                                                                               \
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
         const bool inst = a.sc.n_instances > 0;                                                                     \
         if (count) {                                                                                                \
-            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);  \
-            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
+            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);  \
+            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \
         switch (cfg) {                                                                                              \
             case 1: return launch_cfg_##NAME<1>(a, grid, inst, s);                                                  \
             case 2: return launch_cfg_##NAME<2>(a, grid, inst, s);                                                  \
+            case 3: return launch_cfg_##NAME<3>(a, grid, inst, s);                                                  \
+            case 4: return launch_cfg_##NAME<4>(a, grid, inst, s);                                                  \
             default: return launch_cfg_##NAME<0>(a, grid, inst, s);                                                 \
         }                                                                                                           \
     }                                                                                                               \
     template <int CFG> static const void *fn_cfg_##NAME(bool inst) {                                                \
-        return inst ? (const void *)hpt_path_kernel<false, true, MATS, HPT_CFG_WAVES(CFG), 0>                       \
-                    : (const void *)hpt_path_kernel<false, false, MATS, HPT_CFG_WAVES(CFG), HPT_CFG_EE(CFG)>;       \
+        return inst ? (const void *)HPT_CFG_KERNEL(MATS, true, CFG) : (const void *)HPT_CFG_KERNEL(MATS, false, CFG); \
     }                                                                                                               \
     int occupancy_##NAME(bool inst, int cfg, int *blocks_per_cu, int *vgprs) {                                      \
         if (inst && cfg == 1) cfg = 0;                                                                              \
-        const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : fn_cfg_##NAME<0>(inst); \
+        const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
+                       : cfg == 4 ? fn_cfg_##NAME<4>(inst) : fn_cfg_##NAME<0>(inst);                                \
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, 0) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \
