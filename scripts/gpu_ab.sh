@@ -7,8 +7,8 @@ O=gpurun_out/ab_$(date +%H%M%S)
 mkdir -p $O
 for v in ${VARIANTS:-w2 w3 w4 w5}; do
   for w in ${WORKLOADS:-bunny killeroo soup}; do
-    extra=""; [ "$w" = "soup" ] && extra="--spp 4"
-    HPT_LIB=$PWD/pbrt-v2_amd/build/variants/libhpt_$v.so timeout 300 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline $extra > $O/${v}_$w.json 2> $O/${v}_$w.err
+    extra=""; [ "$w" = "soup" ] && extra="--spp 32"
+    HPT_TUNE=${TUNE:-0} HPT_LIB=$PWD/pbrt-v2_amd/build/variants/libhpt_$v.so timeout 300 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline $extra > $O/${v}_$w.json 2> $O/${v}_$w.err
     python - <<PY
 import json
 try:
