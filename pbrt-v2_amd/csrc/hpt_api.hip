@@ -34,6 +34,8 @@ struct hpt_scene {
     hpt_scene_info info;
     int n_cus;
     int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
+    int kd_mat, kd_nodes; // first measured-BRDF material and the size of its kd-tree (-1: none)
+    int stack_entries;    // per-lane traversal stack entries this scene needs
 };
 
 extern "C" int hpt_device_count(void) {
@@ -84,6 +86,11 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->info.n_tris = ntris; s->info.n_bvh_nodes = (int64_t)fs.nodes.size(); s->info.n_quadrics = desc->n_quadrics;
     s->info.bvh_bytes = (int64_t)(fs.nodes.size() * sizeof(BvhNode64)); s->info.tri_bytes = 48 * ntris;
     s->info.bvh_max_depth = fs.max_depth;
+    s->stack_entries = fs.max_depth + 2;
+    if (s->stack_entries < fs.kd_max_depth + 1) s->stack_entries = fs.kd_max_depth + 1;
+    if (s->stack_entries < 8) s->stack_entries = 8;
+    if (s->stack_entries > HPT_STACK_DEPTH) s->stack_entries = HPT_STACK_DEPTH;
+    s->stack_entries = (s->stack_entries + 1) & ~1;        // keeps the kd head 8-byte aligned behind the stacks
 
     bool ok = true;
     s->d.nodes = (const f4 *)upload(s, fs.nodes.data(), fs.nodes.size(), &ok);
@@ -98,8 +105,10 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->mats = 0;
+    s->kd_mat = -1; s->kd_nodes = 0;
     for (int m = 0; m < desc->n_materials; ++m) {
         int k = desc->materials[m].kind;
+        if (k == HPT_MAT_MEASURED_IRREG && s->kd_mat < 0) { s->kd_mat = m; s->kd_nodes = desc->materials[m].kd_nnodes; }
         s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
                  : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
     }
@@ -212,6 +221,26 @@ template <typename T> struct DevBuf {
     bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
 };
 
+// Resident blocks per CU of configuration `cfg`, and whether the kd-tree head of the scene's measured BRDF
+// rides along in LDS: it does when its {split, bits} pairs (8 bytes a node) fit next to the traversal stacks
+// without costing a resident block.
+static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
+    const bool inst = s->d.n_instances > 0;
+    a->stack_entries = s->stack_entries;
+    a->kd_lds_mat = -1; a->kd_lds_nodes = 0;
+    if (path_kernel_occupancy(s->mats, inst, cfg, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
+    if (s->kd_mat >= 0 && !getenv("HPT_NO_KD_LDS")) {
+        PathKernelArgs t = *a;
+        t.kd_lds_mat = s->kd_mat; t.kd_lds_nodes = s->kd_nodes;
+        int b1 = 0, v1 = 0;
+        if (path_kernel_occupancy(s->mats, inst, cfg, path_kernel_dyn_lds(t), &b1, &v1) == 0 && b1 >= *bpc && b1 > 0) {
+            a->kd_lds_mat = t.kd_lds_mat; a->kd_lds_nodes = t.kd_lds_nodes;
+        }
+    }
+    if (*bpc < 1) *bpc = 1;
+    return 0;
+}
+
 // ---- kernel configuration: which (waves/SIMD, early-exit) build of the path kernel runs this scene ------------
 // Which one is fastest is a property of the scene (how deep its rays go, whether its BVH stays in L2, how heavy
 // its shading is: profiles/r01_ab.md), so the first large render of a scene times every configuration on a probe:
@@ -242,8 +271,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
         if (inst && cfg == 1) continue;                       // early exit is not compiled for instanced scenes
         int bpc = 0, vg = 0;
-        if (path_kernel_occupancy(s->mats, inst, cfg, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
-        if (bpc < 1) bpc = 1;
+        if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
         int grid = s->n_cus * bpc;
         int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
         if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
@@ -271,6 +299,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
@@ -297,7 +326,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     int bpc = 0, vgprs = 0;
-    if (e == hipSuccess && path_kernel_occupancy(s->mats, s->d.n_instances > 0, cfg, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
@@ -387,6 +416,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
     PathKernelArgs a;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);

@@ -231,6 +231,7 @@ struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (
 struct DGeom { f3 p, nn, dpdu; };
 
 HPT_FN int32_t as_int(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
+HPT_FN float as_float(int32_t i) { union { float f; int32_t i; } u; u.i = i; return u.f; }
 
 // Triangle::Intersect core test (shapes/trianglemesh.cpp:127-160)
 HPT_FN bool tri_test(f3 p1, f3 p2, f3 p3, const Ray &ray, float *t_out, float *b1_out, float *b2_out) {
@@ -683,25 +684,40 @@ HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
 // more (smaller) pass at r_k, k > g continues upwards like the reference (1.3 passes, 61 visits).
 struct IrregProc { f3 v; float sumWeights; f3 v2; float sumWeights2; float r2; float m1, m2, m3; };
 // Scratch stack for the kd-tree walk: the lane's LDS traversal-stack column (free while shading).
-struct LaneStack { int32_t *p; int stride; };
+// kd_top: optional copy of one material's {splitPos, bits} pairs in LDS (hpt_kernels_impl.h); the walk of
+// that material's tree then touches HBM / L2 only when it hands a sample to the accumulator.
+// The pointers carry the LDS address space so that the out-of-line irreg_f issues ds_read / ds_write
+// instead of flat loads (measured: flat_load + full s_waitcnt three times per step before).
+#ifdef HPT_HOST_EMU
+#define HPT_LDS
+#else
+#define HPT_LDS __attribute__((address_space(3)))
+#endif
+struct LaneStack {
+    HPT_LDS int32_t *p; int stride;
+    const HPT_LDS uint64_t *kd_top = nullptr; const hpt_material *kd_top_mat = nullptr;
+};
 #define HPT_KD_GRID 16
+// One radius pass.  `cur` (node << 2 | stage) lives in a register, its ancestors on the LDS stack.
+// stage 0: first visit; 1: after the first child; 2: after the second child -> hand the node's sample over.
+// Tree depth <= 24 (checked at scene creation).
+template <int TIER>    // 0: tree in HBM / L2 only; 1: {split, bits} of every node in LDS
 HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2, LaneStack ls) {
     // packed node: {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
     const f4 *nodes = (const f4 *)(sc.fpool + m->kd_data_off);
     const uint32_t nNodes = (uint32_t)m->kd_nnodes;
-    // stage 0: first visit; 1: after first child; 2: after second child -> process node
-    // entries: node << 2 | stage ; tree depth <= 24 (checked at scene creation)
     int sp = 0;
-    ls.p[0] = 0; sp = 1;
-    while (sp > 0) {
-        uint32_t e = (uint32_t)ls.p[(sp - 1) * ls.stride];
-        uint32_t nodeNum = e >> 2, stage = e & 3u;
-        f4 n0 = nodes[2 * (int64_t)nodeNum];
-        uint32_t b = (uint32_t)as_int(n0.y);
-        int axis = (int)(b & 3u);
+    uint32_t cur = 0u;
+    for (;;) {
+        const uint32_t nodeNum = cur >> 2;
+        uint32_t stage = cur & 3u;
+        float sp_; uint32_t b;
+        if (TIER >= 1) { uint64_t t = ls.kd_top[nodeNum]; sp_ = as_float((int32_t)(uint32_t)t); b = (uint32_t)(t >> 32); }   // split | bits << 32
+        else { f4 t = nodes[2 * (int64_t)nodeNum]; sp_ = t.x; b = (uint32_t)as_int(t.y); }
+        const int axis = (int)(b & 3u);
         if (axis != 3 && stage < 2) {
             uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
-            float pa = comp(p, axis), sp_ = n0.x;
+            float pa = comp(p, axis);
             float d2 = (pa - sp_) * (pa - sp_);
             bool leftFirst = pa <= sp_;
             bool hasRight = right < nNodes;
@@ -715,13 +731,12 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
                 stage = 2;
             }
             if (child != 0xffffffffu) {
-                ls.p[(sp - 1) * ls.stride] = (int32_t)((nodeNum << 2) | stage);
-                ls.p[sp * ls.stride] = (int32_t)(child << 2); ++sp;
+                ls.p[sp * ls.stride] = (int32_t)((nodeNum << 2) | stage); ++sp;
+                cur = child << 2;
                 continue;
             }
         }
-        --sp;
-        f4 n1 = nodes[2 * (int64_t)nodeNum + 1];
+        f4 n0 = nodes[2 * (int64_t)nodeNum], n1 = nodes[2 * (int64_t)nodeNum + 1];
         f3 np = mk3(n0.z, n0.w, n1.x);
         float d2 = dist2(np, p);
         if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
@@ -735,11 +750,36 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
                 else proc->m3 = d2;
             }
         }
+        if (sp == 0) break;
+        --sp;
+        cur = (uint32_t)ls.p[sp * ls.stride];
     }
 }
 HPT_FN void irreg_proc_reset(IrregProc *pr, float r2) {
     pr->v = S(0.f); pr->sumWeights = 0.f; pr->v2 = S(0.f); pr->sumWeights2 = 0.f; pr->r2 = r2;
     pr->m1 = pr->m2 = pr->m3 = HPT_INF;
+}
+template <int TIER>
+HPT_FN f3 irreg_query(const DScene &sc, const hpt_material *m, f3 mpt, int level, LaneStack ls) {
+    float r = .001f;
+    for (int i = 0; i < level; ++i) r *= 2.f;            // the reference's lastMaxDist2 after `level` doublings
+    bool last = false;                                   // the pass at the exact final radius (after a too-high guess)
+    while (true) {
+        IrregProc proc;
+        irreg_proc_reset(&proc, (level > 0 && !last) ? r * .5f : 0.f);
+        kd_lookup<TIER>(sc, m, mpt, &proc, r, ls);
+        if (last) return sdivf(sclamp0(proc.v), proc.sumWeights);
+        if (proc.m3 < r) {                               // more than two samples inside r: the reference stopped at k <= level
+            int k = level; float rk = r;
+            while (k > 0 && proc.m3 < rk * .5f) { --k; rk *= .5f; }
+            if (k == level) return sdivf(sclamp0(proc.v), proc.sumWeights);
+            if (k == level - 1) return sdivf(sclamp0(proc.v2), proc.sumWeights2);
+            r = rk; last = true;
+            continue;
+        }
+        if (r > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
+        r *= 2.f; ++level;
+    }
 }
 HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
     float cosi = wi.z, coso = wo.z;
@@ -757,24 +797,8 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     gz = gz < 0 ? 0 : gz > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gz;
     int cell = (gz * HPT_KD_GRID + gy) * HPT_KD_GRID + gx;
     int level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
-    float r = .001f;
-    for (int i = 0; i < level; ++i) r *= 2.f;            // the reference's lastMaxDist2 after `level` doublings
-    while (true) {
-        IrregProc proc;
-        irreg_proc_reset(&proc, level > 0 ? r * .5f : 0.f);
-        kd_lookup(sc, m, mpt, &proc, r, ls);
-        if (proc.m3 < r) {                               // more than two samples inside r: the reference stopped at k <= level
-            int k = level; float rk = r;
-            while (k > 0 && proc.m3 < rk * .5f) { --k; rk *= .5f; }
-            if (k == level) return sdivf(sclamp0(proc.v), proc.sumWeights);
-            if (k == level - 1) return sdivf(sclamp0(proc.v2), proc.sumWeights2);
-            irreg_proc_reset(&proc, 0.f);
-            kd_lookup(sc, m, mpt, &proc, rk, ls);
-            return sdivf(sclamp0(proc.v), proc.sumWeights);
-        }
-        if (r > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
-        r *= 2.f; ++level;
-    }
+    if (m == ls.kd_top_mat) return irreg_query<1>(sc, m, mpt, level, ls);
+    return irreg_query<0>(sc, m, mpt, level, ls);
 }
 
 // FrCond (reflection.cpp:70-79) through FresnelConductor::Evaluate (:110-112), per RGB channel
@@ -902,8 +926,12 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
     *dx = r * cosf(theta);
     *dy = r * sinf(theta);
 }
+// The direction-sampling half of BxDF::Sample_f.  The reference's Sample_f also returns f(wo, wi), but
+// BSDF::Sample_f (reflection.cpp:555-566) discards that value for every non-specular BxDF and re-evaluates f
+// over all matching lobes — and none of the BxDFs on this path is specular — so the value is not computed here
+// (for the measured BRDF it would be a second kd-tree query per sample).
 template <int MATS>
-HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, LaneStack ls) {
+HPT_FN void bxdf_sample_dir(const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf) {
     if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Sample_f (reflection.cpp:446-462)
         if (u1 < .5f) {
             u1 = 2.f * u1;
@@ -914,10 +942,10 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
         } else {
             u1 = 2.f * (u1 - .5f);
             aniso_sample(b.exponent, b.ey, wo, wi, u1, u2, pdf);
-            if (!same_hemisphere(wo, *wi)) return S(0.f);
+            if (!same_hemisphere(wo, *wi)) return;
         }
         *pdf = bxdf_pdf<MATS>(b, i, wo, *wi);
-        return bxdf_f<MATS>(sc, b, i, wo, *wi, ls);
+        return;
     }
     if (b.kind(i) == BX_MICROFACET || b.kind(i) == BX_MICROFACET_COND) { // Microfacet::Sample_f :332-337 + Blinn::Sample_f :346-363
         float costheta = powf(u1, 1.f / (b.exponent + 1));
@@ -929,8 +957,7 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
         float bp = ((b.exponent + 1.f) * powf(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
         if (dot(wo, wh) <= 0.f) bp = 0.f;
         *pdf = bp;
-        if (!same_hemisphere(wo, *wi)) return S(0.f);
-        return bxdf_f<MATS>(sc, b, i, wo, *wi, ls);
+        return;
     }
     f3 w; // BxDF::Sample_f :311-318 (cosine hemisphere)
     concentric_sample_disk(u1, u2, &w.x, &w.y);
@@ -938,7 +965,6 @@ HPT_FN f3 bxdf_sample_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 *wi, f
     if (wo.z < 0.f) w.z *= -1.f;
     *wi = w;
     *pdf = bxdf_pdf<MATS>(b, i, wo, w);
-    return bxdf_f<MATS>(sc, b, i, wo, w, ls);
 }
 HPT_FN bool bx_match(const Bsdf &b, int i, int flags) { int t = b.type(i); return (t & flags) == t; }
 // BSDF::f (reflection.cpp:612-626)
@@ -973,7 +999,8 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
     f3 wo = b.w2l(woW), wi = S(0.f);
     *pdf = 0.f;
-    f3 f = bxdf_sample_f<MATS>(sc, b, sel, wo, &wi, u1, u2, pdf, ls);
+    f3 f = S(0.f);
+    bxdf_sample_dir<MATS>(b, sel, wo, &wi, u1, u2, pdf);
     if (*pdf == 0.f) { *sampledType = 0; return S(0.f); }
     int stype = b.type(sel);
     *sampledType = stype;

@@ -2,6 +2,8 @@
 #include "hpt_flatten.h"
 
 #include <chrono>
+#include <utility>
+#include <vector>
 #include <cstring>
 
 #include "hpt_internal.h"
@@ -126,6 +128,17 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             float r = .001f; int k = 0;
             while (kd_count_within(split, bits, data, (uint32_t)ma.kd_nnodes, 0u, q, r, 3) <= 2 && !(r > 1.5f)) { r *= 2.f; ++k; }
             lev[((size_t)z * G + y) * G + x] = (uint8_t)k;
+        }
+        {   // depth of this tree (the device's walk keeps one stack entry per ancestor)
+            std::vector<std::pair<uint32_t, int> > todo(1, std::make_pair(0u, 1));
+            while (!todo.empty()) {
+                uint32_t n = todo.back().first; int depth = todo.back().second; todo.pop_back();
+                if (depth > out->kd_max_depth) out->kd_max_depth = depth;
+                uint32_t b = (uint32_t)bits[n];
+                if ((b & 3u) == 3u) continue;
+                if ((b >> 2) & 1u) todo.push_back(std::make_pair(n + 1, depth + 1));
+                if ((b >> 3) < (uint32_t)ma.kd_nnodes) todo.push_back(std::make_pair(b >> 3, depth + 1));
+            }
         }
         int64_t gbase = (int64_t)out->fpool.size();
         for (size_t i = 0; i < lev.size(); i += 4) { float w; memcpy(&w, &lev[i], 4); out->fpool.push_back(w); }

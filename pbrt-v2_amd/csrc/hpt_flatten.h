@@ -26,6 +26,7 @@ struct FlatScene {
     std::vector<hpt_material> materials;
     int64_t n_tris = 0;
     int max_depth = 0;
+    int kd_max_depth = 0;             // deepest measured-BRDF kd-tree (levels)
     double build_ms = 0.0;
 };
 

@@ -17,7 +17,16 @@ struct PathKernelArgs {
     float *film;                    // x_count*y_count*4, zeroed before the launch
     unsigned long long *next_item;  // global work counter, zeroed before the launch
     WorkCounters *counters;         // only written by the COUNT instantiation
+    // dynamic LDS of a workgroup: [traversal stacks: stack_entries x 256 x 4 B][kd head: kd_lds_nodes x 8 B]
+    int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2, kd-tree depth + 1)
+    int32_t kd_lds_mat;             // measured-BRDF material whose kd-tree rides in LDS, or -1
+    int32_t kd_lds_nodes;
 };
+inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
+    size_t b = (size_t)a.stack_entries * HPT_BLOCK * 4;
+    if (a.kd_lds_mat >= 0) b += (size_t)a.kd_lds_nodes * 8;
+    return b;
+}
 
 struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     uint32_t *mt;              // [624][nlanes]
@@ -27,7 +36,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 };
 
 #define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step} — hpt_kernels_impl.h */
-int path_kernel_occupancy(int mats, bool inst, int cfg, int *blocks_per_cu, int *vgprs);
+int path_kernel_occupancy(int mats, bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,

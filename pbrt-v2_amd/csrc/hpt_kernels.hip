@@ -52,7 +52,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
             bool anyhit = lane.stage == ST_SHADOW;
             if (anyhit) wc.shadow++; else wc.closest++;
             traverse<true, true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-            LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+            LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
             lane.on_hit(sc, rp, hit, a.film, &wc, ls);
         }
     }
@@ -89,7 +89,7 @@ __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, 
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * 64];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    LaneStack ls; ls.p = lds_stack + threadIdx.x; ls.stride = 64;
+    LaneStack ls; ls.p = (HPT_LDS int32_t *)(lds_stack + threadIdx.x); ls.stride = 64;
     const float *q = in + 16 * i; float *o = out + 12 * i;
     f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
     f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
@@ -120,9 +120,9 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 hipError_t launch_path_basic(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_measured(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_all(const PathKernelArgs &, int, bool, int, hipStream_t);
-int occupancy_basic(bool, int, int *, int *);
-int occupancy_measured(bool, int, int *, int *);
-int occupancy_all(bool, int, int *, int *);
+int occupancy_basic(bool, int, size_t, int *, int *);
+int occupancy_measured(bool, int, size_t, int *, int *);
+int occupancy_all(bool, int, size_t, int *, int *);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
 static int pick_variant(int mats) {
@@ -130,11 +130,11 @@ static int pick_variant(int mats) {
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
     return 2;
 }
-int path_kernel_occupancy(int mats, bool inst, int cfg, int *blocks_per_cu, int *vgprs) {
+int path_kernel_occupancy(int mats, bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
     switch (pick_variant(mats)) {
-        case 0: return occupancy_basic(inst, cfg, blocks_per_cu, vgprs);
-        case 1: return occupancy_measured(inst, cfg, blocks_per_cu, vgprs);
-        default: return occupancy_all(inst, cfg, blocks_per_cu, vgprs);
+        case 0: return occupancy_basic(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
+        case 1: return occupancy_measured(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
+        default: return occupancy_all(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
     }
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {

@@ -54,10 +54,24 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
 template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
-    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
-    int32_t *stack = lds_stack + threadIdx.x;
+    extern __shared__ uint64_t dyn_lds[];      // [stacks][kd head] — sized per scene (path_kernel_dyn_lds)
+    int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
+    LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
+    if ((MATS & MATS_MEASURED) && a.kd_lds_mat >= 0) {
+        // this workgroup's copy of the measured BRDF's kd-tree head: {splitPos, bits} of every node, so that the
+        // walk only leaves LDS when it hands a sample to the accumulator (hpt_device.h: kd_lookup)
+        uint64_t *top = dyn_lds + (size_t)a.stack_entries * (HPT_BLOCK / 2);
+        const hpt_material *km = &sc.materials[a.kd_lds_mat];
+        const f4 *kn = (const f4 *)(sc.fpool + km->kd_data_off);
+        for (int i = (int)threadIdx.x; i < a.kd_lds_nodes; i += HPT_BLOCK) {
+            f4 n0 = kn[2 * i];
+            top[i] = (uint64_t)(uint32_t)as_int(n0.x) | ((uint64_t)(uint32_t)as_int(n0.y) << 32);
+        }
+        __syncthreads();
+        ls.kd_top = (const HPT_LDS uint64_t *)top; ls.kd_top_mat = km;
+    }
     Lane<LdHashSrc, INST, MATS> lane;
     lane.init();
     bool exhausted = false;
@@ -88,13 +102,29 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         if (PHASED) {
             // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for ---------
             while (__ballot(lane.stage == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+#ifdef HPT_TIMING   /* debug build: where do the waves spend their cycles?  (counters reused, see profiles/r01_ab.md) */
+            long long t0 = clock64();
+#endif
             if (lane.stage == phase) {
                 bool anyhit = phase == ST_SHADOW;
+#ifndef HPT_TIMING
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+#endif
                 traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
+            }
+#ifdef HPT_TIMING
+            long long t1 = clock64();
+#endif
+            if (lane.stage == phase) {
                 lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
             }
+#ifdef HPT_TIMING
+            long long t2 = clock64();
+            if (COUNT && lane_id() == 0) {
+                if (phase == ST_EXTEND) { wc.closest += (unsigned long long)(t1 - t0); wc.bad += (unsigned long long)(t2 - t1); }
+                else { wc.shadow += (unsigned long long)(t1 - t0); wc.samples += (unsigned long long)(t2 - t1); }
+            }
+#endif
             phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
@@ -102,7 +132,6 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
                 traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
                 lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
             }
         } else {
@@ -129,13 +158,14 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (tracing && ts.done()) {
                 tracing = false;
                 hit = ts.hit;
-                LaneStack ls; ls.p = stack; ls.stride = HPT_BLOCK;
                 lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
             }
         }
     }
     if (COUNT) {
+#ifndef HPT_TIMING
         wc.nodes = tc.nodes; wc.tris = tc.tris;
+#endif
         atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
         atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
         atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
@@ -151,41 +181,47 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? 3 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
+#ifdef HPT_TIMING
+#define HPT_COUNT_PHASED true
+#else
+#define HPT_COUNT_PHASED false
+#endif
 #define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C)>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
 #define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS)                                                                        \
-    template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, bool inst, hipStream_t s) { \
-        if (inst) hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, true, CFG)), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
-        else hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, false, CFG)), dim3(grid), dim3(HPT_BLOCK), 0, s, a);          \
+    template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, bool inst, size_t dyn_lds, hipStream_t s) { \
+        if (inst) hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, true, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
+        else hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, false, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
         return hipGetLastError();                                                                                   \
     }                                                                                                               \
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
+        const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
         const bool inst = a.sc.n_instances > 0;                                                                     \
         if (count) {                                                                                                \
-            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);  \
-            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);      \
+            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, HPT_COUNT_PHASED>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
+            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, HPT_COUNT_PHASED>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \
         switch (cfg) {                                                                                              \
-            case 1: return launch_cfg_##NAME<1>(a, grid, inst, s);                                                  \
-            case 2: return launch_cfg_##NAME<2>(a, grid, inst, s);                                                  \
-            case 3: return launch_cfg_##NAME<3>(a, grid, inst, s);                                                  \
-            case 4: return launch_cfg_##NAME<4>(a, grid, inst, s);                                                  \
-            default: return launch_cfg_##NAME<0>(a, grid, inst, s);                                                 \
+            case 1: return launch_cfg_##NAME<1>(a, grid, inst, dyn_lds, s);                                                  \
+            case 2: return launch_cfg_##NAME<2>(a, grid, inst, dyn_lds, s);                                                  \
+            case 3: return launch_cfg_##NAME<3>(a, grid, inst, dyn_lds, s);                                                  \
+            case 4: return launch_cfg_##NAME<4>(a, grid, inst, dyn_lds, s);                                                  \
+            default: return launch_cfg_##NAME<0>(a, grid, inst, dyn_lds, s);                                                 \
         }                                                                                                           \
     }                                                                                                               \
     template <int CFG> static const void *fn_cfg_##NAME(bool inst) {                                                \
         return inst ? (const void *)HPT_CFG_KERNEL(MATS, true, CFG) : (const void *)HPT_CFG_KERNEL(MATS, false, CFG); \
     }                                                                                                               \
-    int occupancy_##NAME(bool inst, int cfg, int *blocks_per_cu, int *vgprs) {                                      \
+    int occupancy_##NAME(bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                                      \
         if (inst && cfg == 1) cfg = 0;                                                                              \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
                        : cfg == 4 ? fn_cfg_##NAME<4>(inst) : fn_cfg_##NAME<0>(inst);                                \
         int nb = 0;                                                                                                 \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, 0) != hipSuccess) return -1;           \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \
         *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0;                                      \
         *blocks_per_cu = nb;                                                                                        \

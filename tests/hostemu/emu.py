@@ -24,6 +24,7 @@ def lib():
         L.emu_render_replay.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -57,10 +58,10 @@ class EmuScene:
         lib().emu_intersect(self.h, rays.ctypes.data, n, int(anyhit), hit.ctypes.data, prim.ctypes.data)
         return hit, prim
 
-    def bsdf(self, material, inp):
+    def bsdf(self, material, inp, tier=0):
         inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, 16)
         out = np.zeros((inp.shape[0], 12), dtype=np.float32)
-        lib().emu_bsdf(self.h, material, inp.ctypes.data, inp.shape[0], out.ctypes.data)
+        lib().emu_bsdf_tier(self.h, material, inp.ctypes.data, inp.shape[0], out.ctypes.data, tier)
         return out
 
     def close(self):

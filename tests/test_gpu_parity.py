@@ -175,6 +175,24 @@ def test_kernel_configurations_render_the_same_film(cases, dev, name, monkeypatc
         assert np.allclose(films[0], f, rtol=1e-6, atol=1e-6)   # order of the rare boundary spills
 
 
+def test_measured_brdf_lds_head_renders_the_same_film(cases, dev, monkeypatch):
+    """With and without the LDS copy of the measured BRDF's kd-tree split planes (HPT_NO_KD_LDS):
+    same samples, same summation order, same film."""
+    s = cases["b8"]
+    rd = hash_rd(s, seed=3)
+    monkeypatch.setenv("HPT_TUNE", "3")
+    films = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("HPT_NO_KD_LDS", "1")
+        f, st = dev["b8"].render(s.camera, rd)
+        assert st.bad_samples == 0
+        films.append(f)
+    for f in films[1:]:
+        assert np.array_equal(films[0][..., 3], f[..., 3])
+        assert np.allclose(films[0], f, rtol=1e-6, atol=1e-6)
+
+
 def test_autotune_probes_once_per_scene(monkeypatch):
     """A job big enough to amortise the probe picks a configuration and later renders reuse it;
     the probe leaves nothing behind in the film."""

@@ -60,6 +60,14 @@ def test_bsdf_bit_identical(cases, pairs, name, material):
     assert np.isfinite(a[:, :4]).all()
 
 
+def test_measured_brdf_lds_head_bit_identical(pairs):
+    """The device keeps the split planes of the measured BRDF's kd-tree in LDS; the walk through that copy
+    may not change a single bit of IrregIsotropicBRDF::f."""
+    o, e = pairs["b8"]
+    inp = bsdf_inputs(3000)
+    assert np.array_equal(o.bsdf(1, inp), e.bsdf(1, inp, tier=1), equal_nan=True)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_render_matches_oracle(cases, pairs, name):
     s = cases[name]
