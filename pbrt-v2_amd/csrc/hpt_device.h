@@ -458,22 +458,20 @@ HPT_FN_NOINLINE Xf anim_interpolate(const hpt_instance &in, float time, bool wan
 // wave hit 64 different banks).
 struct TravCounters { uint32_t nodes, tris; };
 
-HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray &ray, f3 invd,
-                 bool nx, bool ny, bool nz, float *tentry) {
-    float tmin = ((nx ? hix : lox) - ray.o.x) * invd.x;
-    float tmax = ((nx ? lox : hix) - ray.o.x) * invd.x;
-    float tymin = ((ny ? hiy : loy) - ray.o.y) * invd.y;
-    float tymax = ((ny ? loy : hiy) - ray.o.y) * invd.y;
-    bool miss = (tmin > tymax) || (tymin > tmax);
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
-    float tzmin = ((nz ? hiz : loz) - ray.o.z) * invd.z;
-    float tzmax = ((nz ? loz : hiz) - ray.o.z) * invd.z;
-    miss = miss || (tmin > tzmax) || (tzmin > tmax);
-    if (tzmin > tmin) tmin = tzmin;
-    if (tzmax < tmax) tmax = tzmax;
-    *tentry = tmin;
-    return !miss && (tmin < ray.maxt) && (tmax > ray.mint);
+// Ray / box overlap for the device's own BVH (not the reference's tree, so only conservativeness matters:
+// a box the ray touches must never be rejected; the triangle tests decide the hit).  min/max form of the slab
+// test — 3 min, 3 max, two 3-way reductions and one compare per box instead of six selects on the direction
+// signs and eight compares (the traversal is VALU-issue bound: profiles/r01_ab.md).  `invd` holds 1/d with
+// infinities clamped to +-FLT_MAX (trav_begin), so a ray lying in a box face with a zero direction component
+// gives 0 * FLT_MAX = 0 instead of NaN and stays inside the slab.  *tentry: entry distance (for near-first order).
+HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, const Ray &ray, f3 invd, float *tentry) {
+    float tx0 = (lox - ray.o.x) * invd.x, tx1 = (hix - ray.o.x) * invd.x;
+    float ty0 = (loy - ray.o.y) * invd.y, ty1 = (hiy - ray.o.y) * invd.y;
+    float tz0 = (loz - ray.o.z) * invd.z, tz1 = (hiz - ray.o.z) * invd.z;
+    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    *tentry = tnear;
+    return fmaxf(tnear, ray.mint) <= fminf(tfar, ray.maxt);
 }
 
 #define HPT_TRAV_EMPTY ((int32_t)0x80000000)
@@ -484,7 +482,7 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
 // against node-XOR-leaf and while-while, profiles/r01_ab.md).  done() when node == HPT_TRAV_EMPTY.
 struct TravState {
     f3 invd;
-    bool nx, ny, nz, anyhit;
+    bool anyhit;
     int32_t node;
     int sp;
     Hit hit;
@@ -505,8 +503,8 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
         }
     }
     if (root < 0) ts.node = HPT_TRAV_EMPTY;
-    ts.invd = mk3(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
-    ts.nx = ts.invd.x < 0; ts.ny = ts.invd.y < 0; ts.nz = ts.invd.z < 0;
+    const float big = 3.402823466e+38f;                    // keeps 0 * invd finite (see slab)
+    ts.invd = mk3(fminf(fmaxf(1.f / ray.d.x, -big), big), fminf(fmaxf(1.f / ray.d.y, -big), big), fminf(fmaxf(1.f / ray.d.z, -big), big));
 }
 
 template <bool COUNT>
@@ -516,8 +514,8 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
         f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
         if (COUNT) cnt->nodes++;
         float t0, t1;
-        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, ts.nx, ts.ny, ts.nz, &t0);
-        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, ts.nx, ts.ny, ts.nz, &t1);
+        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
+        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
         int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
         if (h0 && h1) {
             bool swap = t1 < t0;
@@ -564,7 +562,7 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
     if (INST) for (int k = 0; k < sc.n_instances; ++k) {
         const hpt_instance &in = sc.instances[k];
         float tentry;
-        if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, ts.nx, ts.ny, ts.nz, &tentry)) continue;
+        if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, &tentry)) continue;
         Xf w2p = anim_interpolate(in, time, false);
         Ray r2;
         r2.o = xf_point(w2p.m.m, ray.o); r2.d = xf_vec(w2p.m.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
