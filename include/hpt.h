@@ -243,7 +243,7 @@ int hpt_render_device(hpt_scene *scene, const hpt_camera *cam, const hpt_render_
                       void *d_film_xyzw, void *stream, hpt_stats *stats);
 
 /* Pick the kernel configuration for this scene now (part of scene preparation, like the BVH build):
- * times each configuration on a probe render of the image centre.  Returns the configuration
+ * times each configuration on a probe render of a ninth of the image tiles.  Returns the configuration
  * (>= 0, also reported as hpt_stats.tune_cfg) or a negative HPT_E_*.  Optional: the first large
  * hpt_render* of an untuned scene does the same; HPT_TUNE=<cfg> in the environment pins it. */
 int hpt_scene_tune(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd);

@@ -244,7 +244,7 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
 // ---- kernel configuration: which (waves/SIMD, early-exit) build of the path kernel runs this scene ------------
 // Which one is fastest is a property of the scene (how deep its rays go, whether its BVH stays in L2, how heavy
 // its shading is: profiles/r01_ab.md), so the first large render of a scene times every configuration on a probe:
-// the centre of the image at <= 16 spp, in work items of 4 samples so that lanes regenerate like in the real job.
+// a ninth of the frame's tiles at <= 16 spp, in work items of 4 samples so that lanes regenerate like in the real job.
 // HPT_TUNE=<cfg> pins the choice.  Every configuration computes the same image (same code, different scheduling).
 static int tune_forced() {
     if (const char *e = getenv("HPT_TUNE")) { int c = atoi(e); if (c >= 0 && c < HPT_N_TUNE_CFG) return c; }
@@ -252,46 +252,55 @@ static int tune_forced() {
 }
 static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, PathKernelArgs a, void *d_scr, size_t scr_bytes,
                            hipStream_t stream) {
+    // the probe: every 9th 32x32 tile of the whole frame (the tile sharding of the multi-GPU path picks them), so
+    // that it sees the same mix of rays as the job — a crop of the image centre mispredicted killeroo-simple
     hpt_render_desc prd = *rd;
-    prd.x_count = rd->x_count < 640 ? rd->x_count : 640;
-    prd.y_count = rd->y_count < 360 ? rd->y_count : 360;
-    prd.x_start = rd->x_start + (rd->x_count - prd.x_count) / 2;
-    prd.y_start = rd->y_start + (rd->y_count - prd.y_count) / 2;
-    prd.spp = rd->spp < 16 ? rd->spp : 16;
-    prd.shard_rank = 0; prd.shard_count = 1; prd.count_work = 0;
-    if (fill_params(cam, &prd, &a.rp) != HPT_OK) return hipErrorInvalidValue;
-    a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
-    if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * (prd.spp / 4); }
+    int64_t tiles = (int64_t)((rd->x_count + 31) / 32) * ((rd->y_count + 31) / 32);
+    prd.shard_count = tiles >= 9 * 32 ? 9 : tiles >= 4 * 32 ? 4 : 1;
+    prd.shard_rank = prd.shard_count / 2; prd.count_work = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
-    float best = 0.f;
-    int best_cfg = 0;
     const bool inst = s->d.n_instances > 0;
-    for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
-        if (inst && cfg == 1) continue;                       // early exit is not compiled for instanced scenes
-        int bpc = 0, vg = 0;
-        if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
-        int grid = s->n_cus * bpc;
-        int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
-        if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
-        float t = 0.f;
-        for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) { // first launch also pays the code-object load
-            e = hipMemsetAsync(d_scr, 0, scr_bytes, stream);
-            if (e == hipSuccess) e = hipEventRecord(ev0, stream);
-            if (e == hipSuccess) e = launch_path_kernel(s->mats, a, grid, false, cfg, stream);
-            if (e == hipSuccess) e = hipEventRecord(ev1, stream);
-            if (e == hipSuccess) e = hipEventSynchronize(ev1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-            if (rep == 0 || ms < t) t = ms;
+    float t[HPT_N_TUNE_CFG];
+    bool in_race[HPT_N_TUNE_CFG];
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1); }  // early exit is not compiled for instanced scenes
+    int best_cfg = 0;
+    // round 0: every configuration at <= 16 spp; round 1: the ones within 10 % of the best again at <= 64 spp
+    for (int round = 0; round < 2 && e == hipSuccess; ++round) {
+        prd.spp = rd->spp < (round ? 64 : 16) ? rd->spp : (round ? 64 : 16);
+        if (round == 1 && prd.spp <= 16) break;
+        if (fill_params(cam, &prd, &a.rp) != HPT_OK) { e = hipErrorInvalidValue; break; }
+        a.rp.has_motion = inst ? 1 : 0;
+        if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * (prd.spp / 4); }
+        for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
+            if (!in_race[cfg]) continue;
+            int bpc = 0, vg = 0;
+            if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
+            int grid = s->n_cus * bpc;
+            int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
+            if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+            for (int rep = 0; rep < 2 - round && e == hipSuccess; ++rep) { // a configuration's first launch also pays its code-object load
+                e = hipMemsetAsync(d_scr, 0, scr_bytes, stream);
+                if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+                if (e == hipSuccess) e = launch_path_kernel(s->mats, a, grid, false, cfg, stream);
+                if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+                if (e == hipSuccess) e = hipEventSynchronize(ev1);
+                float ms = 0.f;
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+                if (rep == 0 || ms < t[cfg]) t[cfg] = ms;
+            }
+            if (getenv("HPT_TUNE_VERBOSE")) fprintf(stderr, "hpt autotune: round %d cfg %d  %.3f ms\n", round, cfg, t[cfg]);
         }
-        if (getenv("HPT_TUNE_VERBOSE")) fprintf(stderr, "hpt autotune: cfg %d  %.3f ms\n", cfg, t);
-        if (cfg == 0 || t < best) { best = t; best_cfg = cfg; }
+        best_cfg = -1;
+        for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) if (in_race[cfg] && (best_cfg < 0 || t[cfg] < t[best_cfg])) best_cfg = cfg;
+        int left = 0;
+        for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { in_race[cfg] = in_race[cfg] && t[cfg] <= 1.10f * t[best_cfg]; left += in_race[cfg]; }
+        if (left < 2) break;
     }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (e == hipSuccess) s->tune_cfg = best_cfg;
+    if (e == hipSuccess) s->tune_cfg = best_cfg < 0 ? 0 : best_cfg;
     return e;
 }
 
@@ -424,7 +433,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     struct Scratch { unsigned long long next_item; WorkCounters wc; };
     DevBuf<Scratch> scr;
     DevBuf<float> filmbuf;
-    if (!scr.alloc(1) || !filmbuf.alloc((size_t)4 * 640 * 360)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
+    if (!scr.alloc(1) || !filmbuf.alloc((size_t)4 * rd->x_count * rd->y_count)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
     a.next_item = &scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p;
     hipError_t e = autotune(s, cam, rd, a, scr.p, sizeof(Scratch), nullptr);
     if (e != hipSuccess) { hpt_set_error("autotune failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }

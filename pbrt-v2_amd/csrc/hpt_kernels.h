@@ -35,7 +35,8 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
-#define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step} — hpt_kernels_impl.h */
+#define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
+                              — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);

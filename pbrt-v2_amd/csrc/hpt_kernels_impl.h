@@ -99,36 +99,15 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
+        // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for -------------
+        bool mine = active;
         if (PHASED) {
-            // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for ---------
             while (__ballot(lane.stage == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
-#ifdef HPT_TIMING   /* debug build: where do the waves spend their cycles?  (counters reused, see profiles/r01_ab.md) */
-            long long t0 = clock64();
-#endif
-            if (lane.stage == phase) {
-                bool anyhit = phase == ST_SHADOW;
-#ifndef HPT_TIMING
-                if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-#endif
-                traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-            }
-#ifdef HPT_TIMING
-            long long t1 = clock64();
-#endif
-            if (lane.stage == phase) {
-                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
-            }
-#ifdef HPT_TIMING
-            long long t2 = clock64();
-            if (COUNT && lane_id() == 0) {
-                if (phase == ST_EXTEND) { wc.closest += (unsigned long long)(t1 - t0); wc.bad += (unsigned long long)(t2 - t1); }
-                else { wc.shadow += (unsigned long long)(t1 - t0); wc.samples += (unsigned long long)(t2 - t1); }
-            }
-#endif
-            phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
-        } else if (INST || EE == 0) {
+            mine = lane.stage == phase;
+        }
+        if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
-            if (active) {
+            if (mine) {
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
                 traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
@@ -137,12 +116,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         } else {
             // ---- traversal phase with early exit --------------------------------------------------------
             // Ray lengths inside a wave differ by an order of magnitude; waiting for the longest ray leaves
-            // most lanes idle (measured SIMD utilisation of the walk ~12 %).  So the walk is resumable: once
-            // fewer than EE lanes are still walking and at least one lane has finished, the wave
-            // leaves the loop, the finished lanes shade and start their next ray, and the unfinished lanes
-            // simply continue in the next round (their node / stack pointer stay in registers, their stack in
-            // their LDS column).
-            if (active && !tracing) {
+            // most lanes idle.  So the walk is resumable: once fewer than EE lanes are still walking and at
+            // least one lane has finished, the wave leaves the loop, the finished lanes shade and start their
+            // next ray, and the unfinished lanes simply continue in the next round (their node / stack pointer
+            // stay in registers, their stack in their LDS column).  In lock step a straggler keeps walking
+            // during the other phases and shades when its own phase comes round again.
+            if (mine && !tracing) {
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
                 trav_begin(sc, ts, lane.ray, anyhit, sc.world_root, true);
@@ -155,17 +134,16 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 if (EE > 0 && __popcll(bm) < EE && __ballot(tracing && !busy) != 0ull) break;
                 if (busy) trav_step<COUNT>(sc, ts, lane.ray, stack, HPT_BLOCK, &tc);
             }
-            if (tracing && ts.done()) {
+            if (tracing && ts.done() && mine) {
                 tracing = false;
                 hit = ts.hit;
                 lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
             }
         }
+        if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
     }
     if (COUNT) {
-#ifndef HPT_TIMING
         wc.nodes = tc.nodes; wc.tris = tc.tris;
-#endif
         atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);
         atomicAdd((unsigned long long *)&a.counters->closest, (unsigned long long)wc.closest);
         atomicAdd((unsigned long long *)&a.counters->shadow, (unsigned long long)wc.shadow);
@@ -181,11 +159,6 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? 3 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
-#ifdef HPT_TIMING
-#define HPT_COUNT_PHASED true
-#else
-#define HPT_COUNT_PHASED false
-#endif
 #define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C)>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
@@ -200,8 +173,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
         const bool inst = a.sc.n_instances > 0;                                                                     \
         if (count) {                                                                                                \
-            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, HPT_COUNT_PHASED>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
-            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, HPT_COUNT_PHASED>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
+            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
+            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \

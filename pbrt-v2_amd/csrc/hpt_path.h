@@ -199,9 +199,6 @@ template <class Smp, bool INST, int MATS> struct Lane {
             finish_path(rp, film, wc);
             return;
         }
-#ifdef HPT_TIMING
-        long long tt0 = clock64();
-#endif
         Bsdf bsdf; DGeom dg; int arealight;
         shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
@@ -247,9 +244,6 @@ template <class Smp, bool INST, int MATS> struct Lane {
                     }
                 }
             }
-#ifdef HPT_TIMING
-            if (wc && (__lane_id() == (unsigned)(__ffsll((long long)__ballot(true)) - 1))) wc->nodes += (unsigned long long)(clock64() - tt0);
-#endif
             // BSDF-sampling half (integrator.cpp:145-172)
             if (!isDelta) {
                 int sampledType;
@@ -295,9 +289,6 @@ template <class Smp, bool INST, int MATS> struct Lane {
                 if (bounce == rp.maxdepth) has_next = false;
             }
         }
-#ifdef HPT_TIMING
-        if (wc && (__lane_id() == (unsigned)(__ffsll((long long)__ballot(true)) - 1))) wc->tris += (unsigned long long)(clock64() - tt0);
-#endif
         if (has_shadow) stage = ST_SHADOW;
         else after_shadow(sc, rp, film, wc);
     }
