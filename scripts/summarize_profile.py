@@ -61,6 +61,12 @@ if "SQ_WAVE_CYCLES" in pmc:
         derived["waves_launched"] = pmc["SQ_WAVES"]
 if "SQ_INSTS_VALU" in pmc:
     derived["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
+if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
+    # rocprof's VALUUtilization: share of the 64 lanes that are active in an average VALU instruction
+    derived["valu_lane_utilisation"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for >= 4 cycles
+    derived["valu_pipe_busy_lower_bound"] = pmc["SQ_INSTS_VALU"] * 4.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 
 doc = {"source": os.path.basename(src.rstrip("/")), "kernel": KERNEL, "dispatch": meta, "pmc_per_launch": pmc,
        "derived": derived, "kernel_stats_csv": stats_rows[:4]}
