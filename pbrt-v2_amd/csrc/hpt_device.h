@@ -693,6 +693,7 @@ struct IrregProc { f3 v; float sumWeights; f3 v2; float sumWeights2; float r2; f
 #endif
 struct LaneStack {
     HPT_LDS int32_t *p; int stride;
+    int qrow = 0;         // first stack row of the wave's query queue (path kernel only)
     const HPT_LDS uint64_t *kd_top = nullptr; const hpt_material *kd_top_mat = nullptr;
 };
 #define HPT_KD_GRID 16
@@ -779,7 +780,8 @@ HPT_FN f3 irreg_query(const DScene &sc, const hpt_material *m, f3 mpt, int level
         r *= 2.f; ++level;
     }
 }
-HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
+// The query point of IrregIsotropicBRDF::f (reflection.cpp:248-260, BRDFRemap)
+HPT_FN f3 irreg_point(f3 wo, f3 wi) {
     float cosi = wi.z, coso = wo.z;
     float sini = sin_theta(wi), sino = sin_theta(wo);
     float phii = spherical_phi(wi), phio = spherical_phi(wo);
@@ -787,7 +789,11 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     if (dphi < 0.f) dphi += 2.f * HPT_PI;
     if (dphi > 2.f * HPT_PI) dphi -= 2.f * HPT_PI;
     if (dphi > HPT_PI) dphi = 2.f * HPT_PI - dphi;
-    f3 mpt = mk3(sini * sino, dphi / HPT_PI, cosi * coso);
+    return mk3(sini * sino, dphi / HPT_PI, cosi * coso);
+}
+// ... and the weighted average of the samples around it (reflection.cpp:261-271).  Out of line: called from the
+// wave-cooperative evaluator of the path kernel (hpt_kernels_impl.h) and from irreg_f.
+HPT_FN_NOINLINE f3 irreg_eval(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack ls) {
     // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
     int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
     gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
@@ -797,6 +803,9 @@ HPT_FN_NOINLINE f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi
     int level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
     if (m == ls.kd_top_mat) return irreg_query<1>(sc, m, mpt, level, ls);
     return irreg_query<0>(sc, m, mpt, level, ls);
+}
+HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
+    return irreg_eval(sc, m, irreg_point(wo, wi), ls);
 }
 
 // FrCond (reflection.cpp:70-79) through FresnelConductor::Evaluate (:110-112), per RGB channel
@@ -984,35 +993,59 @@ HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) { ++matching; pdf += bxdf_pdf<MATS>(b, i, wo, wi); }
     return matching > 0 ? pdf / matching : 0.f;
 }
-// BSDF::Sample_f (reflection.cpp:522-580)
+// BSDF::Sample_f (reflection.cpp:522-580) in its two halves.  Direction half: lobe choice, sampled direction,
+// pdf averaged over the matching lobes, sampled type; false = the reference returns black here.
 template <int MATS>
-HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
-                        int flags, int *sampledType, LaneStack ls) {
+HPT_FN bool bsdf_sample_dir(const Bsdf &b, f3 woW, f3 *wo_l, f3 *wi_l, f3 *wiW, float u1, float u2, float uComp, float *pdf,
+                            int flags, int *sampledType) {
     int matching = 0;
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) ++matching;
-    if (matching == 0) { *pdf = 0.f; *sampledType = 0; return S(0.f); }
+    if (matching == 0) { *pdf = 0.f; *sampledType = 0; return false; }
     int which = (int)floorf(uComp * matching);
     if (which > matching - 1) which = matching - 1;
     int sel = -1, count = which;
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
     f3 wo = b.w2l(woW), wi = S(0.f);
     *pdf = 0.f;
-    f3 f = S(0.f);
     bxdf_sample_dir<MATS>(b, sel, wo, &wi, u1, u2, pdf);
-    if (*pdf == 0.f) { *sampledType = 0; return S(0.f); }
+    if (*pdf == 0.f) { *sampledType = 0; return false; }
     int stype = b.type(sel);
     *sampledType = stype;
     *wiW = b.l2w(wi);
     if (!(stype & BSDF_SPECULAR) && matching > 1)
         for (int i = 0; i < b.n; ++i) if (i != sel && bx_match(b, i, flags)) *pdf += bxdf_pdf<MATS>(b, i, wo, wi);
     if (matching > 1) *pdf /= matching;
-    if (!(stype & BSDF_SPECULAR)) {
-        f = S(0.f);
-        if (dot(*wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
-        else flags &= ~BSDF_REFLECTION;
-        for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f<MATS>(sc, b, i, wo, wi, ls);
-    }
+    *wo_l = wo; *wi_l = wi;
+    return true;
+}
+// Value half: f over all lobes matching the reflect / transmit side, with the LOCAL vectors of the direction half
+// (no lobe on this path is specular, so this is the value BSDF::Sample_f returns: reflection.cpp:555-566)
+template <int MATS>
+HPT_FN f3 bsdf_f_local(const DScene &sc, const Bsdf &b, f3 wo, f3 wi, f3 woW, f3 wiW, int flags, LaneStack ls) {
+    if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
+    else flags &= ~BSDF_REFLECTION;
+    f3 f = S(0.f);
+    for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) f = f + bxdf_f<MATS>(sc, b, i, wo, wi, ls);
     return f;
+}
+template <int MATS>
+HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
+                        int flags, int *sampledType, LaneStack ls) {
+    f3 wo, wi;
+    if (!bsdf_sample_dir<MATS>(b, woW, &wo, &wi, wiW, u1, u2, uComp, pdf, flags, sampledType)) return S(0.f);
+    return bsdf_f_local<MATS>(sc, b, wo, wi, woW, *wiW, flags, ls);
+}
+// A BSDF made of the measured lobe alone (materials/measured.cpp:121-131): its f() is a kd-tree query, which the
+// path kernel defers and evaluates wave-cooperatively.  bsdf_query_point: the query point if the lobe contributes
+// for this pair of directions (same side of the geometric normal, lobe type within flags), else f is black.
+template <int MATS>
+HPT_FN bool bsdf_is_measured(const Bsdf &b) { return (MATS & MATS_MEASURED) && b.n == 1 && b.kind(0) == BX_IRREG; }
+HPT_FN bool bsdf_query_point(const Bsdf &b, f3 wo, f3 wi, f3 woW, f3 wiW, int flags, f3 *q) {
+    if (dot(wiW, b.ng) * dot(woW, b.ng) > 0) flags &= ~BSDF_TRANSMISSION;
+    else flags &= ~BSDF_REFLECTION;
+    if (!bx_match(b, 0, flags)) return false;
+    *q = irreg_point(wo, wi);
+    return true;
 }
 
 // Hit -> DifferentialGeometry -> shading geometry -> BSDF:

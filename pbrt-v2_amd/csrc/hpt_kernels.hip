@@ -53,7 +53,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
             if (anyhit) wc.shadow++; else wc.closest++;
             traverse<true, true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
             LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
-            lane.on_hit(sc, rp, hit, a.film, &wc, ls);
+            lane.on_hit_serial(sc, rp, hit, a.film, &wc, ls);
         }
     }
     wc.nodes = tc.nodes; wc.tris = tc.tris;

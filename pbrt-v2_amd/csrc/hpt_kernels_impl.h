@@ -41,6 +41,46 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
     return need ? (int64_t)(base + (unsigned long long)rank) : -1;
 }
 
+// The measured-BRDF values a wave's lanes still owe their path vertices (ShadeV::has[], up to three kd-tree
+// queries per lane) — evaluated by ALL 64 lanes.  After the first bounce only a fraction of a wave's lanes sits
+// on the measured material, each with 2-3 queries; walking the kd-tree lane-by-owner ran that loop at 9 % VALU
+// lane utilisation.  Here the owners append their queries to a wave-wide queue (ballot prefix sums; entry i lives
+// in column i % 64, rows qrow + 4 * (i / 64) .. + 3 of the wave's own LDS stack columns, above the rows the kd walk
+// uses), every lane evaluates entry lane, lane + 64, lane + 128, and the owners read the values back.  Within a
+// wave LDS operations execute in program order, so no barrier is needed — only a compiler fence.
+__device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls, ShadeV &sv, bool shaded) {
+    const bool h0 = shaded && sv.has[0], h1 = shaded && sv.has[1], h2 = shaded && sv.has[2];
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2);
+    const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), total = n0 + n1 + n2;
+    if (total == 0) return;
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int o0 = __popcll(m0 & lt), o1 = n0 + __popcll(m1 & lt), o2 = n0 + n1 + __popcll(m2 & lt);
+    HPT_LDS int32_t *col0 = ls.p - lane;
+    #define HPT_QSLOT(idx, j) col0[((idx) & 63) + (ls.qrow + 4 * ((idx) >> 6) + (j)) * ls.stride]
+    if (h0) { HPT_QSLOT(o0, 0) = as_int(sv.fq[0].x); HPT_QSLOT(o0, 1) = as_int(sv.fq[0].y); HPT_QSLOT(o0, 2) = as_int(sv.fq[0].z); HPT_QSLOT(o0, 3) = sv.mat; }
+    if (h1) { HPT_QSLOT(o1, 0) = as_int(sv.fq[1].x); HPT_QSLOT(o1, 1) = as_int(sv.fq[1].y); HPT_QSLOT(o1, 2) = as_int(sv.fq[1].z); HPT_QSLOT(o1, 3) = sv.mat; }
+    if (h2) { HPT_QSLOT(o2, 0) = as_int(sv.fq[2].x); HPT_QSLOT(o2, 1) = as_int(sv.fq[2].y); HPT_QSLOT(o2, 2) = as_int(sv.fq[2].z); HPT_QSLOT(o2, 3) = sv.mat; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int base = 0; base < total; base += 64) {
+        const int idx = base + lane;
+        if (idx < total) {
+            f3 q = mk3(as_float(HPT_QSLOT(idx, 0)), as_float(HPT_QSLOT(idx, 1)), as_float(HPT_QSLOT(idx, 2)));
+            f3 f = irreg_eval(sc, &sc.materials[HPT_QSLOT(idx, 3)], q, ls);
+            HPT_QSLOT(idx, 0) = as_int(f.x); HPT_QSLOT(idx, 1) = as_int(f.y); HPT_QSLOT(idx, 2) = as_int(f.z);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (h0) sv.fq[0] = mk3(as_float(HPT_QSLOT(o0, 0)), as_float(HPT_QSLOT(o0, 1)), as_float(HPT_QSLOT(o0, 2)));
+    if (h1) sv.fq[1] = mk3(as_float(HPT_QSLOT(o1, 0)), as_float(HPT_QSLOT(o1, 1)), as_float(HPT_QSLOT(o1, 2)));
+    if (h2) sv.fq[2] = mk3(as_float(HPT_QSLOT(o2, 0)), as_float(HPT_QSLOT(o2, 1)), as_float(HPT_QSLOT(o2, 2)));
+    #undef HPT_QSLOT
+}
+
 // WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
 // scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
@@ -59,6 +99,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
     LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
+    ls.qrow = a.stack_entries - 12;            // query queue rows of wave_eval_queries (hpt_api.hip reserves them)
     if ((MATS & MATS_MEASURED) && a.kd_lds_mat >= 0) {
         // this workgroup's copy of the measured BRDF's kd-tree head: {splitPos, bits} of every node, so that the
         // walk only leaves LDS when it hands a sample to the accumulator (hpt_device.h: kd_lookup)
@@ -100,7 +141,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
         // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for -------------
-        bool mine = active;
+        bool mine = active, shaded = false;
+        ShadeV sv;
+        sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
             while (__ballot(lane.stage == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
             mine = lane.stage == phase;
@@ -111,7 +154,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
                 traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
-                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+                shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
         } else {
             // ---- traversal phase with early exit --------------------------------------------------------
@@ -137,9 +180,16 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (tracing && ts.done() && mine) {
                 tracing = false;
                 hit = ts.hit;
-                lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+                shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
         }
+        // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
+        if (MATS & MATS_MEASURED) {
+            if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
+            else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
+                for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k], ls);
+        }
+        if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
         if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
     }
     if (COUNT) {

@@ -67,6 +67,20 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
     return true;
 }
 
+// What shade_prepare leaves for shade_finish.  The three BSDF values of a vertex — f(wo, wi_light), f(wo, wi_mis),
+// f(wo, wi_next) — enter its estimators as plain factors.  Analytic BSDFs are evaluated and applied on the spot;
+// for a measured BRDF the value is a kd-tree query: has[k] marks it pending, fq[k] holds the query point (later the
+// value) and k1 .. pdf3 the scalar factors it is multiplied with (Li and the MIS radiance wait in Lane::Ld / C_mis).
+struct ShadeV {
+    bool has_shadow;
+    bool has[3];
+    f3 fq[3];
+    int mat;              // material index of the measured BRDF
+    float k1;             // |wi.n| * weight / lightPdf
+    float a2, w2, pdf2;   // |wi.n|, MIS weight, bsdfPdf
+    float a3, pdf3;       // |wi.n|, pdf of the continuation direction
+};
+
 // ---- lane -----------------------------------------------------------------------------------------
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
 // MATS: BxDF families compiled in (MATS_* bits, hpt_device.h).
@@ -168,12 +182,15 @@ template <class Smp, bool INST, int MATS> struct Lane {
         } else after_mis(sc, rp, film, wc);
     }
 
-    // Called with the result of the traversal phase for this lane's pending ray.
-    HPT_MFN void on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
+    // Called with the result of the traversal phase for this lane's pending ray.  Shadow / MIS results and
+    // misses are finished here (returns false).  An extension HIT is only prepared: the caller resolves the
+    // BSDF values that are still kd-tree queries (sv->has[], measured BRDF) — wave-cooperatively in the path
+    // kernel, serially elsewhere (on_hit_serial) — and then calls shade_finish().
+    HPT_MFN bool on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls, ShadeV *sv) {
         if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
             if (hit.prim >= 0) Ld = S(0.f);
             after_shadow(sc, rp, film, wc);
-            return;
+            return false;
         }
         if (stage == ST_MIS) {               // integrator.cpp:157-171
             bool sees = false;               // does the ray see light_mis with non-black radiance?
@@ -189,7 +206,7 @@ template <class Smp, bool INST, int MATS> struct Lane {
             } else sees = sc.lights[light_mis].kind == HPT_LIGHT_INFINITE; // light->Le(ray), integrator.cpp:166
             if (sees) Ld = Ld + C_mis;
             after_mis(sc, rp, film, wc);
-            return;
+            return false;
         }
         // ---- ST_EXTEND: closest-hit result of a camera or continuation ray -------------------------
         if (hit.prim < 0) {
@@ -197,8 +214,18 @@ template <class Smp, bool INST, int MATS> struct Lane {
             else if (specular)                                             // path.cpp:114-116
                 for (int i = 0; i < sc.n_lights; ++i) L = L + smul(beta, light_Le(sc, sc.lights[i], ray.d));
             finish_path(rp, film, wc);
-            return;
+            return false;
         }
+        shade_prepare(sc, rp, hit, ls, sv);
+        return true;
+    }
+
+    // Everything of a path vertex that does not need a BSDF VALUE: shading geometry, emission, light sampling,
+    // both BSDF direction samplings and all scalar factors.  The three values f(wo, wi_light), f(wo, wi_mis),
+    // f(wo, wi_next) enter the estimators as plain factors, so they are left in sv->fq[]: already evaluated for
+    // analytic BSDFs, as query points (sv->has[k]) for a measured BRDF.  Sample consumption order is the
+    // reference's (all array / rng draws of the vertex happen here, the Russian-roulette draw in shade_finish).
+    HPT_MFN void shade_prepare(const DScene &sc, const RenderParams &rp, const Hit &hit, LaneStack ls, ShadeV *sv) {
         Bsdf bsdf; DGeom dg; int arealight;
         shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
@@ -206,9 +233,11 @@ template <class Smp, bool INST, int MATS> struct Lane {
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
         p = dg.p;
         f3 n = bsdf.nn;
-        Ld = S(0.f);
-        bool has_shadow = false;
-        has_mis = false;
+        const bool defer = bsdf_is_measured<MATS>(bsdf);
+        sv->mat = defer ? (int)(bsdf.mat - sc.materials) : -1;
+        sv->has_shadow = false;
+        sv->has[0] = sv->has[1] = sv->has[2] = false;
+        Ld = S(0.f); has_mis = false; has_next = false;
         // the incoming ray is dead from here on (wo, p, eps are taken): its registers receive the
         // shadow ray directly
         Ray &shadow = ray;
@@ -229,26 +258,35 @@ template <class Smp, bool INST, int MATS> struct Lane {
             if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
             const hpt_light &light = sc.lights[lightNum];
             const bool isDelta = light.kind == HPT_LIGHT_POINT;
-            // EstimateDirect, light-sampling half (integrator.cpp:123-142)
+            // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
             f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow);
             if (lightPdf > 0.f && !sblack(Li)) {
-                f3 f = bsdf_f<MATS>(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
-                if (!sblack(f)) {
-                    has_shadow = true;
-                    if (isDelta) Ld = smul(f, Li) * (absdot(wi, n) / lightPdf);
-                    else {
-                        bsdfPdf = bsdf_pdf<MATS>(bsdf, wo, wi, BSDF_ALL_NOSPEC);
-                        float weight = power_heuristic(1, lightPdf, 1, bsdfPdf);
-                        Ld = smul(f, Li) * (absdot(wi, n) * weight / lightPdf);
+                if (defer) {
+                    sv->has[0] = bsdf_query_point(bsdf, bsdf.w2l(wo), bsdf.w2l(wi), wo, wi, BSDF_ALL_NOSPEC, &sv->fq[0]);
+                    if (sv->has[0]) {
+                        Ld = Li;                                            // parked until f is known
+                        if (isDelta) sv->k1 = absdot(wi, n) / lightPdf;
+                        else sv->k1 = absdot(wi, n) * power_heuristic(1, lightPdf, 1, bsdf_pdf<MATS>(bsdf, wo, wi, BSDF_ALL_NOSPEC)) / lightPdf;
+                    }
+                } else {
+                    f3 f = bsdf_f<MATS>(sc, bsdf, wo, wi, BSDF_ALL_NOSPEC, ls);
+                    if (!sblack(f)) {
+                        Ld = Li;
+                        if (isDelta) term_light(f, absdot(wi, n) / lightPdf, &sv->has_shadow);
+                        else {
+                            bsdfPdf = bsdf_pdf<MATS>(bsdf, wo, wi, BSDF_ALL_NOSPEC);
+                            float weight = power_heuristic(1, lightPdf, 1, bsdfPdf);
+                            term_light(f, absdot(wi, n) * weight / lightPdf, &sv->has_shadow);
+                        }
                     }
                 }
             }
-            // BSDF-sampling half (integrator.cpp:145-172)
+            // BSDF-sampling half (integrator.cpp:145-172): C = f * Li * |wi.n| * w / pdf, added when the MIS ray
+            // confirms that it reaches the light
             if (!isDelta) {
-                int sampledType;
-                f3 f = bsdf_sample_f<MATS>(sc, bsdf, wo, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType, ls);
-                if (!sblack(f) && bsdfPdf > 0.f) {
+                int sampledType; f3 wo_l, wi_l;
+                if (bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, bs0, bs1, bs2, &bsdfPdf, BSDF_ALL_NOSPEC, &sampledType) && bsdfPdf > 0.f) {
                     float weight = 1.f;
                     bool ok = true;
                     if (!(sampledType & BSDF_SPECULAR)) {
@@ -262,35 +300,71 @@ template <class Smp, bool INST, int MATS> struct Lane {
                         f3 Lic = light.kind == HPT_LIGHT_INFINITE ? light_Le(sc, light, wi)
                                                                   : mk3(light.intensity[0], light.intensity[1], light.intensity[2]);
                         if (!sblack(Lic)) {
-                            has_mis = true; light_mis = lightNum; wi_mis = wi;
-                            C_mis = sdivf((smul(f, Lic) * absdot(wi, n)) * weight, bsdfPdf); // integrator.cpp:169
+                            light_mis = lightNum; wi_mis = wi;
+                            C_mis = Lic;                                    // parked until f is known
+                            if (defer) {
+                                sv->has[1] = bsdf_query_point(bsdf, wo_l, wi_l, wo, wi, BSDF_ALL_NOSPEC, &sv->fq[1]);
+                                sv->a2 = absdot(wi, n); sv->w2 = weight; sv->pdf2 = bsdfPdf;
+                            } else term_mis(bsdf_f_local<MATS>(sc, bsdf, wo_l, wi_l, wo, wi, BSDF_ALL_NOSPEC, ls), absdot(wi, n), weight, bsdfPdf);
                         }
                     }
                 }
             }
         }
-        // continuation (path.cpp:83-110)
+        // continuation (path.cpp:83-110): beta' = beta * f * |wi.n| / pdf
         {
             float ps0, ps1, ps2;
             if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
             else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
-            f3 wi; float pdf; int flags;
-            f3 f = bsdf_sample_f<MATS>(sc, bsdf, wo, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, ls);
-            has_next = !(sblack(f) || pdf == 0.f);
-            if (has_next) {
-                spec_next = (flags & BSDF_SPECULAR) != 0;
-                beta_next = smul(beta, sdivf(f * absdot(wi, n), pdf));
+            f3 wi, wo_l, wi_l; float pdf; int flags;
+            if (bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags)) {
                 wi_next = wi;
-                if (bounce > 3) {
-                    float continueProbability = minf(.5f, sy(beta_next));
-                    if (smp.draw() > continueProbability) has_next = false;
-                    else beta_next = sdivf(beta_next, continueProbability);
-                }
-                if (bounce == rp.maxdepth) has_next = false;
+                spec_next = (flags & BSDF_SPECULAR) != 0;
+                if (defer) {
+                    sv->has[2] = bsdf_query_point(bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, &sv->fq[2]);
+                    sv->a3 = absdot(wi, n); sv->pdf3 = pdf;
+                } else term_next(bsdf_f_local<MATS>(sc, bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, ls), absdot(wi, n), pdf);
             }
         }
-        if (has_shadow) stage = ST_SHADOW;
+    }
+
+    // The three places a BSDF value enters the estimators (Ld / C_mis hold Li / the MIS radiance on entry)
+    HPT_MFN void term_light(f3 f, float k1, bool *has_shadow) {             // integrator.cpp:131-140
+        if (!sblack(f)) { *has_shadow = true; Ld = smul(f, Ld) * k1; }
+        else Ld = S(0.f);
+    }
+    HPT_MFN void term_mis(f3 f, float a2, float w2, float pdf2) {           // integrator.cpp:169
+        has_mis = !sblack(f);
+        if (has_mis) C_mis = sdivf((smul(f, C_mis) * a2) * w2, pdf2);
+    }
+    HPT_MFN void term_next(f3 f, float a3, float pdf3) {                    // path.cpp:95-97
+        has_next = !sblack(f);
+        if (has_next) beta_next = smul(beta, sdivf(f * a3, pdf3));
+    }
+
+    // The deferred terms of the vertex, now that sv.fq[] holds the measured-BRDF values; Russian roulette; transition.
+    HPT_MFN void shade_finish(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc, ShadeV &sv) {
+        if (sv.has[0]) term_light(sv.fq[0], sv.k1, &sv.has_shadow);
+        if (sv.has[1]) term_mis(sv.fq[1], sv.a2, sv.w2, sv.pdf2);
+        if (sv.has[2]) term_next(sv.fq[2], sv.a3, sv.pdf3);
+        if (has_next) {
+            if (bounce > 3) {
+                float continueProbability = minf(.5f, sy(beta_next));
+                if (smp.draw() > continueProbability) has_next = false;
+                else beta_next = sdivf(beta_next, continueProbability);
+            }
+            if (bounce == rp.maxdepth) has_next = false;
+        }
+        if (sv.has_shadow) stage = ST_SHADOW;
         else after_shadow(sc, rp, film, wc);
+    }
+
+    // on_hit with the pending measured-BRDF queries evaluated by this lane itself, one after the other
+    HPT_MFN void on_hit_serial(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
+        ShadeV sv;
+        if (!on_hit(sc, rp, hit, film, wc, ls, &sv)) return;
+        for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k], ls);
+        shade_finish(sc, rp, film, wc, sv);
     }
 };
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void wf_advance_kernel(const WfArgs a) {
         Hit hit; hit.t = h.x; hit.b1 = h.y; hit.b2 = h.z; hit.prim = f2i(h.w); hit.inst = INST ? a.hit_inst[slot] : -1;
         if (hit.prim >= 0 && lane.stage != ST_SHADOW) lane.ray.maxt = hit.t;   // the traversal shrinks the ray to the hit
         LaneStack ls; ls.p = (HPT_LDS int32_t *)(lds_stack + threadIdx.x); ls.stride = HPT_BLOCK;
-        lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
+        lane.on_hit_serial(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls);
     }
     for (;;) {   // regeneration: idle slots pull the next (pixel, sample chunk)
         bool need = (lane.stage == ST_IDLE) && !exhausted;

@@ -91,7 +91,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
                 traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
-                { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit(s->d, rp, hit, film, &wc, ls); }
+                { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit_serial(s->d, rp, hit, film, &wc, ls); }
             }
         }
 #pragma omp critical
@@ -128,7 +128,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
                 Hit hit;
                 traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 LaneStack ls; ls.p = stack; ls.stride = 1;
-                lane.on_hit(s->d, rp, hit, film, &wc, ls);
+                lane.on_hit_serial(s->d, rp, hit, film, &wc, ls);
             }
         }
     }
