@@ -6,12 +6,12 @@
 
 A step = one full frame: every camera sample of the 1920x1080 image traced through the whole
 SamplerRenderer/PathIntegrator path (camera ray .. film accumulation) by ONE persistent HIP
-kernel launch per GPU, plus — for N > 1 — the one film-tile gather to rank 0 over RCCL.
+kernel launch per GPU (kernel configuration picked per scene by hpt_scene_tune during set-up), plus — for N > 1 — the one film-tile gather to rank 0 over RCCL.
 Scene, BVH and film are resident in HBM before the timed region; `value` is whole-job
 samples / max-over-ranks wall time.
 
 Workloads (all 1920x1080, path maxdepth 8, lowdiscrepancy-structured sampler, box filter):
-  bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 453 prims, measured BRDF), 64 spp/GPU
+  bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 454 prims, measured BRDF), 64 spp/GPU  [default]
   killeroo north-star target scene: scenes/killeroo-simple.pbrt (66 533 prims), 64 spp/GPU
   anim     BASELINE.json configs[3] scene: scenes/anim-killeroos-moving.pbrt (2 animated instances), 64 spp/GPU
   soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 16 spp/GPU here
@@ -38,7 +38,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # algorithmic traversal bytes per camera sample of the REFERENCE algorithm
 # (32 B x BVH nodes visited + 48 B x triangles tested, measured on the instrumented reference)
-ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0}
+# soup: no reference count (its parser input is 1M triangles of synthetic text); the device's own algorithmic bytes,
+# 64 B x 265.2 BVH2 nodes + 48 B x 18.5 triangles per camera sample (bench.py --workload soup --count-work)
+ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0, "soup": 17859.0}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 

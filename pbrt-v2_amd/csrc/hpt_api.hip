@@ -331,7 +331,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
         cfg = s->tune_cfg;
     }
-    if (cfg < 0) cfg = 0;
+    if (cfg < 0) cfg = 3;                                // untuned (small job): lock step, the usual winner
     if (rd->count_work) cfg = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);

@@ -202,8 +202,8 @@ def test_autotune_probes_once_per_scene(monkeypatch):
     d = hpt.DeviceScene(s)
     small = abi.copy_struct(s.render)
     small.spp = 4
-    _, st0 = d.render(s.camera, small)                  # too small to tune: configuration 0
-    assert st0.tune_cfg == 0
+    _, st0 = d.render(s.camera, small)                  # too small to tune: the default configuration (lock step)
+    assert st0.tune_cfg == 3
     f1, st1 = d.render(s.camera, s.render)              # tunes
     f2, st2 = d.render(s.camera, s.render)
     assert 0 <= st1.tune_cfg < 5 and st2.tune_cfg == st1.tune_cfg
