@@ -142,7 +142,8 @@ typedef struct hpt_light {
     int32_t env_w, env_h;
     int64_t tex_off, cond_func_off, cond_cdf_off, cond_int_off, marg_func_off, marg_cdf_off;
     float marg_int;
-    int32_t pad;
+    int32_t nsamples;  /* Light::nSamples (core/light.h:60): light samples per camera sample of the
+                        * direct-lighting integrator, strategy "all"; 0 reads as 1; ignored by the path integrator */
     float l2w[16];     /* LightToWorld->m    */
     float l2w_inv[16]; /* LightToWorld->mInv */
 } hpt_light;
@@ -184,6 +185,13 @@ enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1 };
  *                            compacted into a dense queue between the two (ballot + popcount). */
 enum { HPT_PIPELINE_PERSISTENT = 0, HPT_PIPELINE_WAVEFRONT = 1 };
 
+/* Surface integrator.  PATH: PathIntegrator::Li (integrators/path.cpp:52-123).
+ * DIRECT_ALL / DIRECT_ONE: DirectLightingIntegrator::Li (integrators/directlighting.cpp:80-121) with strategy
+ * "all" (UniformSampleAllLights, every light with its own nsamples, core/integrator.cpp:47-79) or "one"
+ * (UniformSampleOneLight, :82-114).  No material on this path has a specular lobe, so SpecularReflect /
+ * SpecularTransmit (directlighting.cpp:111-118) contribute nothing and maxdepth is not used. */
+enum { HPT_INTEGRATOR_PATH = 0, HPT_INTEGRATOR_DIRECT_ALL = 1, HPT_INTEGRATOR_DIRECT_ONE = 2 };
+
 typedef struct hpt_render_desc {
     int32_t xres, yres;               /* Film::xResolution, yResolution                  */
     int32_t x_start, x_count;         /* ImageFilm::xPixelStart/xPixelCount (crop window) */
@@ -196,7 +204,7 @@ typedef struct hpt_render_desc {
     int32_t shard_rank, shard_count;  /* pixel-tile shard of this device (0,1 = all)      */
     int32_t count_work;               /* 1: fill the traversal counters of hpt_stats      */
     int32_t pipeline;                 /* HPT_PIPELINE_*                                   */
-    int32_t pad;
+    int32_t integrator;               /* HPT_INTEGRATOR_*                                 */
 } hpt_render_desc;
 
 typedef struct hpt_stats {

@@ -380,6 +380,99 @@ static inline float draw_float(draw_src *d) {
     return (h & 0xffffff) / (float)(1 << 24);
 }
 
+/* ---- DirectLightingIntegrator sample layout (integrators/directlighting.cpp:54-77) --------------------
+ * Strategy "all": per light i, LightSampleOffsets(n_i) then BSDFSampleOffsets(n_i), n_i = LDSampler::RoundSize
+ * (RoundUpPow2) of Light::nSamples — each adds a 1D component array and a 2D array (core/light.cpp:64-68,
+ * core/reflection.cpp:502-506).  Strategy "one": light (1), light number (1), bsdf (1).  Then
+ * EmissionIntegrator::RequestSamples' two 1D arrays (integrators/emission.cpp:41-42), which the MT stream pays for.
+ * A pixel sample is a vector of `fps` floats: 1D array j element k at o1[j] + k, 2D array j at o2[j] + 2k. */
+typedef struct { int integrator, nl, n1d, n2d, fps; int *ns, *c1, *c2, *o1, *o2; } dl_layout;
+static uint32_t round_up_pow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; } /* pbrt.h:264-271 */
+static void dl_layout_init(const hpt_scene_desc *d, int integrator, dl_layout *L) {
+    L->integrator = integrator; L->nl = d->n_lights;
+    int all = integrator == HPT_INTEGRATOR_DIRECT_ALL;
+    int groups = all ? d->n_lights : 1;
+    L->n1d = (all ? 2 * groups : 3) + 2; L->n2d = 2 * groups;
+    L->ns = (int *)calloc((size_t)groups + 1, sizeof(int));
+    L->c1 = (int *)calloc((size_t)L->n1d + 1, sizeof(int)); L->o1 = (int *)calloc((size_t)L->n1d + 1, sizeof(int));
+    L->c2 = (int *)calloc((size_t)L->n2d + 1, sizeof(int)); L->o2 = (int *)calloc((size_t)L->n2d + 1, sizeof(int));
+    int k1 = 0, k2 = 0;
+    for (int i = 0; i < groups; ++i) {
+        int n = 1;
+        if (all) { int ns = d->lights[i].nsamples; if (ns < 1) ns = 1; n = (int)round_up_pow2((uint32_t)ns); } /* Light ctor: max(1, ns) */
+        L->ns[i] = n;
+        L->c1[k1++] = n; L->c2[k2++] = n;          /* light component, light position */
+        if (!all) L->c1[k1++] = 1;                /* light number */
+        L->c1[k1++] = n; L->c2[k2++] = n;          /* bsdf component, bsdf direction */
+    }
+    L->c1[k1++] = 1; L->c1[k1++] = 1;              /* emission integrator */
+    int off = 0;
+    for (int j = 0; j < L->n1d; ++j) { L->o1[j] = off; off += L->c1[j]; }
+    for (int j = 0; j < L->n2d; ++j) { L->o2[j] = off; off += 2 * L->c2[j]; }
+    L->fps = off;
+}
+static void dl_layout_free(dl_layout *L) { free(L->ns); free(L->c1); free(L->c2); free(L->o1); free(L->o2); }
+/* floats LDPixelSample needs for one pixel (LDSampler ctor, samplers/lowdiscrepancy.cpp:52-58) */
+static size_t dl_buf_floats(const dl_layout *L, int spp) { return (size_t)spp * (size_t)(5 + L->fps); }
+
+/* LDPixelSample (core/montecarlo.cpp:200-252) for an arbitrary array layout; vals: spp x fps */
+static void ld_pixel_sample_mt_dl(const dl_layout *L, int xPos, int yPos, float shutterOpen, float shutterClose,
+                                  int n, cam_sample *cams, float *vals, float *buf, mt_rng *rng) {
+    float *imageSamples = buf; buf += 2 * n;
+    float *lensSamples = buf; buf += 2 * n;
+    float *timeSamples = buf; buf += n;
+    float *arrays = buf;
+    ld_shuffle_scrambled_2d(1, n, imageSamples, rng);
+    ld_shuffle_scrambled_2d(1, n, lensSamples, rng);
+    ld_shuffle_scrambled_1d(1, n, timeSamples, rng);
+    float *b = arrays;
+    for (int j = 0; j < L->n1d; ++j) { ld_shuffle_scrambled_1d(L->c1[j], n, b, rng); b += L->c1[j] * n; }
+    for (int j = 0; j < L->n2d; ++j) { ld_shuffle_scrambled_2d(L->c2[j], n, b, rng); b += 2 * L->c2[j] * n; }
+    for (int i = 0; i < n; ++i) {
+        cams[i].imageX = xPos + imageSamples[2 * i];
+        cams[i].imageY = yPos + imageSamples[2 * i + 1];
+        cams[i].time = (1.f - timeSamples[i]) * shutterOpen + timeSamples[i] * shutterClose;
+        cams[i].lensU = lensSamples[2 * i];
+        cams[i].lensV = lensSamples[2 * i + 1];
+        float *v = vals + (size_t)i * L->fps;
+        b = arrays;
+        for (int j = 0; j < L->n1d; ++j) { for (int k = 0; k < L->c1[j]; ++k) v[L->o1[j] + k] = b[L->c1[j] * i + k]; b += L->c1[j] * n; }
+        for (int j = 0; j < L->n2d; ++j) { for (int k = 0; k < 2 * L->c2[j]; ++k) v[L->o2[j] + k] = b[2 * L->c2[j] * i + k]; b += 2 * L->c2[j] * n; }
+    }
+}
+/* HPT_SAMPLER_LD_HASH for the same layout.  An array of count c is, as in LDShuffleScrambled*D, one scrambled
+ * (0,2)-sequence of spp * c points cut into spp blocks of c: pixel sample i owns block PERM_a(i) and visits its c
+ * points in a keyed order that differs per pixel sample.  Array ids: 1D array j -> 3 + j, 2D array j -> 3 + n1d + j;
+ * scramble words: 1D j -> 5 + j, 2D j -> 5 + n1d + 2j, +1. */
+static void ld_hash_sample_dl(const dl_layout *L, uint32_t pixelIndex, uint32_t seed, int xPos, int yPos, float shutterOpen,
+                              float shutterClose, uint32_t spp, uint32_t i, cam_sample *s, float *v) {
+    uint32_t pk = hash3(pixelIndex, seed, 0x50495845u);
+    uint32_t w = spp - 1;
+#define SCR(k) hash3(pk, (uint32_t)(k), 1u)
+#define PERM(a) perm_pow2(i, w, hash3(pk, (uint32_t)(a), 2u))
+#define WITHIN(a, k, c) perm_pow2((uint32_t)(k), (uint32_t)(c) - 1u, hash3(hash3(pk, (uint32_t)(a), 4u), i, 5u))
+    uint32_t n;
+    n = PERM(0); s->imageX = xPos + van_der_corput(n, SCR(0)); s->imageY = yPos + sobol2(n, SCR(1));
+    n = PERM(1); s->lensU = van_der_corput(n, SCR(2)); s->lensV = sobol2(n, SCR(3));
+    n = PERM(2); { float t = van_der_corput(n, SCR(4)); s->time = (1.f - t) * shutterOpen + t * shutterClose; }
+    for (int j = 0; j < L->n1d - 2; ++j) {                 /* the emission integrator's arrays are not generated */
+        uint32_t c = (uint32_t)L->c1[j], blk = PERM(3 + j);
+        for (uint32_t k = 0; k < c; ++k) v[L->o1[j] + (int)k] = van_der_corput(blk * c + WITHIN(3 + j, k, c), SCR(5 + j));
+    }
+    v[L->o1[L->n1d - 2]] = v[L->o1[L->n1d - 1]] = 0.f;
+    for (int j = 0; j < L->n2d; ++j) {
+        uint32_t c = (uint32_t)L->c2[j], blk = PERM(3 + L->n1d + j);
+        for (uint32_t k = 0; k < c; ++k) {
+            uint32_t q = blk * c + WITHIN(3 + L->n1d + j, k, c);
+            v[L->o2[j] + 2 * (int)k] = van_der_corput(q, SCR(5 + L->n1d + 2 * j));
+            v[L->o2[j] + 2 * (int)k + 1] = sobol2(q, SCR(6 + L->n1d + 2 * j));
+        }
+    }
+#undef SCR
+#undef PERM
+#undef WITHIN
+}
+
 /* ---- scene ------------------------------------------------------------------------------ */
 typedef struct { v3 pmin, pmax; } bbox;
 static inline bbox bbox_empty(void) { bbox b; b.pmin = V(INFINITY, INFINITY, INFINITY); b.pmax = V(-INFINITY, -INFINITY, -INFINITY); return b; }
@@ -1511,6 +1604,53 @@ static rgb path_Li(const orc_scene *s, ray_t ray, const cam_sample *sample, int 
     return L;
 }
 
+/* DirectLightingIntegrator::Li (integrators/directlighting.cpp:80-121) on top of SamplerRenderer::Li
+ * (renderers/samplerrenderer.cpp:320-342).  SpecularReflect / SpecularTransmit (:111-118) sample BSDF_SPECULAR
+ * lobes only (core/integrator.cpp:177-258); no material of this path has one, so both return black — but each
+ * constructs a BSDFSample(rng) first (core/reflection.h:135-139): three RandomFloat() draws apiece from the tile's
+ * generator whenever ray.depth + 1 < maxDepth, which the MT_REPLAY stream has to pay for. */
+static rgb direct_Li(const orc_scene *s, ray_t ray, const dl_layout *Lt, const float *v, int maxDepth, draw_src *rng, uint64_t *st) {
+    isect_t isect;
+    rgb L = S(0.f);
+    int nLights = s->d.n_lights;
+    if (!scene_intersect(s, &ray, &isect, 0, st)) {
+        for (int i = 0; i < nLights; ++i) L = sadd(L, light_Le(s, &s->d.lights[i], ray.d));
+        return L;
+    }
+    bsdf_t bsdf;
+    get_bsdf(s, &isect, &bsdf);
+    v3 wo = vneg(ray.d);
+    v3 p = bsdf.p, n = bsdf.nn;
+    L = sadd(L, isect_Le(s, &isect, wo));
+    if (nLights > 0) {
+        if (Lt->integrator == HPT_INTEGRATOR_DIRECT_ALL) {        /* UniformSampleAllLights core/integrator.cpp:47-79 */
+            rgb La = S(0.f);
+            for (int i = 0; i < nLights; ++i) {
+                int nSamples = Lt->ns[i];
+                rgb Ld = S(0.f);
+                for (int j = 0; j < nSamples; ++j) {
+                    float ls[3], bs[3];
+                    ls[0] = v[Lt->o2[2 * i] + 2 * j]; ls[1] = v[Lt->o2[2 * i] + 2 * j + 1]; ls[2] = v[Lt->o1[2 * i] + j];
+                    bs[0] = v[Lt->o2[2 * i + 1] + 2 * j]; bs[1] = v[Lt->o2[2 * i + 1] + 2 * j + 1]; bs[2] = v[Lt->o1[2 * i + 1] + j];
+                    Ld = sadd(Ld, estimate_direct(s, i, p, n, wo, isect.rayEpsilon, ray.time, &bsdf, ls, bs, st));
+                }
+                La = sadd(La, sdivf(Ld, (float)nSamples));
+            }
+            L = sadd(L, La);
+        } else {                                                   /* UniformSampleOneLight :82-114 */
+            int lightNum = (int)floorf(v[Lt->o1[1]] * nLights);
+            if (lightNum > nLights - 1) lightNum = nLights - 1;
+            float ls[3], bs[3];
+            ls[0] = v[Lt->o2[0]]; ls[1] = v[Lt->o2[0] + 1]; ls[2] = v[Lt->o1[0]];
+            bs[0] = v[Lt->o2[1]]; bs[1] = v[Lt->o2[1] + 1]; bs[2] = v[Lt->o1[2]];
+            rgb Ld = estimate_direct(s, lightNum, p, n, wo, isect.rayEpsilon, ray.time, &bsdf, ls, bs, st);
+            L = sadd(L, sscale(Ld, (float)nLights));
+        }
+    }
+    if (ray.depth + 1 < maxDepth) for (int k = 0; k < 6; ++k) (void)draw_float(rng);
+    return L;
+}
+
 /* PerspectiveCamera::GenerateRayDifferential, lensRadius == 0 (cameras/perspective.cpp:81-138) */
 static void camera_ray(const hpt_camera *cam, const cam_sample *cs, ray_t *ray) {
     v3 Pcamera = xf_point(cam->raster_to_camera, V(cs->imageX, cs->imageY, 0));
@@ -1594,6 +1734,10 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
     /* sample extent == pixel extent for the box filter (film/image.cpp:157-166) */
     int xs = rd->x_start, xe = rd->x_start + rd->x_count, ys = rd->y_start, ye = rd->y_start + rd->y_count;
     uint64_t tot[6] = {0, 0, 0, 0, 0, 0};
+    const int direct = rd->integrator != HPT_INTEGRATOR_PATH;
+    if (rd->integrator < HPT_INTEGRATOR_PATH || rd->integrator > HPT_INTEGRATOR_DIRECT_ONE) return HPT_E_INVALID;
+    dl_layout Lt; memset(&Lt, 0, sizeof(Lt));
+    if (direct) dl_layout_init(&s->d, rd->integrator, &Lt);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -1605,7 +1749,8 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
         {
             uint64_t st[6] = {0, 0, 0, 0, 0, 0};
             cam_sample *samples = (cam_sample *)malloc(sizeof(cam_sample) * (size_t)spp);
-            float *buf = (float *)malloc(sizeof(float) * (size_t)spp * (5 + N1D_ALL + 2 * N2D));
+            float *buf = (float *)malloc(sizeof(float) * (direct ? dl_buf_floats(&Lt, spp) : (size_t)spp * (5 + N1D_ALL + 2 * N2D)));
+            float *vals = direct ? (float *)malloc(sizeof(float) * (size_t)spp * (size_t)Lt.fps) : NULL;
             mt_rng rng;
 #pragma omp for schedule(dynamic, 1)
             for (int task = 0; task < ntasks; ++task) {
@@ -1616,17 +1761,19 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
                 draw_src ds; ds.mode = HPT_SAMPLER_MT_REPLAY; ds.mt = &rng; ds.key = 0; ds.counter = 0;
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) {
-                        ld_pixel_sample_mt(x, y, cam->shutter_open, cam->shutter_close, spp, samples, buf, &rng);
+                        if (direct) ld_pixel_sample_mt_dl(&Lt, x, y, cam->shutter_open, cam->shutter_close, spp, samples, vals, buf, &rng);
+                        else ld_pixel_sample_mt(x, y, cam->shutter_open, cam->shutter_close, spp, samples, buf, &rng);
                         for (int i = 0; i < spp; ++i) {
                             ray_t ray; camera_ray(cam, &samples[i], &ray);
-                            rgb L = path_Li(s, ray, &samples[i], rd->maxdepth, &ds, st);
+                            rgb L = direct ? direct_Li(s, ray, &Lt, vals + (size_t)i * Lt.fps, rd->maxdepth, &ds, st)
+                                           : path_Li(s, ray, &samples[i], rd->maxdepth, &ds, st);
                             L = sanitize(L, &st[5]);
                             film_add(film, rd, samples[i].imageX, samples[i].imageY, L);
                             st[0]++;
                         }
                     }
             }
-            free(samples); free(buf);
+            free(samples); free(buf); free(vals);
 #pragma omp critical
             for (int k = 0; k < 6; ++k) tot[k] += st[k];
         }
@@ -1634,6 +1781,7 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
 #pragma omp parallel
         {
             uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+            float *vals = direct ? (float *)malloc(sizeof(float) * (size_t)Lt.fps) : NULL;
 #pragma omp for schedule(dynamic, 1)
             for (int y = ys; y < ye; ++y)
                 for (int x = xs; x < xe; ++x) {
@@ -1641,19 +1789,22 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
                     uint32_t pk = hash3(pixelIndex, rd->seed, 0x50495845u);
                     for (int i = 0; i < spp; ++i) {
                         cam_sample cs;
-                        ld_hash_sample(pixelIndex, rd->seed, x, y, cam->shutter_open, cam->shutter_close, (uint32_t)spp, (uint32_t)i, &cs);
+                        if (direct) ld_hash_sample_dl(&Lt, pixelIndex, rd->seed, x, y, cam->shutter_open, cam->shutter_close, (uint32_t)spp, (uint32_t)i, &cs, vals);
+                        else ld_hash_sample(pixelIndex, rd->seed, x, y, cam->shutter_open, cam->shutter_close, (uint32_t)spp, (uint32_t)i, &cs);
                         draw_src ds; ds.mode = HPT_SAMPLER_LD_HASH; ds.mt = NULL; ds.key = hash3(pk, (uint32_t)i, 3u); ds.counter = 0;
                         ray_t ray; camera_ray(cam, &cs, &ray);
-                        rgb L = path_Li(s, ray, &cs, rd->maxdepth, &ds, st);
+                        rgb L = direct ? direct_Li(s, ray, &Lt, vals, rd->maxdepth, &ds, st) : path_Li(s, ray, &cs, rd->maxdepth, &ds, st);
                         L = sanitize(L, &st[5]);
                         film_add(film, rd, cs.imageX, cs.imageY, L);
                         st[0]++;
                     }
                 }
+            free(vals);
 #pragma omp critical
             for (int k = 0; k < 6; ++k) tot[k] += st[k];
         }
     }
+    if (direct) dl_layout_free(&Lt);
     if (stats) for (int k = 0; k < 6; ++k) stats[k] = tot[k];
     return HPT_OK;
 }

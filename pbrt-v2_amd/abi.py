@@ -16,6 +16,7 @@ HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_S
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY = 0, 1
 HPT_PIPELINE_PERSISTENT, HPT_PIPELINE_WAVEFRONT = 0, 1
+HPT_INTEGRATOR_PATH, HPT_INTEGRATOR_DIRECT_ALL, HPT_INTEGRATOR_DIRECT_ONE = 0, 1, 2
 SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs
 
 f32, i32, i64, u32, u64 = C.c_float, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
@@ -56,7 +57,7 @@ class Light(C.Structure):
                 ("area", f32), ("env_w", i32), ("env_h", i32),
                 ("tex_off", i64), ("cond_func_off", i64), ("cond_cdf_off", i64),
                 ("cond_int_off", i64), ("marg_func_off", i64), ("marg_cdf_off", i64),
-                ("marg_int", f32), ("pad", i32), ("l2w", M16), ("l2w_inv", M16)]
+                ("marg_int", f32), ("nsamples", i32), ("l2w", M16), ("l2w_inv", M16)]
 
 
 class SceneDesc(C.Structure):
@@ -80,7 +81,7 @@ class RenderDesc(C.Structure):
                 ("y_start", i32), ("y_count", i32), ("spp", i32), ("maxdepth", i32),
                 ("sampler_mode", i32), ("seed", u32), ("ntasks", i32),
                 ("shard_rank", i32), ("shard_count", i32), ("count_work", i32),
-                ("pipeline", i32), ("pad", i32)]
+                ("pipeline", i32), ("integrator", i32)]
 
 
 class Stats(C.Structure):

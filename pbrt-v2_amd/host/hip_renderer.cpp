@@ -11,7 +11,7 @@
 //     ConstantTexture values (textures/constant.h:45-55)
 //   Lights: PointLight, DiffuseAreaLight(+ShapeSet), InfiniteAreaLight(+MIPMap, Distribution2D)
 //   PerspectiveCamera (RasterToCamera, CameraToWorld), ImageFilm (pixel extent, box filter),
-//   LDSampler (nPixelSamples), PathIntegrator (maxDepth)
+//   LDSampler (nPixelSamples), PathIntegrator (maxDepth) or DirectLightingIntegrator (strategy; Light::nSamples)
 // Anything else is outside the hot-path scope and is rejected with Severe().
 #include "stdafx.h"
 #include "hip_renderer.h"
@@ -34,6 +34,7 @@
 #include "film/image.h"
 #include "filters/box.h"
 #include "integrators/path.h"
+#include "integrators/directlighting.h"
 #include "lights/diffuse.h"
 #include "lights/infinite.h"
 #include "lights/point.h"
@@ -129,7 +130,9 @@ struct Flattener {
             std::vector<float> split(n), data(6 * (size_t)n);
             std::vector<int> bits(n);
             for (uint32_t i = 0; i < n; ++i) {
-                split[i] = kd->nodes[i].splitPos;
+                // a leaf's splitPos is never written by KdNode::initLeaf (core/kdtree.h:50-54) nor read by a lookup: it is
+                // uninitialised memory in the reference; zero it so that blobs are reproducible
+                split[i] = kd->nodes[i].splitAxis == 3 ? 0.f : kd->nodes[i].splitPos;
                 bits[i] = (int)(kd->nodes[i].splitAxis | (kd->nodes[i].hasLeftChild << 2) |
                                 (kd->nodes[i].rightChild << 3));
                 const IrregIsotropicBRDFSample &s = kd->nodeData[i];
@@ -277,6 +280,7 @@ struct Flattener {
             r.marg_func_off = r.marg_cdf_off = -1;
             CopyM(l->LightToWorld.m, r.l2w);
             CopyM(l->LightToWorld.mInv, r.l2w_inv);
+            r.nsamples = l->nSamples;
             if (const PointLight *pl = dynamic_cast<const PointLight *>(l)) {
                 r.kind = HPT_LIGHT_POINT;
                 r.pos[0] = pl->lightPos.x; r.pos[1] = pl->lightPos.y; r.pos[2] = pl->lightPos.z;
@@ -411,7 +415,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
     if (!lds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
-    if (!path) Severe("hip renderer: SurfaceIntegrator must be \"path\"");
+    const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
+    if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
     if (scene->volumeRegion) Severe("hip renderer: participating media are outside the scope");
 
     Flattener fl;
@@ -433,7 +438,9 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
     rd.spp = lds->nPixelSamples;
-    rd.maxdepth = path->maxDepth;
+    rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
+    rd.integrator = path ? HPT_INTEGRATOR_PATH
+                         : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
     rd.sampler_mode = samplerMode;
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:298-300)

@@ -4,16 +4,18 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, abi, load_ref
+from tests.util import CASES, DL_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + list(DL_CASES))
 def test_oracle_replays_reference_image_bit_exact(cases, name):
-    s = cases[name]
+    """CASES: PathIntegrator.  DL_CASES: DirectLightingIntegrator, strategy all / one — the
+    shipped killeroo-simple / anim-killeroos-moving scene files as they are, and bunny with its measured BRDF."""
+    s = cases[name] if name in cases else load_case(name)
     o = orc.OracleScene(s)
     rd = abi.copy_struct(s.render)
     rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY

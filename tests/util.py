@@ -39,10 +39,21 @@ def load_case(name):
         return abi.Scene.load(os.path.join(GOLDEN, "ms_soup.hpts.gz"))
     if name == "env":
         return abi.Scene.load(os.path.join(GOLDEN, "env_soup.hpts.gz"))
+    if name in DL_CASES:   # direct-lighting cases: committed geometry + their own camera / render descriptor / light records
+        s = abi.Scene.load(os.path.join(GOLDEN, DL_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        assert len(bytes(lights)) == len(bytes(s.lights))
+        s.lights = lights
+        return s
     raise KeyError(name)
 
 
 CASES = ["cfg1", "k8", "b8", "env", "anim", "ms"]
+# SURVEY.md §8f-1 (tests/golden/make_golden_dl.py): DirectLightingIntegrator, strategy all / one
+DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "dlb": "bunny_b8.hpts.gz", "dlanim": "anim_killeroos.hpts.gz"}
 
 
 def hash_rd(scene, seed=7, spp=None):
