@@ -139,6 +139,12 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
     rp->has_motion = 0;
+    rp->integrator = rd->integrator;
+    if (rd->integrator < HPT_INTEGRATOR_PATH || rd->integrator > HPT_INTEGRATOR_DIRECT_ONE) { hpt_set_error("unknown integrator %d", rd->integrator); return HPT_E_INVALID; }
+    if (rd->integrator != HPT_INTEGRATOR_PATH && (rd->sampler_mode != HPT_SAMPLER_LD_HASH || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
+        hpt_set_error("the direct-lighting integrator runs on the persistent kernel with the LD_HASH sampler (MT_REPLAY and the wavefront pipeline cover the path integrator)");
+        return HPT_E_UNSUPPORTED;
+    }
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     if (rp->shard_rank < 0 || rp->shard_rank >= rp->shard_count) { hpt_set_error("bad shard rank"); return HPT_E_INVALID; }
@@ -229,12 +235,12 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
     const bool inst = s->d.n_instances > 0;
     a->stack_entries = s->stack_entries;
     a->kd_lds_mat = -1; a->kd_lds_nodes = 0;
-    if (path_kernel_occupancy(s->mats, inst, cfg, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
+    if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
     if (s->kd_mat >= 0 && !getenv("HPT_NO_KD_LDS")) {
         PathKernelArgs t = *a;
         t.kd_lds_mat = s->kd_mat; t.kd_lds_nodes = s->kd_nodes;
         int b1 = 0, v1 = 0;
-        if (path_kernel_occupancy(s->mats, inst, cfg, path_kernel_dyn_lds(t), &b1, &v1) == 0 && b1 >= *bpc && b1 > 0) {
+        if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(t), &b1, &v1) == 0 && b1 >= *bpc && b1 > 0) {
             a->kd_lds_mat = t.kd_lds_mat; a->kd_lds_nodes = t.kd_lds_nodes;
         }
     }
@@ -309,7 +315,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
@@ -326,13 +332,16 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     hipError_t e = hipSuccess;
     // configuration: pinned by HPT_TUNE, else tuned once per scene by the first job big enough to amortise the probe
     int cfg = tune_forced();
+    const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
+    a.dl = dl ? 1 : 0;
+    if (dl) cfg = 3;                                     // direct lighting is compiled for the lock-step configuration only
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
         cfg = s->tune_cfg;
     }
     if (cfg < 0) cfg = 3;                                // untuned (small job): lock step, the usual winner
-    if (rd->count_work) cfg = 0;
+    if (rd->count_work && !dl) cfg = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     int bpc = 0, vgprs = 0;
@@ -426,7 +435,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);

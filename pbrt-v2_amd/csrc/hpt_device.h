@@ -189,6 +189,22 @@ struct LdHash {
         *b = sobol2(n, hash3(pk, 3u, 1u));
     }
     HPT_MFN float time01() const { return van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
+    // Direct-lighting layout (integrators/directlighting.cpp:54-77): 1D array j / 2D array j of `c` values per pixel
+    // sample (c a power of two; n1d = number of 1D arrays).  As LDShuffleScrambled*D, an array is one scrambled
+    // (0,2)-sequence of spp * c points cut into spp blocks of c: sample i owns block idx(array) and visits its points
+    // in a keyed order of its own.  Array ids 3 + j / 3 + n1d + j, scramble words 5 + j / 5 + n1d + 2j (+1)
+    // (definition: oracle/hpt_oracle.c, ld_hash_sample_dl).
+    HPT_MFN uint32_t idx_c(uint32_t arr, uint32_t c, uint32_t k) const {
+        return idx(arr) * c + perm_pow2(k, c - 1u, hash3(hash3(pk, arr, 4u), i, 5u));
+    }
+    HPT_MFN float one_c(int j, uint32_t c, uint32_t k) const {
+        return van_der_corput(idx_c(3u + (uint32_t)j, c, k), hash3(pk, 5u + (uint32_t)j, 1u));
+    }
+    HPT_MFN void two_c(int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const {
+        uint32_t n = idx_c(3u + (uint32_t)n1d + (uint32_t)j, c, k);
+        *a = van_der_corput(n, hash3(pk, 5u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));
+        *b = sobol2(n, hash3(pk, 6u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));
+    }
     // draws for bounces >= 3 and Russian roulette: RandomFloat() resolution (core/rng.cpp:59-65)
     HPT_MFN float draw(uint32_t key, uint32_t counter) const {
         uint32_t h = fmix32(key + 0x9e3779b9u * counter);

@@ -21,6 +21,7 @@ struct PathKernelArgs {
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2, kd-tree depth + 1)
     int32_t kd_lds_mat;             // measured-BRDF material whose kd-tree rides in LDS, or -1
     int32_t kd_lds_nodes;
+    int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
     size_t b = (size_t)a.stack_entries * HPT_BLOCK * 4;
@@ -37,7 +38,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 
 #define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
-int path_kernel_occupancy(int mats, bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
+int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,

@@ -120,9 +120,9 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 hipError_t launch_path_basic(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_measured(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_all(const PathKernelArgs &, int, bool, int, hipStream_t);
-int occupancy_basic(bool, int, size_t, int *, int *);
-int occupancy_measured(bool, int, size_t, int *, int *);
-int occupancy_all(bool, int, size_t, int *, int *);
+int occupancy_basic(bool, int, bool, size_t, int *, int *);
+int occupancy_measured(bool, int, bool, size_t, int *, int *);
+int occupancy_all(bool, int, bool, size_t, int *, int *);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
 static int pick_variant(int mats) {
@@ -130,11 +130,11 @@ static int pick_variant(int mats) {
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
     return 2;
 }
-int path_kernel_occupancy(int mats, bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
+int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
     switch (pick_variant(mats)) {
-        case 0: return occupancy_basic(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
-        case 1: return occupancy_measured(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
-        default: return occupancy_all(inst, cfg, dyn_lds, blocks_per_cu, vgprs);
+        case 0: return occupancy_basic(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 1: return occupancy_measured(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        default: return occupancy_all(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
     }
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {

@@ -92,7 +92,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // block behind an extension hit (BSDF set-up, light sampling, three BSDF evaluations — kd-tree queries for a
 // measured BRDF) runs with about a third of the lanes (measured VALU lane utilisation 7-12 %).  In lock step
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
-template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED>
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     extern __shared__ uint64_t dyn_lds[];      // [stacks][kd head] — sized per scene (path_kernel_dyn_lds)
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         __syncthreads();
         ls.kd_top = (const HPT_LDS uint64_t *)top; ls.kd_top_mat = km;
     }
-    Lane<LdHashSrc, INST, MATS> lane;
+    Lane<LdHashSrc, INST, MATS, DL> lane;
     lane.init();
     bool exhausted = false;
     TravState ts;                  // this lane's walk, resumable across iterations (see the traversal phase)
@@ -145,15 +145,19 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         ShadeV sv;
         sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
-            while (__ballot(lane.stage == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
-            mine = lane.stage == phase;
+            // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
+            const int my_phase = (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : lane.stage;
+            while (__ballot(my_phase == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+            mine = my_phase == phase;
         }
         if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (mine) {
-                bool anyhit = lane.stage == ST_SHADOW;
-                if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-                traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+                if (!DL || lane.stage != ST_SHADE) {
+                    bool anyhit = lane.stage == ST_SHADOW;
+                    if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+                    traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+                }
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
         } else {
@@ -209,7 +213,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? 3 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
-#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C)>
+#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false>
+// the direct-lighting integrator: lock step, 4 waves/SIMD (configuration 3)
+#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
@@ -222,9 +228,16 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
         const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
         const bool inst = a.sc.n_instances > 0;                                                                     \
+        if (a.dl) {                                                                                                 \
+            if (inst && count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, true, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);        \
+            else if (inst) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, true, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);           \
+            else if (count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, false, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
+            else hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, false, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);                    \
+            return hipGetLastError();                                                                               \
+        }                                                                                                           \
         if (count) {                                                                                                \
-            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
-            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
+            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
+            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \
@@ -239,10 +252,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     template <int CFG> static const void *fn_cfg_##NAME(bool inst) {                                                \
         return inst ? (const void *)HPT_CFG_KERNEL(MATS, true, CFG) : (const void *)HPT_CFG_KERNEL(MATS, false, CFG); \
     }                                                                                                               \
-    int occupancy_##NAME(bool inst, int cfg, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                                      \
+    int occupancy_##NAME(bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                             \
         if (inst && cfg == 1) cfg = 0;                                                                              \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
                        : cfg == 4 ? fn_cfg_##NAME<4>(inst) : fn_cfg_##NAME<0>(inst);                                \
+        if (dl) fn = inst ? (const void *)HPT_DL_KERNEL(MATS, true, false) : (const void *)HPT_DL_KERNEL(MATS, false, false);      \
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \

@@ -22,7 +22,8 @@
 
 namespace hpt {
 
-enum { ST_IDLE = 0, ST_EXTEND = 1, ST_SHADOW = 2, ST_MIS = 3 };
+enum { ST_IDLE = 0, ST_EXTEND = 1, ST_SHADOW = 2, ST_MIS = 3,
+       ST_SHADE = 4 };   // direct lighting only: no ray pending, the next light sample of the same hit is due
 
 struct RenderParams {
     hpt_camera cam;
@@ -32,6 +33,7 @@ struct RenderParams {
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
     int32_t has_motion;        // scene has animated instances: rays carry a time sample
+    int32_t integrator;        // HPT_INTEGRATOR_*
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
     int64_t n_items;           // items_per_pass x (spp / chunk)
@@ -67,6 +69,14 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
     return true;
 }
 
+// Light samples per camera sample of the direct-lighting integrator: LDSampler::RoundSize(Light::nSamples)
+// (directlighting.cpp:63-65, samplers/lowdiscrepancy.h:53; Light ctor: max(1, ns), core/light.cpp)
+HPT_FN int dl_count(const hpt_light &l) {
+    uint32_t v = (uint32_t)(l.nsamples < 1 ? 1 : l.nsamples);
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return (int)(v + 1u);
+}
+
 // What shade_prepare leaves for shade_finish.  The three BSDF values of a vertex — f(wo, wi_light), f(wo, wi_mis),
 // f(wo, wi_next) — enter its estimators as plain factors.  Analytic BSDFs are evaluated and applied on the spot;
 // for a measured BRDF the value is a kd-tree query: has[k] marks it pending, fq[k] holds the query point (later the
@@ -85,7 +95,12 @@ struct ShadeV {
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
 // MATS: BxDF families compiled in (MATS_* bits, hpt_device.h).
 // INST: compile the animated-instance code in (scenes without instances use the leaner INST=false kernel).
-template <class Smp, bool INST, int MATS> struct Lane {
+// DL:   DirectLightingIntegrator::Li (integrators/directlighting.cpp:80-121) instead of PathIntegrator::Li.  One camera
+//       hit, then EstimateDirect once per (light, sample) — strategy "all", core/integrator.cpp:47-79 — or for one chosen
+//       light — strategy "one", :82-114.  The hit is kept (camera ray + Hit, 13 registers) and its shading geometry /
+//       BSDF rebuilt for every light sample (stage ST_SHADE) instead of carrying a BSDF across the traversal phases.
+//       The specular recursion of directlighting.cpp:111-118 has nothing to sample (no specular lobe on this path).
+template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     int stage;
     // pixel / sample bookkeeping
     int px, py;
@@ -106,6 +121,10 @@ template <class Smp, bool INST, int MATS> struct Lane {
     f3 wi_mis, C_mis;       // BSDF-sampling term f*Li*|wi.n|*w/pdf, evaluated for the radiance the ray
     int light_mis;          // would see if it reaches light_mis; added when the MIS ray confirms it
     f3 wi_next, beta_next;
+    // direct lighting: the camera hit and the (light, sample) loop of UniformSampleAllLights
+    Ray cam; Hit chit;
+    int li, lj;
+    f3 acc;                 // Ld of the current light, summed over its samples
 
     HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; fX = fY = fZ = fW = 0.f; }
 
@@ -167,6 +186,16 @@ template <class Smp, bool INST, int MATS> struct Lane {
     }
 
     HPT_MFN void after_mis(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
+        if (DL) {
+            if (sc.n_lights > 0 && rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {       // integrator.cpp:56-77
+                acc = acc + Ld;
+                const int n = dl_count(sc.lights[li]);
+                if (++lj == n) { L = L + sdivf(acc, (float)n); acc = S(0.f); lj = 0; ++li; }
+                if (li < sc.n_lights) { stage = ST_SHADE; return; }
+            } else if (sc.n_lights > 0) L = L + Ld * (float)sc.n_lights;                // integrator.cpp:110-113
+            finish_path(rp, film, wc);
+            return;
+        }
         if (sc.n_lights > 0) L = L + smul(beta, Ld * (float)sc.n_lights);  // integrator.cpp:110, path.cpp:71-80
         if (has_next) {
             beta = beta_next; specular = spec_next;
@@ -187,6 +216,11 @@ template <class Smp, bool INST, int MATS> struct Lane {
     // BSDF values that are still kd-tree queries (sv->has[], measured BRDF) — wave-cooperatively in the path
     // kernel, serially elsewhere (on_hit_serial) — and then calls shade_finish().
     HPT_MFN bool on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls, ShadeV *sv) {
+        if (DL && stage == ST_SHADE) {       // next light sample of the kept camera hit (no ray was traced)
+            ray = cam;
+            shade_prepare(sc, rp, chit, ls, sv);
+            return true;
+        }
         if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
             if (hit.prim >= 0) Ld = S(0.f);
             after_shadow(sc, rp, film, wc);
@@ -216,6 +250,7 @@ template <class Smp, bool INST, int MATS> struct Lane {
             finish_path(rp, film, wc);
             return false;
         }
+        if (DL) { cam = ray; chit = hit; li = 0; lj = 0; acc = S(0.f); }
         shade_prepare(sc, rp, hit, ls, sv);
         return true;
     }
@@ -229,7 +264,7 @@ template <class Smp, bool INST, int MATS> struct Lane {
         Bsdf bsdf; DGeom dg; int arealight;
         shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
-        if (bounce == 0 || specular)                                        // path.cpp:63-64
+        if (DL ? stage == ST_EXTEND : (bounce == 0 || specular))            // path.cpp:63-64; directlighting.cpp:90 (once per hit)
             if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
         p = dg.p;
         f3 n = bsdf.nn;
@@ -244,7 +279,9 @@ template <class Smp, bool INST, int MATS> struct Lane {
         const bool useArrays = bounce < 3;                                  // SAMPLE_DEPTH (path.h:55)
         if (sc.n_lights > 0) {                                              // UniformSampleOneLight
             float ln, ls0, ls1, ls2, bs0, bs1, bs2;
-            if (useArrays) {
+            int lightPick = -1;
+            if (DL) dl_samples(sc, rp, &lightPick, &ln, &ls0, &ls1, &ls2, &bs0, &bs1, &bs2);
+            else if (useArrays) {
                 ln = smp.one(4 * bounce + 1);
                 smp.two(3 * bounce, &ls0, &ls1); ls2 = smp.one(4 * bounce);
                 smp.two(3 * bounce + 1, &bs0, &bs1); bs2 = smp.one(4 * bounce + 2);
@@ -256,6 +293,7 @@ template <class Smp, bool INST, int MATS> struct Lane {
             (void)ls2;
             int lightNum = (int)floorf(ln * sc.n_lights);
             if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
+            if (DL && lightPick >= 0) lightNum = lightPick;
             const hpt_light &light = sc.lights[lightNum];
             const bool isDelta = light.kind == HPT_LIGHT_POINT;
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
@@ -312,7 +350,7 @@ template <class Smp, bool INST, int MATS> struct Lane {
             }
         }
         // continuation (path.cpp:83-110): beta' = beta * f * |wi.n| / pdf
-        {
+        if (!DL) {
             float ps0, ps1, ps2;
             if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
             else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
@@ -325,6 +363,25 @@ template <class Smp, bool INST, int MATS> struct Lane {
                     sv->a3 = absdot(wi, n); sv->pdf3 = pdf;
                 } else term_next(bsdf_f_local<MATS>(sc, bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, ls), absdot(wi, n), pdf);
             }
+        }
+    }
+
+    // Sample values of the direct-lighting integrator for light sample (li, lj) — layout of RequestSamples,
+    // directlighting.cpp:54-77: strategy "all": light i owns 1D arrays 2i (light component), 2i+1 (bsdf component) and
+    // 2D arrays 2i (light position), 2i+1 (bsdf direction), each of dl_count(light i) values per pixel sample; strategy
+    // "one": 1D arrays 0 light component, 1 light number, 2 bsdf component and 2D arrays 0, 1, one value each.
+    HPT_MFN void dl_samples(const DScene &sc, const RenderParams &rp, int *lightPick, float *ln, float *ls0, float *ls1, float *ls2,
+                            float *bs0, float *bs1, float *bs2) {
+        if (rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {
+            const uint32_t c = (uint32_t)dl_count(sc.lights[li]), k = (uint32_t)lj;
+            const int n1d = 2 * sc.n_lights + 2;
+            *lightPick = li; *ln = 0.f;
+            smp.two_c(2 * li, n1d, c, k, ls0, ls1); *ls2 = smp.one_c(2 * li, c, k);
+            smp.two_c(2 * li + 1, n1d, c, k, bs0, bs1); *bs2 = smp.one_c(2 * li + 1, c, k);
+        } else {
+            *ln = smp.one_c(1, 1u, 0u);
+            smp.two_c(0, 5, 1u, 0u, ls0, ls1); *ls2 = smp.one_c(0, 1u, 0u);
+            smp.two_c(1, 5, 1u, 0u, bs0, bs1); *bs2 = smp.one_c(2, 1u, 0u);
         }
     }
 
@@ -384,6 +441,8 @@ struct LdHashSrc {
     HPT_MFN void image(float *a, float *b) const { h.image(a, b); }
     HPT_MFN void lens(float *a, float *b) const { h.lens(a, b); }
     HPT_MFN float time01() const { return h.time01(); }
+    HPT_MFN float one_c(int j, uint32_t c, uint32_t k) const { return h.one_c(j, c, k); }
+    HPT_MFN void two_c(int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const { h.two_c(j, n1d, c, k, a, b); }
     HPT_MFN float draw() { return h.draw(h.draw_key(), dcount++); }
 };
 

@@ -58,6 +58,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
     rp->has_motion = 0;
+    rp->integrator = rd->integrator;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
@@ -68,7 +69,9 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
 }
 
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
-extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
+// DL: the direct-lighting instantiation of the lane (rd->integrator != HPT_INTEGRATOR_PATH).
+template <bool DL>
+static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
     rp.has_motion = s->d.n_instances > 0;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
@@ -84,13 +87,16 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
             if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashSrc, true, MATS_ALL> lane; lane.init();
+            Lane<LdHashSrc, true, MATS_ALL, DL> lane; lane.init();
             lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
-                bool anyhit = lane.stage == ST_SHADOW;
-                if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
+                if (!DL || lane.stage != ST_SHADE) {
+                    bool anyhit = lane.stage == ST_SHADOW;
+                    if (anyhit) wc.shadow++; else wc.closest++;
+                    traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                }
                 { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit_serial(s->d, rp, hit, film, &wc, ls); }
             }
         }
@@ -99,6 +105,9 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
     }
     if (stats) { stats[0] = total.samples; stats[1] = total.closest; stats[2] = total.shadow; stats[3] = total.nodes; stats[4] = total.tris; stats[5] = total.bad; }
     return 0;
+}
+extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
+    return rd->integrator != HPT_INTEGRATOR_PATH ? emu_render_t<true>(s, cam, rd, film, stats) : emu_render_t<false>(s, cam, rd, film, stats);
 }
 
 // HPT_SAMPLER_MT_REPLAY: the lane of each tile, tiles in ascending task order on one thread —
