@@ -14,6 +14,7 @@ Workloads (all 1920x1080, path maxdepth 8, lowdiscrepancy-structured sampler, bo
   bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 454 prims, measured BRDF), 64 spp/GPU  [default]
   killeroo north-star target scene: scenes/killeroo-simple.pbrt (66 533 prims), 64 spp/GPU
   anim     BASELINE.json configs[3] scene: scenes/anim-killeroos-moving.pbrt (2 animated instances), 64 spp/GPU
+  killeroo-dl  the same scene file with the integrator it selects itself (directlighting, 8 light samples), 64 spp/GPU
   soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 16 spp/GPU here
 Geometry comes from the committed blobs (dumped from the reference's own parser by
 host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does not exist on the
@@ -53,6 +54,14 @@ def load_workload(name, spp):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.render.spp = spp or 64
         desc = "scenes/%s.pbrt" % {"bunny": "bunny", "killeroo": "killeroo-simple", "anim": "anim-killeroos-moving"}[name]
+    elif name == "killeroo-dl":   # scenes/killeroo-simple.pbrt exactly as shipped (directlighting, strategy all)
+        s = abi.Scene.load(os.path.join(GOLDEN, "killeroo_cfg1.hpts.gz"))
+        v = np.load(os.path.join(GOLDEN, "killeroo_dl_1080p.view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.render.spp = spp or 64
+        desc = "scenes/killeroo-simple.pbrt as shipped (DirectLightingIntegrator, strategy all, 8 light samples per camera sample)"
     elif name == "soup":
         s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or 16, maxdepth=8)
         desc = "synthetic 1M random triangles + 1 env light (seed 0x5EED0001)"
@@ -184,8 +193,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "soup" else
             "scene blob dumped from the reference parser (tests/golden), random-free geometry",
-            "config": {"workload": "%s, 1920x1080, path maxdepth 8, %d spp per GPU (%d spp total), LD_HASH sampler seed 0, box filter"
-                                   % (desc, spp_per_gpu, rd.spp),
+            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), LD_HASH sampler seed 0, box filter"
+                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp),
                        "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile gather" % world,
                        "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
                        "scene_bytes_in_hbm": int(info.total_device_bytes)},

@@ -434,6 +434,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
+    if (rd->integrator != HPT_INTEGRATOR_PATH) return 3;    // direct lighting: one configuration (lock step)
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);

@@ -58,8 +58,8 @@ def run_case(name, pbrt_text, tmp, geometry_blob):
     env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", scene_path], env=env, stderr=subprocess.DEVNULL)
     ref = film.read_pfm(os.path.join(tmp, name + "_ref.pfm"))
-    with gzip.open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as f:
-        np.save(f, ref)
+    with open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+        np.save(f, ref)       # mtime=0: re-running the generator reproduces the committed bytes
     v = abi.Scene.load(blob)
     g = abi.Scene.load(os.path.join(HERE, geometry_blob))
     for sc in (v, g):   # a kd-tree leaf's split position is uninitialised memory in the reference (never read): mask it
@@ -74,6 +74,19 @@ def run_case(name, pbrt_text, tmp, geometry_blob):
     print(name, "integrator", v.render.integrator, "nsamples", [l.nsamples for l in v.lights], ref.shape)
 
 
+def dump_view(name, pbrt_text, tmp, geometry_blob):
+    """camera + render descriptor + lights of a bench workload (1920x1080), no reference render"""
+    scene_path = os.path.join(tmp, name + ".pbrt")
+    with open(scene_path, "w") as f:
+        f.write(pbrt_text)
+    blob = os.path.join(tmp, name + ".hpts")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", scene_path], env=env, stderr=subprocess.DEVNULL)
+    v = abi.Scene.load(blob)
+    np.savez(os.path.join(HERE, name + ".view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
+             render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8))
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         kill = open(os.path.join(REF, "killeroo-simple.pbrt")).read()
@@ -86,6 +99,8 @@ def main():
                 'SurfaceIntegrator "directlighting"\n') % os.path.join(tmp, "dlb_ref.pfm")
         run_case("dlb", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
                  .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        # bench workload: the shipped scene file at 1920x1080, its own integrator and sample counts (64 spp x 8 light samples)
+        dump_view("killeroo_dl_1080p", sub(kill, 1920, 1080, 64, os.path.join(tmp, "x.pfm")), tmp, "killeroo_cfg1.hpts.gz")
         anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
         run_case("dlanim", sub(anim, 100, 60, 4, os.path.join(tmp, "dlanim_ref.pfm")), tmp, "anim_killeroos.hpts.gz")
 
