@@ -210,7 +210,10 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 
 // Tuning configurations (index = hpt_stats.tune_cfg): {waves/SIMD, early-exit threshold, lock-step phases}
 #define HPT_N_CFG 5
-#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? 3 : 4)
+#ifndef HPT_W34
+#define HPT_W34 3
+#endif
+#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? HPT_W34 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false>
