@@ -88,10 +88,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->info.bvh_max_depth = fs.max_depth;
     s->stack_entries = fs.max_depth + 2;
     // a measured BRDF: its kd walk (one row per ancestor) + the 12 rows of the wave's query queue (wave_eval_queries)
-    if (fs.kd_max_depth > 0 && s->stack_entries < fs.kd_max_depth + 1 + 12) s->stack_entries = fs.kd_max_depth + 1 + 12;
+    if (fs.kd_max_depth > 0 && s->stack_entries < fs.kd_max_depth - 1 + 12) s->stack_entries = fs.kd_max_depth - 1 + 12;   // (depth - 1 ancestor rows; a row is 1 KiB, so the kd head behind the stacks stays 8-byte aligned)
     if (s->stack_entries < 8) s->stack_entries = 8;
     if (s->stack_entries > HPT_STACK_DEPTH + 12) s->stack_entries = HPT_STACK_DEPTH + 12;
-    s->stack_entries = (s->stack_entries + 1) & ~1;        // keeps the kd head 8-byte aligned behind the stacks
 
     bool ok = true;
     s->d.nodes = (const f4 *)upload(s, fs.nodes.data(), fs.nodes.size(), &ok);
