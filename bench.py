@@ -202,7 +202,7 @@ def main():
                        "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
                        "tune_cfg": "%d (%s)" % (last.tune_cfg, ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases", "3 waves/SIMD, lock-step phases"][last.tune_cfg]),
                        "samples_per_launch": int(per_launch_samples)},
-            "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
+            "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
             "film_mean_Y": round(img_mean, 5),
         }
         bps = ALGO_BYTES_PER_SAMPLE.get(args.workload)

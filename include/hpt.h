@@ -226,7 +226,10 @@ typedef struct hpt_scene_info {
     int64_t n_tris, n_bvh_nodes, n_quadrics;
     int64_t bvh_bytes, tri_bytes, total_device_bytes;
     int32_t bvh_max_depth, pad;
-    double build_ms;
+    double build_ms;           /* flatten + BVH build, wall clock                                            */
+    double device_build_ms;    /* HPT_BVH_BUILD=lbvh: HIP-event time of the device BVH builder's kernels      */
+    int32_t device_built;      /* ... and how many trees (world + instances) it built (0: host binned SAH)    */
+    int32_t pad2;
 } hpt_scene_info;
 
 typedef struct hpt_scene hpt_scene; /* opaque: device-resident flattened scene + BVH */

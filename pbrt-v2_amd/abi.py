@@ -95,7 +95,8 @@ class Stats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_tris", i64), ("n_bvh_nodes", i64), ("n_quadrics", i64),
                 ("bvh_bytes", i64), ("tri_bytes", i64), ("total_device_bytes", i64),
-                ("bvh_max_depth", i32), ("pad", i32), ("build_ms", C.c_double)]
+                ("bvh_max_depth", i32), ("pad", i32), ("build_ms", C.c_double),
+                ("device_build_ms", C.c_double), ("device_built", i32), ("pad2", i32)]
 
 
 class BlobHeader(C.Structure):

@@ -36,6 +36,7 @@ struct hpt_scene {
     int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
     int kd_mat, kd_nodes; // first measured-BRDF material and the size of its kd-tree (-1: none)
     int stack_entries;    // per-lane traversal stack entries this scene needs
+    double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
 };
 
 extern "C" int hpt_device_count(void) {
@@ -79,18 +80,25 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     FlatScene fs;
     int maxLeaf = 4;
     if (const char *e = getenv("HPT_BVH_MAXLEAF")) maxLeaf = atoi(e);   // tuning knob (default 4, range 1..8)
-    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs) != HPT_OK) { delete s; return nullptr; }
-    if (fs.max_depth > HPT_STACK_DEPTH) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
+    // HPT_BVH_BUILD=lbvh: build the trees on the device (hpt_bvh_gpu.hip).  An LBVH is not depth-bounded: the path
+    // kernel sizes its LDS stacks per scene (up to HPT_MAX_STACK_ROWS), the fixed-stack kernels (replay, wavefront,
+    // parity hooks) refuse deeper trees.
+    BvhDeviceBuildFn dev_build = nullptr;
+    if (const char *e = getenv("HPT_BVH_BUILD")) if (!strcmp(e, "lbvh")) dev_build = build_bvh_lbvh_gpu;
+    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs, dev_build, HPT_MAX_STACK_ROWS - 2) != HPT_OK) { delete s; return nullptr; }
+    if (fs.max_depth + 2 > HPT_MAX_STACK_ROWS) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
+    s->device_build_ms = fs.device_build_ms; s->device_built = fs.device_built;
     const int64_t ntris = fs.n_tris;
     s->info.build_ms = fs.build_ms;
     s->info.n_tris = ntris; s->info.n_bvh_nodes = (int64_t)fs.nodes.size(); s->info.n_quadrics = desc->n_quadrics;
     s->info.bvh_bytes = (int64_t)(fs.nodes.size() * sizeof(BvhNode64)); s->info.tri_bytes = 48 * ntris;
     s->info.bvh_max_depth = fs.max_depth;
+    s->info.device_build_ms = fs.device_build_ms; s->info.device_built = fs.device_built;
     s->stack_entries = fs.max_depth + 2;
     // a measured BRDF: its kd walk (one row per ancestor) + the 12 rows of the wave's query queue (wave_eval_queries)
     if (fs.kd_max_depth > 0 && s->stack_entries < fs.kd_max_depth - 1 + 12) s->stack_entries = fs.kd_max_depth - 1 + 12;   // (depth - 1 ancestor rows; a row is 1 KiB, so the kd head behind the stacks stays 8-byte aligned)
     if (s->stack_entries < 8) s->stack_entries = 8;
-    if (s->stack_entries > HPT_STACK_DEPTH + 12) s->stack_entries = HPT_STACK_DEPTH + 12;
+    if (s->stack_entries > HPT_MAX_STACK_ROWS) s->stack_entries = HPT_MAX_STACK_ROWS;
 
     bool ok = true;
     s->d.nodes = (const f4 *)upload(s, fs.nodes.data(), fs.nodes.size(), &ok);
@@ -379,6 +387,11 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         }
         return HPT_OK;
     }
+    if ((replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT) && s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) {
+        (void)hipFree(d_scr);
+        hpt_set_error("BVH depth %d: the replay / wavefront kernels have a fixed %d-row traversal stack (build the scene with the host SAH builder)", s->info.bvh_max_depth, HPT_STACK_DEPTH);
+        return HPT_E_UNSUPPORTED;
+    }
     ReplayArgs ra; memset(&ra, 0, sizeof(ra));
     if (replay && e == hipSuccess) {
         ra.ntasks = rd->ntasks;
@@ -467,6 +480,7 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
 // ---- parity hooks -------------------------------------------------------------------------------------
 extern "C" int hpt_test_intersect(hpt_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim) {
     if (!s || !rays || !out_hit || !out_prim || n < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
+    if (s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) { hpt_set_error("BVH depth %d exceeds the parity hook's fixed traversal stack", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     DevBuf<float> d_rays, d_hit; DevBuf<int32_t> d_prim;
     if (!d_rays.alloc(8 * (size_t)n) || !d_hit.alloc(4 * (size_t)n) || !d_prim.alloc((size_t)n)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }

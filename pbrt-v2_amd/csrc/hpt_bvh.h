@@ -23,5 +23,9 @@ struct BvhResult {
 // maxDepth bounds the leaf depth so a traversal stack of maxDepth entries never overflows.
 void build_bvh(const BvhInputTri *tris, size_t n, int maxLeaf, int maxDepth, BvhResult *out);
 
+// Device builder (hpt_bvh_gpu.hip, LBVH): same output, max_depth unbounded; false = could not run, use build_bvh.
+typedef bool (*BvhDeviceBuildFn)(const BvhInputTri *tris, size_t n, int maxLeaf, BvhResult *out, double *kernel_ms);
+bool build_bvh_lbvh_gpu(const BvhInputTri *tris, size_t n, int maxLeaf, BvhResult *out, double *kernel_ms);
+
 } // namespace hpt
 #endif

@@ -29,7 +29,7 @@ static int kd_count_within(const float *split, const int32_t *bits, const float 
     return found;
 }
 
-int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out) {
+int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out, BvhDeviceBuildFn device_build, int device_max_depth) {
     auto t0 = std::chrono::steady_clock::now();
     int64_t ntris = 0;
     for (int m = 0; m < desc->n_meshes; ++m) ntris += desc->meshes[m].ntris;
@@ -78,7 +78,14 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         }
         if (sub.empty()) continue;
         BvhResult bvh;
-        build_bvh(sub.data(), sub.size(), max_leaf, max_depth, &bvh);
+        double dev_ms = 0.0;
+        // (one triangle per leaf: runs of Morton neighbours make poor leaves — measured 285 vs 456 Msamples/s on bunny)
+        if (device_build && device_build(sub.data(), sub.size(), 1, &bvh, &dev_ms) && bvh.max_depth <= device_max_depth) {
+            out->device_build_ms += dev_ms; out->device_built++;
+        } else {
+            bvh = BvhResult();
+            build_bvh(sub.data(), sub.size(), max_leaf, max_depth, &bvh);
+        }
         const int32_t node_base = (int32_t)out->nodes.size();
         for (size_t i = 0; i < bvh.nodes.size(); ++i) {
             BvhNode64 nd = bvh.nodes[i];

@@ -28,10 +28,15 @@ struct FlatScene {
     int max_depth = 0;
     int kd_max_depth = 0;             // deepest measured-BRDF kd-tree (levels)
     double build_ms = 0.0;
+    double device_build_ms = 0.0;     // kernel time of the device BVH builder, if it ran
+    int device_built = 0;             // groups (world / instances) whose BVH the device builder made
 };
 
 // returns HPT_OK or a negative error code (hpt_last_error() set)
-int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out);
+// device_build: optional device BVH builder (hpt_bvh_gpu.hip); a group falls back to the host binned-SAH builder if it
+// declines or its tree is deeper than device_max_depth.
+int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out,
+                  BvhDeviceBuildFn device_build = nullptr, int device_max_depth = 0);
 
 } // namespace hpt
 #endif

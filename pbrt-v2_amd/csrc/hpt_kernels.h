@@ -36,6 +36,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
+#define HPT_MAX_STACK_ROWS 40   /* dynamic LDS stack rows of the path kernel: 40 KiB a workgroup = 4 workgroups per CU */
 #define HPT_N_TUNE_CFG 5   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);

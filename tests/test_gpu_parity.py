@@ -302,6 +302,33 @@ def test_direct_lighting_is_refused_where_it_is_not_built(cases, dev):
         dev["cfg1"].render(s.camera, rd)
 
 
+@pytest.mark.parametrize("name", ["cfg1", "b8", "anim"])
+def test_gpu_built_bvh_finds_the_same_hits_and_film(cases, dev, ora, name, monkeypatch):
+    """HPT_BVH_BUILD=lbvh builds the trees on the device (Morton codes, rocPRIM radix sort, Karras radix tree,
+    bottom-up fit: csrc/hpt_bvh_gpu.hip).  Which tree finds a hit does not matter: same primitives, bit-identical
+    t / barycentrics as the oracle, and the same film as the scene built with the host SAH builder."""
+    s = cases[name]
+    monkeypatch.setenv("HPT_BVH_BUILD", "lbvh")
+    d = hpt.DeviceScene(s)
+    monkeypatch.delenv("HPT_BVH_BUILD")
+    info = d.info()
+    assert info.device_built >= 1 and info.device_build_ms > 0 and info.n_tris == dev[name].info().n_tris
+    rd = hash_rd(s, seed=6)
+    f_gpu, st = d.render(s.camera, rd)
+    f_host, _ = dev[name].render(s.camera, rd)
+    assert st.bad_samples == 0
+    assert np.array_equal(f_gpu[..., 3], f_host[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(f_gpu), film.xyzw_to_rgb(f_host)) < 1e-4     # ties between equal-t hits may differ
+    if info.bvh_max_depth + 2 <= 26:   # the parity hook has a fixed 26-row stack
+        rays = random_rays(s, 20000, seed=3)
+        hg, pg = d.intersect(rays)
+        ho, po = ora[name].intersect(rays)
+        same = (pg >= 0) == (po >= 0)
+        assert same.mean() > 0.9995
+        both = (pg >= 0) & (po >= 0)
+        assert np.array_equal(hg[both][:, 0], ho[both][:, 0])
+
+
 def test_shards_partition_the_image(cases, dev):
     s = cases["k8"]
     rd = hash_rd(s, seed=2, spp=2)
