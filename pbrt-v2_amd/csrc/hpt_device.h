@@ -730,23 +730,19 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
         if (TIER >= 1) { uint64_t t = ls.kd_top[nodeNum]; sp_ = as_float((int32_t)(uint32_t)t); b = (uint32_t)(t >> 32); }   // split | bits << 32
         else { f4 t = nodes[2 * (int64_t)nodeNum]; sp_ = t.x; b = (uint32_t)as_int(t.y); }
         const int axis = (int)(b & 3u);
-        if (axis != 3 && stage < 2) {
-            uint32_t hasLeft = (b >> 2) & 1u, right = b >> 3;
-            float pa = comp(p, axis);
-            float d2 = (pa - sp_) * (pa - sp_);
-            bool leftFirst = pa <= sp_;
-            bool hasRight = right < nNodes;
-            uint32_t child = 0xffffffffu;
-            if (stage == 0) {                            // first child, else straight on to the second
-                if (leftFirst ? hasLeft != 0u : hasRight) child = leftFirst ? nodeNum + 1 : right;
-                stage = 1;
-            }
-            if (child == 0xffffffffu) {                  // stage 1: the far child, if the slab reaches it
-                if (d2 < maxDist2 && (leftFirst ? hasRight : hasLeft != 0u)) child = leftFirst ? right : nodeNum + 1;
-                stage = 2;
-            }
-            if (child != 0xffffffffu) {
-                ls.p[sp * ls.stride] = (int32_t)((nodeNum << 2) | stage); ++sp;
+        {   // which child to descend into next — straight-line selects (the branchy form cost ~10 scalar branches a step):
+            // stage 0 tries the near child, then the far child if the slab reaches it; stage 1 only the far child
+            const uint32_t NONE = 0xffffffffu;
+            const uint32_t left = ((b >> 2) & 1u) ? nodeNum + 1 : NONE, right = (b >> 3) < nNodes ? (b >> 3) : NONE;
+            const float pa = comp(p, axis);
+            const float d2 = (pa - sp_) * (pa - sp_);
+            const bool leftFirst = pa <= sp_;
+            const uint32_t nearC = leftFirst ? left : right;
+            const uint32_t farC = d2 < maxDist2 ? (leftFirst ? right : left) : NONE;
+            const bool takeNear = stage == 0u && nearC != NONE;
+            const uint32_t child = takeNear ? nearC : farC;
+            if (axis != 3 && stage < 2u && child != NONE) {
+                ls.p[sp * ls.stride] = (int32_t)((nodeNum << 2) | (takeNear ? 1u : 2u)); ++sp;
                 cur = child << 2;
                 continue;
             }
@@ -759,11 +755,13 @@ HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *
             f3 wv = mk3(n1.y, n1.z, n1.w) * weight;
             proc->v = proc->v + wv;
             proc->sumWeights += weight;
-            if (d2 < proc->r2) { proc->v2 = proc->v2 + wv; proc->sumWeights2 += weight; }
-            if (d2 < proc->m3) {                         // keep the three smallest distances, m1 <= m2 <= m3
-                if (d2 < proc->m2) { proc->m3 = proc->m2; if (d2 < proc->m1) { proc->m2 = proc->m1; proc->m1 = d2; } else proc->m2 = d2; }
-                else proc->m3 = d2;
-            }
+            const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
+            proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
+            proc->sumWeights2 += in2 ? weight : 0.f;
+            // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
+            const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
+            const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
+            proc->m3 = minf(proc->m3, t2);
         }
         if (sp == 0) break;
         --sp;
