@@ -532,15 +532,16 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
         float t0, t1;
         bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
         bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
-        int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
-        if (h0 && h1) {
-            bool swap = t1 < t0;
-            stack[ts.sp * stride] = swap ? c0 : c1; ++ts.sp;
-            ts.node = swap ? c1 : c0;
-        } else if (h0) ts.node = c0;
-        else if (h1) ts.node = c1;
-        else if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
-        else ts.node = HPT_TRAV_EMPTY;
+        const int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
+        // near child first, far child stacked — selects instead of a four-way branch
+        const bool both = h0 && h1, swap = t1 < t0;
+        if (both) { stack[ts.sp * stride] = swap ? c0 : c1; ++ts.sp; }
+        int32_t next = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
+        if (!(h0 || h1)) {
+            next = HPT_TRAV_EMPTY;
+            if (ts.sp > 0) { --ts.sp; next = stack[ts.sp * stride]; }
+        }
+        ts.node = next;
     }
     if (ts.node < 0 && ts.node != HPT_TRAV_EMPTY) { // leaf: <= 8 pre-gathered 48-byte triangle records, then pop
         uint32_t code = (uint32_t)~ts.node;
