@@ -329,6 +329,31 @@ def test_gpu_built_bvh_finds_the_same_hits_and_film(cases, dev, ora, name, monke
         assert np.array_equal(hg[both][:, 0], ho[both][:, 0])
 
 
+def test_pbrt_binary_with_the_hip_renderer_end_to_end(tmp_path):
+    """The whole drop-in chain on the GPU box: pbrt's own parser and api.cpp (the reference sources, built with the
+    HipPathRenderer plugin into pbrt-v2_amd/host/_build/pbrt_hip by `make -C pbrt-v2_amd/host` in the build
+    container) read a scene FILE, the plugin flattens the Scene and calls the C ABI, ImageFilm writes the image.
+    The scene file is written by our own exporter (the reference tree does not exist here); the image must equal
+    what the Python binding renders from the same scene at the same seed."""
+    import os
+    import subprocess
+    from tests.util import ROOT
+    exe = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+    if not os.path.exists(exe):
+        pytest.skip("pbrt_hip is built from /root/reference in the build container only")
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    s = scenes.synthetic_soup(n_tris=2000, xres=160, yres=90, spp=8, maxdepth=5, extent=0.08)
+    scene_file, out_pfm = str(tmp_path / "soup.pbrt"), str(tmp_path / "soup.pfm")
+    scenes.export_pbrt(s, scene_file, out_pfm, renderer="hip")
+    subprocess.check_call([exe, "--quiet", scene_file], env=dict(os.environ, HPT_TUNE="3"))
+    got = film.read_pfm(out_pfm)
+    rd = hash_rd(s, seed=0)
+    f, st = hpt.DeviceScene(s).render(s.camera, rd)
+    want = film.xyzw_to_rgb(f)
+    assert got.shape == want.shape and st.bad_samples == 0
+    assert film.rmse(got, want) < 1e-4, film.rmse(got, want)
+
+
 def test_shards_partition_the_image(cases, dev):
     s = cases["k8"]
     rd = hash_rd(s, seed=2, spp=2)
