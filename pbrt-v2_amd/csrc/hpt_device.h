@@ -714,86 +714,105 @@ struct LaneStack {
     const HPT_LDS uint64_t *kd_top = nullptr; const hpt_material *kd_top_mat = nullptr;
 };
 #define HPT_KD_GRID 16
-// One radius pass.  `cur` (node << 2 | stage) lives in a register, its ancestors on the LDS stack.
-// stage 0: first visit; 1: after the first child; 2: after the second child -> hand the node's sample over.
-// Tree depth <= 24 (checked at scene creation).
-template <int TIER>    // 0: tree in HBM / L2 only; 1: {split, bits} of every node in LDS
-HPT_FN void kd_lookup(const DScene &sc, const hpt_material *m, f3 p, IrregProc *proc, float maxDist2, LaneStack ls) {
-    // packed node: {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
-    const f4 *nodes = (const f4 *)(sc.fpool + m->kd_data_off);
-    const uint32_t nNodes = (uint32_t)m->kd_nnodes;
-    int sp = 0;
-    uint32_t cur = 0u;
-    for (;;) {
-        const uint32_t nodeNum = cur >> 2;
-        uint32_t stage = cur & 3u;
-        float sp_; uint32_t b;
-        if (TIER >= 1) { uint64_t t = ls.kd_top[nodeNum]; sp_ = as_float((int32_t)(uint32_t)t); b = (uint32_t)(t >> 32); }   // split | bits << 32
-        else { f4 t = nodes[2 * (int64_t)nodeNum]; sp_ = t.x; b = (uint32_t)as_int(t.y); }
-        const int axis = (int)(b & 3u);
-        {   // which child to descend into next — straight-line selects (the branchy form cost ~10 scalar branches a step):
-            // stage 0 tries the near child, then the far child if the slab reaches it; stage 1 only the far child
-            const uint32_t NONE = 0xffffffffu;
-            const uint32_t left = ((b >> 2) & 1u) ? nodeNum + 1 : NONE, right = (b >> 3) < nNodes ? (b >> 3) : NONE;
-            const float pa = comp(p, axis);
-            const float d2 = (pa - sp_) * (pa - sp_);
-            const bool leftFirst = pa <= sp_;
-            const uint32_t nearC = leftFirst ? left : right;
-            const uint32_t farC = d2 < maxDist2 ? (leftFirst ? right : left) : NONE;
-            const bool takeNear = stage == 0u && nearC != NONE;
-            const uint32_t child = takeNear ? nearC : farC;
-            if (axis != 3 && stage < 2u && child != NONE) {
-                ls.p[sp * ls.stride] = (int32_t)((nodeNum << 2) | (takeNear ? 1u : 2u)); ++sp;
-                cur = child << 2;
-                continue;
-            }
-        }
-        f4 n0 = nodes[2 * (int64_t)nodeNum], n1 = nodes[2 * (int64_t)nodeNum + 1];
-        f3 np = mk3(n0.z, n0.w, n1.x);
-        float d2 = dist2(np, p);
-        if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
-            float weight = expf(-100.f * d2);
-            f3 wv = mk3(n1.y, n1.z, n1.w) * weight;
-            proc->v = proc->v + wv;
-            proc->sumWeights += weight;
-            const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
-            proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
-            proc->sumWeights2 += in2 ? weight : 0.f;
-            // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
-            const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
-            const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
-            proc->m3 = minf(proc->m3, t2);
-        }
-        if (sp == 0) break;
-        --sp;
-        cur = (uint32_t)ls.p[sp * ls.stride];
-    }
-}
+// The whole query — growing-radius passes included — as a resumable walk: kd_begin() positions it, each kd_step()
+// does ONE step of the current radius pass (descend into a child, or hand the node's sample to the accumulator and pop)
+// and, when the pass ends, decides like the reference's loop (reflection.cpp:262-271) whether another pass is needed.
+// Serial callers loop until done (irreg_eval); the path kernel's wave-cooperative evaluator (hpt_kernels_impl.h) steps
+// 64 walks side by side and hands a lane the next queued query the moment its walk ends.
+// `cur` (node << 2 | stage) lives in a register, its ancestors on the lane's LDS stack column.  stage 0: first visit;
+// 1: after the first child; 2: after the second child -> hand the node's sample over.  Depth <= 24 (scene creation).
+struct KdWalk {
+    f3 q;                 // query point
+    uint32_t cur; int sp;
+    float r; int level;   // radius^2 of this pass = .001 * 2^level
+    bool last;            // this pass runs at the exact final radius (after a too-high guess)
+    bool top;             // this material's split planes are in LDS (LaneStack::kd_top)
+    const f4 *nodes; uint32_t nNodes;   // packed node records {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
+    IrregProc pr;
+};
 HPT_FN void irreg_proc_reset(IrregProc *pr, float r2) {
     pr->v = S(0.f); pr->sumWeights = 0.f; pr->v2 = S(0.f); pr->sumWeights2 = 0.f; pr->r2 = r2;
     pr->m1 = pr->m2 = pr->m3 = HPT_INF;
 }
-template <int TIER>
-HPT_FN f3 irreg_query(const DScene &sc, const hpt_material *m, f3 mpt, int level, LaneStack ls) {
+HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack ls, KdWalk *w) {
+    w->nodes = (const f4 *)(sc.fpool + m->kd_data_off); w->nNodes = (uint32_t)m->kd_nnodes; w->top = m == ls.kd_top_mat;
+    // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
+    int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
+    gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
+    gy = gy < 0 ? 0 : gy > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gy;
+    gz = gz < 0 ? 0 : gz > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gz;
+    int cell = (gz * HPT_KD_GRID + gy) * HPT_KD_GRID + gx;
+    w->level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
+    w->q = mpt;
     float r = .001f;
-    for (int i = 0; i < level; ++i) r *= 2.f;            // the reference's lastMaxDist2 after `level` doublings
-    bool last = false;                                   // the pass at the exact final radius (after a too-high guess)
-    while (true) {
-        IrregProc proc;
-        irreg_proc_reset(&proc, (level > 0 && !last) ? r * .5f : 0.f);
-        kd_lookup<TIER>(sc, m, mpt, &proc, r, ls);
-        if (last) return sdivf(sclamp0(proc.v), proc.sumWeights);
-        if (proc.m3 < r) {                               // more than two samples inside r: the reference stopped at k <= level
-            int k = level; float rk = r;
-            while (k > 0 && proc.m3 < rk * .5f) { --k; rk *= .5f; }
-            if (k == level) return sdivf(sclamp0(proc.v), proc.sumWeights);
-            if (k == level - 1) return sdivf(sclamp0(proc.v2), proc.sumWeights2);
-            r = rk; last = true;
-            continue;
+    for (int i = 0; i < w->level; ++i) r *= 2.f;         // the reference's lastMaxDist2 after `level` doublings
+    w->r = r; w->last = false;
+    w->cur = 0u; w->sp = 0;
+    irreg_proc_reset(&w->pr, w->level > 0 ? r * .5f : 0.f);
+}
+// returns true when the query is finished: *out = IrregIsotropicBRDF::f
+template <int TIER>    // 0: tree in HBM / L2 only; 1: {split, bits} of every node in LDS
+HPT_FN bool kd_step(KdWalk *w, LaneStack ls, f3 *out) {
+    const f4 *nodes = w->nodes;
+    const uint32_t nNodes = w->nNodes;
+    const f3 p = w->q;
+    const float maxDist2 = w->r;
+    const uint32_t nodeNum = w->cur >> 2, stage = w->cur & 3u;
+    float sp_; uint32_t b;
+    if (TIER >= 1) { uint64_t t = ls.kd_top[nodeNum]; sp_ = as_float((int32_t)(uint32_t)t); b = (uint32_t)(t >> 32); }   // split | bits << 32
+    else { f4 t = nodes[2 * (int64_t)nodeNum]; sp_ = t.x; b = (uint32_t)as_int(t.y); }
+    const int axis = (int)(b & 3u);
+    {   // which child to descend into next — straight-line selects (the branchy form cost ~10 scalar branches a step):
+        // stage 0 tries the near child, then the far child if the slab reaches it; stage 1 only the far child
+        const uint32_t NONE = 0xffffffffu;
+        const uint32_t left = ((b >> 2) & 1u) ? nodeNum + 1 : NONE, right = (b >> 3) < nNodes ? (b >> 3) : NONE;
+        const float pa = comp(p, axis);
+        const float d2 = (pa - sp_) * (pa - sp_);
+        const bool leftFirst = pa <= sp_;
+        const uint32_t nearC = leftFirst ? left : right;
+        const uint32_t farC = d2 < maxDist2 ? (leftFirst ? right : left) : NONE;
+        const bool takeNear = stage == 0u && nearC != NONE;
+        const uint32_t child = takeNear ? nearC : farC;
+        if (axis != 3 && stage < 2u && child != NONE) {
+            ls.p[w->sp * ls.stride] = (int32_t)((nodeNum << 2) | (takeNear ? 1u : 2u)); ++w->sp;
+            w->cur = child << 2;
+            return false;
         }
-        if (r > 1.5f) return sdivf(sclamp0(proc.v), proc.sumWeights);
-        r *= 2.f; ++level;
     }
+    IrregProc *proc = &w->pr;
+    f4 n0 = nodes[2 * (int64_t)nodeNum], n1 = nodes[2 * (int64_t)nodeNum + 1];
+    f3 np = mk3(n0.z, n0.w, n1.x);
+    float d2 = dist2(np, p);
+    if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
+        float weight = expf(-100.f * d2);
+        f3 wv = mk3(n1.y, n1.z, n1.w) * weight;
+        proc->v = proc->v + wv;
+        proc->sumWeights += weight;
+        const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
+        proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
+        proc->sumWeights2 += in2 ? weight : 0.f;
+        // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
+        const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
+        const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
+        proc->m3 = minf(proc->m3, t2);
+    }
+    if (w->sp > 0) { --w->sp; w->cur = (uint32_t)ls.p[w->sp * ls.stride]; return false; }
+    // ---- the pass is over ------------------------------------------------------------------------------------------
+    if (w->last) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
+    if (proc->m3 < w->r) {                               // more than two samples inside r: the reference stopped at k <= level
+        int k = w->level; float rk = w->r;
+        while (k > 0 && proc->m3 < rk * .5f) { --k; rk *= .5f; }
+        if (k == w->level) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
+        if (k == w->level - 1) { *out = sdivf(sclamp0(proc->v2), proc->sumWeights2); return true; }
+        w->r = rk; w->last = true;                       // guessed too high by two or more levels: one pass at the exact radius
+        irreg_proc_reset(proc, 0.f);
+    } else {
+        if (w->r > 1.5f) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
+        w->r *= 2.f; ++w->level;
+        irreg_proc_reset(proc, w->r * .5f);
+    }
+    w->cur = 0u; w->sp = 0;
+    return false;
 }
 // The query point of IrregIsotropicBRDF::f (reflection.cpp:248-260, BRDFRemap)
 HPT_FN f3 irreg_point(f3 wo, f3 wi) {
@@ -806,18 +825,14 @@ HPT_FN f3 irreg_point(f3 wo, f3 wi) {
     if (dphi > HPT_PI) dphi = 2.f * HPT_PI - dphi;
     return mk3(sini * sino, dphi / HPT_PI, cosi * coso);
 }
-// ... and the weighted average of the samples around it (reflection.cpp:261-271).  Out of line: called from the
-// wave-cooperative evaluator of the path kernel (hpt_kernels_impl.h) and from irreg_f.
+// ... and the weighted average of the samples around it (reflection.cpp:261-271), one lane for itself.  Out of line.
 HPT_FN_NOINLINE f3 irreg_eval(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack ls) {
-    // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
-    int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
-    gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
-    gy = gy < 0 ? 0 : gy > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gy;
-    gz = gz < 0 ? 0 : gz > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gz;
-    int cell = (gz * HPT_KD_GRID + gy) * HPT_KD_GRID + gx;
-    int level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
-    if (m == ls.kd_top_mat) return irreg_query<1>(sc, m, mpt, level, ls);
-    return irreg_query<0>(sc, m, mpt, level, ls);
+    KdWalk w;
+    kd_begin(sc, m, mpt, ls, &w);
+    f3 out = S(0.f);
+    if (w.top) { while (!kd_step<1>(&w, ls, &out)) {} }
+    else { while (!kd_step<0>(&w, ls, &out)) {} }
+    return out;
 }
 HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
     return irreg_eval(sc, m, irreg_point(wo, wi), ls);

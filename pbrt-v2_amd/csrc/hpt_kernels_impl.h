@@ -46,8 +46,51 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
 // on the measured material, each with 2-3 queries; walking the kd-tree lane-by-owner ran that loop at 9 % VALU
 // lane utilisation.  Here the owners append their queries to a wave-wide queue (ballot prefix sums; entry i lives
 // in column i % 64, rows qrow + 4 * (i / 64) .. + 3 of the wave's own LDS stack columns, above the rows the kd walk
-// uses), every lane evaluates entry lane, lane + 64, lane + 128, and the owners read the values back.  Within a
-// wave LDS operations execute in program order, so no barrier is needed — only a compiler fence.
+// uses), the 64 lanes step 64 resumable walks side by side (kd_step, hpt_device.h) and a lane whose walk ends takes
+// the next queue entry at once — walks differ several-fold in length, so fixed rounds of 64 would idle most lanes —
+// and finally the owners read the values back.  Within a wave LDS operations execute in program order, so no
+// barrier is needed — only compiler fences.
+#ifndef HPT_KD_BURST
+#define HPT_KD_BURST 8
+#endif
+#define HPT_QSLOT(idx, j) col0[((idx) & 63) + (ls.qrow + 4 * ((idx) >> 6) + (j)) * ls.stride]
+// The walks: out of line so that the loop has a register budget of its own (the caller's live lane state is saved
+// around ONE call per vertex instead of being spilled inside the loop).
+__device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int total) {
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    HPT_LDS int32_t *col0 = ls.p - lane;
+    int next = total < 64 ? total : 64;                  // wave-uniform: first queue entry nobody has taken yet
+    int slot = lane < total ? lane : -1;
+    KdWalk w;
+    w.top = false;
+    if (slot >= 0)
+        kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), ls, &w);
+    for (;;) {
+        if (__ballot(slot >= 0) == 0ull) break;
+        if (slot >= 0) {                                 // a burst of steps between two looks at the queue
+            f3 f;
+            bool done = false;
+            if (w.top) { for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step<1>(&w, ls, &f); }
+            else { for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step<0>(&w, ls, &f); }
+            if (done) {
+                HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z);
+                slot = -1;
+            }
+        }
+        if (next < total) {                              // uniform: entries left — hand them to the lanes that just finished
+            const unsigned long long mneed = __ballot(slot < 0);
+            if (mneed != 0ull) {
+                const int idx = next + __popcll(mneed & lt);
+                next += __popcll(mneed);
+                if (slot < 0 && idx < total) {
+                    slot = idx;
+                    kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), ls, &w);
+                }
+            }
+        }
+    }
+}
 __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls, ShadeV &sv, bool shaded) {
     const bool h0 = shaded && sv.has[0], h1 = shaded && sv.has[1], h2 = shaded && sv.has[2];
     const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2);
@@ -57,29 +100,21 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int o0 = __popcll(m0 & lt), o1 = n0 + __popcll(m1 & lt), o2 = n0 + n1 + __popcll(m2 & lt);
     HPT_LDS int32_t *col0 = ls.p - lane;
-    #define HPT_QSLOT(idx, j) col0[((idx) & 63) + (ls.qrow + 4 * ((idx) >> 6) + (j)) * ls.stride]
     if (h0) { HPT_QSLOT(o0, 0) = as_int(sv.fq[0].x); HPT_QSLOT(o0, 1) = as_int(sv.fq[0].y); HPT_QSLOT(o0, 2) = as_int(sv.fq[0].z); HPT_QSLOT(o0, 3) = sv.mat; }
     if (h1) { HPT_QSLOT(o1, 0) = as_int(sv.fq[1].x); HPT_QSLOT(o1, 1) = as_int(sv.fq[1].y); HPT_QSLOT(o1, 2) = as_int(sv.fq[1].z); HPT_QSLOT(o1, 3) = sv.mat; }
     if (h2) { HPT_QSLOT(o2, 0) = as_int(sv.fq[2].x); HPT_QSLOT(o2, 1) = as_int(sv.fq[2].y); HPT_QSLOT(o2, 2) = as_int(sv.fq[2].z); HPT_QSLOT(o2, 3) = sv.mat; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int base = 0; base < total; base += 64) {
-        const int idx = base + lane;
-        if (idx < total) {
-            f3 q = mk3(as_float(HPT_QSLOT(idx, 0)), as_float(HPT_QSLOT(idx, 1)), as_float(HPT_QSLOT(idx, 2)));
-            f3 f = irreg_eval(sc, &sc.materials[HPT_QSLOT(idx, 3)], q, ls);
-            HPT_QSLOT(idx, 0) = as_int(f.x); HPT_QSLOT(idx, 1) = as_int(f.y); HPT_QSLOT(idx, 2) = as_int(f.z);
-        }
-    }
+    wave_kd_run(sc, ls, total);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (h0) sv.fq[0] = mk3(as_float(HPT_QSLOT(o0, 0)), as_float(HPT_QSLOT(o0, 1)), as_float(HPT_QSLOT(o0, 2)));
     if (h1) sv.fq[1] = mk3(as_float(HPT_QSLOT(o1, 0)), as_float(HPT_QSLOT(o1, 1)), as_float(HPT_QSLOT(o1, 2)));
     if (h2) sv.fq[2] = mk3(as_float(HPT_QSLOT(o2, 0)), as_float(HPT_QSLOT(o2, 1)), as_float(HPT_QSLOT(o2, 2)));
-    #undef HPT_QSLOT
 }
+#undef HPT_QSLOT
 
 // WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
