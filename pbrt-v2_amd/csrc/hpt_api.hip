@@ -36,6 +36,7 @@ struct hpt_scene {
     int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
     int kd_mat, kd_nodes; // first measured-BRDF material and the size of its kd-tree (-1: none)
     int stack_entries;    // per-lane traversal stack entries this scene needs
+    float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
 };
 
@@ -112,6 +113,13 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
+    s->inst_xf = nullptr; s->inst_xf_lanes = 0;
+    if (desc->n_instances > 0) {       // 16 floats x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
+        s->inst_xf_lanes = (size_t)s->n_cus * 4 * HPT_BLOCK;
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(float) * 16 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
+        else ok = false;
+    }
     s->mats = 0;
     s->kd_mat = -1; s->kd_nodes = 0;
     for (int m = 0; m < desc->n_materials; ++m) {
@@ -294,6 +302,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
             int grid = s->n_cus * bpc;
             int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
             if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+            a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
             for (int rep = 0; rep < 2 - round && e == hipSuccess; ++rep) { // a configuration's first launch also pays its code-object load
                 e = hipMemsetAsync(d_scr, 0, scr_bytes, stream);
                 if (e == hipSuccess) e = hipEventRecord(ev0, stream);
@@ -322,7 +331,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
@@ -357,6 +366,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
+    a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
         float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
         int wrc = render_wavefront(s, a, rd, stream, stats, &d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
@@ -448,7 +458,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (tune_forced() >= 0) return tune_forced();
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 3;    // direct lighting: one configuration (lock step)
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);

@@ -569,8 +569,12 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
 // whose motion bounds the ray crosses (TransformedPrimitive::Intersect / IntersectP,
 // core/primitive.cpp:95-124): WorldToPrimitive interpolated at the ray's time carries the ray into the
 // instance's own BVH.  `ray.maxt` is shrunk to the hit distance like the reference does.
+// xf_cache (optional): this lane's column of the per-path instance-transform cache — WorldToPrimitive of every instance
+// interpolated at the path's time, 16 floats an instance, element j of instance k at xf_cache[(16 k + j) * xf_stride]
+// (filled by the path kernel once per camera sample; every ray of the path carries the same time, geometry.h:329-332).
 template <bool COUNT, bool INST>
-HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt) {
+HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
+                     const float *xf_cache = nullptr, int64_t xf_stride = 0) {
     TravState ts;
     trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
     while (!ts.done()) trav_step<COUNT>(sc, ts, ray, stack, stride, cnt);
@@ -580,9 +584,11 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         const hpt_instance &in = sc.instances[k];
         float tentry;
         if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, &tentry)) continue;
-        Xf w2p = anim_interpolate(in, time, false);
+        M4 w2p;
+        if (xf_cache) { for (int j = 0; j < 16; ++j) w2p.m[j] = xf_cache[(int64_t)(16 * k + j) * xf_stride]; }
+        else w2p = anim_interpolate(in, time, false).m;
         Ray r2;
-        r2.o = xf_point(w2p.m.m, ray.o); r2.d = xf_vec(w2p.m.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
+        r2.o = xf_point(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
         trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
         while (!t2.done()) trav_step<COUNT>(sc, t2, r2, stack, stride, cnt);

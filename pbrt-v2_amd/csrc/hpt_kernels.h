@@ -21,6 +21,7 @@ struct PathKernelArgs {
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2, kd-tree depth + 1)
     int32_t kd_lds_mat;             // measured-BRDF material whose kd-tree rides in LDS, or -1
     int32_t kd_lds_nodes;
+    float *inst_xf;                 // animated instances: per-path transform cache, [16 x n_instances][grid x 256] floats, or null
     int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {

@@ -157,6 +157,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
     int phase = ST_EXTEND;         // wave-uniform (PHASED only)
+    // animated instances: WorldToPrimitive of every instance at the path's time, interpolated ONCE per camera sample into
+    // this lane's column of a.inst_xf instead of once per ray and instance (slerp + two matrix products, ~400 instructions,
+    // in an out-of-line call with the lane state spilled around it: 850 GB of scratch traffic per frame on anim-killeroos)
+    const int64_t xf_stride = (int64_t)gridDim.x * HPT_BLOCK;
+    float *xf_col = (INST && a.inst_xf) ? a.inst_xf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x : nullptr;
+    float xf_time = -HPT_INF;
     for (;;) {
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
         for (;;) {
@@ -172,6 +178,13 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             }
         }
         const bool active = lane.stage != ST_IDLE;
+        if (INST && xf_col && active && lane.time != xf_time) {
+            xf_time = lane.time;
+            for (int k = 0; k < sc.n_instances; ++k) {
+                Xf x = anim_interpolate(sc.instances[k], lane.time, false);
+                for (int j = 0; j < 16; ++j) xf_col[(int64_t)(16 * k + j) * xf_stride] = x.m.m[j];
+            }
+        }
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
         if (__ballot(active) == 0ull) break;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 if (!DL || lane.stage != ST_SHADE) {
                     bool anyhit = lane.stage == ST_SHADOW;
                     if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-                    traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+                    traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc, xf_col, xf_stride);
                 }
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
