@@ -200,7 +200,7 @@ def main():
                        "scene_bytes_in_hbm": int(info.total_device_bytes)},
             "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
                        "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
-                       "tune_cfg": "%d (%s)" % (last.tune_cfg, ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases", "3 waves/SIMD, lock-step phases"][last.tune_cfg]),
+                       "tune_cfg": "%d (%s)" % (last.tune_cfg, ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases", "3 waves/SIMD, lock-step phases", "4 waves/SIMD, lock-step phases, subtree stealing", "3 waves/SIMD, lock-step phases, subtree stealing"][last.tune_cfg]),
                        "samples_per_launch": int(per_launch_samples)},
             "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
             "film_mean_Y": round(img_mean, 5),

@@ -217,7 +217,7 @@ typedef struct hpt_stats {
     uint32_t resident_waves, grid_blocks, block_threads, vgprs;
     uint32_t tune_cfg;         /* kernel configuration that ran: 0 = 4 waves/SIMD, 1 = 4 waves + early-exit
                                 * traversal, 2 = 3 waves/SIMD, 3 / 4 = 4 / 3 waves with the wave's lanes in lock
-                                * step (extension, shadow, MIS phases); picked per scene by a probe render,
+                                * step (extension, shadow, MIS phases), 5 / 6 = 3 / 4 + idle lanes steal subtrees from the wave's long rays; picked per scene by a probe render,
                                 * HPT_TUNE=<n> pins it.  All configurations compute the same film. */
     uint32_t pad;
 } hpt_stats;

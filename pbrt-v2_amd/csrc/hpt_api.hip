@@ -248,7 +248,8 @@ template <typename T> struct DevBuf {
 // without costing a resident block.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries;
+    a->stack_entries = s->stack_entries + (!inst && (cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0);
+    if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
     a->kd_lds_mat = -1; a->kd_lds_nodes = 0;
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
     if (s->kd_mat >= 0 && !getenv("HPT_NO_KD_LDS")) {
@@ -286,7 +287,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     const bool inst = s->d.n_instances > 0;
     float t[HPT_N_TUNE_CFG];
     bool in_race[HPT_N_TUNE_CFG];
-    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1); }  // early exit is not compiled for instanced scenes
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && (cfg == 1 || cfg >= 5)); }  // early exit / stealing are not compiled for instanced scenes
     int best_cfg = 0;
     // round 0: every configuration at <= 16 spp; round 1: the ones within 10 % of the best again at <= 64 spp
     for (int round = 0; round < 2 && e == hipSuccess; ++round) {
@@ -298,7 +299,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
         for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
             if (!in_race[cfg]) continue;
             int bpc = 0, vg = 0;
-            if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { e = hipErrorUnknown; break; }
+            if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { if (cfg >= 5) { in_race[cfg] = false; continue; } e = hipErrorUnknown; break; }
             int grid = s->n_cus * bpc;
             int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
             if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
@@ -350,18 +351,22 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int cfg = tune_forced();
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     a.dl = dl ? 1 : 0;
-    if (dl) cfg = 3;                                     // direct lighting is compiled for the lock-step configuration only
+    if (dl) cfg = s->d.n_instances > 0 ? 3 : 5;          // direct lighting is compiled for lock step (+ stealing without instances) only
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
         cfg = s->tune_cfg;
     }
-    if (cfg < 0) cfg = 3;                                // untuned (small job): lock step, the usual winner
+    if (cfg < 0) cfg = s->d.n_instances > 0 ? 3 : 5;     // untuned (small job): lock step (+ subtree stealing), the usual winner
     if (rd->count_work && !dl) cfg = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     int bpc = 0, vgprs = 0;
-    if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
+        if (cfg >= 5 && !dl) { cfg -= 2; if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown; }   // tree too deep for the stealing rows
+        else if (dl) { (void)hipFree(d_scr); hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
+        else e = hipErrorUnknown;
+    }
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
@@ -456,7 +461,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
-    if (rd->integrator != HPT_INTEGRATOR_PATH) return 3;    // direct lighting: one configuration (lock step)
+    if (rd->integrator != HPT_INTEGRATOR_PATH) return s->d.n_instances > 0 ? 3 : 5;    // direct lighting: one configuration
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);

@@ -116,6 +116,106 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 }
 #undef HPT_QSLOT
 
+// ---- one traversal phase of the whole wave with SUBTREE STEALING ------------------------------------------------------
+// Measured (profiles/r01_ab.md): in a lock-step phase on average 9-12 of the 64 lanes are still walking — the wave waits for its
+// few long rays.  The traversal stacks live in LDS as stack[row][thread], so any lane can read any lane's stack: after every step
+// the lanes without work (their own ray done, or no ray in this phase at all) each take the OLDEST entry (bottom of the stack =
+// largest pending subtree) off a lane that still has pending entries, copy that lane's ray through cross-lane shuffles, and walk
+// the subtree for it.  All lanes working on one ray (its owner + helpers, transitively) publish their finds in five LDS words of
+// the OWNER's column (rows aux+1 .. aux+4: nearest t as its bit pattern — atomic min; 0 = "this any-hit ray is occluded" — and
+// the b1, b2, prim of the lane that holds that t) at the same points, and pull the shared t back as their maxt, so a helper does
+// not keep walking a subtree that a nearer hit has already shadowed and may forget its own find when it takes the next job.
+// Must be called by ALL 64 lanes (has_ray = false for lanes with nothing to trace in this phase).  aux: five stack rows above
+// everything the walk uses (row aux: donor table).  Closest hits with exactly equal t (shared edges) are resolved by publishing
+// order here and by visiting order in the plain walk.
+#define HPT_STEAL_ROWS 5
+template <bool COUNT>
+__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux, TravCounters *cnt) {
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
+    #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
+    #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    TravState ts;
+    Ray r = ray;
+    int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
+    if (has_ray) trav_begin(sc, ts, r, anyhit, sc.world_root, true);
+    else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
+    HPT_AUX(aux + 1, lane) = as_int(r.maxt);                        // r.maxt >= 0: float order == unsigned order of the bits
+    HPT_AUX(aux + 4, lane) = -1;
+    HPT_WAVE_SYNC();
+    for (;;) {
+        const bool busy = ts.node != HPT_TRAV_EMPTY;
+        const bool any_busy = __ballot(busy) != 0ull;
+        if (busy) trav_step<COUNT>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+        // (after every step — measured: every 16 / 8 / 4 / 2 / 1 steps = 612 / 660 / 708 / 775 / 800 Msamples/s on killeroo —
+        //  but only the parts that have something to do: a publish when some lane found a hit, a steal when some lane idles)
+        const bool found = ts.hit.prim >= 0;
+        const bool any_found = __ballot(found) != 0ull;
+        if (any_found || !any_busy) {
+            // ---- publish finds, share the hit distance inside every group (owner + helpers) ------------------------------
+            if (found) {
+                if (ts.anyhit) HPT_AUX(aux + 1, owner) = 0;
+                else atomicMin((unsigned *)&HPT_AUX(aux + 1, owner), (unsigned)as_int(ts.hit.t));
+            }
+            HPT_WAVE_SYNC();
+            const int shared = HPT_AUX(aux + 1, owner);
+            if (found && !ts.anyhit && as_int(ts.hit.t) == shared) {    // this lane holds the group's nearest hit so far
+                HPT_AUX(aux + 2, owner) = as_int(ts.hit.b1); HPT_AUX(aux + 3, owner) = as_int(ts.hit.b2); HPT_AUX(aux + 4, owner) = ts.hit.prim;
+            }
+            ts.hit.prim = -1;                                           // published (or beaten)
+            if (ts.node != HPT_TRAV_EMPTY) {
+                if (ts.anyhit) { if (shared == 0) ts.node = HPT_TRAV_EMPTY; }   // somebody found an occluder
+                else r.maxt = fminf(r.maxt, as_float(shared));
+            }
+            if (!any_busy) break;                                       // (the last publish has just happened)
+        }
+        // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
+        const bool still = ts.node != HPT_TRAV_EMPTY;
+        const bool donor = still && ts.sp >= 1;
+        const unsigned long long mi = __ballot(!still), md = __ballot(donor);
+        int n = __popcll(mi);
+        const int nd = __popcll(md);
+        if (nd < n) n = nd;
+        if (n == 0) continue;
+        const int ri = __popcll(mi & lt), rd = __popcll(md & lt);
+        int give = 0;
+        if (donor && rd < n) {
+            HPT_AUX(aux, rd) = lane;
+            give = stack[sb * HPT_BLOCK];                           // bottom entry: the oldest = largest pending subtree
+            ++sb; --ts.sp;
+        }
+        HPT_WAVE_SYNC();
+        const bool take = !still && ri < n;
+        const int src = take ? HPT_AUX(aux, ri) : lane;
+        // the donor's ray and bookkeeping, through cross-lane shuffles executed by every lane
+        const float ox = __shfl(r.o.x, src), oy = __shfl(r.o.y, src), oz = __shfl(r.o.z, src);
+        const float dx = __shfl(r.d.x, src), dy = __shfl(r.d.y, src), dz = __shfl(r.d.z, src);
+        const float mint = __shfl(r.mint, src), maxt = __shfl(r.maxt, src);
+        const float ix = __shfl(ts.invd.x, src), iy = __shfl(ts.invd.y, src), iz = __shfl(ts.invd.z, src);
+        const int any_s = __shfl((int)ts.anyhit, src), own_s = __shfl(owner, src), node_s = __shfl(give, src);
+        if (take) {
+            r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
+            ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s;
+            ts.node = node_s; ts.sp = 0; sb = 0;
+        }
+    }
+    HPT_WAVE_SYNC();
+    // ---- every owner collects the nearest hit of its group ----------------------------------------------------------------
+    hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
+    if (has_ray) {
+        const int shared = HPT_AUX(aux + 1, lane);
+        if (anyhit) { if (shared == 0) hit->prim = 0; }
+        else if (HPT_AUX(aux + 4, lane) >= 0) {
+            hit->t = as_float(shared); hit->b1 = as_float(HPT_AUX(aux + 2, lane)); hit->b2 = as_float(HPT_AUX(aux + 3, lane)); hit->prim = HPT_AUX(aux + 4, lane);
+            ray.maxt = hit->t;
+        }
+    }
+    HPT_WAVE_SYNC();
+    #undef HPT_AUX
+    #undef HPT_WAVE_SYNC
+}
+
 // WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
 // scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
@@ -127,7 +227,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // block behind an extension hit (BSDF set-up, light sampling, three BSDF evaluations — kd-tree queries for a
 // measured BRDF) runs with about a third of the lanes (measured VALU lane utilisation 7-12 %).  In lock step
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
-template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL>
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     extern __shared__ uint64_t dyn_lds[];      // [stacks][kd head] — sized per scene (path_kernel_dyn_lds)
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
@@ -198,7 +298,14 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             while (__ballot(my_phase == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
-        if (INST || EE == 0) {
+        if (STEAL && PHASED && !INST) {
+            // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
+            const bool tr = mine && (!DL || lane.stage != ST_SHADE);
+            const bool anyhit = lane.stage == ST_SHADOW;
+            if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
+            traverse_steal<COUNT>(sc, lane.ray, anyhit, tr, &hit, stack, a.stack_entries - HPT_STEAL_ROWS, &tc);
+            if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
+        } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (mine) {
                 if (!DL || lane.stage != ST_SHADE) {
@@ -257,16 +364,17 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 
 
 // Tuning configurations (index = hpt_stats.tune_cfg): {waves/SIMD, early-exit threshold, lock-step phases}
-#define HPT_N_CFG 5
+#define HPT_N_CFG 7
 #ifndef HPT_W34
 #define HPT_W34 3
 #endif
-#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 ? HPT_W34 : 4)
+#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 || (c) == 6 ? HPT_W34 : 4)
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
-#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false>
-// the direct-lighting integrator: lock step, 4 waves/SIMD (configuration 3)
-#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true>
+#define HPT_CFG_STEAL(c) ((c) >= 5)
+#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, (INST) ? false : HPT_CFG_STEAL(C)>
+// the direct-lighting integrator: lock step, 4 waves/SIMD, subtree stealing where there are no instances (configuration 5 / 3)
+#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true, !(INST)>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
@@ -292,11 +400,15 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \
+        if (inst && cfg == 5) cfg = 3;                                                                              \
+        if (inst && cfg == 6) cfg = 4;                                                                              \
         switch (cfg) {                                                                                              \
             case 1: return launch_cfg_##NAME<1>(a, grid, inst, dyn_lds, s);                                                  \
             case 2: return launch_cfg_##NAME<2>(a, grid, inst, dyn_lds, s);                                                  \
             case 3: return launch_cfg_##NAME<3>(a, grid, inst, dyn_lds, s);                                                  \
             case 4: return launch_cfg_##NAME<4>(a, grid, inst, dyn_lds, s);                                                  \
+            case 5: return launch_cfg_##NAME<5>(a, grid, inst, dyn_lds, s);                                                  \
+            case 6: return launch_cfg_##NAME<6>(a, grid, inst, dyn_lds, s);                                                  \
             default: return launch_cfg_##NAME<0>(a, grid, inst, dyn_lds, s);                                                 \
         }                                                                                                           \
     }                                                                                                               \
@@ -305,8 +417,10 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     }                                                                                                               \
     int occupancy_##NAME(bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                             \
         if (inst && cfg == 1) cfg = 0;                                                                              \
+        if (inst && cfg == 5) cfg = 3;                                                                              \
+        if (inst && cfg == 6) cfg = 4;                                                                              \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
-                       : cfg == 4 ? fn_cfg_##NAME<4>(inst) : fn_cfg_##NAME<0>(inst);                                \
+                       : cfg == 4 ? fn_cfg_##NAME<4>(inst) : cfg == 5 ? fn_cfg_##NAME<5>(inst) : cfg == 6 ? fn_cfg_##NAME<6>(inst) : fn_cfg_##NAME<0>(inst); \
         if (dl) fn = inst ? (const void *)HPT_DL_KERNEL(MATS, true, false) : (const void *)HPT_DL_KERNEL(MATS, false, false);      \
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \

@@ -13,7 +13,7 @@ for w in ${WORKLOADS:-bunny killeroo anim soup}; do
   python - <<PY
 import json; d=json.load(open("$O/bench_${w}_auto.json")); print("$w auto", d["value"], d["kernel"]["tune_cfg"], d["kernel"]["vgprs"], d["setup_s"])
 PY
-  for c in ${CFGS:-0 1 2 3 4}; do
+  for c in ${CFGS:-0 1 2 3 4 5 6}; do
     HPT_TUNE=$c timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${w}_c$c.json 2> $O/bench_${w}_c$c.err
     python - <<PY
 import json; d=json.load(open("$O/bench_${w}_c$c.json")); print("$w cfg$c", d["value"], d["kernel"]["tune_cfg"], d["kernel"]["vgprs"])

@@ -165,7 +165,7 @@ def test_kernel_configurations_render_the_same_film(cases, dev, name, monkeypatc
     s = cases[name]
     rd = hash_rd(s, seed=9)
     films = []
-    for cfg in range(5):
+    for cfg in range(7):
         monkeypatch.setenv("HPT_TUNE", str(cfg))
         f, st = dev[name].render(s.camera, rd)
         assert st.tune_cfg == cfg and st.bad_samples == 0
@@ -202,11 +202,11 @@ def test_autotune_probes_once_per_scene(monkeypatch):
     d = hpt.DeviceScene(s)
     small = abi.copy_struct(s.render)
     small.spp = 4
-    _, st0 = d.render(s.camera, small)                  # too small to tune: the default configuration (lock step)
-    assert st0.tune_cfg == 3
+    _, st0 = d.render(s.camera, small)                  # too small to tune: the default configuration (lock step + stealing)
+    assert st0.tune_cfg == 5
     f1, st1 = d.render(s.camera, s.render)              # tunes
     f2, st2 = d.render(s.camera, s.render)
-    assert 0 <= st1.tune_cfg < 5 and st2.tune_cfg == st1.tune_cfg
+    assert 0 <= st1.tune_cfg < 7 and st2.tune_cfg == st1.tune_cfg
     assert st1.camera_samples == 1024 * 576 * 64
     assert np.array_equal(f1[..., 3], f2[..., 3]) and np.allclose(f1, f2, rtol=1e-6, atol=1e-6)
     monkeypatch.setenv("HPT_TUNE", "0")
