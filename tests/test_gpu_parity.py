@@ -193,6 +193,28 @@ def test_measured_brdf_lds_head_renders_the_same_film(cases, dev, monkeypatch):
         assert np.allclose(films[0], f, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_subtree_stealing_equals_the_plain_walk_on_random_scenes(seed, monkeypatch):
+    """Configurations 5 / 6 let idle lanes walk subtrees for the wave's long rays (traverse_steal): a different
+    schedule of the same box and triangle tests.  Random soups of different sizes / depths / lights: the film must
+    equal the plain lock-step walk's (closest hits can only differ on exactly equal t)."""
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(300, 60000))
+    s = scenes.synthetic_soup(n_tris=n, xres=int(rng.integers(90, 300)), yres=int(rng.integers(60, 200)), spp=int(2 ** rng.integers(1, 5)),
+                              maxdepth=int(rng.integers(1, 9)), extent=float(rng.uniform(0.02, 0.2)), seed=seed)
+    d = hpt.DeviceScene(s)
+    rd = hash_rd(s, seed=seed)
+    films = {}
+    for cfg in (3, 5, 6):
+        monkeypatch.setenv("HPT_TUNE", str(cfg))
+        films[cfg], st = d.render(s.camera, rd)
+        assert st.tune_cfg == cfg and st.bad_samples == 0
+    for cfg in (5, 6):
+        assert np.array_equal(films[3][..., 3], films[cfg][..., 3])
+        assert np.allclose(films[3], films[cfg], rtol=1e-6, atol=1e-6)
+
+
 def test_autotune_probes_once_per_scene(monkeypatch):
     """A job big enough to amortise the probe picks a configuration and later renders reuse it;
     the probe leaves nothing behind in the film."""
