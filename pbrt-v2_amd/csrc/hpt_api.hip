@@ -248,7 +248,7 @@ template <typename T> struct DevBuf {
 // without costing a resident block.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries + (!inst && (cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0);
+    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0);
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
     a->kd_lds_mat = -1; a->kd_lds_nodes = 0;
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
@@ -287,7 +287,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     const bool inst = s->d.n_instances > 0;
     float t[HPT_N_TUNE_CFG];
     bool in_race[HPT_N_TUNE_CFG];
-    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && (cfg == 1 || cfg >= 5)); }  // early exit / stealing are not compiled for instanced scenes
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1); }  // early exit is not compiled for instanced scenes
     int best_cfg = 0;
     // round 0: every configuration at <= 16 spp; round 1: the ones within 10 % of the best again at <= 64 spp
     for (int round = 0; round < 2 && e == hipSuccess; ++round) {
@@ -351,13 +351,13 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int cfg = tune_forced();
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     a.dl = dl ? 1 : 0;
-    if (dl) cfg = s->d.n_instances > 0 ? 3 : 5;          // direct lighting is compiled for lock step (+ stealing without instances) only
+    if (dl) cfg = 5;                                     // direct lighting is compiled for lock step + subtree stealing only
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
         cfg = s->tune_cfg;
     }
-    if (cfg < 0) cfg = s->d.n_instances > 0 ? 3 : 5;     // untuned (small job): lock step (+ subtree stealing), the usual winner
+    if (cfg < 0) cfg = 5;                                // untuned (small job): lock step + subtree stealing, the usual winner
     if (rd->count_work && !dl) cfg = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
@@ -461,7 +461,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
-    if (rd->integrator != HPT_INTEGRATOR_PATH) return s->d.n_instances > 0 ? 3 : 5;    // direct lighting: one configuration
+    if (rd->integrator != HPT_INTEGRATOR_PATH) return 5;    // direct lighting: one configuration
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);

@@ -128,9 +128,14 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // Must be called by ALL 64 lanes (has_ray = false for lanes with nothing to trace in this phase).  aux: five stack rows above
 // everything the walk uses (row aux: donor table).  Closest hits with exactly equal t (shared edges) are resolved by publishing
 // order here and by visiting order in the plain walk.
-#define HPT_STEAL_ROWS 5
-template <bool COUNT>
-__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux, TravCounters *cnt) {
+#define HPT_STEAL_ROWS 6
+// INST: animated instances (TransformedPrimitive, core/primitive.cpp:95-124).  A ray's OWNER walks the world tree and then, one after
+// the other, the tree of every instance whose motion bounds the (shrinking) ray still crosses, each in the instance's own space at
+// the ray's time (xf_cache: the per-path transform cache, or null -> anim_interpolate).  Helpers only ever walk the subtree they were
+// given, in whatever space the donor was in, and publish the instance number with the hit.
+template <bool COUNT, bool INST>
+__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
+                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
@@ -139,6 +144,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
     TravState ts;
     Ray r = ray;
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
+    // instances: the segment this lane's OWN ray is in (-1 world, k instance k, n_inst: all done) and the instance of the tree being walked
+    const int n_inst = INST ? sc.n_instances : 0;
+    int seg = (INST && has_ray) ? -1 : n_inst, cur_inst = -1;
     if (has_ray) trav_begin(sc, ts, r, anyhit, sc.world_root, true);
     else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
     HPT_AUX(aux + 1, lane) = as_int(r.maxt);                        // r.maxt >= 0: float order == unsigned order of the bits
@@ -146,7 +154,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
     HPT_WAVE_SYNC();
     for (;;) {
         const bool busy = ts.node != HPT_TRAV_EMPTY;
-        const bool any_busy = __ballot(busy) != 0ull;
+        const bool any_busy = __ballot(busy || seg < n_inst) != 0ull;
         if (busy) trav_step<COUNT>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
         // (after every step — measured: every 16 / 8 / 4 / 2 / 1 steps = 612 / 660 / 708 / 775 / 800 Msamples/s on killeroo —
         //  but only the parts that have something to do: a publish when some lane found a hit, a steal when some lane idles)
@@ -162,6 +170,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
             const int shared = HPT_AUX(aux + 1, owner);
             if (found && !ts.anyhit && as_int(ts.hit.t) == shared) {    // this lane holds the group's nearest hit so far
                 HPT_AUX(aux + 2, owner) = as_int(ts.hit.b1); HPT_AUX(aux + 3, owner) = as_int(ts.hit.b2); HPT_AUX(aux + 4, owner) = ts.hit.prim;
+                if (INST) HPT_AUX(aux + 5, owner) = cur_inst;
             }
             ts.hit.prim = -1;                                           // published (or beaten)
             if (ts.node != HPT_TRAV_EMPTY) {
@@ -170,10 +179,32 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
             }
             if (!any_busy) break;                                       // (the last publish has just happened)
         }
+        if (INST && ts.node == HPT_TRAV_EMPTY && seg < n_inst) {
+            // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
+            const int shared = HPT_AUX(aux + 1, lane);                  // (seg < n_inst only on the owner: owner == lane)
+            ++seg;
+            if (anyhit && shared == 0) seg = n_inst;
+            if (seg < n_inst) {
+                const hpt_instance &in = sc.instances[seg];
+                Ray rw = ray; rw.maxt = anyhit ? ray.maxt : fminf(ray.maxt, as_float(shared));
+                const float big = 3.402823466e+38f;
+                f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
+                float tentry;
+                if (sc.inst_root[seg] >= 0 && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
+                    M4 w2p;
+                    if (xf_cache) { for (int j = 0; j < 16; ++j) w2p.m[j] = xf_cache[(int64_t)(16 * seg + j) * xf_stride]; }
+                    else w2p = anim_interpolate(in, time, false).m;
+                    r.o = xf_point(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
+                    trav_begin(sc, ts, r, anyhit, sc.inst_root[seg], false);
+                    cur_inst = seg; sb = 0;
+                }
+            }
+        }
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
+        const bool idle = !still && seg >= n_inst;
         const bool donor = still && ts.sp >= 1;
-        const unsigned long long mi = __ballot(!still), md = __ballot(donor);
+        const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
         const int nd = __popcll(md);
         if (nd < n) n = nd;
@@ -186,7 +217,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
             ++sb; --ts.sp;
         }
         HPT_WAVE_SYNC();
-        const bool take = !still && ri < n;
+        const bool take = idle && ri < n;
         const int src = take ? HPT_AUX(aux, ri) : lane;
         // the donor's ray and bookkeeping, through cross-lane shuffles executed by every lane
         const float ox = __shfl(r.o.x, src), oy = __shfl(r.o.y, src), oz = __shfl(r.o.z, src);
@@ -194,9 +225,10 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
         const float mint = __shfl(r.mint, src), maxt = __shfl(r.maxt, src);
         const float ix = __shfl(ts.invd.x, src), iy = __shfl(ts.invd.y, src), iz = __shfl(ts.invd.z, src);
         const int any_s = __shfl((int)ts.anyhit, src), own_s = __shfl(owner, src), node_s = __shfl(give, src);
+        const int inst_s = INST ? __shfl(cur_inst, src) : -1;
         if (take) {
             r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
-            ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s;
+            ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s; cur_inst = inst_s;
             ts.node = node_s; ts.sp = 0; sb = 0;
         }
     }
@@ -208,6 +240,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, bool 
         if (anyhit) { if (shared == 0) hit->prim = 0; }
         else if (HPT_AUX(aux + 4, lane) >= 0) {
             hit->t = as_float(shared); hit->b1 = as_float(HPT_AUX(aux + 2, lane)); hit->b2 = as_float(HPT_AUX(aux + 3, lane)); hit->prim = HPT_AUX(aux + 4, lane);
+            if (INST) hit->inst = HPT_AUX(aux + 5, lane);
             ray.maxt = hit->t;
         }
     }
@@ -298,12 +331,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             while (__ballot(my_phase == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
-        if (STEAL && PHASED && !INST) {
+        if (STEAL && PHASED) {
             // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
             const bool tr = mine && (!DL || lane.stage != ST_SHADE);
             const bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse_steal<COUNT>(sc, lane.ray, anyhit, tr, &hit, stack, a.stack_entries - HPT_STEAL_ROWS, &tc);
+            traverse_steal<COUNT, INST>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, a.stack_entries - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
@@ -372,9 +405,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_STEAL(c) ((c) >= 5)
-#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, (INST) ? false : HPT_CFG_STEAL(C)>
+#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, HPT_CFG_STEAL(C)>
 // the direct-lighting integrator: lock step, 4 waves/SIMD, subtree stealing where there are no instances (configuration 5 / 3)
-#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true, !(INST)>
+#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true, true>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
@@ -400,8 +433,6 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (inst && cfg == 1) cfg = 0;                                                                              \
-        if (inst && cfg == 5) cfg = 3;                                                                              \
-        if (inst && cfg == 6) cfg = 4;                                                                              \
         switch (cfg) {                                                                                              \
             case 1: return launch_cfg_##NAME<1>(a, grid, inst, dyn_lds, s);                                                  \
             case 2: return launch_cfg_##NAME<2>(a, grid, inst, dyn_lds, s);                                                  \
@@ -417,8 +448,6 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     }                                                                                                               \
     int occupancy_##NAME(bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                             \
         if (inst && cfg == 1) cfg = 0;                                                                              \
-        if (inst && cfg == 5) cfg = 3;                                                                              \
-        if (inst && cfg == 6) cfg = 4;                                                                              \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
                        : cfg == 4 ? fn_cfg_##NAME<4>(inst) : cfg == 5 ? fn_cfg_##NAME<5>(inst) : cfg == 6 ? fn_cfg_##NAME<6>(inst) : fn_cfg_##NAME<0>(inst); \
         if (dl) fn = inst ? (const void *)HPT_DL_KERNEL(MATS, true, false) : (const void *)HPT_DL_KERNEL(MATS, false, false);      \
