@@ -278,17 +278,17 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         Ray &shadow = ray;
         const bool useArrays = bounce < 3;                                  // SAMPLE_DEPTH (path.h:55)
         if (sc.n_lights > 0) {                                              // UniformSampleOneLight
-            float ln, ls0, ls1, ls2, bs0, bs1, bs2;
+            // sample values are fetched right before their use (fewer registers live across the light sampling and the first
+            // BSDF evaluation); the rng draws of bounces >= 3 keep the reference's order: ln, ls0, ls1, ls2, then bs0, bs1, bs2
+            float ln, ls0, ls1, ls2, bs0 = 0.f, bs1 = 0.f, bs2 = 0.f;
             int lightPick = -1;
             if (DL) dl_samples(sc, rp, &lightPick, &ln, &ls0, &ls1, &ls2, &bs0, &bs1, &bs2);
             else if (useArrays) {
                 ln = smp.one(4 * bounce + 1);
                 smp.two(3 * bounce, &ls0, &ls1); ls2 = smp.one(4 * bounce);
-                smp.two(3 * bounce + 1, &bs0, &bs1); bs2 = smp.one(4 * bounce + 2);
             } else {
                 ln = smp.draw();
                 ls0 = smp.draw(); ls1 = smp.draw(); ls2 = smp.draw();
-                bs0 = smp.draw(); bs1 = smp.draw(); bs2 = smp.draw();
             }
             (void)ls2;
             int lightNum = (int)floorf(ln * sc.n_lights);
@@ -319,6 +319,10 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
                         }
                     }
                 }
+            }
+            if (!DL) {                                                      // (see above: fetched late)
+                if (useArrays) { smp.two(3 * bounce + 1, &bs0, &bs1); bs2 = smp.one(4 * bounce + 2); }
+                else { bs0 = smp.draw(); bs1 = smp.draw(); bs2 = smp.draw(); }
             }
             // BSDF-sampling half (integrator.cpp:145-172): C = f * Li * |wi.n| * w / pdf, added when the MIS ray
             // confirms that it reaches the light
