@@ -11,6 +11,7 @@ Cases (the shipped scene files select `SurfaceIntegrator "directlighting"` thems
   dl1     killeroo-simple.pbrt as shipped: strategy "all", area light nsamples 8; 128x128, 4 spp
   dlone   the same with "string strategy" "one"; 128x128, 4 spp
   dlb     bunny.pbrt with directlighting (measured BRDF; point light + disk area light); 120x68, 4 spp
+  dlbone  the same with "string strategy" "one" (two lights: the light-number sample matters); 120x68, 4 spp
   dlanim  anim-killeroos-moving.pbrt as shipped (animated instances, motion blur); 100x60, 4 spp
 """
 import gzip
@@ -99,6 +100,9 @@ def main():
                 'SurfaceIntegrator "directlighting"\n') % os.path.join(tmp, "dlb_ref.pfm")
         run_case("dlb", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
                  .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        run_case("dlbone", (head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF).replace('"brdfs/', '"%s/brdfs/' % REF))
+                 .replace("dlb_ref.pfm", "dlbone_ref.pfm").replace('SurfaceIntegrator "directlighting"', 'SurfaceIntegrator "directlighting" "string strategy" "one"'),
+                 tmp, "bunny_b8.hpts.gz")
         # bench workload: the shipped scene file at 1920x1080, its own integrator and sample counts (64 spp x 8 light samples)
         dump_view("killeroo_dl_1080p", sub(kill, 1920, 1080, 64, os.path.join(tmp, "x.pfm")), tmp, "killeroo_cfg1.hpts.gz")
         anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()

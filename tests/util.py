@@ -53,7 +53,8 @@ def load_case(name):
 
 CASES = ["cfg1", "k8", "b8", "env", "anim", "ms"]
 # SURVEY.md §8f-1 (tests/golden/make_golden_dl.py): DirectLightingIntegrator, strategy all / one
-DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "dlb": "bunny_b8.hpts.gz", "dlanim": "anim_killeroos.hpts.gz"}
+DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "dlb": "bunny_b8.hpts.gz", "dlbone": "bunny_b8.hpts.gz",
+            "dlanim": "anim_killeroos.hpts.gz"}
 
 
 def hash_rd(scene, seed=7, spp=None):
