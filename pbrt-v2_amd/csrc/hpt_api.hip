@@ -304,7 +304,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
             int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
             if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
             a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
-            for (int rep = 0; rep < 2 - round && e == hipSuccess; ++rep) { // a configuration's first launch also pays its code-object load
+            for (int rep = 0; rep < (round ? 3 : 2) && e == hipSuccess; ++rep) { // best of: a first launch also pays its code-object load; the finalists are within a few %
                 e = hipMemsetAsync(d_scr, 0, scr_bytes, stream);
                 if (e == hipSuccess) e = hipEventRecord(ev0, stream);
                 if (e == hipSuccess) e = launch_path_kernel(s->mats, a, grid, false, cfg, stream);
@@ -324,6 +324,9 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    // a tie between a 4-wave configuration and its 3-wave sibling (3/4, 5/6) goes to the sibling: on the full job — fewer, longer
+    // work items per lane than the probe's — the build that spills less has measured 3 % ahead whenever the probe saw them level
+    if (best_cfg == 3 || best_cfg == 5) { const int sib = best_cfg + 1; if (in_race[sib] && t[sib] <= 1.01f * t[best_cfg]) best_cfg = sib; }
     if (e == hipSuccess) s->tune_cfg = best_cfg < 0 ? 0 : best_cfg;
     return e;
 }
