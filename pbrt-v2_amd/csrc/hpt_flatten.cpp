@@ -126,9 +126,9 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             for (int k = 0; k < 6; ++k) out->fpool.push_back(data[6 * i + k]);
         }
         // starting-level table for irreg_f (hpt_device.h): the level k at which the reference's growing-radius
-        // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 16^3 grid over
+        // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 32^3 grid (HPT_KD_GRID) over
         // (sin*sin, dphi/pi, cos*cos) in [0,1] x [0,1] x [-1,1]; one byte per cell, four to a pool word
-        const int G = 16;
+        const int G = HPT_KD_GRID;
         std::vector<uint8_t> lev((size_t)G * G * G);
         for (int z = 0; z < G; ++z) for (int y = 0; y < G; ++y) for (int x = 0; x < G; ++x) {
             float q[3] = {(x + .5f) / G, (y + .5f) / G, -1.f + 2.f * (z + .5f) / G};
