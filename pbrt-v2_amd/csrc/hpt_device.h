@@ -699,7 +699,7 @@ HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
 // the sums of THAT pass (3.1 passes and 98 node visits per lookup on bunny.pbrt's BRDF).  The result
 // only depends on the final radius r_k, k = min{k : #(d2 < r_k) > 2}, and a pass at any radius visits
 // the samples in the same relative order (the order is a function of the query point alone; the radius
-// only prunes).  So the device starts at a guessed level g (a 32^3 table of the level at cell centres,
+// only prunes).  So the device starts at a guessed level g (a 64^3 table of the level at cell centres,
 // built at scene creation: hpt_flatten.cpp), tracks the third-smallest d2 of the pass, and sums for
 // r_g and r_(g-1) at once: k == g or g-1 ends after ONE pass with bit-identical sums, k < g-1 takes one
 // more (smaller) pass at r_k, k > g continues upwards like the reference (1.3 passes, 61 visits).
@@ -719,7 +719,7 @@ struct LaneStack {
     int qrow = 0;         // first stack row of the wave's query queue (path kernel only)
     const HPT_LDS uint64_t *kd_top = nullptr; const hpt_material *kd_top_mat = nullptr;
 };
-#define HPT_KD_GRID 32
+#define HPT_KD_GRID 64
 // The whole query — growing-radius passes included — as a resumable walk: kd_begin() positions it, each kd_step()
 // does ONE step of the current radius pass (descend into a child, or hand the node's sample to the accumulator and pop)
 // and, when the pass ends, decides like the reference's loop (reflection.cpp:262-271) whether another pass is needed.

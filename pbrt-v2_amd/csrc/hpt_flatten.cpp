@@ -2,6 +2,7 @@
 #include "hpt_flatten.h"
 
 #include <chrono>
+#include <thread>
 #include <utility>
 #include <vector>
 #include <cstring>
@@ -126,15 +127,26 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             for (int k = 0; k < 6; ++k) out->fpool.push_back(data[6 * i + k]);
         }
         // starting-level table for irreg_f (hpt_device.h): the level k at which the reference's growing-radius
-        // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 32^3 grid (HPT_KD_GRID) over
+        // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 64^3 grid (HPT_KD_GRID) over
         // (sin*sin, dphi/pi, cos*cos) in [0,1] x [0,1] x [-1,1]; one byte per cell, four to a pool word
         const int G = HPT_KD_GRID;
         std::vector<uint8_t> lev((size_t)G * G * G);
-        for (int z = 0; z < G; ++z) for (int y = 0; y < G; ++y) for (int x = 0; x < G; ++x) {
-            float q[3] = {(x + .5f) / G, (y + .5f) / G, -1.f + 2.f * (z + .5f) / G};
-            float r = .001f; int k = 0;
-            while (kd_count_within(split, bits, data, (uint32_t)ma.kd_nnodes, 0u, q, r, 3) <= 2 && !(r > 1.5f)) { r *= 2.f; ++k; }
-            lev[((size_t)z * G + y) * G + x] = (uint8_t)k;
+        {   // z-slices over the host's threads (the table is G^3 independent little queries)
+            unsigned nth = std::thread::hardware_concurrency();
+            if (nth < 1) nth = 1;
+            if (nth > 16) nth = 16;
+            const uint32_t nn = (uint32_t)ma.kd_nnodes;
+            auto work = [&](int z0, int z1) {
+                for (int z = z0; z < z1; ++z) for (int y = 0; y < G; ++y) for (int x = 0; x < G; ++x) {
+                    float q[3] = {(x + .5f) / G, (y + .5f) / G, -1.f + 2.f * (z + .5f) / G};
+                    float r = .001f; int k = 0;
+                    while (kd_count_within(split, bits, data, nn, 0u, q, r, 3) <= 2 && !(r > 1.5f)) { r *= 2.f; ++k; }
+                    lev[((size_t)z * G + y) * G + x] = (uint8_t)k;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nth; ++t) pool.emplace_back(work, (int)((int64_t)G * t / nth), (int)((int64_t)G * (t + 1) / nth));
+            for (auto &t : pool) t.join();
         }
         {   // depth of this tree (the device's walk keeps one stack entry per ancestor)
             std::vector<std::pair<uint32_t, int> > todo(1, std::make_pair(0u, 1));

@@ -21,7 +21,7 @@ struct FlatScene {
     // into 32-byte node records {splitPos, bits, p.xyz, v.rgb} appended to the pool (one sector per
     // node visit instead of three scattered loads); materials[i].kd_data_off then points at the
     // packed records (in floats, a multiple of 8), kd_split_off == HPT_KD_PACKED marks the form and
-    // kd_bits_off points at the 32^3 starting-level table of irreg_f (bytes, four to a pool word)
+    // kd_bits_off points at the 64^3 starting-level table of irreg_f (bytes, four to a pool word)
     std::vector<float> fpool;
     std::vector<hpt_material> materials;
     int64_t n_tris = 0;
