@@ -14,6 +14,7 @@
 #include "hpt_bvh.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -41,6 +42,7 @@ struct Builder {
     std::vector<BvhNode64> nodes;
     std::vector<uint32_t> order; // leaf order -> input triangle
     int maxLeaf, maxDepth, deepest;
+    int nbins = 16;     // SAH bins per axis (HPT_BVH_BINS, 4..64)
 
     static int ceil_log2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 
@@ -75,12 +77,13 @@ struct Builder {
             std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
                              [&](uint32_t a, uint32_t b) { return cent[3 * (size_t)a + dim] < cent[3 * (size_t)b + dim]; });
         } else {
-            const int NB = 16;
+            enum { NBMAX = 64 };
+            const int NB = nbins;
             float bestCost = std::numeric_limits<float>::infinity();
             int bestDim = -1, bestSplit = -1;
             for (int d = 0; d < 3; ++d) {
                 if (ext[d] <= 0.f) continue;
-                int cnt[NB]; Box bx[NB];
+                int cnt[NBMAX]; Box bx[NBMAX];
                 for (int b = 0; b < NB; ++b) { cnt[b] = 0; bx[b].reset(); }
                 float scale = NB / ext[d];
                 for (uint32_t i = start; i < end; ++i) {
@@ -89,7 +92,7 @@ struct Builder {
                     if (b < 0) b = 0;
                     cnt[b]++; bx[b].grow(boxes[idx[i]]);
                 }
-                float rightArea[NB]; int rightCnt[NB];
+                float rightArea[NBMAX]; int rightCnt[NBMAX];
                 Box acc; acc.reset(); int c = 0;
                 for (int b = NB - 1; b > 0; --b) { acc.grow(bx[b]); c += cnt[b]; rightArea[b] = acc.area(); rightCnt[b] = c; }
                 acc.reset(); c = 0;
@@ -144,6 +147,7 @@ void build_bvh(const BvhInputTri *tris, size_t n, int maxLeaf, int maxDepth, Bvh
     if (n == 0) return;
     Builder b;
     b.tris = tris; b.maxLeaf = std::min(std::max(maxLeaf, 1), 8); b.maxDepth = maxDepth; b.deepest = 0;
+    if (const char *e = getenv("HPT_BVH_BINS")) { int v = atoi(e); if (v >= 4 && v <= 64) b.nbins = v; }
     b.boxes.resize(n); b.cent.resize(3 * n); b.idx.resize(n);
     for (size_t i = 0; i < n; ++i) {
         Box bx; bx.reset();
