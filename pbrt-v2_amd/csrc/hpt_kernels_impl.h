@@ -6,14 +6,15 @@
 // hpt_path_kernel: ONE persistent-threads launch renders the whole frame.  Grid = (CUs x resident
 // blocks per CU) workgroups of 256 threads = 4 wave64; every wave loops
 //     refill idle lanes (one device-scope atomicAdd per wave, ballot + popcount prefix) ->
-//     one BVH traversal phase for whatever ray each lane has pending (closest- or any-hit) ->
-//     per-lane state machine step (hpt_path.h)
-// until the global work counter is exhausted and all 64 lanes are idle.  Lanes whose path ended
-// are refilled immediately ("path regeneration"), which is this design's form of wavefront
-// compaction: instead of squeezing live rays together between bounces, dead lanes are repopulated
-// in place, so the traversal loop always runs with a full exec mask.
-// Traversal stacks live in LDS, laid out stack[entry][thread] so that the 64 lanes of a wave
-// address 64 consecutive banks (conflict-free ds_read/ds_write_b32).
+//     one BVH traversal phase (free-running: whatever ray each lane has pending; lock step: the extension, shadow
+//     or MIS rays of the wave, optionally with idle lanes stealing subtrees from the long rays: traverse_steal) ->
+//     per-lane state machine step (hpt_path.h): shade_prepare -> wave-cooperative measured-BRDF queries -> shade_finish
+// until the global work counter is exhausted and all 64 lanes are idle.  Lanes whose path ended are refilled
+// immediately ("path regeneration"), which is this design's form of wavefront compaction: instead of squeezing
+// live rays together between bounces, dead lanes are repopulated in place and path state never travels through HBM.
+// Traversal stacks live in LDS (dynamic, sized per scene), laid out stack[row][thread] so that the 64 lanes of a
+// wave address 64 consecutive banks — and so that any lane can read any lane's stack (stealing, query queue).
+// Which schedule runs is a tuning configuration picked per scene (hpt_api.hip, autotune).
 // No MFMA anywhere: the workload is divergent pointer chasing, not a contraction.
 #ifndef HPT_KERNELS_IMPL_H
 #define HPT_KERNELS_IMPL_H

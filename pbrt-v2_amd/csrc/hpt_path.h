@@ -11,9 +11,11 @@
 // (any-hit), the MIS BSDF-sampled ray (closest-hit) and the continuation ray (closest-hit).  The
 // recursive reference interleaves shading and tracing; here ALL shading of a vertex (BSDF build,
 // light sampling, both BSDF samplings, Russian roulette) happens in one block right after the
-// closest hit, leaving only small "pending ray" records in registers.  The wave then runs ONE
-// traversal loop per iteration in which each lane traces whichever ray it has pending, so the
-// traversal — the part bound by memory latency — always runs with every lane populated.
+// closest hit, leaving only small "pending ray" records in registers; the kernel (hpt_kernels_impl.h) then
+// traces those rays either lane by lane as they come (free-running configurations) or phase by phase for the
+// whole wave (lock step), so that every live lane shades at once.  The BSDF VALUES of the vertex are kept apart
+// from the rest (shade_prepare / shade_finish): for a measured BRDF they are kd-tree queries the wave evaluates
+// cooperatively.  The direct-lighting integrator is the same machine with one more stage (Lane<..., DL>).
 // Random-number consumption order is kept identical to the reference (it matters for the
 // MT_REPLAY parity mode): light number, LightSample(3), BSDFSample(3), path BSDFSample(3), RR.
 #ifndef HPT_PATH_H
