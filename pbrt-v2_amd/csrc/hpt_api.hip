@@ -354,7 +354,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int cfg = tune_forced();
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     a.dl = dl ? 1 : 0;
-    if (dl) cfg = 5;                                     // direct lighting is compiled for lock step + subtree stealing only
+    if (dl) cfg = 6;                                     // direct lighting is compiled for lock step + subtree stealing at HPT_DL_WAVES = 3 waves/SIMD only
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
@@ -464,7 +464,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     if (!s || !cam || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (tune_forced() >= 0) return tune_forced();
-    if (rd->integrator != HPT_INTEGRATOR_PATH) return 5;    // direct lighting: one configuration
+    if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     int rc = fill_params(cam, rd, &a.rp);

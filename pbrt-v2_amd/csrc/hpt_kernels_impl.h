@@ -407,8 +407,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_STEAL(c) ((c) >= 5)
 #define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, HPT_CFG_STEAL(C)>
-// the direct-lighting integrator: lock step, 4 waves/SIMD, subtree stealing where there are no instances (configuration 5 / 3)
-#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, 4, 0, true, true, true>
+// the direct-lighting integrator: lock step + subtree stealing, HPT_DL_WAVES waves/SIMD
+#ifndef HPT_DL_WAVES
+#define HPT_DL_WAVES 3   /* measured on killeroo-simple.pbrt as shipped: 4 / 3 / 2 waves per SIMD = 374 / 461 / 384 M camera samples/s (lane utilisation is 69 % there: the spills cost more than the fourth wave hides) */
+#endif
+#define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
 // build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
