@@ -343,10 +343,10 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.sc = s->d;
     a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
     a.film = (float *)d_film;
-    struct Scratch { unsigned long long next_item; WorkCounters wc; };
+    struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
     Scratch *d_scr = nullptr;
     HIP_CHECK_RET(hipMalloc((void **)&d_scr, sizeof(Scratch)), HPT_E_HIP);
-    a.next_item = &d_scr->next_item;
+    a.next_item = d_scr->next_item;
     a.counters = &d_scr->wc;
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
     hipError_t e = hipSuccess;
@@ -377,7 +377,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
         float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
-        int wrc = render_wavefront(s, a, rd, stream, stats, &d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
+        int wrc = render_wavefront(s, a, rd, stream, stats, d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
         Scratch h_scr2; memset(&h_scr2, 0, sizeof(h_scr2));
         if (wrc == HPT_OK && hipMemcpy(&h_scr2, d_scr, sizeof(Scratch), hipMemcpyDeviceToHost) != hipSuccess) wrc = HPT_E_HIP;
         (void)hipFree(d_scr);
@@ -471,11 +471,11 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     a.sc = s->d;
-    struct Scratch { unsigned long long next_item; WorkCounters wc; };
+    struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
     DevBuf<Scratch> scr;
     DevBuf<float> filmbuf;
     if (!scr.alloc(1) || !filmbuf.alloc((size_t)4 * rd->x_count * rd->y_count)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
-    a.next_item = &scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p;
+    a.next_item = scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p;
     hipError_t e = autotune(s, cam, rd, a, scr.p, sizeof(Scratch), nullptr);
     if (e != hipSuccess) { hpt_set_error("autotune failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
     return s->tune_cfg;

@@ -15,7 +15,7 @@ struct PathKernelArgs {
     DScene sc;
     RenderParams rp;
     float *film;                    // x_count*y_count*4, zeroed before the launch
-    unsigned long long *next_item;  // global work counter, zeroed before the launch
+    unsigned long long *next_item;  // 8 work-queue heads (one per XCD, hpt_kernels_impl.h), zeroed before the launch
     WorkCounters *counters;         // only written by the COUNT instantiation
     // dynamic LDS of a workgroup: [traversal stacks: stack_entries x 256 x 4 B][kd head: kd_lds_nodes x 8 B]
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2, kd-tree depth + 1)

@@ -291,6 +291,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
     int phase = ST_EXTEND;         // wave-uniform (PHASED only)
+    int src = (int)(blockIdx.x & 7u);   // wave-uniform: the queue head this wave pulls from (its XCD's, until that runs dry)
+    unsigned dead_heads = 0u;
     // animated instances: WorldToPrimitive of every instance at the path's time, interpolated ONCE per camera sample into
     // this lane's column of a.inst_xf instead of once per ray and instance (slerp + two matrix products, ~400 instructions,
     // in an out-of-line call with the lane state spilled around it: 850 GB of scratch traffic per frame on anim-killeroos)
@@ -299,17 +301,25 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     float xf_time = -HPT_INF;
     for (;;) {
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
+        // Eight queue heads, one per XCD: the dispatcher is observed to put workgroup b on XCD b % 8 (a speed assumption only),
+        // each XCD has its own 4 MiB L2, and head k hands out the k-th eighth of the frame's 32x32 tiles (all their sample
+        // chunks), so an XCD's L2 sees the rays of one band of the image.  A wave whose own head has run dry takes from the
+        // next head that has not.
         for (;;) {
             bool need = (lane.stage == ST_IDLE) && !exhausted;
             if (__ballot(need) == 0ull) break;
-            int64_t item = wave_fetch(a.next_item, need);
-            if (need) {
-                if (item >= rp.n_items) exhausted = true;
-                else {
-                    int x, y; uint32_t s0;
-                    if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
-                }
+            if (dead_heads == 0xff) { if (need) exhausted = true; break; }
+            while ((dead_heads >> src) & 1) src = (src + 1) & 7;
+            const int64_t tiles = rp.items_per_pass >> 10, passes = rp.n_items / rp.items_per_pass;
+            const int64_t t0 = tiles * src / 8, per = ((tiles * (src + 1) / 8) - t0) << 10, lim = per * passes;
+            int64_t v = wave_fetch(a.next_item + src, need);
+            const bool over = need && v >= lim;
+            if (need && !over) {
+                const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
+                int x, y; uint32_t s0;
+                if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
+            if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }
         const bool active = lane.stage != ST_IDLE;
         if (INST && xf_col && active && lane.time != xf_time) {
