@@ -155,6 +155,10 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->seed = rd->seed;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
+    // per-XCD queue heads: same-box A/B killeroo +1.5 %, bunny +1.8 %, anim +4 %, soup -1.6 %, direct lighting -6 % (its work items are
+    // 17 rays x 64 samples long; bands of the image drain unevenly) -> on for the path integrator only; HPT_XCD_QUEUE=0/1 overrides
+    rp->n_heads = rd->integrator == HPT_INTEGRATOR_PATH ? 8 : 1;
+    if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;
     if (rd->integrator < HPT_INTEGRATOR_PATH || rd->integrator > HPT_INTEGRATOR_DIRECT_ONE) { hpt_set_error("unknown integrator %d", rd->integrator); return HPT_E_INVALID; }
     if (rd->integrator != HPT_INTEGRATOR_PATH && (rd->sampler_mode != HPT_SAMPLER_LD_HASH || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
         hpt_set_error("the direct-lighting integrator runs on the persistent kernel with the LD_HASH sampler (MT_REPLAY and the wavefront pipeline cover the path integrator)");

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
     int phase = ST_EXTEND;         // wave-uniform (PHASED only)
-    int src = (int)(blockIdx.x & 7u);   // wave-uniform: the queue head this wave pulls from (its XCD's, until that runs dry)
-    unsigned dead_heads = 0u;
+    int src = (int)(blockIdx.x & 7u) & (rp.n_heads - 1);   // wave-uniform: the queue head this wave pulls from (its XCD's, until that runs dry)
+    unsigned dead_heads = rp.n_heads == 8 ? 0u : 0xfeu;
     // animated instances: WorldToPrimitive of every instance at the path's time, interpolated ONCE per camera sample into
     // this lane's column of a.inst_xf instead of once per ray and instance (slerp + two matrix products, ~400 instructions,
     // in an out-of-line call with the lane state spilled around it: 850 GB of scratch traffic per frame on anim-killeroos)
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (dead_heads == 0xff) { if (need) exhausted = true; break; }
             while ((dead_heads >> src) & 1) src = (src + 1) & 7;
             const int64_t tiles = rp.items_per_pass >> 10, passes = rp.n_items / rp.items_per_pass;
-            const int64_t t0 = tiles * src / 8, per = ((tiles * (src + 1) / 8) - t0) << 10, lim = per * passes;
+            const int64_t t0 = tiles * src / rp.n_heads, per = ((tiles * (src + 1) / rp.n_heads) - t0) << 10, lim = per * passes;
             int64_t v = wave_fetch(a.next_item + src, need);
             const bool over = need && v >= lim;
             if (need && !over) {

@@ -36,6 +36,7 @@ struct RenderParams {
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
     int32_t has_motion;        // scene has animated instances: rays carry a time sample
     int32_t integrator;        // HPT_INTEGRATOR_*
+    int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
     int64_t n_items;           // items_per_pass x (spp / chunk)

@@ -59,6 +59,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->seed = rd->seed;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
+    rp->n_heads = 1;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
