@@ -259,6 +259,24 @@ int hpt_render_device(hpt_scene *scene, const hpt_camera *cam, const hpt_render_
  * hpt_render* of an untuned scene does the same; HPT_TUNE=<cfg> in the environment pins it. */
 int hpt_scene_tune(hpt_scene *scene, const hpt_camera *cam, const hpt_render_desc *rd);
 
+/* Pixel reconstruction filter.  Replaces ImageFilm's `Filter *filter` + `filterTable`
+ * (film/image.cpp:41-75): xwidth / ywidth are Filter::xWidth / yWidth, table[y * 16 + x] is
+ * filter->Evaluate((x + .5) * xwidth / 16, (y + .5) * ywidth / 16) — the host computes it from whatever Filter
+ * plugin the scene named (box, gaussian, mitchell, sinc, triangle), the device only looks weights up, exactly
+ * as ImageFilm::AddSample does (film/image.cpp:77-137).  The filter also widens the SAMPLE extent
+ * (ImageFilm::GetSampleExtent, film/image.cpp:157-166): camera samples are generated for pixels up to a filter
+ * radius outside [x_start, x_start + x_count), the film stays x_count * y_count.
+ * State of the scene handle, used by every later hpt_render* / hpt_scene_tune; NULL restores the default
+ * (box, width 0.5: a sample lands in its own pixel).  With a filter wider than 0.5 the shards of a multi-GPU
+ * render overlap at tile borders: each rank's film holds partial sums over the whole frame and the film
+ * exchange is a sum (reduce) instead of a gather. */
+#define HPT_FILTER_TABLE_SIZE 16
+typedef struct hpt_filter {
+    float xwidth, ywidth;
+    float table[HPT_FILTER_TABLE_SIZE * HPT_FILTER_TABLE_SIZE];
+} hpt_filter;
+int hpt_scene_set_filter(hpt_scene *scene, const hpt_filter *filter);
+
 /* ---- scene blob (serialised hpt_scene_desc + camera + render defaults); host only ------ */
 typedef struct hpt_blob hpt_blob;
 int hpt_blob_save(const char *path, const hpt_scene_desc *desc, const hpt_camera *cam,

@@ -31,6 +31,10 @@ void orc_scene_destroy(orc_scene *s);
 int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc *rd,
                float *film_xyzw, int nthreads, uint64_t *stats);
 
+/* The film's reconstruction filter for the following orc_render calls (process-wide; NULL = box of width 0.5):
+ * ImageFilm's filter + filterTable, film/image.cpp:41-75. */
+void orc_set_filter(const hpt_filter *f);
+
 /* Function-level entry points with the same array conventions as hpt_test_* (include/hpt.h). */
 int orc_intersect(const orc_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit,
                   int32_t *out_prim);

@@ -34,6 +34,8 @@ def lib():
         L.orc_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
         L.orc_mt_fill.argtypes = [C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_set_filter.argtypes = [C.POINTER(abi.Filter)]
+        L.orc_set_filter.restype = None
         _lib = L
     return _lib
 
@@ -54,7 +56,9 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, cam, rd, nthreads=0):
+    def render(self, cam, rd, nthreads=0, flt=None):
+        """flt: abi.Filter (ImageFilm's reconstruction filter) or None = box of width 0.5"""
+        lib().orc_set_filter(C.byref(flt) if flt is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         rc = lib().orc_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, nthreads,

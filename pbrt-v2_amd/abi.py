@@ -84,6 +84,78 @@ class RenderDesc(C.Structure):
                 ("pipeline", i32), ("integrator", i32)]
 
 
+class Filter(C.Structure):
+    """hpt_filter: Filter::xWidth / yWidth + ImageFilm::filterTable (film/image.cpp:56-68)"""
+    _fields_ = [("xwidth", f32), ("ywidth", f32), ("table", f32 * 256)]
+
+
+def make_filter(kind, xwidth=None, ywidth=None, **kw):
+    """hpt_filter for one of the reference's Filter plugins, with the plugin's default parameters
+    (filters/{box,gaussian,mitchell,triangle,sinc}.cpp Create*Filter) — what ImageFilm's constructor tabulates
+    (film/image.cpp:56-68): table[y][x] = Evaluate((x + .5) * xWidth / 16, (y + .5) * yWidth / 16).
+    The pbrt host plugin fills the table from the scene's own Filter object; this mirror serves tests and bench.py."""
+    import numpy as np
+    defaults = {"box": 0.5, "gaussian": 2.0, "mitchell": 2.0, "triangle": 2.0, "sinc": 4.0}
+    xw = np.float32(defaults[kind] if xwidth is None else xwidth)
+    yw = np.float32(defaults[kind] if ywidth is None else ywidth)
+    one = np.float32(1)
+    fx = (np.arange(16, dtype=np.float32) + np.float32(.5)) * xw / np.float32(16)
+    fy = (np.arange(16, dtype=np.float32) + np.float32(.5)) * yw / np.float32(16)
+    if kind == "box":
+        ex, ey = np.ones(16, np.float32), np.ones(16, np.float32)
+    elif kind == "gaussian":       # filters/gaussian.h:46-58
+        alpha = np.float32(kw.get("alpha", 2.0))
+        g = lambda d, w: np.maximum(np.float32(0), np.exp(-alpha * d * d, dtype=np.float32) - np.exp(-alpha * w * w, dtype=np.float32))
+        ex, ey = g(fx, xw), g(fy, yw)
+    elif kind == "mitchell":       # filters/mitchell.h:46-62
+        B = np.float32(kw.get("B", 1.0 / 3.0)); Cc = np.float32(kw.get("C", 1.0 / 3.0))
+        def m1(x):
+            x = np.abs(np.float32(2) * x)
+            far = ((-B - 6 * Cc) * x * x * x + (6 * B + 30 * Cc) * x * x + (-12 * B - 48 * Cc) * x + (8 * B + 24 * Cc)) * np.float32(1.0 / 6.0)
+            near = ((12 - 9 * B - 6 * Cc) * x * x * x + (-18 + 12 * B + 6 * Cc) * x * x + (6 - 2 * B)) * np.float32(1.0 / 6.0)
+            return np.where(x > 1, far, near).astype(np.float32)
+        ex, ey = m1(fx * (one / xw)), m1(fy * (one / yw))
+    elif kind == "triangle":       # filters/triangle.cpp:40-43
+        ex, ey = np.maximum(np.float32(0), xw - np.abs(fx)), np.maximum(np.float32(0), yw - np.abs(fy))
+    elif kind == "sinc":           # filters/sinc.h:49-57 (Lanczos-windowed sinc)
+        tau = np.float32(kw.get("tau", 3.0))
+        def s1(x):
+            x = np.abs(x)
+            xs = x * np.float32(np.pi)
+            sinc = np.where(x < 1e-5, one, np.sin(xs * tau) / np.where(xs * tau == 0, one, xs * tau))
+            lanc = np.where(x < 1e-5, one, np.sin(xs) / np.where(xs == 0, one, xs))
+            return np.where(x > 1, np.float32(0), sinc * lanc).astype(np.float32)
+        ex, ey = s1(fx * (one / xw)), s1(fy * (one / yw))
+    else:
+        raise ValueError(kind)
+    f = Filter()
+    f.xwidth, f.ywidth = float(xw), float(yw)
+    t = (ey[:, None].astype(np.float32) * ex[None, :].astype(np.float32)).astype(np.float32)
+    C.memmove(f.table, t.ctypes.data, 1024)
+    return f
+
+
+def filter_from_array(a):
+    """258 floats {xwidth, ywidth, table[256]} (the .filter sidecar the host plugin dumps) -> Filter"""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.size == 258
+    f = Filter()
+    C.memmove(C.addressof(f), a.ctypes.data, 258 * 4)
+    return f
+
+
+def sample_extent(rd, flt):
+    """ImageFilm::GetSampleExtent (film/image.cpp:157-166) -> (xs, xe, ys, ye)"""
+    import numpy as np
+    fl = lambda v: int(np.floor(np.float32(v)))
+    ce = lambda v: int(np.ceil(np.float32(v)))
+    xw = np.float32(flt.xwidth if flt is not None else 0.5); yw = np.float32(flt.ywidth if flt is not None else 0.5)
+    h = np.float32(0.5)
+    return (fl(np.float32(rd.x_start) + h - xw), ce(np.float32(rd.x_start) - h + np.float32(rd.x_count) + xw),
+            fl(np.float32(rd.y_start) + h - yw), ce(np.float32(rd.y_start) - h + np.float32(rd.y_count) + yw))
+
+
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("camera_samples", u64), ("closest_rays", u64),
                 ("shadow_rays", u64), ("nodes_visited", u64), ("tris_tested", u64),

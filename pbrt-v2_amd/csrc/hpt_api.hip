@@ -38,6 +38,7 @@ struct hpt_scene {
     int stack_entries;    // per-lane traversal stack entries this scene needs
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
+    float *d_ftable, *d_ftable_alloc; hpt_filter filter;         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
 };
 
 extern "C" int hpt_device_count(void) {
@@ -72,6 +73,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     hpt_scene *s = new hpt_scene();
     s->device = device;
     s->tune_cfg = -1;
+    s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
     hipDeviceProp_t prop;
@@ -140,7 +142,25 @@ extern "C" int hpt_scene_get_info(const hpt_scene *s, hpt_scene_info *info) {
     return HPT_OK;
 }
 
-static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
+// ImageFilm's filter + filterTable (film/image.cpp:41-75) as state of the scene handle; see include/hpt.h
+extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
+    if (!s) { hpt_set_error("null scene"); return HPT_E_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    if (!f) { s->d_ftable = nullptr; return HPT_OK; }       // the table's allocation stays with the scene
+    if (!(f->xwidth > 0.f) || !(f->ywidth > 0.f) || f->xwidth > 64.f || f->ywidth > 64.f) { hpt_set_error("filter widths must be in (0, 64]"); return HPT_E_INVALID; }
+    for (int i = 0; i < HPT_FILTER_TABLE_SIZE * HPT_FILTER_TABLE_SIZE; ++i)
+        if (!(f->table[i] == f->table[i]) || f->table[i] > 3.0e38f || f->table[i] < -3.0e38f) { hpt_set_error("filter table entry %d is not finite", i); return HPT_E_INVALID; }
+    float *d = s->d_ftable_alloc;
+    if (!d) {
+        HIP_CHECK_RET(hipMalloc((void **)&d, sizeof(f->table)), HPT_E_HIP);
+        s->allocs.push_back(d); s->d_ftable_alloc = d;
+    }
+    HIP_CHECK_RET(hipMemcpy(d, f->table, sizeof(f->table), hipMemcpyHostToDevice), HPT_E_HIP);
+    s->filter = *f; s->d_ftable = d;
+    return HPT_OK;
+}
+
+static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp, const hpt_scene *s = nullptr) {
     if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
     if (rd->spp <= 0 || (rd->spp & (rd->spp - 1))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
@@ -167,7 +187,19 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     if (rp->shard_rank < 0 || rp->shard_rank >= rp->shard_count) { hpt_set_error("bad shard rank"); return HPT_E_INVALID; }
-    rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
+    // ImageFilm::GetSampleExtent (film/image.cpp:157-166); the default box of width 0.5 gives the pixel extent back
+    rp->ftable = nullptr; rp->fxw = rp->fyw = 0.5f; rp->finvx = rp->finvy = 2.f;
+    rp->sx_start = rd->x_start; rp->sx_count = rd->x_count; rp->sy_start = rd->y_start; rp->sy_count = rd->y_count;
+    if (s && s->d_ftable) {
+        rp->ftable = s->d_ftable; rp->fxw = s->filter.xwidth; rp->fyw = s->filter.ywidth;
+        rp->finvx = 1.f / rp->fxw; rp->finvy = 1.f / rp->fyw;
+        rp->sx_start = (int)floorf((float)rd->x_start + 0.5f - rp->fxw);
+        rp->sx_count = (int)ceilf((float)rd->x_start - 0.5f + (float)rd->x_count + rp->fxw) - rp->sx_start;
+        rp->sy_start = (int)floorf((float)rd->y_start + 0.5f - rp->fyw);
+        rp->sy_count = (int)ceilf((float)rd->y_start - 0.5f + (float)rd->y_count + rp->fyw) - rp->sy_start;
+        if (rp->sx_count <= 0 || rp->sy_count <= 0) { hpt_set_error("filter narrower than a pixel leaves no samples"); return HPT_E_INVALID; }
+    }
+    rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
     // a pixel's samples are split into items of `chunk` samples: keeps items small next to the job
@@ -282,7 +314,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     // the probe: every 9th 32x32 tile of the whole frame (the tile sharding of the multi-GPU path picks them), so
     // that it sees the same mix of rays as the job — a crop of the image centre mispredicted killeroo-simple
     hpt_render_desc prd = *rd;
-    int64_t tiles = (int64_t)((rd->x_count + 31) / 32) * ((rd->y_count + 31) / 32);
+    int64_t tiles = (int64_t)a.rp.n_stx * a.rp.n_sty;   // of the sample extent (fill_params)
     prd.shard_count = tiles >= 9 * 32 ? 9 : tiles >= 4 * 32 ? 4 : 1;
     prd.shard_rank = prd.shard_count / 2; prd.count_work = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -297,7 +329,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     for (int round = 0; round < 2 && e == hipSuccess; ++round) {
         prd.spp = rd->spp < (round ? 64 : 16) ? rd->spp : (round ? 64 : 16);
         if (round == 1 && prd.spp <= 16) break;
-        if (fill_params(cam, &prd, &a.rp) != HPT_OK) { e = hipErrorInvalidValue; break; }
+        if (fill_params(cam, &prd, &a.rp, s) != HPT_OK) { e = hipErrorInvalidValue; break; }
         a.rp.has_motion = inst ? 1 : 0;
         if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * (prd.spp / 4); }
         for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
@@ -340,7 +372,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
-    int rc = fill_params(cam, rd, &a.rp);
+    int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     hipStream_t stream = (hipStream_t)stream_v;
@@ -360,7 +392,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.dl = dl ? 1 : 0;
     if (dl) cfg = 6;                                     // direct lighting is compiled for lock step + subtree stealing at HPT_DL_WAVES = 3 waves/SIMD only
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
-        if (s->tune_cfg < 0 && (int64_t)rd->x_count * rd->y_count * rd->spp >= ((int64_t)32 << 20))
+        if (s->tune_cfg < 0 && (int64_t)a.rp.sx_count * a.rp.sy_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
         cfg = s->tune_cfg;
     }
@@ -389,13 +421,13 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             stats->kernel_ms = wms;
-            stats->camera_samples = (uint64_t)rd->x_count * rd->y_count * rd->spp;
+            stats->camera_samples = (uint64_t)a.rp.sx_count * a.rp.sy_count * rd->spp;
             if (rd->shard_count > 1) {
                 uint64_t px = 0; int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
                 for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
                     int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
-                    int w = rd->x_count - x0; if (w > 32) w = 32;
-                    int h = rd->y_count - y0; if (h > 32) h = 32;
+                    int w = a.rp.sx_count - x0; if (w > 32) w = 32;
+                    int h = a.rp.sy_count - y0; if (h > 32) h = 32;
                     px += (uint64_t)w * (uint64_t)h;
                 }
                 stats->camera_samples = px * (uint64_t)rd->spp;
@@ -448,8 +480,8 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
         for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
             int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
-            int w = rd->x_count - x0; if (w > 32) w = 32;
-            int h = rd->y_count - y0; if (h > 32) h = 32;
+            int w = a.rp.sx_count - x0; if (w > 32) w = 32;
+            int h = a.rp.sy_count - y0; if (h > 32) h = 32;
             px += (uint64_t)w * (uint64_t)h;
         }
         stats->camera_samples = px * (uint64_t)rd->spp;
@@ -471,7 +503,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
-    int rc = fill_params(cam, rd, &a.rp);
+    int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     a.sc = s->d;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
     TileWalk tw; tw.started = false; tw.x0 = tw.x1 = tw.y0 = tw.y1 = tw.x = tw.y = 0;
     bool exhausted = gid >= ra.ntasks;
     if (!exhausted) {
-        compute_sub_window(rp.x_start, rp.x_start + rp.x_count, rp.y_start, rp.y_start + rp.y_count, (int)gid, ra.ntasks,
+        compute_sub_window(rp.sx_start, rp.sx_start + rp.sx_count, rp.sy_start, rp.sy_start + rp.sy_count, (int)gid, ra.ntasks,
                            &tw.x0, &tw.x1, &tw.y0, &tw.y1);
         lane.smp.seed((uint32_t)gid);                       // RNG rng(taskNum), samplerrenderer.cpp:168
     }

@@ -30,10 +30,14 @@ enum { ST_IDLE = 0, ST_EXTEND = 1, ST_SHADOW = 2, ST_MIS = 3,
 struct RenderParams {
     hpt_camera cam;
     int32_t xres, yres, x_start, x_count, y_start, y_count;
+    int32_t sx_start, sx_count, sy_start, sy_count;   // sample extent (ImageFilm::GetSampleExtent): the pixel extent
+                                                      // grown by the filter radius; equal to it for the default box
+    const float *ftable;       // 16x16 filter weights in HBM; nullptr: box filter of width 0.5 (fast path)
+    float fxw, fyw, finvx, finvy;   // Filter::xWidth, yWidth, invXWidth, invYWidth
     int32_t spp, maxdepth;
     uint32_t seed;
     int32_t shard_rank, shard_count;
-    int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the pixel extent
+    int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
     int32_t has_motion;        // scene has animated instances: rays carry a time sample
     int32_t integrator;        // HPT_INTEGRATOR_*
     int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
@@ -48,8 +52,37 @@ struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
 #if defined(__HIPCC__)
 HPT_FN void film_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
 #else
-HPT_FN void film_atomic_add(float *p, float v) { *p += v; }
+HPT_FN void film_atomic_add(float *p, float v) {   // tests/hostemu: OpenMP threads stand in for the lanes
+#ifdef _OPENMP
+#pragma omp atomic
 #endif
+    *p += v;
+}
+#endif
+
+// ImageFilm::AddSample for a filter from the table (film/image.cpp:77-137): every pixel within the filter's width of
+// the sample gets weight table[ify * 16 + ifx].  Inlined: as a call it cost every kernel 350-400 B of scratch per lane
+// (the path state spilled around the call site); inlined, the box fast path of Lane::finish_path pays nothing.
+HPT_FN void film_splat_table(const RenderParams &rp, float *film, float imgx, float imgy, float X, float Y, float Z) {
+    float dimageX = imgx - 0.5f, dimageY = imgy - 0.5f;
+    int x0 = (int)ceilf(dimageX - rp.fxw), x1 = (int)floorf(dimageX + rp.fxw);
+    int y0 = (int)ceilf(dimageY - rp.fyw), y1 = (int)floorf(dimageY + rp.fyw);
+    if (x0 < rp.x_start) x0 = rp.x_start;
+    if (x1 > rp.x_start + rp.x_count - 1) x1 = rp.x_start + rp.x_count - 1;
+    if (y0 < rp.y_start) y0 = rp.y_start;
+    if (y1 > rp.y_start + rp.y_count - 1) y1 = rp.y_start + rp.y_count - 1;
+    for (int y = y0; y <= y1; ++y) {
+        float fy = fabsf((y - dimageY) * rp.finvy * 16.f);
+        int iy = (int)floorf(fy); if (iy > 15) iy = 15;
+        for (int x = x0; x <= x1; ++x) {
+            float fx = fabsf((x - dimageX) * rp.finvx * 16.f);
+            int ix = (int)floorf(fx); if (ix > 15) ix = 15;
+            float wt = rp.ftable[iy * 16 + ix];
+            float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+            film_atomic_add(f + 0, wt * X); film_atomic_add(f + 1, wt * Y); film_atomic_add(f + 2, wt * Z); film_atomic_add(f + 3, wt);
+        }
+    }
+}
 
 // Work item -> pixel.  Items enumerate this shard's 32x32 super-tiles (round-robin over shards),
 // inside a super-tile 8x8 micro-tiles, inside a micro-tile row-major pixels: 64 consecutive items
@@ -67,8 +100,8 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
     int micro = r >> 6, p = r & 63;
     int x = (int)(st % rp.n_stx) * 32 + (micro & 3) * 8 + (p & 7);
     int y = (int)(st / rp.n_stx) * 32 + (micro >> 2) * 8 + (p >> 3);
-    if (x >= rp.x_count || y >= rp.y_count) return false;
-    *px = rp.x_start + x; *py = rp.y_start + y;
+    if (x >= rp.sx_count || y >= rp.sy_count) return false;
+    *px = rp.sx_start + x; *py = rp.sy_start + y;
     return true;
 }
 
@@ -161,6 +194,18 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         float ia, ib;
         smp.image(&ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
         float imgx = px + ia, imgy = py + ib;
+        float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
+        float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
+        float Z = 0.019334f * Ls.x + 0.119193f * Ls.y + 0.950227f * Ls.z;
+        if (rp.ftable) {   // a filter from the table (uniform branch): all pixels under it, straight to the film
+            film_splat_table(rp, film, imgx, imgy, X, Y, Z);
+            if (wc) wc->samples++;
+            ++si;
+            if (si < s_end) { begin_sample(rp); return; }
+            stage = ST_IDLE;
+            smp.end_pixel(rp);
+            return;
+        }
         float dimageX = imgx - 0.5f, dimageY = imgy - 0.5f;
         int x0 = (int)ceilf(dimageX - 0.5f), x1 = (int)floorf(dimageX + 0.5f);
         int y0 = (int)ceilf(dimageY - 0.5f), y1 = (int)floorf(dimageY + 0.5f);
@@ -168,9 +213,6 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         if (x1 > rp.x_start + rp.x_count - 1) x1 = rp.x_start + rp.x_count - 1;
         if (y0 < rp.y_start) y0 = rp.y_start;
         if (y1 > rp.y_start + rp.y_count - 1) y1 = rp.y_start + rp.y_count - 1;
-        float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
-        float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
-        float Z = 0.019334f * Ls.x + 0.119193f * Ls.y + 0.950227f * Ls.z;
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x) {
                 if (x == px && y == py) { fX += X; fY += Y; fZ += Z; fW += 1.f; }

@@ -10,7 +10,7 @@
 //   Materials: MatteMaterial, PlasticMaterial, MeasuredMaterial (materials/*.h) with
 //     ConstantTexture values (textures/constant.h:45-55)
 //   Lights: PointLight, DiffuseAreaLight(+ShapeSet), InfiniteAreaLight(+MIPMap, Distribution2D)
-//   PerspectiveCamera (RasterToCamera, CameraToWorld), ImageFilm (pixel extent, box filter),
+//   PerspectiveCamera (RasterToCamera, CameraToWorld), ImageFilm (pixel extent, filter table),
 //   LDSampler (nPixelSamples), PathIntegrator (maxDepth) or DirectLightingIntegrator (strategy; Light::nSamples)
 // Anything else is outside the hot-path scope and is rejected with Severe().
 #include "stdafx.h"
@@ -408,10 +408,15 @@ void HipPathRenderer::Render(const Scene *scene) {
         Severe("hip renderer: animated cameras are outside the hot-path scope");
     ImageFilm *film = dynamic_cast<ImageFilm *>(camera->film);
     if (!film) Severe("hip renderer: Film must be \"image\"");
+    // PixelFilter: any Filter plugin.  The device looks weights up in ImageFilm's own 16x16 table (film/image.cpp:56-68),
+    // so the floats it uses are the ones this build's filter->Evaluate produced.  The default box of width 0.5 (every
+    // sample lands in its own pixel) keeps the table-free fast path.
     const BoxFilter *box = dynamic_cast<const BoxFilter *>(film->filter);
-    if (!box || box->xWidth != 0.5f || box->yWidth != 0.5f)
-        Severe("hip renderer: PixelFilter must be \"box\" with the default width 0.5 "
-               "(wider filters are a \"next\" row, SURVEY.md §8f-4)");
+    const bool defaultBox = box && box->xWidth == 0.5f && box->yWidth == 0.5f;
+    hpt_filter flt;
+    memset(&flt, 0, sizeof(flt));
+    flt.xwidth = film->filter->xWidth; flt.ywidth = film->filter->yWidth;
+    memcpy(flt.table, film->filterTable, sizeof(flt.table));
     const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
     if (!lds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
@@ -451,12 +456,19 @@ void HipPathRenderer::Render(const Scene *scene) {
     if (dumpPath != "") {
         if (hpt_blob_save(dumpPath.c_str(), &desc, &cam, &rd) != HPT_OK)
             Severe("hip renderer: %s", hpt_last_error());
+        if (!defaultBox) {   // sidecar: 258 floats {xwidth, ywidth, table[256]} = hpt_filter
+            string fpath = dumpPath + ".filter";
+            FILE *ff = fopen(fpath.c_str(), "wb");
+            if (!ff || fwrite(&flt, sizeof(flt), 1, ff) != 1) Severe("hip renderer: cannot write %s", fpath.c_str());
+            fclose(ff);
+        }
         Info("hip renderer: scene blob written to %s; not rendering", dumpPath.c_str());
         return;
     }
 
     hpt_scene *hs = hpt_scene_create(&desc, device);
     if (!hs) Severe("hip renderer: %s", hpt_last_error());
+    if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
     std::vector<float> xyzw(4 * (size_t)rd.x_count * rd.y_count);
     hpt_stats st;
     ProgressReporter reporter(1, "Rendering (HIP)");

@@ -18,7 +18,7 @@ _lib = None
 
 EXPORTS = [
     "hpt_device_count", "hpt_last_error", "hpt_scene_create", "hpt_scene_destroy",
-    "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_scene_tune", "hpt_blob_save", "hpt_blob_load",
+    "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_scene_tune", "hpt_scene_set_filter", "hpt_blob_save", "hpt_blob_load",
     "hpt_blob_scene", "hpt_blob_camera", "hpt_blob_render", "hpt_blob_free",
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
 ]
@@ -53,6 +53,7 @@ def lib():
         L.hpt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc),
                                         C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.hpt_scene_tune.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc)]
+        L.hpt_scene_set_filter.argtypes = [C.c_void_p, C.POINTER(abi.Filter)]
         L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.hpt_test_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -101,6 +102,10 @@ class DeviceScene:
         if rc < 0:
             _check(rc)
         return rc
+
+    def set_filter(self, flt):
+        """ImageFilm's reconstruction filter for the following renders (abi.Filter; None = box of width 0.5)."""
+        _check(lib().hpt_scene_set_filter(self.h, C.byref(flt) if flt is not None else None))
 
     def render(self, cam, rd):
         """-> (film (H, W, 4) float32 {X,Y,Z,weight}, Stats).  Film copied to host."""

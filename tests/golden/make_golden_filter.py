@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Golden fixtures of the reconstruction filters, from the REAL reference.
+
+Same procedure as make_golden.py / make_golden_dl.py (build container only): each case's scene file is rendered
+by oracle/_ref/pbrt (-> *.ref.npy.gz) and flattened by pbrt_hip with HPT_DUMP_SCENE, which also writes the
+film's filter — widths + ImageFilm::filterTable as this build of the reference computed it — to <blob>.filter.
+The geometry of these cases is already committed, so only camera, render descriptor, light records and the
+258 filter floats are stored in <case>.view.npz.
+
+Cases (`PixelFilter` added to the shipped scene files)
+  fgauss  killeroo-simple, path maxdepth 3, "gaussian" (defaults: width 2 x 2, alpha 2); 128x128, 4 spp
+  fmitch  bunny, path maxdepth 8, "mitchell" xwidth 3 ywidth 2.5 (negative lobes, unequal widths); 120x68, 4 spp
+  ftri    killeroo-simple as shipped (directlighting) with cropwindow [.25 .75 .3 .8] and "triangle" xwidth 1.5
+          ywidth 1: sample extent inside the image, pixel extent not at the origin; 128x128, 4 spp
+  fsinc   anim-killeroos-moving, path maxdepth 5, "sinc" (defaults: width 4 x 4, tau 3); 100x60, 4 spp
+"""
+import gzip
+import importlib
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+abi = importlib.import_module("pbrt-v2_amd.abi")
+film = importlib.import_module("pbrt-v2_amd.film")
+
+REF = "/root/reference/scenes"
+PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+PBRT_HIP = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+
+
+def sub(text, xres, yres, spp, out_pfm, pixel_filter, integrator=None, film_extra=""):
+    text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
+    text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
+    if '"string filename"' in text:
+        text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_pfm, text)
+        text = re.sub(r'Film "image"', '%s\nFilm "image" %s' % (pixel_filter, film_extra), text, count=1)
+    else:
+        text = re.sub(r'Film "image"', '%s\nFilm "image" "string filename" "%s" %s' % (pixel_filter, out_pfm, film_extra), text, count=1)
+    text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+    if integrator:
+        text = text.replace('SurfaceIntegrator "directlighting"', integrator)
+    text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
+    text = text.replace('"brdfs/', '"%s/brdfs/' % REF)
+    return text
+
+
+def run_case(name, pbrt_text, tmp, geometry_blob):
+    scene_path = os.path.join(tmp, name + ".pbrt")
+    with open(scene_path, "w") as f:
+        f.write(pbrt_text)
+    subprocess.check_call([PBRT, "--quiet", "--ncores", "1", scene_path], stderr=subprocess.DEVNULL)
+    blob = os.path.join(tmp, name + ".hpts")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", scene_path], env=env, stderr=subprocess.DEVNULL)
+    ref = film.read_pfm(os.path.join(tmp, name + "_ref.pfm"))
+    with open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+        np.save(f, ref)
+    v = abi.Scene.load(blob)
+    g = abi.Scene.load(os.path.join(HERE, geometry_blob))
+    for sc in (v, g):   # a kd-tree leaf's split position is uninitialised memory in the reference (never read): mask it
+        for m in sc.materials:
+            if m.kind == abi.HPT_MAT_MEASURED_IRREG:
+                leaf = (sc.ipool[m.kd_bits_off:m.kd_bits_off + m.kd_nnodes] & 3) == 3
+                sc.fpool[m.kd_split_off:m.kd_split_off + m.kd_nnodes][leaf] = 0.0
+    assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool), "geometry differs from " + geometry_blob
+    flt = np.fromfile(blob + ".filter", dtype=np.float32)
+    assert flt.size == 258
+    np.savez(os.path.join(HERE, name + ".view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
+             render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8),
+             filter=flt)
+    print(name, "integrator", v.render.integrator, "extent", v.render.x_start, v.render.x_count, v.render.y_start, v.render.y_count,
+          "filter widths", flt[0], flt[1], "table", flt[2:].min(), flt[2:].max(), ref.shape)
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        kill = open(os.path.join(REF, "killeroo-simple.pbrt")).read()
+        run_case("fgauss", sub(kill, 128, 128, 4, os.path.join(tmp, "fgauss_ref.pfm"), 'PixelFilter "gaussian"',
+                               'SurfaceIntegrator "path" "integer maxdepth" [3]'), tmp, "killeroo_cfg1.hpts.gz")
+        run_case("ftri", sub(kill, 128, 128, 4, os.path.join(tmp, "ftri_ref.pfm"),
+                             'PixelFilter "triangle" "float xwidth" [1.5] "float ywidth" [1]',
+                             film_extra='"float cropwindow" [.25 .75 .3 .8]'), tmp, "killeroo_cfg1.hpts.gz")
+        bunny = open(os.path.join(REF, "bunny.pbrt")).read().split("\n", 2)[2]  # drop the 2 Film lines
+        head = ('PixelFilter "mitchell" "float xwidth" [3] "float ywidth" [2.5]\n'
+                'Film "image" "integer xresolution" [120] "integer yresolution" [68] "string filename" "%s"\n'
+                'Sampler "lowdiscrepancy" "integer pixelsamples" [4]\n'
+                'SurfaceIntegrator "path" "integer maxdepth" [8]\n') % os.path.join(tmp, "fmitch_ref.pfm")
+        run_case("fmitch", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
+                 .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
+        run_case("fsinc", sub(anim, 100, 60, 4, os.path.join(tmp, "fsinc_ref.pfm"), 'PixelFilter "sinc"',
+                              'SurfaceIntegrator "path" "integer maxdepth" [5]'), tmp, "anim_killeroos.hpts.gz")
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,8 @@ def lib():
         L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
+        L.emu_set_filter.restype = None
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -43,7 +45,8 @@ class EmuScene:
         lib().emu_scene_info(self.h, out.ctypes.data)
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2])}
 
-    def render(self, cam, rd):
+    def render(self, cam, rd, flt=None):
+        lib().emu_set_filter(C.byref(flt) if flt is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         fn = lib().emu_render_replay if rd.sampler_mode == abi.HPT_SAMPLER_MT_REPLAY else lib().emu_render

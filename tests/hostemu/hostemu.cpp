@@ -52,6 +52,10 @@ extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
     out[0] = s->fs.n_tris; out[1] = (int64_t)s->fs.nodes.size(); out[2] = s->fs.max_depth;
 }
 
+// hpt_scene_set_filter's stand-in (process-wide; NULL = box of width 0.5)
+static hpt_filter g_filter; static bool g_filter_set = false;
+extern "C" void emu_set_filter(const hpt_filter *f) { g_filter_set = f != nullptr; if (f) g_filter = *f; }
+
 static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
     rp->cam = *cam;
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
@@ -62,7 +66,17 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->n_heads = 1;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
-    rp->n_stx = (rd->x_count + 31) / 32; rp->n_sty = (rd->y_count + 31) / 32;
+    rp->ftable = nullptr; rp->fxw = rp->fyw = 0.5f; rp->finvx = rp->finvy = 2.f;
+    rp->sx_start = rd->x_start; rp->sx_count = rd->x_count; rp->sy_start = rd->y_start; rp->sy_count = rd->y_count;
+    if (g_filter_set) {   // as fill_params of csrc/hpt_api.hip
+        rp->ftable = g_filter.table; rp->fxw = g_filter.xwidth; rp->fyw = g_filter.ywidth;
+        rp->finvx = 1.f / rp->fxw; rp->finvy = 1.f / rp->fyw;
+        rp->sx_start = (int)floorf((float)rd->x_start + 0.5f - rp->fxw);
+        rp->sx_count = (int)ceilf((float)rd->x_start - 0.5f + (float)rd->x_count + rp->fxw) - rp->sx_start;
+        rp->sy_start = (int)floorf((float)rd->y_start + 0.5f - rp->fyw);
+        rp->sy_count = (int)ceilf((float)rd->y_start - 0.5f + (float)rd->y_count + rp->fyw) - rp->sy_start;
+    }
+    rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
     rp->items_per_pass = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
@@ -126,7 +140,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
         Lane<MtReplaySrc, true, MATS_ALL> lane; lane.init();
         lane.smp.mt = mt.data(); lane.smp.buf = buf.data(); lane.smp.stride = 1; lane.smp.n = (uint32_t)rd->spp; lane.smp.i = 0;
         TileWalk tw; tw.started = false;
-        compute_sub_window(rp.x_start, rp.x_start + rp.x_count, rp.y_start, rp.y_start + rp.y_count, task, rd->ntasks,
+        compute_sub_window(rp.sx_start, rp.sx_start + rp.sx_count, rp.sy_start, rp.sy_start + rp.sy_count, task, rd->ntasks,
                            &tw.x0, &tw.x1, &tw.y0, &tw.y1);
         lane.smp.seed((uint32_t)task);
         int x, y;

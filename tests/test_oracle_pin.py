@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, abi, load_case, load_ref
+from tests.util import CASES, DL_CASES, FILTER_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -19,7 +19,7 @@ def test_oracle_replays_reference_image_bit_exact(cases, name):
     o = orc.OracleScene(s)
     rd = abi.copy_struct(s.render)
     rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
-    # one thread: tiles in ascending task order, exactly the order `pbrt --ncores 1` produced the
+    # one thread: tiles in the queue's order (descending task numbers), exactly the order `pbrt --ncores 1` produced the
     # golden image in, so even the rare samples that spill into a neighbouring tile's pixel
     # (film/image.cpp:82-89) are summed in the same order
     f, st = o.render(s.camera, rd, nthreads=1)
@@ -29,6 +29,39 @@ def test_oracle_replays_reference_image_bit_exact(cases, name):
     assert st[0] == rd.x_count * rd.y_count * rd.spp
     assert st[5] == 0  # no NaN / negative radiance
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
+@pytest.mark.parametrize("name", list(FILTER_CASES))
+def test_oracle_replays_filtered_reference_image_bit_exact(name):
+    """SURVEY.md §8f-4: ImageFilm::AddSample under gaussian / mitchell / triangle / sinc filters (negative lobes, unequal
+    widths, a crop window) and the wider sample extent of ImageFilm::GetSampleExtent, which also moves the sampler's
+    tiles (Sampler::ComputeSubWindow over the SAMPLE extent) and with them every tile's RNG stream."""
+    s = load_case(name)
+    o = orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = o.render(s.camera, rd, nthreads=1, flt=s.filter)
+    xs, xe, ys, ye = abi.sample_extent(rd, s.filter)
+    assert st[0] == (xe - xs) * (ye - ys) * rd.spp and (xe - xs) > rd.x_count
+    assert st[5] == 0
+    img = film.xyzw_to_rgb(f)
+    ref = load_ref(name)
+    assert img.shape == ref.shape
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    # and the filter matters: the box-filtered film of the same scene is a different image
+    fb, _ = o.render(s.camera, rd, nthreads=1)
+    assert not np.array_equal(film.xyzw_to_rgb(fb), ref)
+
+
+def test_filter_tables_match_the_reference_build():
+    """abi.make_filter (the numpy mirror of filters/*.cpp used by tests and bench.py) against the tables the reference
+    binary itself tabulated for the golden cases (ImageFilm::filterTable, dumped by the host plugin)."""
+    for name, kw in [("fgauss", dict(kind="gaussian")), ("fmitch", dict(kind="mitchell", xwidth=3, ywidth=2.5)),
+                     ("ftri", dict(kind="triangle", xwidth=1.5, ywidth=1)), ("fsinc", dict(kind="sinc"))]:
+        ref = load_case(name).filter
+        mine = abi.make_filter(**kw)
+        assert (mine.xwidth, mine.ywidth) == (ref.xwidth, ref.ywidth)
+        np.testing.assert_allclose(np.array(mine.table), np.array(ref.table), rtol=2e-5, atol=2e-7)
 
 
 def test_mt19937_known_answers():

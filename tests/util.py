@@ -48,6 +48,14 @@ def load_case(name):
         assert len(bytes(lights)) == len(bytes(s.lights))
         s.lights = lights
         return s
+    if name in FILTER_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
+        s = abi.Scene.load(os.path.join(GOLDEN, FILTER_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.filter = abi.filter_from_array(v["filter"])
+        return s
     raise KeyError(name)
 
 
@@ -55,6 +63,11 @@ CASES = ["cfg1", "k8", "b8", "env", "anim", "ms"]
 # SURVEY.md §8f-1 (tests/golden/make_golden_dl.py): DirectLightingIntegrator, strategy all / one
 DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "dlb": "bunny_b8.hpts.gz", "dlbone": "bunny_b8.hpts.gz",
             "dlanim": "anim_killeroos.hpts.gz"}
+
+
+# SURVEY.md §8f-4 (tests/golden/make_golden_filter.py): PixelFilter gaussian / mitchell / triangle (+ crop window) / sinc
+FILTER_CASES = {"fgauss": "killeroo_cfg1.hpts.gz", "fmitch": "bunny_b8.hpts.gz", "ftri": "killeroo_cfg1.hpts.gz",
+                "fsinc": "anim_killeroos.hpts.gz"}
 
 
 def hash_rd(scene, seed=7, spp=None):
