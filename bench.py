@@ -87,7 +87,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(scene, budget_s=12.0):
+def cpu_baseline(scene, budget_s=12.0, flt=None):
     """The oracle (plain-C restatement of the reference path, bit-identical to pbrt-v2's images —
     tests/test_oracle_pin.py) timed on this host's cores on a bounded sample of the same frame."""
     from oracle import orc  # checker / baseline only — never on the product path
@@ -95,14 +95,14 @@ def cpu_baseline(scene, budget_s=12.0):
     cores = usable_cores()
     rd = abi.copy_struct(scene.render)
     rd.spp = 1
-    t = time.time(); _, st = o.render(scene.camera, rd, nthreads=cores); dt1 = time.time() - t
+    t = time.time(); _, st = o.render(scene.camera, rd, nthreads=cores, flt=flt); dt1 = time.time() - t
     rate = st[0] / dt1
     spp = 1
     while spp * 2 <= scene.render.spp and (spp * 2) * rd.x_count * rd.y_count / rate < budget_s:
         spp *= 2
     if spp > 1:
         rd.spp = spp
-        t = time.time(); _, st = o.render(scene.camera, rd, nthreads=cores); dt1 = time.time() - t
+        t = time.time(); _, st = o.render(scene.camera, rd, nthreads=cores, flt=flt); dt1 = time.time() - t
         rate = st[0] / dt1
     return {"value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%dx%d, %d spp of the same frame (%.1f s, oracle/liboracle.so, OpenMP, %d threads = usable cores "
@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--workload", default="bunny")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (power of two)")
     ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
+    ap.add_argument("--filter", default="box", choices=["box", "gaussian", "mitchell", "triangle", "sinc"],
+                    help="PixelFilter with the reference plugin's default widths (box 0.5 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
     args = ap.parse_args()
@@ -145,6 +147,9 @@ def main():
     rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.HPT_PIPELINE_PERSISTENT
     t0 = time.time()
     dev = hpt.DeviceScene(scene, local)
+    flt = None if args.filter == "box" else abi.make_filter(args.filter)
+    if flt is not None:
+        dev.set_filter(flt)
     t1 = time.time()
     if args.pipeline == "persistent" and not args.count_work:
         dev.tune(scene.camera, rd)                   # scene preparation: BVH build + kernel-configuration probe
@@ -165,7 +170,7 @@ def main():
         nonlocal last
         last = dev.render_device(scene.camera, rd, film.data_ptr(), stream)
         kernel_ms.append(last.kernel_ms)
-        return hdist.gather_film(film, rank, world)
+        return hdist.exchange_film(film, rank, world, wide_filter=flt is not None)
 
     for _ in range(args.warmup):
         step()
@@ -193,9 +198,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "soup" else
             "scene blob dumped from the reference parser (tests/golden), random-free geometry",
-            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), LD_HASH sampler seed 0, box filter"
-                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp),
-                       "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile gather" % world,
+            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), LD_HASH sampler seed 0, %s filter"
+                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp,
+                                      "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
+                       "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
                        "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
                        "scene_bytes_in_hbm": int(info.total_device_bytes)},
             "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
@@ -224,7 +230,7 @@ def main():
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "algorithmic_bytes_per_sample": bps}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene)
+            out["cpu_baseline"] = cpu_baseline(scene, flt=flt)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

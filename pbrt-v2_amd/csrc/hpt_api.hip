@@ -38,7 +38,8 @@ struct hpt_scene {
     int stack_entries;    // per-lane traversal stack entries this scene needs
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
-    float *d_ftable, *d_ftable_alloc; hpt_filter filter;         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
+    float *d_ftable, *d_ftable_alloc; hpt_filter filter;
+    float *sbuf; size_t sbuf_floats;             // two-pass film: per-sample records of the last filtered render (grown on demand)         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
 };
 
 extern "C" int hpt_device_count(void) {
@@ -61,6 +62,7 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
+    if (s->sbuf) (void)hipFree(s->sbuf);
     delete s;
 }
 
@@ -73,6 +75,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     hpt_scene *s = new hpt_scene();
     s->device = device;
     s->tune_cfg = -1;
+    s->sbuf = nullptr; s->sbuf_floats = 0;
     s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
@@ -160,7 +163,7 @@ extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
     return HPT_OK;
 }
 
-static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp, const hpt_scene *s = nullptr) {
+static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp, hpt_scene *s = nullptr) {
     if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
     if (rd->spp <= 0 || (rd->spp & (rd->spp - 1))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
@@ -189,6 +192,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (rp->shard_rank < 0 || rp->shard_rank >= rp->shard_count) { hpt_set_error("bad shard rank"); return HPT_E_INVALID; }
     // ImageFilm::GetSampleExtent (film/image.cpp:157-166); the default box of width 0.5 gives the pixel extent back
     rp->ftable = nullptr; rp->fxw = rp->fyw = 0.5f; rp->finvx = rp->finvy = 2.f;
+    rp->sbuf_xyzw = rp->sbuf_pos = nullptr;
     rp->sx_start = rd->x_start; rp->sx_count = rd->x_count; rp->sy_start = rd->y_start; rp->sy_count = rd->y_count;
     if (s && s->d_ftable) {
         rp->ftable = s->d_ftable; rp->fxw = s->filter.xwidth; rp->fyw = s->filter.ywidth;
@@ -198,6 +202,24 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         rp->sy_start = (int)floorf((float)rd->y_start + 0.5f - rp->fyw);
         rp->sy_count = (int)ceilf((float)rd->y_start - 0.5f + (float)rd->y_count + rp->fyw) - rp->sy_start;
         if (rp->sx_count <= 0 || rp->sy_count <= 0) { hpt_set_error("filter narrower than a pixel leaves no samples"); return HPT_E_INVALID; }
+        // Two-pass film: 24 B per camera sample of the SAMPLE extent ({X, Y, Z, 1} + {imageX, imageY}), summed per film pixel
+        // by hpt_film_gather_kernel.  1080p / 64 spp: 3.2 GB.  Above HPT_SBUF_MAX_GB (default 48 of the 288 GB) or with
+        // HPT_FILM=atomic the samples splat with float atomics instead (16 pixels x 4 atomics per sample under a 2-pixel filter:
+        // measured 2-3x the whole box-filter render, profiles/r01_ab.md).
+        const char *fm = getenv("HPT_FILM");
+        double cap_gb = 48.0;
+        if (const char *e = getenv("HPT_SBUF_MAX_GB")) cap_gb = atof(e);
+        const size_t need = (size_t)rp->sx_count * rp->sy_count * (size_t)rd->spp * 6;
+        if (!(fm && !strcmp(fm, "atomic")) && (double)need * 4.0 <= cap_gb * 1e9) {
+            if (s->sbuf_floats < need) {
+                if (s->sbuf) (void)hipFree(s->sbuf);
+                s->sbuf = nullptr; s->sbuf_floats = 0;
+                if (hipMalloc((void **)&s->sbuf, need * sizeof(float)) != hipSuccess) { hpt_set_error("hipMalloc of the %.1f GB sample buffer failed (HPT_FILM=atomic renders without it)", need * 4e-9); return HPT_E_HIP; }
+                s->sbuf_floats = need;
+            }
+            rp->sbuf_xyzw = s->sbuf;
+            rp->sbuf_pos = s->sbuf + (need / 6) * 4;
+        }
     }
     rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
@@ -411,6 +433,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
     a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
+    if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) a.rp.sbuf_xyzw = a.rp.sbuf_pos = nullptr;   // the wavefront pipeline keeps the one-pass (atomic) splat
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
         float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
         int wrc = render_wavefront(s, a, rd, stream, stats, d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
@@ -458,7 +481,10 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+    // two-pass film: w = 0 marks a sample this shard does not render; then the path kernel parks its samples, the gather sums them
+    if (e == hipSuccess && a.rp.sbuf_xyzw) e = hipMemsetAsync(a.rp.sbuf_xyzw, 0, sizeof(float) * 4 * (size_t)a.rp.sx_count * a.rp.sy_count * (size_t)rd->spp, stream);
     if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
+    if (e == hipSuccess && a.rp.sbuf_xyzw) e = launch_film_gather(a.rp, a.film, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
     float ms = 0.f;

@@ -65,6 +65,71 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
     atomicAdd((unsigned long long *)&a.counters->bad, (unsigned long long)wc.bad);
 }
 
+// ---- second pass of the two-pass film (reconstruction filters from a table) ------------------------------------------
+// film_gather_pixel (hpt_path.h) with the loads made wave-uniform.  A wave owns an 8 x 8 block of film pixels (a workgroup
+// 16 x 16), one pixel per lane.  The sample records that can reach the block lie in (8 + 2r) rows of the sample extent, and
+// within a row they are ONE contiguous array (slot = pixel * spp + sample, pixels row-major): the wave reads it 64 records at
+// a time, one per lane (coalesced, each record once per block it can reach: (8 + 2r)^2 / 64 = 2.25x for r = 2 instead of
+// the 25 scattered re-reads of the per-pixel walk), each lane prepares its record's AddSample extent (film/image.cpp:80-85),
+// and the records are then broadcast one by one (v_readlane) to all 64 pixels, which test the extent, look the weight up and
+// accumulate in registers.  No atomics, no cross-lane sums: every pixel adds its samples in the order rows, pixels, sample
+// index — the order of film_gather_pixel, so the film is bit-identical to it and from run to run.
+__global__ __launch_bounds__(256) void hpt_film_gather_kernel(const RenderParams rp, float *film) {
+    __shared__ float s_tab[256];
+    s_tab[threadIdx.x] = rp.ftable[threadIdx.x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx0 = rp.x_start + (int)blockIdx.x * 16 + (wave & 1) * 8, ty0 = rp.y_start + (int)blockIdx.y * 16 + (wave >> 1) * 8;
+    if (tx0 >= rp.x_start + rp.x_count || ty0 >= rp.y_start + rp.y_count) return;   // the whole block lies outside the film
+    const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
+    const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
+    int qx0 = tx0 - rx, qx1 = tx0 + 7 + rx, qy0 = ty0 - ry, qy1 = ty0 + 7 + ry;
+    if (qx0 < rp.sx_start) qx0 = rp.sx_start;
+    if (qx1 > rp.sx_start + rp.sx_count - 1) qx1 = rp.sx_start + rp.sx_count - 1;
+    if (qy0 < rp.sy_start) qy0 = rp.sy_start;
+    if (qy1 > rp.sy_start + rp.sy_count - 1) qy1 = rp.sy_start + rp.sy_count - 1;
+    const int NONE = 0x7fffffff;
+    float aX = 0.f, aY = 0.f, aZ = 0.f, aW = 0.f;
+    for (int qy = qy0; qy <= qy1; ++qy) {
+        const int64_t rowbase = ((int64_t)(qy - rp.sy_start) * rp.sx_count + (qx0 - rp.sx_start)) * rp.spp;
+        const int nrec = (qx1 - qx0 + 1) * rp.spp;
+        const f4 *rec = (const f4 *)rp.sbuf_xyzw + rowbase;
+        const float *pos = rp.sbuf_pos + 2 * rowbase;
+        for (int j0 = 0; j0 < nrec; j0 += 64) {
+            const int j = j0 + lane;
+            int ex0 = NONE, ex1 = 0, ey0 = 0, ey1 = 0;
+            float dX = 0.f, dY = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
+            if (j < nrec) {
+                const f4 r = rec[j];
+                if (r.w != 0.f) {                                   // 0: not rendered by this shard
+                    dX = pos[2 * j] - 0.5f; dY = pos[2 * j + 1] - 0.5f;
+                    ex0 = (int)ceilf(dX - rp.fxw); ex1 = (int)floorf(dX + rp.fxw);
+                    ey0 = (int)ceilf(dY - rp.fyw); ey1 = (int)floorf(dY + rp.fyw);
+                    X = r.x; Y = r.y; Z = r.z;
+                    if (ex1 < tx0 || ex0 > tx0 + 7 || ey1 < ty0 || ey0 > ty0 + 7) ex0 = NONE;   // reaches no pixel of this block
+                }
+            }
+            const int n = nrec - j0 < 64 ? nrec - j0 : 64;
+            for (int k = 0; k < n; ++k) {
+                const int sx0 = __builtin_amdgcn_readlane(ex0, k);
+                if (sx0 == NONE) continue;                           // wave-uniform
+                const int sx1 = __builtin_amdgcn_readlane(ex1, k), sy0 = __builtin_amdgcn_readlane(ey0, k), sy1 = __builtin_amdgcn_readlane(ey1, k);
+                const float sdX = as_float(__builtin_amdgcn_readlane(as_int(dX), k)), sdY = as_float(__builtin_amdgcn_readlane(as_int(dY), k));
+                const float sX = as_float(__builtin_amdgcn_readlane(as_int(X), k)), sY = as_float(__builtin_amdgcn_readlane(as_int(Y), k)),
+                            sZ = as_float(__builtin_amdgcn_readlane(as_int(Z), k));
+                if (x < sx0 || x > sx1 || y < sy0 || y > sy1) continue;
+                int ix = (int)floorf(fabsf((x - sdX) * rp.finvx * 16.f)); if (ix > 15) ix = 15;
+                int iy = (int)floorf(fabsf((y - sdY) * rp.finvy * 16.f)); if (iy > 15) iy = 15;
+                const float wt = s_tab[iy * 16 + ix];
+                aX += wt * sX; aY += wt * sY; aZ += wt * sZ; aW += wt;
+            }
+        }
+    }
+    if (x >= rp.x_start + rp.x_count || y >= rp.y_start + rp.y_count) return;
+    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+    f[0] = aX; f[1] = aY; f[2] = aZ; f[3] = aW;
+}
+
 // ---- function-level parity kernels (same device functions, array in / array out) --------------------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene sc, const float *rays, int64_t n, int anyhit,
                                                                   float *out_hit, int32_t *out_prim) {
@@ -147,6 +212,11 @@ hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {
     int grid = (int)(ra.nlanes / HPT_BLOCK);
     hipLaunchKernelGGL(hpt_replay_kernel, dim3(grid), dim3(HPT_BLOCK), 0, stream, a, ra);
+    return hipGetLastError();
+}
+hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream) {
+    dim3 grid((unsigned)((rp.x_count + 15) / 16), (unsigned)((rp.y_count + 15) / 16));
+    hipLaunchKernelGGL(hpt_film_gather_kernel, grid, dim3(256), 0, stream, rp, film);
     return hipGetLastError();
 }
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {

@@ -34,6 +34,10 @@ struct RenderParams {
                                                       // grown by the filter radius; equal to it for the default box
     const float *ftable;       // 16x16 filter weights in HBM; nullptr: box filter of width 0.5 (fast path)
     float fxw, fyw, finvx, finvy;   // Filter::xWidth, yWidth, invXWidth, invYWidth
+    float *sbuf_xyzw;          // table filters, two-pass film: per camera sample {X, Y, Z, 1} (zeroed: 0 = not rendered by this
+    float *sbuf_pos;           // shard) and {imageX, imageY}, slot (pixel of the sample extent) * spp + sample; the gather
+                               // kernel (film_gather_pixel) then sums every film pixel's samples without atomics.
+                               // nullptr: every sample splats with float atomics (film_splat_table)
     int32_t spp, maxdepth;
     uint32_t seed;
     int32_t shard_rank, shard_count;
@@ -82,6 +86,39 @@ HPT_FN void film_splat_table(const RenderParams &rp, float *film, float imgx, fl
             film_atomic_add(f + 0, wt * X); film_atomic_add(f + 1, wt * Y); film_atomic_add(f + 2, wt * Z); film_atomic_add(f + 3, wt);
         }
     }
+}
+
+// Second pass of the two-pass film: film pixel (x, y) sums the samples that reach it — ImageFilm::AddSample
+// (film/image.cpp:77-137) turned inside out.  A sample of sample-extent pixel q has imageX in [qx, qx + 1], so it can
+// reach x only if |x - qx| <= floor(xWidth + 0.5); each candidate takes AddSample's own extent test and table lookup.
+// Fixed summation order (rows of q, then q, then sample index): the film is bit-reproducible, and the 16 x 4 atomics
+// per sample of the one-pass splat (a 2-pixel-wide filter) become two stores.
+HPT_FN void film_gather_pixel(const RenderParams &rp, float *film, int x, int y) {
+    const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
+    int qx0 = x - rx, qx1 = x + rx, qy0 = y - ry, qy1 = y + ry;
+    if (qx0 < rp.sx_start) qx0 = rp.sx_start;
+    if (qx1 > rp.sx_start + rp.sx_count - 1) qx1 = rp.sx_start + rp.sx_count - 1;
+    if (qy0 < rp.sy_start) qy0 = rp.sy_start;
+    if (qy1 > rp.sy_start + rp.sy_count - 1) qy1 = rp.sy_start + rp.sy_count - 1;
+    float sX = 0.f, sY = 0.f, sZ = 0.f, sW = 0.f;
+    for (int qy = qy0; qy <= qy1; ++qy)
+        for (int qx = qx0; qx <= qx1; ++qx) {
+            const int64_t base = ((int64_t)(qy - rp.sy_start) * rp.sx_count + (qx - rp.sx_start)) * rp.spp;
+            const float *rec = rp.sbuf_xyzw + 4 * base;
+            const float *pos = rp.sbuf_pos + 2 * base;
+            for (int k = 0; k < rp.spp; ++k) {
+                if (rec[4 * k + 3] == 0.f) continue;                    // not rendered by this shard
+                const float dimageX = pos[2 * k] - 0.5f, dimageY = pos[2 * k + 1] - 0.5f;
+                if (x < (int)ceilf(dimageX - rp.fxw) || x > (int)floorf(dimageX + rp.fxw)) continue;
+                if (y < (int)ceilf(dimageY - rp.fyw) || y > (int)floorf(dimageY + rp.fyw)) continue;
+                int ix = (int)floorf(fabsf((x - dimageX) * rp.finvx * 16.f)); if (ix > 15) ix = 15;
+                int iy = (int)floorf(fabsf((y - dimageY) * rp.finvy * 16.f)); if (iy > 15) iy = 15;
+                const float wt = rp.ftable[iy * 16 + ix];
+                sX += wt * rec[4 * k]; sY += wt * rec[4 * k + 1]; sZ += wt * rec[4 * k + 2]; sW += wt;
+            }
+        }
+    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+    f[0] = sX; f[1] = sY; f[2] = sZ; f[3] = sW;
 }
 
 // Work item -> pixel.  Items enumerate this shard's 32x32 super-tiles (round-robin over shards),
@@ -198,7 +235,13 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
         float Z = 0.019334f * Ls.x + 0.119193f * Ls.y + 0.950227f * Ls.z;
         if (rp.ftable) {   // a filter from the table (uniform branch): all pixels under it, straight to the film
-            film_splat_table(rp, film, imgx, imgy, X, Y, Z);
+            if (rp.sbuf_xyzw) {   // two-pass film: park the sample, film_gather_pixel sums it later
+                const int64_t slot = ((int64_t)(py - rp.sy_start) * rp.sx_count + (px - rp.sx_start)) * rp.spp + (int64_t)si;
+                float *r4 = rp.sbuf_xyzw + 4 * slot;
+                r4[0] = X; r4[1] = Y; r4[2] = Z; r4[3] = 1.f;
+                rp.sbuf_pos[2 * slot] = imgx; rp.sbuf_pos[2 * slot + 1] = imgy;
+            } else
+                film_splat_table(rp, film, imgx, imgy, X, Y, Z);
             if (wc) wc->samples++;
             ++si;
             if (si < s_end) { begin_sample(rp); return; }

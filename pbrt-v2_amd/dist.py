@@ -5,6 +5,11 @@ renders the 32x32 super-tiles t with t % world == r (hpt_render_desc.shard_rank/
 the same round-robin the kernel's work counter walks), and the only communication is ONE gather
 of film tiles to rank 0 at end of frame: 16 B/pixel, 33 MB at 1080p, point-to-point over xGMI
 (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+
+Under a reconstruction filter wider than the default box (hpt_scene_set_filter) a sample reaches
+pixels of neighbouring tiles, so every rank's film holds partial sums over the whole frame and the exchange is one
+sum-reduce of the full-frame films to rank 0 (reduce_film; 33 MB at 1080p — ring-reduced over xGMI it is per-link
+bound and still well under a millisecond).
 """
 import numpy as np
 import torch
@@ -54,3 +59,19 @@ def gather_film(film, rank, world, group=None):
         return tiles_to_film(out, W, H)
     dist.gather(send, gather_list=None, dst=0, group=group)
     return None
+
+
+def reduce_film(film, rank, world, group=None):
+    """Wide reconstruction filter: each rank passes its full-frame film of partial sums {X, Y, Z, weightSum};
+    rank 0 receives their sum (ImageFilm::AddSample is a sum, film/image.cpp:96-136), other ranks get None.
+    One collective."""
+    if world == 1:
+        return film
+    buf = film.contiguous().clone()
+    dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return buf if rank == 0 else None
+
+
+def exchange_film(film, rank, world, wide_filter=False, group=None):
+    """The end-of-frame film exchange: gather of owned tiles (default box filter) or sum-reduce (wide filter)."""
+    return reduce_film(film, rank, world, group) if wide_filter else gather_film(film, rank, world, group)

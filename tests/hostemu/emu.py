@@ -27,6 +27,8 @@ def lib():
         L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
         L.emu_set_filter.restype = None
+        L.emu_set_two_pass.argtypes = [C.c_int]
+        L.emu_set_two_pass.restype = None
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -45,8 +47,11 @@ class EmuScene:
         lib().emu_scene_info(self.h, out.ctypes.data)
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2])}
 
-    def render(self, cam, rd, flt=None):
+    def render(self, cam, rd, flt=None, two_pass=False):
+        """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the
+        one-pass atomic splat"""
         lib().emu_set_filter(C.byref(flt) if flt is not None else None)
+        lib().emu_set_two_pass(1 if two_pass else 0)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         fn = lib().emu_render_replay if rd.sampler_mode == abi.HPT_SAMPLER_MT_REPLAY else lib().emu_render

@@ -54,7 +54,14 @@ extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
 
 // hpt_scene_set_filter's stand-in (process-wide; NULL = box of width 0.5)
 static hpt_filter g_filter; static bool g_filter_set = false;
+static bool g_two_pass = false;   // the device's two-pass film (sample records + film_gather_pixel) instead of the atomic splat
 extern "C" void emu_set_filter(const hpt_filter *f) { g_filter_set = f != nullptr; if (f) g_filter = *f; }
+extern "C" void emu_set_two_pass(int on) { g_two_pass = on != 0; }
+static void gather_film(const RenderParams &rp, float *film) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = rp.y_start; y < rp.y_start + rp.y_count; ++y)
+        for (int x = rp.x_start; x < rp.x_start + rp.x_count; ++x) film_gather_pixel(rp, film, x, y);
+}
 
 static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
     rp->cam = *cam;
@@ -67,6 +74,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
     rp->ftable = nullptr; rp->fxw = rp->fyw = 0.5f; rp->finvx = rp->finvy = 2.f;
+    rp->sbuf_xyzw = rp->sbuf_pos = nullptr;
     rp->sx_start = rd->x_start; rp->sx_count = rd->x_count; rp->sy_start = rd->y_start; rp->sy_count = rd->y_count;
     if (g_filter_set) {   // as fill_params of csrc/hpt_api.hip
         rp->ftable = g_filter.table; rp->fxw = g_filter.xwidth; rp->fyw = g_filter.ywidth;
@@ -90,6 +98,12 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
     RenderParams rp; fill_params(cam, rd, &rp);
     rp.has_motion = s->d.n_instances > 0;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
+    std::vector<float> sbuf;
+    if (g_two_pass && rp.ftable) {
+        const size_t n = (size_t)rp.sx_count * rp.sy_count * (size_t)rd->spp;
+        sbuf.assign(n * 6, 0.f);
+        rp.sbuf_xyzw = sbuf.data(); rp.sbuf_pos = sbuf.data() + n * 4;
+    }
     WorkCounters total = {0, 0, 0, 0, 0, 0};
 #pragma omp parallel
     {
@@ -118,6 +132,7 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
 #pragma omp critical
         { total.samples += wc.samples; total.closest += wc.closest; total.shadow += wc.shadow; total.nodes += tc.nodes; total.tris += tc.tris; total.bad += wc.bad; }
     }
+    if (rp.sbuf_xyzw) gather_film(rp, film);
     if (stats) { stats[0] = total.samples; stats[1] = total.closest; stats[2] = total.shadow; stats[3] = total.nodes; stats[4] = total.tris; stats[5] = total.bad; }
     return 0;
 }
@@ -131,6 +146,12 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
     RenderParams rp; fill_params(cam, rd, &rp);
     rp.has_motion = s->d.n_instances > 0;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
+    std::vector<float> sbuf;
+    if (g_two_pass && rp.ftable) {
+        const size_t n = (size_t)rp.sx_count * rp.sy_count * (size_t)rd->spp;
+        sbuf.assign(n * 6, 0.f);
+        rp.sbuf_xyzw = sbuf.data(); rp.sbuf_pos = sbuf.data() + n * 4;
+    }
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
     std::vector<uint32_t> mt(HPT_MT_N);
@@ -156,6 +177,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
             }
         }
     }
+    if (rp.sbuf_xyzw) gather_film(rp, film);
     if (stats) { stats[0] = wc.samples; stats[1] = wc.closest; stats[2] = wc.shadow; stats[3] = tc.nodes; stats[4] = tc.tris; stats[5] = wc.bad; }
     return 0;
 }

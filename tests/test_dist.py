@@ -52,6 +52,38 @@ def test_sharded_render_and_gather_equals_single_rank(tmp_path, world):
     assert np.array_equal(got[..., 3], want[..., 3])
 
 
+def _worker_filtered(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.hostemu import emu
+    hdist = importlib.import_module("pbrt-v2_amd.dist")
+    s = load_case("fmitch")
+    rd = hash_rd(s, seed=4)
+    rd.shard_rank, rd.shard_count = rank, world
+    f, _ = emu.EmuScene(s).render(s.camera, rd, flt=s.filter)
+    full = hdist.exchange_film(torch.from_numpy(f), rank, world, wide_filter=True)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_render_under_a_wide_filter_reduces_to_the_single_rank_film(tmp_path):
+    """with PixelFilter "mitchell" 3 x 2.5 the shards overlap at tile borders; the exchange is a
+    sum-reduce of full-frame partial films."""
+    from tests.hostemu import emu
+    out = str(tmp_path / "reduced.npy")
+    mp.spawn(_worker_filtered, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    s = load_case("fmitch")
+    rd = hash_rd(s, seed=4)
+    want, _ = emu.EmuScene(s).render(s.camera, rd, flt=s.filter)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
 def test_tile_roundtrip():
     hdist = importlib.import_module("pbrt-v2_amd.dist")
     f = torch.arange(45 * 70 * 4, dtype=torch.float32).reshape(45, 70, 4)

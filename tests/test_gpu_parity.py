@@ -14,7 +14,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sub_windows
+from tests.util import CASES, DL_CASES, FILTER_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sub_windows
 
 film = importlib.import_module("pbrt-v2_amd.film")
 hpt = importlib.import_module("pbrt-v2_amd.hpt")
@@ -374,6 +374,125 @@ def test_pbrt_binary_with_the_hip_renderer_end_to_end(tmp_path):
     want = film.xyzw_to_rgb(f)
     assert got.shape == want.shape and st.bad_samples == 0
     assert film.rmse(got, want) < 1e-4, film.rmse(got, want)
+
+
+@pytest.mark.parametrize("name", list(FILTER_CASES))
+def test_filtered_render_matches_oracle_sample_for_sample(name):
+    """PixelFilter gaussian / mitchell 3 x 2.5 / triangle 1.5 x 1 under a crop window (direct lighting) /
+    sinc 4 x 4 on animated instances — the table splat and the wider sample extent on the device against the oracle's
+    ImageFilm::AddSample, which is pinned bit-identical to the reference binary on exactly these scenes.  Same seed, same
+    samples, same weights; the float sums of a pixel arrive in another order (atomics)."""
+    s = load_case(name)
+    d, o = hpt.DeviceScene(s), orc.OracleScene(s)
+    d.set_filter(s.filter)
+    rd = hash_rd(s, seed=5)
+    rd.count_work = 1
+    f, st = d.render(s.camera, rd)
+    fo, so = o.render(s.camera, rd, flt=s.filter)
+    xs, xe, ys, ye = abi.sample_extent(rd, s.filter)
+    assert st.camera_samples == so[0] == (xe - xs) * (ye - ys) * rd.spp and st.bad_samples == 0
+    assert abs(int(st.closest_rays) - int(so[1])) <= 8 and abs(int(st.shadow_rays) - int(so[2])) <= 8
+    np.testing.assert_allclose(f[..., 3], fo[..., 3], rtol=3e-5, atol=2e-5)          # weight sums
+    assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3              # north-star tolerance
+    scale = float(np.abs(fo[..., :3]).max())
+    close = (np.abs(f - fo)[..., :3].max(axis=2) <= 1e-4 * scale).mean()
+    assert close > 0.99, close
+    # back to the default: the handle's filter state is cleared and the box fast path renders the box film
+    d.set_filter(None)
+    rd.count_work = 0
+    fb, _ = d.render(s.camera, rd)
+    fob, _ = o.render(s.camera, rd)
+    assert np.array_equal(fb[..., 3], fob[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(fb), film.xyzw_to_rgb(fob)) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["fgauss", "fmitch"])
+def test_two_pass_film_equals_the_atomic_splat_and_is_bit_reproducible(name, monkeypatch):
+    """Default under a table filter: two-pass film (sample records in HBM + hpt_film_gather_kernel, fixed summation order).
+    HPT_FILM=atomic: one pass, float atomics.  Same film to float rounding; the two-pass film is bit-identical run to run."""
+    s = load_case(name)
+    d = hpt.DeviceScene(s)
+    d.set_filter(s.filter)
+    rd = hash_rd(s, seed=9)
+    f1, st1 = d.render(s.camera, rd)
+    f2, _ = d.render(s.camera, rd)
+    assert np.array_equal(f1, f2)
+    monkeypatch.setenv("HPT_FILM", "atomic")
+    fa, sta = d.render(s.camera, rd)
+    assert st1.camera_samples == sta.camera_samples
+    scale = float(np.abs(f1[..., :3]).max())
+    assert np.allclose(f1, fa, rtol=1e-4, atol=2e-5 * scale)
+
+
+def test_filtered_replay_reproduces_the_reference_binary_image():
+    """MT_REPLAY with PixelFilter "gaussian" against the image the reference binary wrote: the tiles (and their RNG
+    streams) are cut from the sample extent, 2 pixels beyond the image on every side."""
+    s = load_case("fgauss")
+    d = hpt.DeviceScene(s)
+    d.set_filter(s.filter)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = d.render(s.camera, rd)
+    xs, xe, ys, ye = abi.sample_extent(rd, s.filter)
+    assert st.camera_samples == (xe - xs) * (ye - ys) * rd.spp
+    img, ref = film.xyzw_to_rgb(f), load_ref("fgauss")
+    assert np.isclose(img, ref, rtol=2e-3, atol=1e-4).all(axis=2).mean() > 0.9
+    assert abs(float(img.mean()) / float(ref.mean()) - 1) < 0.02
+
+
+def test_box_table_equals_fast_path_and_filter_validation(cases, dev):
+    s = cases["k8"]
+    d = dev["k8"]
+    rd = hash_rd(s, seed=4, spp=4)
+    f0, _ = d.render(s.camera, rd)
+    try:
+        d.set_filter(abi.make_filter("box"))
+        f1, _ = d.render(s.camera, rd)
+        assert np.array_equal(f0[..., 3], f1[..., 3])
+        assert np.allclose(f0, f1, rtol=1e-6, atol=1e-7)
+        bad = abi.make_filter("gaussian")
+        bad.xwidth = 0.0
+        with pytest.raises(hpt.HptError):
+            d.set_filter(bad)
+        bad = abi.make_filter("gaussian")
+        bad.table[17] = float("nan")
+        with pytest.raises(hpt.HptError):
+            d.set_filter(bad)
+    finally:
+        d.set_filter(None)
+    f2, _ = d.render(s.camera, rd)
+    assert np.array_equal(f0, f2) or np.allclose(f0, f2, rtol=1e-6, atol=1e-7)
+
+
+def test_wide_filter_full_size_properties_and_shards():
+    """1920x1080 under the gaussian filter, through size-independent properties: total weight = (sum of the table's
+    reach) is the same whether the frame is rendered whole or as 3 shards whose films are summed (the multi-GPU reduce);
+    interior pixels all carry nearly the same weight; radiance finite, filtered image close to the box image in the mean."""
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    s = scenes.synthetic_soup(n_tris=50000, spp=4, maxdepth=4)
+    d = hpt.DeviceScene(s)
+    rd = s.render
+    fb, _ = d.render(s.camera, rd)
+    g = abi.make_filter("gaussian")
+    d.set_filter(g)
+    rd.count_work = 1
+    f, st = d.render(s.camera, rd)
+    assert st.camera_samples == (1920 + 4) * (1080 + 4) * 4 and st.bad_samples == 0
+    rd.count_work = 0
+    w = f[..., 3]
+    inner = w[4:-4, 4:-4]
+    assert np.isfinite(f).all() and inner.min() > 0
+    assert inner.std() / inner.mean() < 0.2
+    acc = np.zeros_like(f)
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        fr, _ = d.render(s.camera, rd)
+        acc += fr
+    assert np.allclose(acc, f, rtol=1e-4, atol=1e-4)
+    img, imb = film.xyzw_to_rgb(f), film.xyzw_to_rgb(fb)
+    assert (img >= 0).all() and abs(float(img.mean()) / float(imb.mean()) - 1) < 0.01
+    # a low-pass filter: less pixel-to-pixel noise than the box image of the same samples
+    assert np.abs(np.diff(img[..., 1], axis=1)).mean() < np.abs(np.diff(imb[..., 1], axis=1)).mean()
 
 
 def test_shards_partition_the_image(cases, dev):

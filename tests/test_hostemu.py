@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
+from tests.util import CASES, DL_CASES, FILTER_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc
@@ -147,3 +147,93 @@ def test_sample_chunking_above_64_spp(cases, pairs):
     assert so[0] == se[0] == 40 * 24 * 256
     assert np.array_equal(fo[..., 3], fe[..., 3])
     assert np.allclose(fo, fe, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(FILTER_CASES))
+def test_filtered_render_matches_oracle(name):
+    """the device's table splat (film_splat_table in hpt_path.h) and its sample extent against the
+    oracle's ImageFilm::AddSample, on the cases the oracle is pinned to the reference binary with.  Same samples, same
+    weights; only the order of the float sums differs (one lane per pixel here, raster order there)."""
+    s = load_case(name)
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = hash_rd(s, seed=5)
+    fo, so = o.render(s.camera, rd, flt=s.filter)
+    fe, se = e.render(s.camera, rd, flt=s.filter)
+    xs, xe, ys, ye = abi.sample_extent(rd, s.filter)
+    assert so[0] == se[0] == (xe - xs) * (ye - ys) * rd.spp
+    assert abs(int(so[1]) - int(se[1])) <= 4 and abs(int(so[2]) - int(se[2])) <= 4
+    np.testing.assert_allclose(fe[..., 3], fo[..., 3], rtol=2e-5, atol=1e-5)     # weight sums
+    scale = float(np.abs(fo[..., :3]).max())
+    close = (np.abs(fe - fo)[..., :3].max(axis=2) <= 2e-5 * scale).mean()
+    assert close > 0.999, close
+    assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)) < 1e-4
+
+
+def test_filtered_replay_reproduces_the_reference_image():
+    """MT_REPLAY through the device lane + table splat against the image the reference binary wrote with
+    PixelFilter "gaussian": tiles are cut from the SAMPLE extent (Sampler::ComputeSubWindow over
+    ImageFilm::GetSampleExtent), so every tile's generator sees the reference's pixels."""
+    s = load_case("fgauss")
+    e = emu.EmuScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = e.render(s.camera, rd, flt=s.filter)
+    img, ref = film.xyzw_to_rgb(f), load_ref("fgauss")
+    assert film.rmse(img, ref) < 1e-3
+    assert np.isclose(img, ref, rtol=1e-4, atol=1e-6).all(axis=2).mean() > 0.99
+
+
+def test_box_filter_through_the_table_equals_the_fast_path(cases, pairs):
+    """A box of width 0.5 given as a table (all ones) takes the generic splat; the default takes the fast path that
+    keeps a pixel's sum in registers.  Same weights, same pixels; sums regrouped."""
+    s = cases["k8"]
+    _, e = pairs["k8"]
+    rd = hash_rd(s, seed=4, spp=4)
+    f0, s0 = e.render(s.camera, rd)
+    f1, s1 = e.render(s.camera, rd, flt=abi.make_filter("box"))
+    assert s0[0] == s1[0]
+    assert np.array_equal(f0[..., 3], f1[..., 3])
+    assert np.allclose(f0, f1, rtol=1e-6, atol=1e-7)
+
+
+def test_wide_filter_shards_sum_to_the_frame():
+    """Multi-GPU under a wide filter: tiles of the SAMPLE extent are dealt round-robin, every shard's film covers the
+    whole frame with partial sums, and the frame is their sum (a reduce instead of the box filter's gather)."""
+    s = load_case("fmitch")
+    e = emu.EmuScene(s)
+    rd = hash_rd(s, seed=3)
+    full, st = e.render(s.camera, rd, flt=s.filter)
+    for count in (2, 3):
+        acc = np.zeros_like(full)
+        n = 0
+        for r in range(count):
+            rd.shard_rank, rd.shard_count = r, count
+            f, sr = e.render(s.camera, rd, flt=s.filter)
+            acc += f
+            n += int(sr[0])
+        assert n == int(st[0])
+        assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(FILTER_CASES))
+def test_two_pass_film_matches_oracle_and_is_reproducible(name):
+    """The device's default film under a table filter: the lane parks {X, Y, Z, 1} + {imageX, imageY} per camera sample,
+    film_gather_pixel (hpt_path.h) then sums every film pixel's samples in a fixed order.  Same film as the oracle's
+    AddSample to float rounding, bit-identical run to run, and shards sum to the frame."""
+    s = load_case(name)
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = hash_rd(s, seed=5)
+    fo, so = o.render(s.camera, rd, flt=s.filter)
+    fg, sg = e.render(s.camera, rd, flt=s.filter, two_pass=True)
+    fg2, _ = e.render(s.camera, rd, flt=s.filter, two_pass=True)
+    assert sg[0] == so[0]
+    assert np.array_equal(fg, fg2)
+    np.testing.assert_allclose(fg[..., 3], fo[..., 3], rtol=2e-5, atol=1e-5)
+    scale = float(np.abs(fo[..., :3]).max())
+    assert (np.abs(fg - fo)[..., :3].max(axis=2) <= 2e-5 * scale).mean() > 0.999
+    acc = np.zeros_like(fg)
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        f, _ = e.render(s.camera, rd, flt=s.filter, two_pass=True)
+        acc += f
+    assert np.allclose(acc, fg, rtol=1e-5, atol=2e-5 * scale)
