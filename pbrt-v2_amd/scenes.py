@@ -222,7 +222,7 @@ def _fmt(a):
     return " ".join("%.9g" % float(v) for v in np.asarray(a).reshape(-1))
 
 
-def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres=None, renderer=None):
+def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres=None, renderer=None, pixel_filter=None):
     """Write `scene` as a pbrt-v2 scene file.  Supported: triangle meshes (P world space; N are
     exported as world-space normals with an identity object transform), matte / plastic materials,
     point and constant infinite lights, sphere / disk emitters."""
@@ -235,6 +235,8 @@ def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres
     out = []
     out.append("Transform [%s]" % _fmt(w2c.T))  # pbrt reads column-major (core/api.cpp:733-738)
     out.append('Camera "perspective" "float fov" [%.9g]' % fov)
+    if pixel_filter:
+        out.append(pixel_filter)                 # e.g. 'PixelFilter "gaussian"'
     out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" "%s"'
                % (xres, yres, film_path))
     out.append('Sampler "lowdiscrepancy" "integer pixelsamples" [%d]' % spp)

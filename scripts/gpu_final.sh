@@ -11,5 +11,8 @@ for w in bunny killeroo anim soup killeroo-dl; do
   python -c "
 import json; d=json.load(open('$O/bench_$w.json')); print('$w', d['value'], d['kernel']['tune_cfg'], 'roofline', d.get('roofline',{}).get('frac'), 'cpu', d['cpu_baseline']['value'])"
 done
+timeout 600 python bench.py --workload bunny --filter gaussian --steps 3 --warmup 1 > $O/bench_bunny_gaussian.json 2> $O/bench_bunny_gaussian.err
+python -c "
+import json; d=json.load(open('$O/bench_bunny_gaussian.json')); print('bunny gaussian', d['value'], d['kernel']['tune_cfg'], 'cpu', d['cpu_baseline']['value'])"
 timeout 600 python bench.py --workload soup --steps 2 --warmup 1 --count-work --no-cpu-baseline > $O/bench_soup_count.json 2>/dev/null
 echo done > $O/done

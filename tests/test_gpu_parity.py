@@ -376,6 +376,34 @@ def test_pbrt_binary_with_the_hip_renderer_end_to_end(tmp_path):
     assert film.rmse(got, want) < 1e-4, film.rmse(got, want)
 
 
+def test_pbrt_binary_with_a_pixel_filter_end_to_end(tmp_path):
+    """The same chain with `PixelFilter "mitchell"` in the scene file: pbrt's parser builds the MitchellFilter, ImageFilm
+    tabulates it, the plugin hands the table to hpt_scene_set_filter, ImageFilm::WriteImage normalises the film.  Against the
+    Python binding rendering the same scene with abi.make_filter's table (the numpy restatement of the filter)."""
+    import os
+    import subprocess
+    from tests.util import ROOT
+    exe = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+    if not os.path.exists(exe):
+        pytest.skip("pbrt_hip is built from /root/reference in the build container only")
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    s = scenes.synthetic_soup(n_tris=2000, xres=160, yres=90, spp=8, maxdepth=5, extent=0.08)
+    scene_file, out_pfm = str(tmp_path / "soup.pbrt"), str(tmp_path / "soup.pfm")
+    scenes.export_pbrt(s, scene_file, out_pfm, renderer="hip", pixel_filter='PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]')
+    subprocess.check_call([exe, "--quiet", scene_file], env=dict(os.environ, HPT_TUNE="3"))
+    got = film.read_pfm(out_pfm)
+    d = hpt.DeviceScene(s)
+    d.set_filter(abi.make_filter("mitchell", xwidth=2.5, ywidth=1.5))
+    f, st = d.render(s.camera, hash_rd(s, seed=0))
+    want = film.xyzw_to_rgb(f)
+    assert got.shape == want.shape and st.bad_samples == 0
+    assert st.camera_samples == 164 * 92 * 8      # sample extent [-2, 162) x [-1, 91) (ImageFilm::GetSampleExtent)
+    assert film.rmse(got, want) < 1e-4, film.rmse(got, want)
+    d.set_filter(None)
+    fb, _ = d.render(s.camera, hash_rd(s, seed=0))
+    assert film.rmse(got, film.xyzw_to_rgb(fb)) > 1e-3           # and it is not the box image
+
+
 @pytest.mark.parametrize("name", list(FILTER_CASES))
 def test_filtered_render_matches_oracle_sample_for_sample(name):
     """PixelFilter gaussian / mitchell 3 x 2.5 / triangle 1.5 x 1 under a crop window (direct lighting) /
