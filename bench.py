@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
     ap.add_argument("--filter", default="box", choices=["box", "gaussian", "mitchell", "triangle", "sinc"],
                     help="PixelFilter with the reference plugin's default widths (box 0.5 = the metric's configuration)")
+    ap.add_argument("--sampler", default="lowdiscrepancy", choices=["lowdiscrepancy", "random"],
+                    help='Sampler: "lowdiscrepancy" (the metric\'s configuration, HPT_SAMPLER_LD_HASH) or "random" (HPT_SAMPLER_RANDOM_HASH)')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
     args = ap.parse_args()
@@ -143,6 +145,9 @@ def main():
     rd = abi.copy_struct(scene.render)
     rd.spp = spp_per_gpu * world                     # weak scaling: per-rank samples fixed
     rd.shard_rank, rd.shard_count = rank, world
+    if args.sampler == "random":
+        rd.sampler_mode = abi.HPT_SAMPLER_RANDOM_HASH
+        scene.render.sampler_mode = abi.HPT_SAMPLER_RANDOM_HASH      # the CPU baseline runs the same sampler
     rd.count_work = 1 if args.count_work else 0
     rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.HPT_PIPELINE_PERSISTENT
     t0 = time.time()
@@ -198,8 +203,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "soup" else
             "scene blob dumped from the reference parser (tests/golden), random-free geometry",
-            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), LD_HASH sampler seed 0, %s filter"
-                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp,
+            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
+                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp, "RANDOM_HASH" if args.sampler == "random" else "LD_HASH",
                                       "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
                        "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
                        "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),

@@ -176,7 +176,13 @@ typedef struct hpt_camera {
  *                          (samplerrenderer.cpp:168), LDPixelSample (montecarlo.cpp:200-252),
  *                          rng draws for bounces >= 3 and Russian roulette in reference order.
  *                          One lane per tile, serial inside the tile: slow, bit-for-bit sequence. */
-enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1 };
+enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
+       /* Sampler "random" (samplers/random.cpp): every sample value an independent uniform draw, any
+        * spp >= 1 (RandomSampler::RoundSize is the identity, so light sample counts are not rounded either).
+        * RANDOM_HASH: production — value = 24-bit uniform from a stateless hash of (pixel, seed, sample, array, index),
+        * RandomFloat()'s resolution (core/rng.cpp:59-65).  RANDOM_MT_REPLAY: the reference's own stream (the tile's
+        * MT19937 + the sub-sampler's constructor generator, random.cpp:39-60) — oracle only, the device refuses it. */
+       HPT_SAMPLER_RANDOM_HASH = 2, HPT_SAMPLER_RANDOM_MT_REPLAY = 3 };
 
 /* Kernel organisation of the same path state machine:
  *  HPT_PIPELINE_PERSISTENT : one persistent-threads launch per frame, path state in registers,

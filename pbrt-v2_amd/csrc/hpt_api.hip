@@ -165,9 +165,11 @@ extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
 
 static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp, hpt_scene *s = nullptr) {
     if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
-    if (rd->spp <= 0 || (rd->spp & (rd->spp - 1))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42)"); return HPT_E_INVALID; }
+    if (rd->sampler_mode == HPT_SAMPLER_RANDOM_MT_REPLAY) { hpt_set_error("RANDOM_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"random\" as HPT_SAMPLER_RANDOM_HASH"); return HPT_E_UNSUPPORTED; }
+    const bool random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH;
+    if (rd->spp <= 0 || (!random_sampler && (rd->spp & (rd->spp - 1)))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42; Sampler \"random\" takes any)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
-    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
+    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY && !random_sampler) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
     if (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY) {
         if (rd->ntasks <= 0 || (rd->ntasks & (rd->ntasks - 1))) { hpt_set_error("MT_REPLAY needs ntasks = the reference's nTasks (a power of two, samplerrenderer.cpp:298-300)"); return HPT_E_INVALID; }
         if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
@@ -178,12 +180,13 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->seed = rd->seed;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
+    rp->random_sampler = random_sampler ? 1 : 0;
     // per-XCD queue heads: same-box A/B killeroo +1.5 %, bunny +1.8 %, anim +4 %, soup -1.6 %, direct lighting -6 % (its work items are
     // 17 rays x 64 samples long; bands of the image drain unevenly) -> on for the path integrator only; HPT_XCD_QUEUE=0/1 overrides
     rp->n_heads = rd->integrator == HPT_INTEGRATOR_PATH ? 8 : 1;
     if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;
     if (rd->integrator < HPT_INTEGRATOR_PATH || rd->integrator > HPT_INTEGRATOR_DIRECT_ONE) { hpt_set_error("unknown integrator %d", rd->integrator); return HPT_E_INVALID; }
-    if (rd->integrator != HPT_INTEGRATOR_PATH && (rd->sampler_mode != HPT_SAMPLER_LD_HASH || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
+    if (rd->integrator != HPT_INTEGRATOR_PATH && (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
         hpt_set_error("the direct-lighting integrator runs on the persistent kernel with the LD_HASH sampler (MT_REPLAY and the wavefront pipeline cover the path integrator)");
         return HPT_E_UNSUPPORTED;
     }
@@ -229,7 +232,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
     if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
     rp->items_per_pass = local * 1024;
-    rp->n_items = rp->items_per_pass * (rd->spp / rp->chunk);
+    rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);   // the last chunk of a non-power-of-two spp is short (Lane::begin_pixel)
     return HPT_OK;
 }
 
@@ -353,7 +356,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
         if (round == 1 && prd.spp <= 16) break;
         if (fill_params(cam, &prd, &a.rp, s) != HPT_OK) { e = hipErrorInvalidValue; break; }
         a.rp.has_motion = inst ? 1 : 0;
-        if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * (prd.spp / 4); }
+        if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * ((prd.spp + 3) / 4); }
         for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
             if (!in_race[cfg]) continue;
             int bpc = 0, vg = 0;

@@ -167,28 +167,40 @@ HPT_FN uint32_t perm_pow2(uint32_t i, uint32_t w, uint32_t key) {
 // oneD/twoD indices per path depth d<3 (integrators/path.cpp:41-49):
 //   oneD: 4d light component, 4d+1 light number, 4d+2 bsdf component, 4d+3 path component
 //   twoD: 3d light position,  3d+1 bsdf direction, 3d+2 path direction
+// HPT_SAMPLER_RANDOM_HASH (Sampler "random", samplers/random.cpp): w == HPT_RANDOM_W switches every getter to an independent
+// uniform value rnd(a, k) = (hash3(hash3(pk, i, 6), a, 8 + k) & 0xffffff) / 2^24, a = the array's scramble-word id, k = the index
+// inside the array (definition: oracle/hpt_oracle.c, rnd_u).  A wave-uniform branch on a field the lane carries anyway.
+#define HPT_RANDOM_W 0xffffffffu
 struct LdHash {
     uint32_t pk;   // hash3(pixelIndex, seed, 'PIXE')
-    uint32_t w;    // spp - 1
+    uint32_t w;    // spp - 1, or HPT_RANDOM_W
     uint32_t i;    // sample index within the pixel
+    HPT_MFN bool rnd_mode() const { return w == HPT_RANDOM_W; }
+    HPT_MFN float rnd(uint32_t a, uint32_t k) const { return (hash3(hash3(pk, i, 6u), a, 8u + k) & 0xffffff) / (float)(1 << 24); }
     HPT_MFN uint32_t idx(uint32_t arr) const { return perm_pow2(i, w, hash3(pk, arr, 2u)); }
-    HPT_MFN float one(int j) const { return van_der_corput(idx(3u + (uint32_t)j), hash3(pk, 5u + (uint32_t)j, 1u)); }
+    HPT_MFN float one(int j) const {
+        if (rnd_mode()) return rnd(5u + (uint32_t)j, 0u);
+        return van_der_corput(idx(3u + (uint32_t)j), hash3(pk, 5u + (uint32_t)j, 1u));
+    }
     HPT_MFN void two(int j, float *a, float *b) const {
+        if (rnd_mode()) { *a = rnd(17u + 2u * (uint32_t)j, 0u); *b = rnd(18u + 2u * (uint32_t)j, 0u); return; }
         uint32_t n = idx(15u + (uint32_t)j);
         *a = van_der_corput(n, hash3(pk, 17u + 2u * (uint32_t)j, 1u));
         *b = sobol2(n, hash3(pk, 18u + 2u * (uint32_t)j, 1u));
     }
     HPT_MFN void image(float *a, float *b) const {
+        if (rnd_mode()) { *a = rnd(0u, 0u); *b = rnd(1u, 0u); return; }
         uint32_t n = idx(0u);
         *a = van_der_corput(n, hash3(pk, 0u, 1u));
         *b = sobol2(n, hash3(pk, 1u, 1u));
     }
     HPT_MFN void lens(float *a, float *b) const {
+        if (rnd_mode()) { *a = rnd(2u, 0u); *b = rnd(3u, 0u); return; }
         uint32_t n = idx(1u);
         *a = van_der_corput(n, hash3(pk, 2u, 1u));
         *b = sobol2(n, hash3(pk, 3u, 1u));
     }
-    HPT_MFN float time01() const { return van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
+    HPT_MFN float time01() const { return rnd_mode() ? rnd(4u, 0u) : van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
     // Direct-lighting layout (integrators/directlighting.cpp:54-77): 1D array j / 2D array j of `c` values per pixel
     // sample (c a power of two; n1d = number of 1D arrays).  As LDShuffleScrambled*D, an array is one scrambled
     // (0,2)-sequence of spp * c points cut into spp blocks of c: sample i owns block idx(array) and visits its points
@@ -198,9 +210,11 @@ struct LdHash {
         return idx(arr) * c + perm_pow2(k, c - 1u, hash3(hash3(pk, arr, 4u), i, 5u));
     }
     HPT_MFN float one_c(int j, uint32_t c, uint32_t k) const {
+        if (rnd_mode()) return rnd(5u + (uint32_t)j, k);
         return van_der_corput(idx_c(3u + (uint32_t)j, c, k), hash3(pk, 5u + (uint32_t)j, 1u));
     }
     HPT_MFN void two_c(int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const {
+        if (rnd_mode()) { *a = rnd(5u + (uint32_t)n1d + 2u * (uint32_t)j, k); *b = rnd(6u + (uint32_t)n1d + 2u * (uint32_t)j, k); return; }
         uint32_t n = idx_c(3u + (uint32_t)n1d + (uint32_t)j, c, k);
         *a = van_der_corput(n, hash3(pk, 5u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));
         *b = sobol2(n, hash3(pk, 6u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));

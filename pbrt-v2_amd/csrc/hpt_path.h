@@ -44,6 +44,7 @@ struct RenderParams {
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
     int32_t has_motion;        // scene has animated instances: rays carry a time sample
     int32_t integrator;        // HPT_INTEGRATOR_*
+    int32_t random_sampler;    // HPT_SAMPLER_RANDOM_HASH: independent uniform values, any spp, light sample counts not rounded
     int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
@@ -144,8 +145,9 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
 
 // Light samples per camera sample of the direct-lighting integrator: LDSampler::RoundSize(Light::nSamples)
 // (directlighting.cpp:63-65, samplers/lowdiscrepancy.h:53; Light ctor: max(1, ns), core/light.cpp)
-HPT_FN int dl_count(const hpt_light &l) {
+HPT_FN int dl_count(const hpt_light &l, const RenderParams &rp) {
     uint32_t v = (uint32_t)(l.nsamples < 1 ? 1 : l.nsamples);
+    if (rp.random_sampler) return (int)v;          // RandomSampler::RoundSize is the identity (samplers/random.h:52)
     v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
     return (int)(v + 1u);
 }
@@ -217,6 +219,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     }
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y, uint32_t s0 = 0, uint32_t n = 0) {
         px = x; py = y; si = s0; s_end = s0 + (n ? n : (uint32_t)rp.spp); fX = fY = fZ = fW = 0.f;
+        if (s_end > (uint32_t)rp.spp) s_end = (uint32_t)rp.spp;          // last chunk of an spp that is no multiple of the chunk
         smp.begin_pixel(rp, x, y);
         begin_sample(rp);
     }
@@ -277,7 +280,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         if (DL) {
             if (sc.n_lights > 0 && rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {       // integrator.cpp:56-77
                 acc = acc + Ld;
-                const int n = dl_count(sc.lights[li]);
+                const int n = dl_count(sc.lights[li], rp);
                 if (++lj == n) { L = L + sdivf(acc, (float)n); acc = S(0.f); lj = 0; ++li; }
                 if (li < sc.n_lights) { stage = ST_SHADE; return; }
             } else if (sc.n_lights > 0) L = L + Ld * (float)sc.n_lights;                // integrator.cpp:110-113
@@ -465,7 +468,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     HPT_MFN void dl_samples(const DScene &sc, const RenderParams &rp, int *lightPick, float *ln, float *ls0, float *ls1, float *ls2,
                             float *bs0, float *bs1, float *bs2) {
         if (rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {
-            const uint32_t c = (uint32_t)dl_count(sc.lights[li]), k = (uint32_t)lj;
+            const uint32_t c = (uint32_t)dl_count(sc.lights[li], rp), k = (uint32_t)lj;
             const int n1d = 2 * sc.n_lights + 2;
             *lightPick = li; *ln = 0.f;
             smp.two_c(2 * li, n1d, c, k, ls0, ls1); *ls2 = smp.one_c(2 * li, c, k);
@@ -524,7 +527,7 @@ struct LdHashSrc {
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
         uint32_t pixelIndex = (uint32_t)y * (uint32_t)rp.xres + (uint32_t)x;
         h.pk = pixel_key(pixelIndex, rp.seed);
-        h.w = (uint32_t)rp.spp - 1u;
+        h.w = rp.random_sampler ? HPT_RANDOM_W : (uint32_t)rp.spp - 1u;
     }
     HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; }
     HPT_MFN void end_pixel(const RenderParams &) {}

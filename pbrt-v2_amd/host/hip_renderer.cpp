@@ -44,6 +44,7 @@
 #include "materials/substrate.h"
 #include "materials/plastic.h"
 #include "samplers/lowdiscrepancy.h"
+#include "samplers/random.h"
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
@@ -418,7 +419,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     flt.xwidth = film->filter->xWidth; flt.ywidth = film->filter->yWidth;
     memcpy(flt.table, film->filterTable, sizeof(flt.table));
     const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
-    if (!lds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\"");
+    const RandomSampler *rnds = dynamic_cast<const RandomSampler *>(sampler);
+    if (!lds && !rnds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\" or \"random\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
     const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
     if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
@@ -442,11 +444,11 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.xres = film->xResolution; rd.yres = film->yResolution;
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
-    rd.spp = lds->nPixelSamples;
+    rd.spp = lds ? lds->nPixelSamples : rnds->nSamples;
     rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
     rd.integrator = path ? HPT_INTEGRATOR_PATH
                          : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
-    rd.sampler_mode = samplerMode;
+    rd.sampler_mode = lds ? samplerMode : (samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_RANDOM_MT_REPLAY : HPT_SAMPLER_RANDOM_HASH);
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:298-300)
     int nPixels = film->xResolution * film->yResolution;

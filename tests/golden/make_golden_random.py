@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Golden fixtures of `Sampler "random"`, from the REAL reference.
+
+Same procedure as the other generators (build container only): oracle/_ref/pbrt renders the scene file
+(-> *.ref.npy.gz), pbrt_hip with HPT_DUMP_SCENE flattens it; the geometry is already committed, so only camera,
+render descriptor (sampler mode, spp) and light records are stored in <case>.view.npz.
+
+Cases (the shipped scene files with their Sampler line replaced)
+  rk     killeroo-simple, path maxdepth 5, random 6 spp (not a power of two); 96x96
+  rdl    killeroo-simple as shipped (directlighting, strategy all) with the area light's nsamples 5 (RandomSampler does
+         not round light sample counts), random 3 spp; 64x64
+  rb     bunny, path maxdepth 8 (measured BRDF, two lights), random 4 spp; 120x68
+  ranim  anim-killeroos-moving, directlighting as shipped, random 5 spp; 100x60
+"""
+import gzip
+import importlib
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+abi = importlib.import_module("pbrt-v2_amd.abi")
+film = importlib.import_module("pbrt-v2_amd.film")
+
+REF = "/root/reference/scenes"
+PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+PBRT_HIP = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+
+
+def sub(text, xres, yres, spp, out_pfm, integrator=None):
+    text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
+    text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
+    if '"string filename"' in text:
+        text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_pfm, text)
+    else:
+        text = re.sub(r'Film "image"', 'Film "image" "string filename" "%s"' % out_pfm, text, count=1)
+    text = re.sub(r'Sampler "lowdiscrepancy" "integer pixelsamples" \[\d+\]', 'Sampler "random" "integer pixelsamples" [%d]' % spp, text)
+    assert 'Sampler "random"' in text
+    if integrator:
+        text = text.replace('SurfaceIntegrator "directlighting"', integrator)
+    text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
+    text = text.replace('"brdfs/', '"%s/brdfs/' % REF)
+    return text
+
+
+def run_case(name, pbrt_text, tmp, geometry_blob):
+    scene_path = os.path.join(tmp, name + ".pbrt")
+    with open(scene_path, "w") as f:
+        f.write(pbrt_text)
+    subprocess.check_call([PBRT, "--quiet", "--ncores", "1", scene_path], stderr=subprocess.DEVNULL)
+    blob = os.path.join(tmp, name + ".hpts")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", scene_path], env=env, stderr=subprocess.DEVNULL)
+    ref = film.read_pfm(os.path.join(tmp, name + "_ref.pfm"))
+    with open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+        np.save(f, ref)
+    v = abi.Scene.load(blob)
+    g = abi.Scene.load(os.path.join(HERE, geometry_blob))
+    for sc in (v, g):   # a kd-tree leaf's split position is uninitialised memory in the reference (never read): mask it
+        for m in sc.materials:
+            if m.kind == abi.HPT_MAT_MEASURED_IRREG:
+                leaf = (sc.ipool[m.kd_bits_off:m.kd_bits_off + m.kd_nnodes] & 3) == 3
+                sc.fpool[m.kd_split_off:m.kd_split_off + m.kd_nnodes][leaf] = 0.0
+    assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool), "geometry differs from " + geometry_blob
+    assert v.render.sampler_mode == abi.HPT_SAMPLER_RANDOM_HASH
+    np.savez(os.path.join(HERE, name + ".view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
+             render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8))
+    print(name, "integrator", v.render.integrator, "spp", v.render.spp, "nsamples", [l.nsamples for l in v.lights], ref.shape)
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        kill = open(os.path.join(REF, "killeroo-simple.pbrt")).read()
+        run_case("rk", sub(kill, 96, 96, 6, os.path.join(tmp, "rk_ref.pfm"), 'SurfaceIntegrator "path" "integer maxdepth" [5]'), tmp, "killeroo_cfg1.hpts.gz")
+        dl = sub(kill, 64, 64, 3, os.path.join(tmp, "rdl_ref.pfm"))
+        assert '"integer nsamples" [8]' in dl
+        run_case("rdl", dl.replace('"integer nsamples" [8]', '"integer nsamples" [5]'), tmp, "killeroo_cfg1.hpts.gz")
+        bunny = open(os.path.join(REF, "bunny.pbrt")).read().split("\n", 2)[2]  # drop the 2 Film lines
+        head = ('Film "image" "integer xresolution" [120] "integer yresolution" [68] "string filename" "%s"\n'
+                'Sampler "random" "integer pixelsamples" [4]\n'
+                'SurfaceIntegrator "path" "integer maxdepth" [8]\n') % os.path.join(tmp, "rb_ref.pfm")
+        run_case("rb", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
+                 .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
+        run_case("ranim", sub(anim, 100, 60, 5, os.path.join(tmp, "ranim_ref.pfm")), tmp, "anim_killeroos.hpts.gz")
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->seed = rd->seed;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
+    rp->random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH ? 1 : 0;
     rp->n_heads = 1;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
@@ -88,7 +89,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
     rp->items_per_pass = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
-    rp->n_items = rp->items_per_pass * (rd->spp / rp->chunk);
+    rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);
 }
 
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).

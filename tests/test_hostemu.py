@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
+from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc
@@ -237,3 +237,41 @@ def test_two_pass_film_matches_oracle_and_is_reproducible(name):
         f, _ = e.render(s.camera, rd, flt=s.filter, two_pass=True)
         acc += f
     assert np.allclose(acc, fg, rtol=1e-5, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("name", list(RANDOM_CASES))
+def test_random_sampler_render_matches_oracle(name):
+    """SURVEY.md §8f-4, `Sampler "random"` as HPT_SAMPLER_RANDOM_HASH: the device lane's sampler getters in their
+    independent-uniform mode (hpt_device.h LdHash::rnd), spp that are not powers of two (6, 3, 5), light sample counts that
+    are not rounded (5) — against the oracle, which is pinned to the reference binary on these scenes in its replay mode."""
+    s = load_case(name)
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = abi.copy_struct(s.render)
+    assert rd.sampler_mode == abi.HPT_SAMPLER_RANDOM_HASH
+    rd.seed = 5
+    fo, so = o.render(s.camera, rd)
+    fe, se = e.render(s.camera, rd)
+    assert so[0] == se[0] == rd.x_count * rd.y_count * rd.spp
+    assert abs(int(so[1]) - int(se[1])) <= 4 and abs(int(so[2]) - int(se[2])) <= 4
+    assert np.array_equal(fo[..., 3], fe[..., 3])
+    io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
+    assert (np.abs(io - ie).max(axis=2) > 0).mean() < 1e-3 and film.rmse(io, ie) < 1e-4
+
+
+def test_random_sampler_values_and_chunking(cases):
+    """Bit-identical sample values (oracle vs device getters); uniform in [0, 1) per dimension; 100 spp = a full chunk of
+    64 and a short one of 36."""
+    s = load_case("rk")
+    rd = abi.copy_struct(s.render)
+    rd.seed, rd.spp = 11, 64
+    a, b = orc.sampler(rd, 3, 7), emu.sampler(rd, 3, 7)
+    assert np.array_equal(a, b)
+    v = a[:, 5:]
+    assert ((v >= 0) & (v < 1)).all() and 0.4 < float(v.mean()) < 0.6
+    assert np.all((a[:, 0] >= 3) & (a[:, 0] < 4) & (a[:, 1] >= 7) & (a[:, 1] < 8))
+    rd = abi.copy_struct(s.render)
+    rd.spp, rd.x_start, rd.y_start, rd.x_count, rd.y_count = 100, 40, 40, 16, 16
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    fe, se = emu.EmuScene(s).render(s.camera, rd)
+    assert so[0] == se[0] == 16 * 16 * 100
+    assert np.array_equal(fo[..., 3], fe[..., 3]) and np.allclose(fo, fe, rtol=1e-5, atol=1e-4)

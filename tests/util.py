@@ -48,6 +48,13 @@ def load_case(name):
         assert len(bytes(lights)) == len(bytes(s.lights))
         s.lights = lights
         return s
+    if name in RANDOM_CASES:   # Sampler "random" cases: committed geometry + camera / render descriptor (sampler mode, spp) / lights
+        s = abi.Scene.load(os.path.join(GOLDEN, RANDOM_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        return s
     if name in FILTER_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
         s = abi.Scene.load(os.path.join(GOLDEN, FILTER_CASES[name]))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
@@ -68,6 +75,11 @@ DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "d
 # SURVEY.md §8f-4 (tests/golden/make_golden_filter.py): PixelFilter gaussian / mitchell / triangle (+ crop window) / sinc
 FILTER_CASES = {"fgauss": "killeroo_cfg1.hpts.gz", "fmitch": "bunny_b8.hpts.gz", "ftri": "killeroo_cfg1.hpts.gz",
                 "fsinc": "anim_killeroos.hpts.gz"}
+
+
+# SURVEY.md §8f-4 (tests/golden/make_golden_random.py): Sampler "random" — path 6 spp, direct lighting with 5 light samples
+# at 3 spp, bunny path 4 spp, animated scene direct lighting 5 spp
+RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "rb": "bunny_b8.hpts.gz", "ranim": "anim_killeroos.hpts.gz"}
 
 
 def hash_rd(scene, seed=7, spp=None):
