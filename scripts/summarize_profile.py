@@ -18,7 +18,7 @@ src, tag = sys.argv[1], sys.argv[2]          # e.g. gpurun_out/prof_bunny_234126
 root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
-KERNEL = "hpt_path_kernel"
+KERNEL = os.environ.get("PROF_KERNEL", "hpt_path_kernel")   # PROF_KERNEL=hpt_film_gather_kernel: the second pass of a filtered frame
 
 stats_rows = []
 for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
