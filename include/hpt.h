@@ -182,7 +182,17 @@ enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
         * RANDOM_HASH: production — value = 24-bit uniform from a stateless hash of (pixel, seed, sample, array, index),
         * RandomFloat()'s resolution (core/rng.cpp:59-65).  RANDOM_MT_REPLAY: the reference's own stream (the tile's
         * MT19937 + the sub-sampler's constructor generator, random.cpp:39-60) — oracle only, the device refuses it. */
-       HPT_SAMPLER_RANDOM_HASH = 2, HPT_SAMPLER_RANDOM_MT_REPLAY = 3 };
+       HPT_SAMPLER_RANDOM_HASH = 2, HPT_SAMPLER_RANDOM_MT_REPLAY = 3,
+       /* Sampler "stratified" (samplers/stratified.cpp): xsamples x ysamples jittered strata per pixel for
+        * the image and lens samples (lens and time shuffled), Latin-hypercube arrays for the integrators; spp = xs * ys,
+        * counts not rounded.  The sampler's parameters ride in the upper bits of sampler_mode (the descriptor's layout is
+        * frozen by the scene blobs): HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter).  STRATIFIED_HASH: production,
+        * stateless; STRATIFIED_MT_REPLAY: the reference's stream — oracle only. */
+       HPT_SAMPLER_STRATIFIED_HASH = 4, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 5 };
+#define HPT_SAMPLER_KIND(mode) ((mode) & 0x7f)
+#define HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter) ((kind) | ((jitter) ? 0x80 : 0) | ((xsamples) << 8))
+#define HPT_SAMPLER_STRAT_XS(mode) (((mode) >> 8) & 0xfff)
+#define HPT_SAMPLER_STRAT_JITTER(mode) (((mode) >> 7) & 1)
 
 /* Kernel organisation of the same path state machine:
  *  HPT_PIPELINE_PERSISTENT : one persistent-threads launch per frame, path state in registers,

@@ -15,6 +15,16 @@ HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER_RANDOM_MT_REPLAY = 0, 1, 2, 3
+HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
+
+
+def sampler_kind(mode):
+    return mode & 0x7f
+
+
+def stratified_mode(kind, xsamples, jitter=True):
+    """HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter): the sampler's parameters ride in sampler_mode's upper bits"""
+    return kind | (0x80 if jitter else 0) | (xsamples << 8)
 HPT_PIPELINE_PERSISTENT, HPT_PIPELINE_WAVEFRONT = 0, 1
 HPT_INTEGRATOR_PATH, HPT_INTEGRATOR_DIRECT_ALL, HPT_INTEGRATOR_DIRECT_ONE = 0, 1, 2
 SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs

@@ -45,6 +45,7 @@
 #include "materials/plastic.h"
 #include "samplers/lowdiscrepancy.h"
 #include "samplers/random.h"
+#include "samplers/stratified.h"
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
@@ -420,7 +421,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     memcpy(flt.table, film->filterTable, sizeof(flt.table));
     const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
     const RandomSampler *rnds = dynamic_cast<const RandomSampler *>(sampler);
-    if (!lds && !rnds) Severe("hip renderer: Sampler must be \"lowdiscrepancy\" or \"random\"");
+    const StratifiedSampler *strat = dynamic_cast<const StratifiedSampler *>(sampler);
+    if (!lds && !rnds && !strat) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\" or \"stratified\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
     const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
     if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
@@ -444,11 +446,16 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.xres = film->xResolution; rd.yres = film->yResolution;
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
-    rd.spp = lds ? lds->nPixelSamples : rnds->nSamples;
+    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : strat->xPixelSamples * strat->yPixelSamples;
     rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
     rd.integrator = path ? HPT_INTEGRATOR_PATH
                          : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
     rd.sampler_mode = lds ? samplerMode : (samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_RANDOM_MT_REPLAY : HPT_SAMPLER_RANDOM_HASH);
+    if (strat) {
+        if (strat->xPixelSamples > 0xfff) Severe("hip renderer: stratified xsamples above 4095");
+        rd.sampler_mode = HPT_SAMPLER_STRATIFIED(samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_STRATIFIED_MT_REPLAY : HPT_SAMPLER_STRATIFIED_HASH,
+                                                 strat->xPixelSamples, strat->jitterSamples);
+    }
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:298-300)
     int nPixels = film->xResolution * film->yResolution;

@@ -33,15 +33,15 @@ PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
 PBRT_HIP = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
 
 
-def sub(text, xres, yres, spp, out_pfm, integrator=None):
+def sub(text, xres, yres, spp, out_pfm, integrator=None, sampler=None):
     text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
     text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
     if '"string filename"' in text:
         text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_pfm, text)
     else:
         text = re.sub(r'Film "image"', 'Film "image" "string filename" "%s"' % out_pfm, text, count=1)
-    text = re.sub(r'Sampler "lowdiscrepancy" "integer pixelsamples" \[\d+\]', 'Sampler "random" "integer pixelsamples" [%d]' % spp, text)
-    assert 'Sampler "random"' in text
+    text = re.sub(r'Sampler "lowdiscrepancy" "integer pixelsamples" \[\d+\]', sampler or ('Sampler "random" "integer pixelsamples" [%d]' % spp), text)
+    assert 'Sampler "random"' in text or 'Sampler "stratified"' in text
     if integrator:
         text = text.replace('SurfaceIntegrator "directlighting"', integrator)
     text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
@@ -68,10 +68,10 @@ def run_case(name, pbrt_text, tmp, geometry_blob):
                 leaf = (sc.ipool[m.kd_bits_off:m.kd_bits_off + m.kd_nnodes] & 3) == 3
                 sc.fpool[m.kd_split_off:m.kd_split_off + m.kd_nnodes][leaf] = 0.0
     assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool), "geometry differs from " + geometry_blob
-    assert v.render.sampler_mode == abi.HPT_SAMPLER_RANDOM_HASH
+    assert abi.sampler_kind(v.render.sampler_mode) in (abi.HPT_SAMPLER_RANDOM_HASH, abi.HPT_SAMPLER_STRATIFIED_HASH)
     np.savez(os.path.join(HERE, name + ".view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
              render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8))
-    print(name, "integrator", v.render.integrator, "spp", v.render.spp, "nsamples", [l.nsamples for l in v.lights], ref.shape)
+    print(name, "integrator", v.render.integrator, "sampler mode", hex(v.render.sampler_mode), "spp", v.render.spp, "nsamples", [l.nsamples for l in v.lights], ref.shape)
 
 
 def main():
@@ -87,7 +87,15 @@ def main():
                 'SurfaceIntegrator "path" "integer maxdepth" [8]\n') % os.path.join(tmp, "rb_ref.pfm")
         run_case("rb", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
                  .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        # Sampler "stratified": 3 x 2 jittered on the path integrator; 2 x 2 (the plugin's defaults) under direct lighting with 5
+        # light samples (Latin hypercube over 5); 2 x 3 without jitter on the animated scene
+        run_case("sk", sub(kill, 96, 96, 0, os.path.join(tmp, "sk_ref.pfm"), 'SurfaceIntegrator "path" "integer maxdepth" [5]',
+                           sampler='Sampler "stratified" "integer xsamples" [3] "integer ysamples" [2]'), tmp, "killeroo_cfg1.hpts.gz")
+        sdl = sub(kill, 64, 64, 0, os.path.join(tmp, "sdl_ref.pfm"), sampler='Sampler "stratified"')
+        run_case("sdl", sdl.replace('"integer nsamples" [8]', '"integer nsamples" [5]'), tmp, "killeroo_cfg1.hpts.gz")
         anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
+        run_case("sanim", sub(anim, 100, 60, 0, os.path.join(tmp, "sanim_ref.pfm"), 'SurfaceIntegrator "path" "integer maxdepth" [4]',
+                              sampler='Sampler "stratified" "integer xsamples" [2] "integer ysamples" [3] "bool jitter" ["false"]'), tmp, "anim_killeroos.hpts.gz")
         run_case("ranim", sub(anim, 100, 60, 5, os.path.join(tmp, "ranim_ref.pfm")), tmp, "anim_killeroos.hpts.gz")
 
 

@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, abi, load_case, load_ref
+from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -63,6 +63,22 @@ def test_oracle_replays_random_sampler_reference_image_bit_exact(name):
     rd = abi.copy_struct(s.render)
     assert rd.sampler_mode == abi.HPT_SAMPLER_RANDOM_HASH
     rd.sampler_mode = abi.HPT_SAMPLER_RANDOM_MT_REPLAY
+    f, st = o.render(s.camera, rd, nthreads=1)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert img.shape == ref.shape
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
+@pytest.mark.parametrize("name", list(STRATIFIED_CASES))
+def test_oracle_replays_stratified_sampler_reference_image_bit_exact(name):
+    """`Sampler "stratified"` (samplers/stratified.cpp) — jittered strata for image / lens / time, the lens
+    and time shuffles, a Latin hypercube per sample array (over 5 light samples in sdl), and the unjittered variant."""
+    s = load_case(name)
+    o = orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    assert abi.sampler_kind(rd.sampler_mode) == abi.HPT_SAMPLER_STRATIFIED_HASH
+    rd.sampler_mode = (rd.sampler_mode & ~0x7f) | abi.HPT_SAMPLER_STRATIFIED_MT_REPLAY
     f, st = o.render(s.camera, rd, nthreads=1)
     assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
     img, ref = film.xyzw_to_rgb(f), load_ref(name)

@@ -48,8 +48,8 @@ def load_case(name):
         assert len(bytes(lights)) == len(bytes(s.lights))
         s.lights = lights
         return s
-    if name in RANDOM_CASES:   # Sampler "random" cases: committed geometry + camera / render descriptor (sampler mode, spp) / lights
-        s = abi.Scene.load(os.path.join(GOLDEN, RANDOM_CASES[name]))
+    if name in RANDOM_CASES or name in STRATIFIED_CASES:   # Sampler "random" / "stratified" cases: committed geometry + camera / render descriptor (sampler mode, spp) / lights
+        s = abi.Scene.load(os.path.join(GOLDEN, (RANDOM_CASES.get(name) or STRATIFIED_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
@@ -80,6 +80,9 @@ FILTER_CASES = {"fgauss": "killeroo_cfg1.hpts.gz", "fmitch": "bunny_b8.hpts.gz",
 # SURVEY.md §8f-4 (tests/golden/make_golden_random.py): Sampler "random" — path 6 spp, direct lighting with 5 light samples
 # at 3 spp, bunny path 4 spp, animated scene direct lighting 5 spp
 RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "rb": "bunny_b8.hpts.gz", "ranim": "anim_killeroos.hpts.gz"}
+# Sampler "stratified" (same generator): 3 x 2 jittered, path; 2 x 2 jittered, direct lighting with 5 light samples; 2 x 3 unjittered,
+# path on the animated scene
+STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz", "sanim": "anim_killeroos.hpts.gz"}
 
 
 def hash_rd(scene, seed=7, spp=None):
