@@ -119,8 +119,8 @@ def main():
     ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
     ap.add_argument("--filter", default="box", choices=["box", "gaussian", "mitchell", "triangle", "sinc"],
                     help="PixelFilter with the reference plugin's default widths (box 0.5 = the metric's configuration)")
-    ap.add_argument("--sampler", default="lowdiscrepancy", choices=["lowdiscrepancy", "random"],
-                    help='Sampler: "lowdiscrepancy" (the metric\'s configuration, HPT_SAMPLER_LD_HASH) or "random" (HPT_SAMPLER_RANDOM_HASH)')
+    ap.add_argument("--sampler", default="lowdiscrepancy", choices=["lowdiscrepancy", "random", "stratified"],
+                    help='Sampler: "lowdiscrepancy" (the metric\'s configuration, HPT_SAMPLER_LD_HASH) "random" (HPT_SAMPLER_RANDOM_HASH) or "stratified" (HPT_SAMPLER_STRATIFIED_HASH, 8 x spp/8 jittered strata)')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
     args = ap.parse_args()
@@ -148,6 +148,10 @@ def main():
     if args.sampler == "random":
         rd.sampler_mode = abi.HPT_SAMPLER_RANDOM_HASH
         scene.render.sampler_mode = abi.HPT_SAMPLER_RANDOM_HASH      # the CPU baseline runs the same sampler
+    if args.sampler == "stratified":
+        xs = 8 if rd.spp % 8 == 0 else (4 if rd.spp % 4 == 0 else 1)
+        rd.sampler_mode = abi.stratified_mode(abi.HPT_SAMPLER_STRATIFIED_HASH, xs, True)
+        scene.render.sampler_mode = rd.sampler_mode
     rd.count_work = 1 if args.count_work else 0
     rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.HPT_PIPELINE_PERSISTENT
     t0 = time.time()
@@ -204,7 +208,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "soup" else
             "scene blob dumped from the reference parser (tests/golden), random-free geometry",
             "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
-                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp, "RANDOM_HASH" if args.sampler == "random" else "LD_HASH",
+                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp, {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)"}.get(args.sampler, "LD_HASH"),
                                       "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
                        "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
                        "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),

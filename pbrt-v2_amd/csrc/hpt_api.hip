@@ -166,7 +166,14 @@ extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
 static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp, hpt_scene *s = nullptr) {
     if (!cam || !rd) { hpt_set_error("null camera / render descriptor"); return HPT_E_INVALID; }
     if (rd->sampler_mode == HPT_SAMPLER_RANDOM_MT_REPLAY) { hpt_set_error("RANDOM_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"random\" as HPT_SAMPLER_RANDOM_HASH"); return HPT_E_UNSUPPORTED; }
-    const bool random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH;
+    const int skind = HPT_SAMPLER_KIND(rd->sampler_mode);
+    if (skind == HPT_SAMPLER_STRATIFIED_MT_REPLAY) { hpt_set_error("STRATIFIED_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"stratified\" as HPT_SAMPLER_STRATIFIED_HASH"); return HPT_E_UNSUPPORTED; }
+    const bool stratified = skind == HPT_SAMPLER_STRATIFIED_HASH;
+    const bool random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH || stratified;
+    if (stratified) {
+        const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode);
+        if (xs <= 0 || rd->spp <= 0 || rd->spp % xs || rd->spp > 0xfff) { hpt_set_error("stratified sampler: spp = xsamples * ysamples, at most 4095 (got spp %d, xsamples %d)", rd->spp, xs); return HPT_E_INVALID; }
+    }
     if (rd->spp <= 0 || (!random_sampler && (rd->spp & (rd->spp - 1)))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42; Sampler \"random\" takes any)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
     if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY && !random_sampler) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
@@ -181,12 +188,20 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
     rp->random_sampler = random_sampler ? 1 : 0;
+    rp->sampler_kind = stratified ? 2 : random_sampler ? 1 : 0;
+    rp->sampler_w = stratified ? HPT_STRAT_W : random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
+    rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
+    if (stratified) {
+        const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
+        rp->strat_jitter = HPT_SAMPLER_STRAT_JITTER(rd->sampler_mode);
+        rp->strat_fxs = (float)xs; rp->strat_dx = 1.f / (float)xs; rp->strat_dy = 1.f / (float)ys; rp->strat_dt = 1.f / (float)rd->spp;
+    }
     // per-XCD queue heads: same-box A/B killeroo +1.5 %, bunny +1.8 %, anim +4 %, soup -1.6 %, direct lighting -6 % (its work items are
     // 17 rays x 64 samples long; bands of the image drain unevenly) -> on for the path integrator only; HPT_XCD_QUEUE=0/1 overrides
     rp->n_heads = rd->integrator == HPT_INTEGRATOR_PATH ? 8 : 1;
     if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;
     if (rd->integrator < HPT_INTEGRATOR_PATH || rd->integrator > HPT_INTEGRATOR_DIRECT_ONE) { hpt_set_error("unknown integrator %d", rd->integrator); return HPT_E_INVALID; }
-    if (rd->integrator != HPT_INTEGRATOR_PATH && (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
+    if (rd->integrator != HPT_INTEGRATOR_PATH && (skind == HPT_SAMPLER_MT_REPLAY || rd->pipeline != HPT_PIPELINE_PERSISTENT)) {
         hpt_set_error("the direct-lighting integrator runs on the persistent kernel with the LD_HASH sampler (MT_REPLAY and the wavefront pipeline cover the path integrator)");
         return HPT_E_UNSUPPORTED;
     }

@@ -170,37 +170,63 @@ HPT_FN uint32_t perm_pow2(uint32_t i, uint32_t w, uint32_t key) {
 // HPT_SAMPLER_RANDOM_HASH (Sampler "random", samplers/random.cpp): w == HPT_RANDOM_W switches every getter to an independent
 // uniform value rnd(a, k) = (hash3(hash3(pk, i, 6), a, 8 + k) & 0xffffff) / 2^24, a = the array's scramble-word id, k = the index
 // inside the array (definition: oracle/hpt_oracle.c, rnd_u).  A wave-uniform branch on a field the lane carries anyway.
+// HPT_SAMPLER_STRATIFIED_HASH (Sampler "stratified", samplers/stratified.cpp): w = HPT_STRAT_W (any value >= it that is not HPT_RANDOM_W);
+// the grid comes from RenderParams (scalar registers: strat_*), the mode switch of the camera / light-array getters is a scalar branch.
+// Image sample i sits in stratum (i % xs, i / xs); lens and time strata are keyed permutations of [0, spp) (perm_n: perm_pow2 on the
+// next power of two, cycle-walked into range); an array of c values per pixel sample is a Latin hypercube, entry k of dimension a =
+// (perm_n(k, c, hash3(hash3(pk, i, 9), a, 10)) + rnd(a, k)) / c — which for c = 1 (every array of the path integrator) is rnd(a, 0),
+// the random sampler's value (definition: oracle/hpt_oracle.c, strat_hash_sample).
 #define HPT_RANDOM_W 0xffffffffu
+#define HPT_STRAT_W 0xc0000000u
+HPT_FN uint32_t perm_n(uint32_t v, uint32_t n, uint32_t key) {
+    uint32_t m = n - 1u; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+    do { v = perm_pow2(v, m, key); } while (v >= n);
+    return v;
+}
 struct LdHash {
     uint32_t pk;   // hash3(pixelIndex, seed, 'PIXE')
-    uint32_t w;    // spp - 1, or HPT_RANDOM_W
+    uint32_t w;    // spp - 1, or HPT_RANDOM_W, or HPT_STRAT_W | ...
     uint32_t i;    // sample index within the pixel
     HPT_MFN bool rnd_mode() const { return w == HPT_RANDOM_W; }
+    HPT_MFN bool special() const { return w >= HPT_STRAT_W; }           // random or stratified
     HPT_MFN float rnd(uint32_t a, uint32_t k) const { return (hash3(hash3(pk, i, 6u), a, 8u + k) & 0xffffff) / (float)(1 << 24); }
+    HPT_MFN float lhs(uint32_t a, uint32_t k, uint32_t c) const {
+        const float v = ((float)perm_n(k, c, hash3(hash3(pk, i, 9u), a, 10u)) + rnd(a, k)) * (1.f / (float)c);
+        return v < HPT_ONE_MINUS_EPS ? v : HPT_ONE_MINUS_EPS;
+    }
+    // stratum `cell` of the xs x ys grid, jitter words a, a + 1.  cell / xs through float: exact below 4096 (the quotient's fraction is
+    // at least 0.5 / xs away from an integer, the float error under 1e-3 of that) and far cheaper than the integer-division expansion.
+    HPT_MFN void strat2(uint32_t cell, uint32_t a, bool jitter, float fxs, float dx, float dy, float *x, float *y) const {
+        const float fc = (float)cell, cy = floorf((fc + 0.5f) * dx), cx = fc - cy * fxs;
+        const float vx = (cx + (jitter ? rnd(a, 0u) : 0.5f)) * dx, vy = (cy + (jitter ? rnd(a + 1u, 0u) : 0.5f)) * dy;
+        *x = vx < HPT_ONE_MINUS_EPS ? vx : HPT_ONE_MINUS_EPS; *y = vy < HPT_ONE_MINUS_EPS ? vy : HPT_ONE_MINUS_EPS;
+    }
+    HPT_MFN float strat1(uint32_t cell, uint32_t a, bool jitter, float dt) const {
+        const float t = ((float)cell + (jitter ? rnd(a, 0u) : 0.5f)) * dt;
+        return t < HPT_ONE_MINUS_EPS ? t : HPT_ONE_MINUS_EPS;
+    }
     HPT_MFN uint32_t idx(uint32_t arr) const { return perm_pow2(i, w, hash3(pk, arr, 2u)); }
     HPT_MFN float one(int j) const {
-        if (rnd_mode()) return rnd(5u + (uint32_t)j, 0u);
+        if (special()) return rnd(5u + (uint32_t)j, 0u);
         return van_der_corput(idx(3u + (uint32_t)j), hash3(pk, 5u + (uint32_t)j, 1u));
     }
     HPT_MFN void two(int j, float *a, float *b) const {
-        if (rnd_mode()) { *a = rnd(17u + 2u * (uint32_t)j, 0u); *b = rnd(18u + 2u * (uint32_t)j, 0u); return; }
+        if (special()) { *a = rnd(17u + 2u * (uint32_t)j, 0u); *b = rnd(18u + 2u * (uint32_t)j, 0u); return; }
         uint32_t n = idx(15u + (uint32_t)j);
         *a = van_der_corput(n, hash3(pk, 17u + 2u * (uint32_t)j, 1u));
         *b = sobol2(n, hash3(pk, 18u + 2u * (uint32_t)j, 1u));
     }
     HPT_MFN void image(float *a, float *b) const {
-        if (rnd_mode()) { *a = rnd(0u, 0u); *b = rnd(1u, 0u); return; }
         uint32_t n = idx(0u);
         *a = van_der_corput(n, hash3(pk, 0u, 1u));
         *b = sobol2(n, hash3(pk, 1u, 1u));
     }
     HPT_MFN void lens(float *a, float *b) const {
-        if (rnd_mode()) { *a = rnd(2u, 0u); *b = rnd(3u, 0u); return; }
         uint32_t n = idx(1u);
         *a = van_der_corput(n, hash3(pk, 2u, 1u));
         *b = sobol2(n, hash3(pk, 3u, 1u));
     }
-    HPT_MFN float time01() const { return rnd_mode() ? rnd(4u, 0u) : van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
+    HPT_MFN float time01() const { return van_der_corput(idx(2u), hash3(pk, 4u, 1u)); }
     // Direct-lighting layout (integrators/directlighting.cpp:54-77): 1D array j / 2D array j of `c` values per pixel
     // sample (c a power of two; n1d = number of 1D arrays).  As LDShuffleScrambled*D, an array is one scrambled
     // (0,2)-sequence of spp * c points cut into spp blocks of c: sample i owns block idx(array) and visits its points
@@ -210,11 +236,9 @@ struct LdHash {
         return idx(arr) * c + perm_pow2(k, c - 1u, hash3(hash3(pk, arr, 4u), i, 5u));
     }
     HPT_MFN float one_c(int j, uint32_t c, uint32_t k) const {
-        if (rnd_mode()) return rnd(5u + (uint32_t)j, k);
         return van_der_corput(idx_c(3u + (uint32_t)j, c, k), hash3(pk, 5u + (uint32_t)j, 1u));
     }
     HPT_MFN void two_c(int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const {
-        if (rnd_mode()) { *a = rnd(5u + (uint32_t)n1d + 2u * (uint32_t)j, k); *b = rnd(6u + (uint32_t)n1d + 2u * (uint32_t)j, k); return; }
         uint32_t n = idx_c(3u + (uint32_t)n1d + (uint32_t)j, c, k);
         *a = van_der_corput(n, hash3(pk, 5u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));
         *b = sobol2(n, hash3(pk, 6u + (uint32_t)n1d + 2u * (uint32_t)j, 1u));

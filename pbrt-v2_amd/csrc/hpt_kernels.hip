@@ -174,9 +174,9 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
     LdHashSrc s; s.begin_pixel(rp, x, y); s.begin_sample((uint32_t)i);
     float *o = out + 35 * i;
     float a, b;
-    s.image(&a, &b); o[0] = x + a; o[1] = y + b;
-    s.lens(&a, &b); o[2] = a; o[3] = b;
-    { float t = s.h.time01(); o[4] = (1.f - t) * 0.f + t * 1.f; }
+    s.image(rp, &a, &b); o[0] = x + a; o[1] = y + b;
+    s.lens(rp, &a, &b); o[2] = a; o[3] = b;
+    { float t = s.time01(rp); o[4] = (1.f - t) * 0.f + t * 1.f; }
     for (int j = 0; j < 12; ++j) o[5 + j] = s.one(j);
     for (int j = 0; j < 9; ++j) { s.two(j, &a, &b); o[17 + 2 * j] = a; o[18 + 2 * j] = b; }
 }

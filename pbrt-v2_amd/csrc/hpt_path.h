@@ -44,7 +44,11 @@ struct RenderParams {
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
     int32_t has_motion;        // scene has animated instances: rays carry a time sample
     int32_t integrator;        // HPT_INTEGRATOR_*
-    int32_t random_sampler;    // HPT_SAMPLER_RANDOM_HASH: independent uniform values, any spp, light sample counts not rounded
+    int32_t random_sampler;    // HPT_SAMPLER_RANDOM_HASH / STRATIFIED_HASH: any spp, light sample counts not rounded
+    uint32_t sampler_w;        // LdHash::w of this job: spp - 1 (low discrepancy), HPT_RANDOM_W, HPT_STRAT_W
+    int32_t sampler_kind;      // 0 low discrepancy, 1 random, 2 stratified
+    int32_t strat_n, strat_jitter;                 // stratified: spp, jitter
+    float strat_fxs, strat_dx, strat_dy, strat_dt; // (float)xsamples, 1.f / xsamples, 1.f / ysamples, 1.f / spp
     int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
@@ -207,13 +211,13 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     HPT_MFN void begin_sample(const RenderParams &rp) {
         smp.begin_sample(si);
         float a, b;
-        smp.image(&a, &b);
+        smp.image(rp, &a, &b);
         float imgx = px + a, imgy = py + b; // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
         float lu = 0.f, lv = 0.f;
-        if (rp.cam.lens_radius > 0.f) smp.lens(&lu, &lv);
+        if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
         time = 0.f;
-        if (INST && rp.has_motion) { float t = smp.time01(); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
+        if (INST && rp.has_motion) { float t = smp.time01(rp); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
         L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
         stage = ST_EXTEND;
     }
@@ -232,7 +236,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
         if (bad) { Ls = S(0.f); if (wc) wc->bad++; }
         float ia, ib;
-        smp.image(&ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
+        smp.image(rp, &ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
         float imgx = px + ia, imgy = py + ib;
         float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
         float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
@@ -471,12 +475,12 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
             const uint32_t c = (uint32_t)dl_count(sc.lights[li], rp), k = (uint32_t)lj;
             const int n1d = 2 * sc.n_lights + 2;
             *lightPick = li; *ln = 0.f;
-            smp.two_c(2 * li, n1d, c, k, ls0, ls1); *ls2 = smp.one_c(2 * li, c, k);
-            smp.two_c(2 * li + 1, n1d, c, k, bs0, bs1); *bs2 = smp.one_c(2 * li + 1, c, k);
+            smp.two_c(rp, 2 * li, n1d, c, k, ls0, ls1); *ls2 = smp.one_c(rp, 2 * li, c, k);
+            smp.two_c(rp, 2 * li + 1, n1d, c, k, bs0, bs1); *bs2 = smp.one_c(rp, 2 * li + 1, c, k);
         } else {
-            *ln = smp.one_c(1, 1u, 0u);
-            smp.two_c(0, 5, 1u, 0u, ls0, ls1); *ls2 = smp.one_c(0, 1u, 0u);
-            smp.two_c(1, 5, 1u, 0u, bs0, bs1); *bs2 = smp.one_c(2, 1u, 0u);
+            *ln = smp.one_c(rp, 1, 1u, 0u);
+            smp.two_c(rp, 0, 5, 1u, 0u, ls0, ls1); *ls2 = smp.one_c(rp, 0, 1u, 0u);
+            smp.two_c(rp, 1, 5, 1u, 0u, bs0, bs1); *bs2 = smp.one_c(rp, 2, 1u, 0u);
         }
     }
 
@@ -527,17 +531,37 @@ struct LdHashSrc {
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
         uint32_t pixelIndex = (uint32_t)y * (uint32_t)rp.xres + (uint32_t)x;
         h.pk = pixel_key(pixelIndex, rp.seed);
-        h.w = rp.random_sampler ? HPT_RANDOM_W : (uint32_t)rp.spp - 1u;
+        h.w = rp.sampler_w;
     }
     HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; }
     HPT_MFN void end_pixel(const RenderParams &) {}
     HPT_MFN float one(int j) const { return h.one(j); }
     HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
-    HPT_MFN void image(float *a, float *b) const { h.image(a, b); }
-    HPT_MFN void lens(float *a, float *b) const { h.lens(a, b); }
-    HPT_MFN float time01() const { return h.time01(); }
-    HPT_MFN float one_c(int j, uint32_t c, uint32_t k) const { return h.one_c(j, c, k); }
-    HPT_MFN void two_c(int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const { h.two_c(j, n1d, c, k, a, b); }
+    // camera samples and the direct-lighting arrays: the sampler kind is a scalar (kernel argument) branch
+    HPT_MFN void image(const RenderParams &rp, float *a, float *b) const {
+        if (rp.sampler_kind == 0) { h.image(a, b); return; }
+        if (rp.sampler_kind == 1) { *a = h.rnd(0u, 0u); *b = h.rnd(1u, 0u); return; }
+        h.strat2(h.i, 0u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
+    }
+    HPT_MFN void lens(const RenderParams &rp, float *a, float *b) const {
+        if (rp.sampler_kind == 0) { h.lens(a, b); return; }
+        if (rp.sampler_kind == 1) { *a = h.rnd(2u, 0u); *b = h.rnd(3u, 0u); return; }
+        h.strat2(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 1u, 2u)), 2u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
+    }
+    HPT_MFN float time01(const RenderParams &rp) const {
+        if (rp.sampler_kind == 0) return h.time01();
+        if (rp.sampler_kind == 1) return h.rnd(4u, 0u);
+        return h.strat1(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 2u, 2u)), 4u, rp.strat_jitter != 0, rp.strat_dt);
+    }
+    HPT_MFN float one_c(const RenderParams &rp, int j, uint32_t c, uint32_t k) const {
+        if (rp.sampler_kind == 0) return h.one_c(j, c, k);
+        return (rp.sampler_kind == 1 || c == 1u) ? h.rnd(5u + (uint32_t)j, k) : h.lhs(5u + (uint32_t)j, k, c);
+    }
+    HPT_MFN void two_c(const RenderParams &rp, int j, int n1d, uint32_t c, uint32_t k, float *a, float *b) const {
+        if (rp.sampler_kind == 0) { h.two_c(j, n1d, c, k, a, b); return; }
+        const uint32_t wa = 5u + (uint32_t)n1d + 2u * (uint32_t)j;
+        if (rp.sampler_kind == 1 || c == 1u) { *a = h.rnd(wa, k); *b = h.rnd(wa + 1u, k); } else { *a = h.lhs(wa, k, c); *b = h.lhs(wa + 1u, k, c); }
+    }
     HPT_MFN float draw() { return h.draw(h.draw_key(), dcount++); }
 };
 

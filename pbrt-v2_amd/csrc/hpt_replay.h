@@ -118,12 +118,12 @@ struct MtReplaySrc {
     HPT_MFN void end_pixel(const RenderParams &) {}
     HPT_MFN float one(int j) { return at(off_1d(j) + i); }
     HPT_MFN void two(int j, float *a, float *b) { *a = at(off_2d(j) + 2 * i); *b = at(off_2d(j) + 2 * i + 1); }
-    HPT_MFN void image(float *a, float *b) { *a = at(2 * i); *b = at(2 * i + 1); }
-    HPT_MFN void lens(float *a, float *b) { *a = at(2u * n + 2 * i); *b = at(2u * n + 2 * i + 1); }
-    HPT_MFN float time01() { return at(4u * n + i); }
+    HPT_MFN void image(const RenderParams &, float *a, float *b) { *a = at(2 * i); *b = at(2 * i + 1); }
+    HPT_MFN void lens(const RenderParams &, float *a, float *b) { *a = at(2u * n + 2 * i); *b = at(2u * n + 2 * i + 1); }
+    HPT_MFN float time01(const RenderParams &) { return at(4u * n + i); }
     // the replay parity mode covers the path integrator only (the direct-lighting sample layout is not tabulated)
-    HPT_MFN float one_c(int, uint32_t, uint32_t) { return 0.f; }
-    HPT_MFN void two_c(int, int, uint32_t, uint32_t, float *a, float *b) { *a = 0.f; *b = 0.f; }
+    HPT_MFN float one_c(const RenderParams &, int, uint32_t, uint32_t) { return 0.f; }
+    HPT_MFN void two_c(const RenderParams &, int, int, uint32_t, uint32_t, float *a, float *b) { *a = 0.f; *b = 0.f; }
     HPT_MFN float draw() { return (next_uint() & 0xffffff) / (float)(1 << 24); } // RandomFloat (rng.cpp:59-65)
 };
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ void lane_load(LaneT &l, const float4 *st, int64_t P,
     l.px = (int)(pxy & 0xffffu); l.py = (int)(pxy >> 16); l.si = f2u(v.z); l.s_end = f2u(v.w);
     v = st[1 * P + slot];
     l.smp.h.pk = f2u(v.x); l.smp.dcount = f2u(v.y); l.time = v.z; l.eps = v.w;
-    l.smp.h.w = (uint32_t)rp.spp - 1u; l.smp.h.i = l.si;
+    l.smp.h.w = rp.sampler_w; l.smp.h.i = l.si;
     v = st[2 * P + slot]; l.fX = v.x; l.fY = v.y; l.fZ = v.z; l.fW = v.w;
     v = st[3 * P + slot]; l.L = mk3(v.x, v.y, v.z); l.beta.x = v.w;
     v = st[4 * P + slot]; l.beta.y = v.x; l.beta.z = v.y; l.p.x = v.z; l.p.y = v.w;

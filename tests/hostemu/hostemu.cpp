@@ -70,7 +70,16 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->seed = rd->seed;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
-    rp->random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH ? 1 : 0;
+    { const int skind = HPT_SAMPLER_KIND(rd->sampler_mode); const bool strat = skind == HPT_SAMPLER_STRATIFIED_HASH;   // as fill_params of csrc/hpt_api.hip
+      rp->random_sampler = (rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH || strat) ? 1 : 0;
+      rp->sampler_kind = strat ? 2 : rp->random_sampler ? 1 : 0;
+      rp->sampler_w = strat ? HPT_STRAT_W : rp->random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
+      rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
+      if (strat) {
+          const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
+          rp->strat_jitter = HPT_SAMPLER_STRAT_JITTER(rd->sampler_mode);
+          rp->strat_fxs = (float)xs; rp->strat_dx = 1.f / (float)xs; rp->strat_dy = 1.f / (float)ys; rp->strat_dt = 1.f / (float)rd->spp;
+      } }
     rp->n_heads = 1;
     rp->shard_count = rd->shard_count > 0 ? rd->shard_count : 1;
     rp->shard_rank = rd->shard_count > 0 ? rd->shard_rank : 0;
@@ -245,9 +254,9 @@ extern "C" int emu_sampler(const hpt_render_desc *rd, int x, int y, float *out) 
         LdHashSrc s; s.begin_pixel(rp, x, y); s.begin_sample((uint32_t)i);
         float *o = out + 35 * i;
         float a, b;
-        s.image(&a, &b); o[0] = x + a; o[1] = y + b;
-        s.lens(&a, &b); o[2] = a; o[3] = b;
-        { float t = s.h.time01(); o[4] = (1.f - t) * 0.f + t * 1.f; }
+        s.image(rp, &a, &b); o[0] = x + a; o[1] = y + b;
+        s.lens(rp, &a, &b); o[2] = a; o[3] = b;
+        { float t = s.time01(rp); o[4] = (1.f - t) * 0.f + t * 1.f; }
         for (int j = 0; j < 12; ++j) o[5 + j] = s.one(j);
         for (int j = 0; j < 9; ++j) { s.two(j, &a, &b); o[17 + 2 * j] = a; o[18 + 2 * j] = b; }
     }
