@@ -222,7 +222,7 @@ def _fmt(a):
     return " ".join("%.9g" % float(v) for v in np.asarray(a).reshape(-1))
 
 
-def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres=None, renderer=None, pixel_filter=None):
+def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres=None, renderer=None, pixel_filter=None, sampler=None):
     """Write `scene` as a pbrt-v2 scene file.  Supported: triangle meshes (P world space; N are
     exported as world-space normals with an identity object transform), matte / plastic materials,
     point and constant infinite lights, sphere / disk emitters."""
@@ -239,7 +239,7 @@ def export_pbrt(scene, path, film_path, spp=None, maxdepth=None, xres=None, yres
         out.append(pixel_filter)                 # e.g. 'PixelFilter "gaussian"'
     out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" "%s"'
                % (xres, yres, film_path))
-    out.append('Sampler "lowdiscrepancy" "integer pixelsamples" [%d]' % spp)
+    out.append(sampler or 'Sampler "lowdiscrepancy" "integer pixelsamples" [%d]' % spp)   # sampler: a full Sampler line
     out.append('SurfaceIntegrator "path" "integer maxdepth" [%d]' % maxdepth)
     if renderer:
         out.append('Renderer "%s"' % renderer)
