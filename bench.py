@@ -10,7 +10,8 @@ kernel launch per GPU (kernel configuration picked per scene by hpt_scene_tune d
 Scene, BVH and film are resident in HBM before the timed region; `value` is whole-job
 samples / max-over-ranks wall time.
 
-Workloads (all 1920x1080, path maxdepth 8, lowdiscrepancy-structured sampler, box filter):
+Workloads (all 1920x1080, path maxdepth 8; defaults: lowdiscrepancy-structured sampler, box filter — the metric's configuration;
+--sampler / --filter select the others):
   bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 454 prims, measured BRDF), 64 spp/GPU  [default]
   killeroo north-star target scene: scenes/killeroo-simple.pbrt (66 533 prims), 64 spp/GPU
   anim     BASELINE.json configs[3] scene: scenes/anim-killeroos-moving.pbrt (2 animated instances), 64 spp/GPU

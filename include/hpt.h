@@ -212,7 +212,8 @@ typedef struct hpt_render_desc {
     int32_t xres, yres;               /* Film::xResolution, yResolution                  */
     int32_t x_start, x_count;         /* ImageFilm::xPixelStart/xPixelCount (crop window) */
     int32_t y_start, y_count;
-    int32_t spp;                      /* LDSampler::nPixelSamples (power of two)          */
+    int32_t spp;                      /* samples per pixel: LDSampler::nPixelSamples (a power of two), RandomSampler::nSamples
+                                       * (any), StratifiedSampler xs * ys (<= 4095)                                          */
     int32_t maxdepth;                 /* PathIntegrator::maxDepth                         */
     int32_t sampler_mode;
     uint32_t seed;                    /* LD_HASH seed                                     */
