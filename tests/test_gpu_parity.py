@@ -623,6 +623,51 @@ def test_random_sampler_values_bit_identical_and_any_spp(cases, dev):
         d.render(s.camera, rd)
 
 
+def test_pbrt_binary_reads_an_exr_environment_map_end_to_end(tmp_path):
+    """The whole chain with an .exr on the GPU box: pbrt_hip (linked with the reference's vendored OpenEXR) parses a scene file
+    whose infinite light names tests/golden/small_env.exr, InfiniteAreaLight builds its MIPMap and Distribution2D, the plugin
+    flattens them, the device renders.  Against the Python binding rendering the committed blob of the same scene."""
+    import os
+    import subprocess
+    from tests.util import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+    if not os.path.exists(exe):
+        pytest.skip("pbrt_hip is built from /root/reference in the build container only")
+    scenes = importlib.import_module("pbrt-v2_amd.scenes")
+    syn = scenes.synthetic_soup(n_tris=2000, xres=160, yres=90, spp=8, maxdepth=5, extent=0.08)
+    scene_file, out_pfm = str(tmp_path / "envmap.pbrt"), str(tmp_path / "envmap.pfm")
+    scenes.export_pbrt(syn, scene_file, out_pfm, renderer="hip")
+    text = open(scene_file).read()
+    i = text.index('LightSource "infinite"')
+    text = text[:i] + 'LightSource "infinite" "string mapname" ["%s"] "integer nsamples" [1]' % os.path.join(GOLDEN, "small_env.exr") + text[text.index("\n", i):]
+    open(scene_file, "w").write(text)
+    subprocess.check_call([exe, "--quiet", scene_file], env=dict(os.environ, HPT_TUNE="3"))
+    got = film.read_pfm(out_pfm)
+    s = load_case("envmap")
+    f, st = hpt.DeviceScene(s).render(s.camera, hash_rd(s, seed=0))
+    want = film.xyzw_to_rgb(f)
+    assert got.shape == want.shape and st.bad_samples == 0
+    assert float(want.max()) > 10 * float(want.mean())                  # the structured map, not a grey substitute
+    assert (np.abs(got - want).max(axis=2) > 1e-4).mean() < 1e-3 and film.rmse(got, want) < 1e-3
+
+
+def test_exr_environment_map_matches_oracle_sample_for_sample():
+    """SURVEY.md §8f-3, first step: infinite light with a 32x16 HDR map read from .exr by the reference's own (vendored) OpenEXR;
+    importance-sampled through the Distribution2D tables in the scene blob."""
+    s = load_case("envmap")
+    d, o = hpt.DeviceScene(s), orc.OracleScene(s)
+    rd = hash_rd(s, seed=5)
+    rd.count_work = 1
+    f, st = d.render(s.camera, rd)
+    fo, so = o.render(s.camera, rd)
+    assert st.camera_samples == so[0] == rd.x_count * rd.y_count * rd.spp and st.bad_samples == 0
+    assert abs(int(st.closest_rays) - int(so[1])) <= 8 and abs(int(st.shadow_rays) - int(so[2])) <= 8
+    assert np.array_equal(f[..., 3], fo[..., 3])
+    io, idv = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(f)
+    assert film.rmse(io, idv) < 1e-3
+    assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
+
+
 def test_shards_partition_the_image(cases, dev):
     s = cases["k8"]
     rd = hash_rd(s, seed=2, spp=2)

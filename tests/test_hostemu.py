@@ -314,3 +314,17 @@ def test_stratified_sampler_values_stratify():
     rd.spp, rd.sampler_mode = 6, abi.stratified_mode(abi.HPT_SAMPLER_STRATIFIED_HASH, 3, False)
     a = emu.sampler(rd, 0, 0)
     assert np.allclose(np.sort(a[:, 0]), np.repeat([1 / 6, 3 / 6, 5 / 6], 2)) and np.allclose(np.sort(a[:, 1]), np.repeat([.25, .75], 3))
+
+
+def test_exr_environment_map_render_matches_oracle():
+    """SURVEY.md §8f-3, first step: an importance-sampled 32x16 HDR environment map (Distribution2D sampling, pdf, bilinear
+    lookup) through the device lane against the oracle, which is pinned to the EXR-enabled reference on this scene."""
+    s = load_case("envmap")
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = hash_rd(s, seed=5)
+    fo, so = o.render(s.camera, rd)
+    fe, se = e.render(s.camera, rd)
+    assert so[0] == se[0] == rd.x_count * rd.y_count * rd.spp
+    assert np.array_equal(fo[..., 3], fe[..., 3])
+    io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
+    assert (np.abs(io - ie).max(axis=2) > 0).mean() < 2e-3 and film.rmse(io, ie) < 1e-4

@@ -86,6 +86,22 @@ def test_oracle_replays_stratified_sampler_reference_image_bit_exact(name):
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
 
 
+def test_oracle_replays_exr_environment_map_reference_image_bit_exact():
+    """First step of SURVEY.md §8f-3: `LightSource "infinite" "string mapname" x.exr` — the reference built with its vendored
+    OpenEXR (oracle/_ref/pbrt_exr) reads a 32x16 HDR map; InfiniteAreaLight's MIPMap level 0 and Distribution2D arrive in the
+    blob; importance-sampled Sample_L, Pdf and the bilinear Le lookup (lights/infinite.cpp) against the reference image."""
+    s = load_case("envmap")
+    l = [x for x in s.lights if x.kind == abi.HPT_LIGHT_INFINITE][0]
+    assert (l.env_w, l.env_h) == (32, 16)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
+    img, ref = film.xyzw_to_rgb(f), load_ref("envmap")
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    assert float(ref.max()) > 10 * float(ref.mean())       # a structured HDR map, not the constant light of the `env` case
+
+
 def test_filter_tables_match_the_reference_build():
     """abi.make_filter (the numpy mirror of filters/*.cpp used by tests and bench.py) against the tables the reference
     binary itself tabulated for the golden cases (ImageFilm::filterTable, dumped by the host plugin)."""

@@ -39,6 +39,8 @@ def load_case(name):
         return abi.Scene.load(os.path.join(GOLDEN, "ms_soup.hpts.gz"))
     if name == "env":
         return abi.Scene.load(os.path.join(GOLDEN, "env_soup.hpts.gz"))
+    if name == "envmap":   # SURVEY.md §8f-3, first step: infinite light with a 32x16 .exr map (tests/golden/make_golden_envmap.py)
+        return abi.Scene.load(os.path.join(GOLDEN, "envmap_soup.hpts.gz"))
     if name in DL_CASES:   # direct-lighting cases: committed geometry + their own camera / render descriptor / light records
         s = abi.Scene.load(os.path.join(GOLDEN, DL_CASES[name]))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
