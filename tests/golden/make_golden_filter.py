@@ -13,6 +13,9 @@ Cases (`PixelFilter` added to the shipped scene files)
   ftri    killeroo-simple as shipped (directlighting) with cropwindow [.25 .75 .3 .8] and "triangle" xwidth 1.5
           ywidth 1: sample extent inside the image, pixel extent not at the origin; 128x128, 4 spp
   fsinc   anim-killeroos-moving, path maxdepth 5, "sinc" (defaults: width 4 x 4, tau 3); 100x60, 4 spp
+  fcombo  everything at once: killeroo-simple as shipped (directlighting) with the light's nsamples 3, Sampler "stratified" 3 x 2,
+          PixelFilter "mitchell" 2.5 x 1.5 and cropwindow [.1 .9 .2 .7] — the sampler's tiles are cut from a sample extent that
+          is wider than the crop window; 96x96
 """
 import gzip
 import importlib
@@ -35,7 +38,7 @@ PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
 PBRT_HIP = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
 
 
-def sub(text, xres, yres, spp, out_pfm, pixel_filter, integrator=None, film_extra=""):
+def sub(text, xres, yres, spp, out_pfm, pixel_filter, integrator=None, film_extra="", sampler=None):
     text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
     text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
     if '"string filename"' in text:
@@ -44,6 +47,9 @@ def sub(text, xres, yres, spp, out_pfm, pixel_filter, integrator=None, film_extr
     else:
         text = re.sub(r'Film "image"', '%s\nFilm "image" "string filename" "%s" %s' % (pixel_filter, out_pfm, film_extra), text, count=1)
     text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+    if sampler:
+        text = re.sub(r'Sampler "lowdiscrepancy" "integer pixelsamples" \[\d+\]', sampler, text)
+        assert sampler in text
     if integrator:
         text = text.replace('SurfaceIntegrator "directlighting"', integrator)
     text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
@@ -94,6 +100,10 @@ def main():
                 'SurfaceIntegrator "path" "integer maxdepth" [8]\n') % os.path.join(tmp, "fmitch_ref.pfm")
         run_case("fmitch", head + bunny.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
                  .replace('"brdfs/', '"%s/brdfs/' % REF), tmp, "bunny_b8.hpts.gz")
+        combo = sub(kill, 96, 96, 4, os.path.join(tmp, "fcombo_ref.pfm"), 'PixelFilter "mitchell" "float xwidth" [2.5] "float ywidth" [1.5]',
+                    film_extra='"float cropwindow" [.1 .9 .2 .7]', sampler='Sampler "stratified" "integer xsamples" [3] "integer ysamples" [2]')
+        assert '"integer nsamples" [8]' in combo
+        run_case("fcombo", combo.replace('"integer nsamples" [8]', '"integer nsamples" [3]'), tmp, "killeroo_cfg1.hpts.gz")
         anim = open(os.path.join(REF, "anim-killeroos-moving.pbrt")).read()
         run_case("fsinc", sub(anim, 100, 60, 4, os.path.join(tmp, "fsinc_ref.pfm"), 'PixelFilter "sinc"',
                               'SurfaceIntegrator "path" "integer maxdepth" [5]'), tmp, "anim_killeroos.hpts.gz")

@@ -102,6 +102,22 @@ def test_oracle_replays_exr_environment_map_reference_image_bit_exact():
     assert float(ref.max()) > 10 * float(ref.mean())       # a structured HDR map, not the constant light of the `env` case
 
 
+def test_oracle_replays_everything_at_once_bit_exact():
+    """killeroo-simple as shipped (direct lighting, the light with 3 samples) under Sampler "stratified" 3 x 2, PixelFilter
+    "mitchell" 2.5 x 1.5 and a crop window: the stratified sub-samplers' tiles are cut from a sample extent wider than the
+    cropped film, the Latin hypercube runs over 3 (unrounded) light samples, the film sums mix tiles in the queue's order."""
+    s = load_case("fcombo")
+    rd = abi.copy_struct(s.render)
+    assert abi.sampler_kind(rd.sampler_mode) == abi.HPT_SAMPLER_STRATIFIED_HASH and rd.integrator == abi.HPT_INTEGRATOR_DIRECT_ALL
+    assert (rd.x_start, rd.x_count, rd.y_start, rd.y_count) == (10, 77, 20, 48)
+    rd.sampler_mode = (rd.sampler_mode & ~0x7f) | abi.HPT_SAMPLER_STRATIFIED_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1, flt=s.filter)
+    xs, xe, ys, ye = abi.sample_extent(rd, s.filter)
+    assert st[0] == (xe - xs) * (ye - ys) * rd.spp and st[5] == 0
+    img, ref = film.xyzw_to_rgb(f), load_ref("fcombo")
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
 def test_filter_tables_match_the_reference_build():
     """abi.make_filter (the numpy mirror of filters/*.cpp used by tests and bench.py) against the tables the reference
     binary itself tabulated for the golden cases (ImageFilm::filterTable, dumped by the host plugin)."""

@@ -57,8 +57,8 @@ def load_case(name):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
         return s
-    if name in FILTER_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
-        s = abi.Scene.load(os.path.join(GOLDEN, FILTER_CASES[name]))
+    if name in FILTER_CASES or name in COMBO_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
+        s = abi.Scene.load(os.path.join(GOLDEN, (FILTER_CASES.get(name) or COMBO_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
@@ -77,6 +77,8 @@ DL_CASES = {"dl1": "killeroo_cfg1.hpts.gz", "dlone": "killeroo_cfg1.hpts.gz", "d
 # SURVEY.md §8f-4 (tests/golden/make_golden_filter.py): PixelFilter gaussian / mitchell / triangle (+ crop window) / sinc
 FILTER_CASES = {"fgauss": "killeroo_cfg1.hpts.gz", "fmitch": "bunny_b8.hpts.gz", "ftri": "killeroo_cfg1.hpts.gz",
                 "fsinc": "anim_killeroos.hpts.gz"}
+# everything at once (CPU tests): direct lighting with 3 light samples, Sampler "stratified" 3 x 2, PixelFilter "mitchell" 2.5 x 1.5, crop window
+COMBO_CASES = {"fcombo": "killeroo_cfg1.hpts.gz"}
 
 
 # SURVEY.md §8f-4 (tests/golden/make_golden_random.py): Sampler "random" — path 6 spp, direct lighting with 5 light samples
