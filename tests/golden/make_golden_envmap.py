@@ -68,6 +68,27 @@ def main():
         s.save(os.path.join(HERE, "envmap_soup.hpts.gz"))
         l = [x for x in s.lights if x.kind == abi.HPT_LIGHT_INFINITE][0]
         print("envmap: map %dx%d, image mean %.4f max %.3f" % (l.env_w, l.env_h, float(ref.mean()), float(ref.max())))
+        # envmap_dl: the same scene under DirectLightingIntegrator, strategy all, the map sampled 4 times per camera sample,
+        # Sampler "random" 3 spp; only camera / render descriptor / lights are stored (geometry + texels: envmap_soup.hpts.gz)
+        text2 = text.replace('"integer nsamples" [1]', '"integer nsamples" [4]')
+        text2 = text2.replace('SurfaceIntegrator "path" "integer maxdepth" [5]', 'SurfaceIntegrator "directlighting"')
+        text2 = text2.replace('Sampler "lowdiscrepancy" "integer pixelsamples" [8]', 'Sampler "random" "integer pixelsamples" [3]')
+        text2 = text2.replace("envmap_ref.pfm", "envmap_dl_ref.pfm")
+        assert 'directlighting' in text2 and 'Sampler "random"' in text2 and '[4]' in text2
+        p2 = os.path.join(tmp, "envmap_dl.pbrt")
+        open(p2, "w").write(text2)
+        subprocess.check_call([PBRT_EXR, "--quiet", "--ncores", "1", p2], stderr=subprocess.DEVNULL)
+        blob2 = os.path.join(tmp, "envmap_dl.hpts")
+        subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", p2],
+                              env=dict(os.environ, HPT_DUMP_SCENE=blob2, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+        ref2 = film.read_pfm(os.path.join(tmp, "envmap_dl_ref.pfm"))
+        with open(os.path.join(HERE, "envmap_dl.ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+            np.save(f, ref2)
+        v = abi.Scene.load(blob2)
+        assert np.array_equal(v.fpool, s.fpool) and np.array_equal(v.ipool, s.ipool)
+        np.savez(os.path.join(HERE, "envmap_dl.view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
+                 render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8))
+        print("envmap_dl: integrator", v.render.integrator, "sampler", hex(v.render.sampler_mode), "spp", v.render.spp, "nsamples", [x.nsamples for x in v.lights])
 
 
 if __name__ == "__main__":

@@ -343,3 +343,16 @@ def test_everything_at_once_matches_oracle():
     np.testing.assert_allclose(fe[..., 3], fo[..., 3], rtol=2e-5, atol=1e-5)
     scale = float(np.abs(fo[..., :3]).max())
     assert (np.abs(fe - fo)[..., :3].max(axis=2) <= 2e-5 * scale).mean() > 0.999
+
+
+def test_exr_environment_map_under_direct_lighting_matches_oracle():
+    s = load_case("envmap_dl")
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.seed = 5
+    fo, so = o.render(s.camera, rd)
+    fe, se = e.render(s.camera, rd)
+    assert so[0] == se[0] and abs(int(so[2]) - int(se[2])) <= 4
+    assert np.array_equal(fo[..., 3], fe[..., 3])
+    io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
+    assert (np.abs(io - ie).max(axis=2) > 0).mean() < 2e-3 and film.rmse(io, ie) < 1e-4

@@ -102,6 +102,18 @@ def test_oracle_replays_exr_environment_map_reference_image_bit_exact():
     assert float(ref.max()) > 10 * float(ref.mean())       # a structured HDR map, not the constant light of the `env` case
 
 
+def test_oracle_replays_exr_environment_map_under_direct_lighting_bit_exact():
+    """The .exr map sampled 4 times per camera sample by DirectLightingIntegrator (strategy all), Sampler "random" 3 spp."""
+    s = load_case("envmap_dl")
+    rd = abi.copy_struct(s.render)
+    assert rd.integrator == abi.HPT_INTEGRATOR_DIRECT_ALL and rd.sampler_mode == abi.HPT_SAMPLER_RANDOM_HASH and rd.spp == 3
+    rd.sampler_mode = abi.HPT_SAMPLER_RANDOM_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
+    img, ref = film.xyzw_to_rgb(f), load_ref("envmap_dl")
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
 def test_oracle_replays_everything_at_once_bit_exact():
     """killeroo-simple as shipped (direct lighting, the light with 3 samples) under Sampler "stratified" 3 x 2, PixelFilter
     "mitchell" 2.5 x 1.5 and a crop window: the stratified sub-samplers' tiles are cut from a sample extent wider than the

@@ -50,6 +50,13 @@ def load_case(name):
         assert len(bytes(lights)) == len(bytes(s.lights))
         s.lights = lights
         return s
+    if name == "envmap_dl":   # the envmap scene under direct lighting (map sampled 4x per camera sample) with Sampler "random" 3 spp
+        s = abi.Scene.load(os.path.join(GOLDEN, "envmap_soup.hpts.gz"))
+        v = np.load(os.path.join(GOLDEN, "envmap_dl.view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        return s
     if name in RANDOM_CASES or name in STRATIFIED_CASES:   # Sampler "random" / "stratified" cases: committed geometry + camera / render descriptor (sampler mode, spp) / lights
         s = abi.Scene.load(os.path.join(GOLDEN, (RANDOM_CASES.get(name) or STRATIFIED_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
