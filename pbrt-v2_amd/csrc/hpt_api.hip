@@ -149,7 +149,11 @@ extern "C" int hpt_scene_get_info(const hpt_scene *s, hpt_scene_info *info) {
 extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
     if (!s) { hpt_set_error("null scene"); return HPT_E_INVALID; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
-    if (!f) { s->d_ftable = nullptr; return HPT_OK; }       // the table's allocation stays with the scene
+    if (!f) {                                                // back to the default box: the two-pass film's sample records go too
+        s->d_ftable = nullptr;                               // (the 1 KB table allocation stays with the scene)
+        if (s->sbuf) { (void)hipFree(s->sbuf); s->sbuf = nullptr; s->sbuf_floats = 0; }
+        return HPT_OK;
+    }
     if (!(f->xwidth > 0.f) || !(f->ywidth > 0.f) || f->xwidth > 64.f || f->ywidth > 64.f) { hpt_set_error("filter widths must be in (0, 64]"); return HPT_E_INVALID; }
     for (int i = 0; i < HPT_FILTER_TABLE_SIZE * HPT_FILTER_TABLE_SIZE; ++i)
         if (!(f->table[i] == f->table[i]) || f->table[i] > 3.0e38f || f->table[i] < -3.0e38f) { hpt_set_error("filter table entry %d is not finite", i); return HPT_E_INVALID; }
