@@ -1,32 +1,38 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the path-tracing hot path at 1920x1080, 8-bounce path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload bunny|killeroo|soup]
+    python bench.py --gpus N --steps K --warmup W [--workload bunny|killeroo|anim|soup|killeroo-dl]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one full frame: every camera sample of the 1920x1080 image traced through the whole
 SamplerRenderer/PathIntegrator path (camera ray .. film accumulation) by ONE persistent HIP
-kernel launch per GPU (kernel configuration picked per scene by hpt_scene_tune during set-up), plus — for N > 1 — the one film-tile gather to rank 0 over RCCL.
-Scene, BVH and film are resident in HBM before the timed region; `value` is whole-job
-samples / max-over-ranks wall time.
+kernel launch per GPU (kernel configuration picked per scene by hpt_scene_tune during set-up), plus — for N > 1 — the one
+film-tile gather to rank 0 over RCCL.  Scene, BVH and film are resident in HBM before the timed region; `value` is
+whole-job samples / max-over-ranks wall time.
 
-Workloads (all 1920x1080, path maxdepth 8; defaults: lowdiscrepancy-structured sampler, box filter — the metric's configuration;
---sampler / --filter select the others):
-  bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 454 prims, measured BRDF), 64 spp/GPU  [default]
+The timed film is CHECKED, not just timed: the film weights must add up to the number of camera samples, and six 64x64
+crop windows (corners, centre, across two per-XCD bands of the work queue) are re-rendered by the CPU oracle at full spp
+and compared sample for sample (`verify.rmse_vs_oracle`, tolerance 1e-3 — SURVEY.md §8d's RMSE definition).
+
+Workloads (all 1920x1080, path maxdepth 8; lowdiscrepancy-structured sampler, box filter — the metric's configuration):
+  bunny    BASELINE.json configs[1]: scenes/bunny.pbrt (69 454 prims, measured BRDF), 64 spp/GPU  [default = the headline line]
   killeroo north-star target scene: scenes/killeroo-simple.pbrt (66 533 prims), 64 spp/GPU
-  anim     BASELINE.json configs[3] scene: scenes/anim-killeroos-moving.pbrt (2 animated instances), 64 spp/GPU
-  killeroo-dl  the same scene file with the integrator it selects itself (directlighting, 8 light samples), 64 spp/GPU
-  soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 16 spp/GPU here
-Geometry comes from the committed blobs (dumped from the reference's own parser by
-host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does not exist on the
-GPU box.  Multi-GPU is weak scaling: every rank traces the same number of samples (spp = N x
-spp_per_gpu over the same frame, pixel tiles sharded round-robin, scene replicated).
+  anim     BASELINE.json configs[3]: scenes/anim-killeroos-moving.pbrt (2 animated instances), 128 spp/GPU
+  soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 256 spp/GPU
+  killeroo-dl  killeroo-simple.pbrt with the integrator it selects itself (directlighting, 8 light samples), 64 spp/GPU
+The default run (N = 1, no --workload) prints the headline line for bunny and, under `workloads`, the same measurement for
+killeroo, anim and soup at the spp BASELINE.json names (fewer steps each).  Geometry comes from the committed blobs
+(dumped from the reference's own parser by host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does
+not exist on the GPU box.  Multi-GPU is weak scaling: every rank traces the same number of samples (spp = N x spp_per_gpu
+over the same frame, pixel tiles sharded round-robin, scene replicated); `strong` adds the fixed frame split N ways.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -36,6 +42,7 @@ sys.path.insert(0, ROOT)
 abi = importlib.import_module("pbrt-v2_amd.abi")
 hpt = importlib.import_module("pbrt-v2_amd.hpt")
 scenes = importlib.import_module("pbrt-v2_amd.scenes")
+film_mod = importlib.import_module("pbrt-v2_amd.film")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # algorithmic traversal bytes per camera sample of the REFERENCE algorithm
@@ -43,7 +50,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # soup: no reference count (its parser input is 1M triangles of synthetic text); the device's own algorithmic bytes,
 # 64 B x 265.2 BVH2 nodes + 48 B x 18.5 triangles per camera sample (bench.py --workload soup --count-work)
 ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0, "soup": 17859.0}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+DEFAULT_SPP = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "killeroo-dl": 64}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue peak (MI355X_MICROARCH.md, wave scheduling): 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0 * 1e0      # = 1228.8 G wave-instructions / s
+TUNE_NAMES = ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases",
+              "3 waves/SIMD, lock-step phases", "4 waves/SIMD, lock-step phases, subtree stealing",
+              "3 waves/SIMD, lock-step phases, subtree stealing"]
+REF_SCENE_FILE = {"bunny": "bunny.pbrt", "killeroo": "killeroo-simple.pbrt", "anim": "anim-killeroos-moving.pbrt"}
 
 
 def load_workload(name, spp):
@@ -53,7 +67,7 @@ def load_workload(name, spp):
         v = np.load(os.path.join(GOLDEN, name + "_1080p.view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        s.render.spp = spp or 64
+        s.render.spp = spp or DEFAULT_SPP[name]
         desc = "scenes/%s.pbrt" % {"bunny": "bunny", "killeroo": "killeroo-simple", "anim": "anim-killeroos-moving"}[name]
     elif name == "killeroo-dl":   # scenes/killeroo-simple.pbrt exactly as shipped (directlighting, strategy all)
         s = abi.Scene.load(os.path.join(GOLDEN, "killeroo_cfg1.hpts.gz"))
@@ -61,10 +75,10 @@ def load_workload(name, spp):
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
-        s.render.spp = spp or 64
+        s.render.spp = spp or DEFAULT_SPP[name]
         desc = "scenes/killeroo-simple.pbrt as shipped (DirectLightingIntegrator, strategy all, 8 light samples per camera sample)"
     elif name == "soup":
-        s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or 16, maxdepth=8)
+        s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or DEFAULT_SPP[name], maxdepth=8)
         desc = "synthetic 1M random triangles + 1 env light (seed 0x5EED0001)"
     else:
         raise SystemExit("unknown workload " + name)
@@ -88,7 +102,8 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(scene, budget_s=12.0, flt=None):
+# ---- CPU baselines -------------------------------------------------------------------------------------------------
+def cpu_baseline_port(scene, budget_s=10.0, flt=None):
     """The oracle (plain-C restatement of the reference path, bit-identical to pbrt-v2's images —
     tests/test_oracle_pin.py) timed on this host's cores on a bounded sample of the same frame."""
     from oracle import orc  # checker / baseline only — never on the product path
@@ -110,41 +125,132 @@ def cpu_baseline(scene, budget_s=12.0, flt=None):
                       "of %d logical: cgroup quota / affinity)" % (rd.x_count, rd.y_count, rd.spp, dt1, cores, os.cpu_count() or 0)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="bunny")
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (power of two)")
-    ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
-    ap.add_argument("--filter", default="box", choices=["box", "gaussian", "mitchell", "triangle", "sinc"],
-                    help="PixelFilter with the reference plugin's default widths (box 0.5 = the metric's configuration)")
-    ap.add_argument("--sampler", default="lowdiscrepancy", choices=["lowdiscrepancy", "random", "stratified"],
-                    help='Sampler: "lowdiscrepancy" (the metric\'s configuration, HPT_SAMPLER_LD_HASH) "random" (HPT_SAMPLER_RANDOM_HASH) or "stratified" (HPT_SAMPLER_STRATIFIED_HASH, 8 x spp/8 jittered strata)')
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
-    args = ap.parse_args()
+def ref_scene_text(workload, xres, yres, spp, maxdepth, out_file, renderer=None):
+    """The reference's own scene file for `workload` (oracle/_ref/scenes, copied there by `make -C oracle ref-scenes`) with
+    film size / samples / integrator substituted — the recipe of SURVEY.md §8d and tests/golden/make_golden.py."""
+    import re
+    sd = os.path.join(ROOT, "oracle", "_ref", "scenes")
+    text = open(os.path.join(sd, REF_SCENE_FILE[workload])).read()
+    if workload == "bunny":     # bunny.pbrt sets only the Film; sampler and integrator come from the api defaults
+        text = text.split("\n", 2)[2]
+        text = ('Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" "%s"\n'
+                'Sampler "lowdiscrepancy" "integer pixelsamples" [%d]\nSurfaceIntegrator "path" "integer maxdepth" [%d]\n'
+                % (xres, yres, out_file, spp, maxdepth)) + text
+    else:
+        text = re.sub(r'"integer xresolution" \[\d+\]', '"integer xresolution" [%d]' % xres, text)
+        text = re.sub(r'"integer yresolution" \[\d+\]', '"integer yresolution" [%d]' % yres, text)
+        if '"string filename"' in text:
+            text = re.sub(r'"string filename" "[^"]*"', '"string filename" "%s"' % out_file, text)
+        else:
+            text = re.sub(r'Film "image"', 'Film "image" "string filename" "%s"' % out_file, text, count=1)
+        text = re.sub(r'"integer pixelsamples" \[\d+\]', '"integer pixelsamples" [%d]' % spp, text)
+        text = text.replace('SurfaceIntegrator "directlighting"', 'SurfaceIntegrator "path" "integer maxdepth" [%d]' % maxdepth)
+    if renderer:
+        text = text.replace("WorldBegin", 'Renderer "%s"\nWorldBegin' % renderer, 1)
+    text = text.replace('Include "geometry/', 'Include "%s/geometry/' % sd).replace('"brdfs/', '"%s/brdfs/' % sd)
+    return text
 
-    import torch
-    import torch.distributed as dist
-    hdist = importlib.import_module("pbrt-v2_amd.dist")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
-    if not torch.cuda.is_available() or hpt.device_count() <= 0:
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    scene, desc = load_workload(args.workload, args.spp)
+def cpu_baseline_reference(workload, scene):
+    """pbrt-v2's OWN multithreaded CPU path (oracle/_ref/pbrt = the reference compiled from /root/reference/src by
+    oracle/Makefile) on the same scene file, same frame, on this host's cores: two-point fit t(spp_b) - t(spp_a) so that
+    parsing and the BVH build drop out.  None when the binary / scene files did not travel."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+    if workload not in REF_SCENE_FILE or not os.path.exists(exe) or \
+            not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "scenes", REF_SCENE_FILE[workload])):
+        return None
+    cores = usable_cores()
+    rd = scene.render
+    a, b = 2, 16
+    ts = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for spp in (a, b):
+            sf = os.path.join(tmp, "s%d.pbrt" % spp)
+            open(sf, "w").write(ref_scene_text(workload, rd.xres, rd.yres, spp, rd.maxdepth, os.path.join(tmp, "o.pfm")))
+            t = time.time()
+            subprocess.check_call([exe, "--quiet", "--ncores", str(cores), sf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            ts[spp] = time.time() - t
+    rate = (b - a) * rd.xres * rd.yres / max(ts[b] - ts[a], 1e-9)
+    return {"value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": "pbrt-v2 itself (oracle/_ref/pbrt --ncores %d) on %s at %dx%d, path maxdepth %d: (%d - %d) spp / (%.2f s - %.2f s) — "
+                      "two-point fit, parse + BVH build cancel" % (cores, REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.maxdepth, b, a, ts[b], ts[a])}
+
+
+def end_to_end_pbrt_hip(workload, scene):
+    """Wall time of the whole drop-in chain in its own process: pbrt's parser + api.cpp + scene construction, the plugin's
+    flattening, hpt_scene_create (BVH build, upload), kernel-configuration probe, render, film D2H, ImageFilm::WriteImage."""
+    exe = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+    if workload not in REF_SCENE_FILE or not os.path.exists(exe) or \
+            not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "scenes", REF_SCENE_FILE[workload])):
+        return None
+    rd = scene.render
+    with tempfile.TemporaryDirectory() as tmp:
+        sf = os.path.join(tmp, "s.pbrt")
+        open(sf, "w").write(ref_scene_text(workload, rd.xres, rd.yres, rd.spp, rd.maxdepth, os.path.join(tmp, "o.pfm"), renderer="hip"))
+        t = time.time()
+        p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        dt = time.time() - t
+        if p.returncode != 0 or not os.path.exists(os.path.join(tmp, "o.pfm")):
+            return {"error": p.stderr.decode(errors="replace")[-300:]}
+    n = rd.xres * rd.yres * rd.spp
+    return {"wall_s": round(dt, 3), "msamples_per_s_inclusive": round(n / dt / 1e6, 2),
+            "what": "pbrt_hip --quiet %s (%dx%d, %d spp): process start, parse, pbrt scene construction, flatten, BVH build + upload, "
+                    "autotune probe, render, film D2H, WriteImage (.pfm)" % (REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.spp)}
+
+
+# ---- verification of the timed film ----------------------------------------------------------------------------------
+def verify_film(scene, rd, full, flt, n_crop=64):
+    """full: the (gathered) film of the LAST timed step, host numpy (H, W, 4).  Weight sums + oracle crops."""
+    from oracle import orc  # the checker
+    from tests.util import crop_windows
+    out = {}
+    samples = rd.x_count * rd.y_count * rd.spp
+    wsum = float(full[..., 3].astype(np.float64).sum())
+    out["film_weight_sum"], out["camera_samples"] = wsum, samples
+    if flt is None:
+        # box filter: one unit of weight per sample, plus one per sample that sits on an exact pixel boundary (film/image.cpp:82-89)
+        if not (samples <= wsum <= samples + 4096):
+            raise SystemExit("bench: the timed film holds weight %.0f for %d camera samples" % (wsum, samples))
+    o = orc.OracleScene(scene)
+    worst, t0 = 0.0, time.time()
+    for name, x0, y0 in crop_windows(rd.x_count, rd.y_count, n_crop):
+        apron = 1 if flt is None else 0
+        ax0, ay0 = max(x0 - apron, 0), max(y0 - apron, 0)
+        ax1, ay1 = min(x0 + n_crop + apron, rd.x_count), min(y0 + n_crop + apron, rd.y_count)
+        crd = abi.copy_struct(rd)
+        crd.x_start, crd.y_start, crd.x_count, crd.y_count = rd.x_start + ax0, rd.y_start + ay0, ax1 - ax0, ay1 - ay0
+        crd.shard_rank, crd.shard_count, crd.count_work = 0, 1, 0
+        fo, _ = o.render(scene.camera, crd, nthreads=usable_cores(), flt=flt)
+        fo = fo[y0 - ay0:y0 - ay0 + n_crop, x0 - ax0:x0 - ax0 + n_crop]
+        fd = full[y0:y0 + n_crop, x0:x0 + n_crop]
+        if flt is None and not np.array_equal(fo[..., 3], fd[..., 3]):
+            raise SystemExit("bench: crop %s of the timed film differs from the oracle in its film weights" % name)
+        err = film_mod.rmse(film_mod.xyzw_to_rgb(fo), film_mod.xyzw_to_rgb(fd))
+        worst = max(worst, err)
+    out["rmse_vs_oracle"] = worst
+    out["crops"] = "%d windows of %dx%d px at %d spp (corners, centre, across two XCD bands), oracle %.1f s" % (6, n_crop, n_crop, rd.spp, time.time() - t0)
+    out["tolerance"] = 1e-3
+    if not worst < 1e-3:
+        raise SystemExit("bench: per-pixel RMSE of the timed film against the oracle is %.3g (tolerance 1e-3)" % worst)
+    return out
+
+
+def pmc_profile(workload):
+    """Counter figures of the committed rocprofv3 summary of this workload (profiles/pmc_<workload>.json,
+    scripts/summarize_profile.py): HBM-side bytes and VALU wave-instructions per launch, lane utilisation."""
+    for fn in ("pmc_%s.json" % workload, "hbm_traffic_%s.json" % workload):
+        p = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(p):
+            return json.load(open(p))
+    return {}
+
+
+# ---- one workload, measured ----------------------------------------------------------------------------------------------
+def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch, hdist, strong=False):
+    scene, desc = load_workload(workload, spp)
     spp_per_gpu = scene.render.spp
     rd = abi.copy_struct(scene.render)
-    rd.spp = spp_per_gpu * world                     # weak scaling: per-rank samples fixed
+    rd.spp = spp_per_gpu if strong else spp_per_gpu * world     # weak scaling: per-rank samples fixed; strong: the frame is fixed
     rd.shard_rank, rd.shard_count = rank, world
     if args.sampler == "random":
         rd.sampler_mode = abi.HPT_SAMPLER_RANDOM_HASH
@@ -174,7 +280,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, last = [], None
+    kernel_ms, last, full = [], None, None
 
     def step():
         nonlocal last
@@ -182,12 +288,12 @@ def main():
         kernel_ms.append(last.kernel_ms)
         return hdist.exchange_film(film, rank, world, wide_filter=flt is not None)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     kernel_ms.clear()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         full = step()
     sync()
     dt = time.perf_counter() - t0
@@ -195,52 +301,129 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_samples = rd.x_count * rd.y_count * rd.spp * args.steps
+    total_samples = rd.x_count * rd.y_count * rd.spp * steps
     value = total_samples / dt / 1e6
+    if rank != 0:
+        return None, scene, flt
+    full_h = full.cpu().numpy()
+    k_ms = float(np.mean(kernel_ms))
+    per_launch_samples = last.camera_samples
+    out = {
+        "metric": "Msamples/sec at 1920x1080, 8-bounce path", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" if workload == "soup" else
+        "scene blob dumped from the reference parser (tests/golden), random-free geometry",
+        "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
+                               % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting",
+                                  rd.spp // world if strong else spp_per_gpu, rd.spp,
+                                  {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)"}.get(args.sampler, "LD_HASH"),
+                                  "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
+                   "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
+                   "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
+                   "scene_bytes_in_hbm": int(info.total_device_bytes)},
+        "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)",
+                   "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
+                   "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
+                   "occupancy": round(last.resident_waves / 32.0, 3),
+                   "tune_cfg": "%d (%s)" % (last.tune_cfg, TUNE_NAMES[last.tune_cfg]),
+                   "samples_per_launch": int(per_launch_samples)},
+        "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
+        "film_mean_Y": round(float(full_h[..., 1].astype(np.float64).sum() / max(float(full_h[..., 3].astype(np.float64).sum()), 1.0)), 5),
+    }
+    if not args.no_verify:
+        out["verify"] = verify_film(scene, rd, full_h, flt)
+        out["rmse_vs_oracle"] = out["verify"]["rmse_vs_oracle"]
+    bps = ALGO_BYTES_PER_SAMPLE.get(workload)
+    if args.count_work:
+        out["work"] = {"closest_rays_per_sample": last.closest_rays / per_launch_samples,
+                       "shadow_rays_per_sample": last.shadow_rays / per_launch_samples,
+                       "nodes64_per_sample": last.nodes_visited / per_launch_samples,
+                       "tris_per_sample": last.tris_tested / per_launch_samples,
+                       "device_bytes_per_sample": (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples}
+    if bps is None and args.count_work:
+        bps = (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples
+    prof = pmc_profile(workload)
+    if bps is not None:
+        achieved = bps * per_launch_samples / (k_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": prof.get("bytes_per_launch"),
+                           "algorithmic_bytes_per_sample": bps}
+    if prof.get("valu_wave_instructions_per_launch") and prof.get("samples_per_launch"):
+        # second roofline for the cache-resident scenes (7 MB of scene data never leaves L2 / Infinity Cache): VALU issue.
+        # wave-instructions per camera sample from the committed PMC pass x this run's samples / this run's kernel time
+        ipl = prof["valu_wave_instructions_per_launch"] / prof["samples_per_launch"] * per_launch_samples
+        ach = ipl / (k_ms * 1e-3) / 1e9
+        out["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 2), "peak": VALU_PEAK_GINST, "unit": "Gwave-inst/s",
+                                "frac": round(ach / VALU_PEAK_GINST, 4), "lane_utilisation": prof.get("valu_lane_utilisation"),
+                                "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"), "source": prof.get("source")}
+    return out, scene, flt
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (power of two)")
+    ap.add_argument("--pipeline", default=os.environ.get("HPT_PIPELINE", "persistent"), choices=["persistent", "wavefront"])
+    ap.add_argument("--filter", default="box", choices=["box", "gaussian", "mitchell", "triangle", "sinc"],
+                    help="PixelFilter with the reference plugin's default widths (box 0.5 = the metric's configuration)")
+    ap.add_argument("--sampler", default="lowdiscrepancy", choices=["lowdiscrepancy", "random", "stratified"],
+                    help='Sampler: "lowdiscrepancy" (the metric\'s configuration, HPT_SAMPLER_LD_HASH) "random" (HPT_SAMPLER_RANDOM_HASH) or "stratified" (HPT_SAMPLER_STRATIFIED_HASH, 8 x spp/8 jittered strata)')
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed film")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no killeroo / anim / soup lines, no pbrt_hip end-to-end run)")
+    ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
+    args = ap.parse_args()
+    default_run = args.workload is None and args.filter == "box" and args.sampler == "lowdiscrepancy" and \
+        args.pipeline == "persistent" and not args.count_work and not args.spp
+    workload = args.workload or "bunny"
+
+    import torch
+    import torch.distributed as dist
+    hdist = importlib.import_module("pbrt-v2_amd.dist")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    if not torch.cuda.is_available() or hpt.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, hdist)
+    extras = []
+    if default_run and not args.no_extra:
+        if world == 1:
+            # the other BASELINE configurations, as written (north-star scene 64 spp, configs[3] 128 spp, configs[2] 256 spp)
+            for w, st, wu in (("killeroo", 3, 1), ("anim", 3, 1), ("soup", 2, 1)):
+                o, _, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, hdist)
+                extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "kernel", "setup_s", "rmse_vs_oracle", "verify", "roofline", "roofline_valu") if k in o})
+                extras[-1]["workload"] = w
+        else:
+            # strong scaling of the north-star frame: the fixed 256-spp 1M-triangle frame split N ways (BASELINE configs[2])
+            o, _, _ = measure(args, "soup", 0, min(2, args.steps), min(1, args.warmup), world, rank, local, dist, torch, hdist, strong=True)
+            if rank == 0:
+                extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle") if k in o})
+                extras[-1]["workload"] = "soup (strong scaling: fixed 256-spp frame)"
     if rank == 0:
-        img_mean = float(full[..., :3].sum() / max(float(full[..., 3].sum()), 1.0))
-        k_ms = float(np.mean(kernel_ms))
-        per_launch_samples = last.camera_samples
-        out = {
-            "metric": "Msamples/sec at 1920x1080, 8-bounce path", "value": round(value, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "soup" else
-            "scene blob dumped from the reference parser (tests/golden), random-free geometry",
-            "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
-                                   % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting", spp_per_gpu, rd.spp, {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)"}.get(args.sampler, "LD_HASH"),
-                                      "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
-                       "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
-                       "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
-                       "scene_bytes_in_hbm": int(info.total_device_bytes)},
-            "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)", "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
-                       "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
-                       "tune_cfg": "%d (%s)" % (last.tune_cfg, ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases", "3 waves/SIMD, lock-step phases", "4 waves/SIMD, lock-step phases, subtree stealing", "3 waves/SIMD, lock-step phases, subtree stealing"][last.tune_cfg]),
-                       "samples_per_launch": int(per_launch_samples)},
-            "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
-            "film_mean_Y": round(img_mean, 5),
-        }
-        bps = ALGO_BYTES_PER_SAMPLE.get(args.workload)
-        if args.count_work:
-            out["work"] = {"closest_rays_per_sample": last.closest_rays / per_launch_samples,
-                           "shadow_rays_per_sample": last.shadow_rays / per_launch_samples,
-                           "nodes64_per_sample": last.nodes_visited / per_launch_samples,
-                           "tris_per_sample": last.tris_tested / per_launch_samples,
-                           "device_bytes_per_sample": (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples}
-        if bps is None and args.count_work:
-            bps = (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples
-        if bps is not None:
-            achieved = bps * per_launch_samples / (k_ms * 1e-3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)
-            if os.path.exists(tf):
-                traffic = json.load(open(tf)).get("bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "algorithmic_bytes_per_sample": bps}
+        if extras:
+            out["workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, flt=flt)
+            port = cpu_baseline_port(scene, flt=flt)
+            ref = cpu_baseline_reference(workload, scene) if (flt is None and args.sampler == "lowdiscrepancy") else None
+            out["cpu_baseline"] = ref or port          # pbrt-v2's own binary when it (and its scene files) travelled; else the port
+            if ref:
+                out["cpu_baseline_port"] = port
+        if world == 1 and default_run and not args.no_extra:
+            e2e = end_to_end_pbrt_hip(workload, scene)
+            if e2e:
+                out["end_to_end"] = e2e
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -26,9 +26,12 @@ using namespace hpt;
         }                                                                                   \
     } while (0)
 
+struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; };   // one work-queue head per XCD
+
 struct hpt_scene {
     int device;
     int mats;             // MATS_* bits of the BxDF families the scene's materials need
+    int n_materials;
     DScene d;             // device pointers
     std::vector<void *> allocs;
     hpt_scene_info info;
@@ -39,6 +42,8 @@ struct hpt_scene {
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
+    void *d_film; size_t film_bytes;               // device film of hpt_render (host-film entry point), grown on demand
+    void *d_scr; hipEvent_t ev0, ev1;              // per-frame scratch (work-queue heads + counters) and timing events, created once
     float *sbuf; size_t sbuf_floats;             // two-pass film: per-sample records of the last filtered render (grown on demand)         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
 };
 
@@ -63,6 +68,10 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->sbuf) (void)hipFree(s->sbuf);
+    if (s->d_scr) (void)hipFree(s->d_scr);
+    if (s->d_film) (void)hipFree(s->d_film);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
 
@@ -76,6 +85,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->device = device;
     s->tune_cfg = -1;
     s->sbuf = nullptr; s->sbuf_floats = 0;
+    s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0;
     s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
@@ -125,7 +135,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         if (hipMalloc(&p, sizeof(float) * 16 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
         else ok = false;
     }
-    s->mats = 0;
+    s->mats = 0; s->n_materials = desc->n_materials;
     s->kd_mat = -1; s->kd_nodes = 0;
     for (int m = 0; m < desc->n_materials; ++m) {
         int k = desc->materials[m].kind;
@@ -135,6 +145,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     }
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
+    // what every frame needs besides the film: allocated once, so that a render call neither allocates nor frees (hipFree synchronises the device)
+    if (ok && (hipMalloc(&s->d_scr, sizeof(RenderScratch)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) ok = false;
     if (!ok) { hpt_set_error("device allocation / upload failed: %s", hipGetErrorString(hipGetLastError())); hpt_scene_destroy(s); return nullptr; }
     return s;
 }
@@ -416,16 +428,15 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
-    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     hipStream_t stream = (hipStream_t)stream_v;
     a.sc = s->d;
     a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
     a.film = (float *)d_film;
-    struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
-    Scratch *d_scr = nullptr;
-    HIP_CHECK_RET(hipMalloc((void **)&d_scr, sizeof(Scratch)), HPT_E_HIP);
+    typedef RenderScratch Scratch;
+    Scratch *d_scr = (Scratch *)s->d_scr;                // (one render at a time per scene handle)
     a.next_item = d_scr->next_item;
     a.counters = &d_scr->wc;
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
@@ -444,10 +455,16 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (rd->count_work && !dl) cfg = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
+    if (e == hipSuccess && a.rp.n_items == 0) {           // a shard that owns no tile (tiny image, many shards): an empty film
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+        if (stats) { memset(stats, 0, sizeof(*stats)); stats->block_threads = HPT_BLOCK; }
+        return HPT_OK;
+    }
     int bpc = 0, vgprs = 0;
     if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
         if (cfg >= 5 && !dl) { cfg -= 2; if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown; }   // tree too deep for the stealing rows
-        else if (dl) { (void)hipFree(d_scr); hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
+        else if (dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         else e = hipErrorUnknown;
     }
     if (bpc < 1) bpc = 1;
@@ -455,13 +472,16 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
     a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
+    if ((replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT) && s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) {
+        hpt_set_error("BVH depth %d: the replay / wavefront kernels have a fixed %d-row traversal stack (build the scene with the host SAH builder)", s->info.bvh_max_depth, HPT_STACK_DEPTH);
+        return HPT_E_UNSUPPORTED;
+    }
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) a.rp.sbuf_xyzw = a.rp.sbuf_pos = nullptr;   // the wavefront pipeline keeps the one-pass (atomic) splat
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
         float wms = 0.f; int wgrid = 0, wvg = 0, wbpc = 0;
         int wrc = render_wavefront(s, a, rd, stream, stats, d_scr->next_item, &d_scr->wc, &wms, &wgrid, &wvg, &wbpc);
         Scratch h_scr2; memset(&h_scr2, 0, sizeof(h_scr2));
         if (wrc == HPT_OK && hipMemcpy(&h_scr2, d_scr, sizeof(Scratch), hipMemcpyDeviceToHost) != hipSuccess) wrc = HPT_E_HIP;
-        (void)hipFree(d_scr);
         if (wrc != HPT_OK) return wrc;
         if (stats) {
             memset(stats, 0, sizeof(*stats));
@@ -486,11 +506,6 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         }
         return HPT_OK;
     }
-    if ((replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT) && s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) {
-        (void)hipFree(d_scr);
-        hpt_set_error("BVH depth %d: the replay / wavefront kernels have a fixed %d-row traversal stack (build the scene with the host SAH builder)", s->info.bvh_max_depth, HPT_STACK_DEPTH);
-        return HPT_E_UNSUPPORTED;
-    }
     ReplayArgs ra; memset(&ra, 0, sizeof(ra));
     if (replay && e == hipSuccess) {
         ra.ntasks = rd->ntasks;
@@ -499,9 +514,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         if (e == hipSuccess) e = hipMalloc((void **)&ra.buf, sizeof(float) * HPT_REPLAY_FLOATS_PER_SAMPLE * (size_t)rd->spp * (size_t)ra.nlanes);
         grid = (int)(ra.nlanes / HPT_BLOCK);
     }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e == hipSuccess) e = hipEventCreate(&ev0);
-    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    hipEvent_t ev0 = s->ev0, ev1 = s->ev1;
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
     // two-pass film: w = 0 marks a sample this shard does not render; then the path kernel parks its samples, the gather sums them
     if (e == hipSuccess && a.rp.sbuf_xyzw) e = hipMemsetAsync(a.rp.sbuf_xyzw, 0, sizeof(float) * 4 * (size_t)a.rp.sx_count * a.rp.sy_count * (size_t)rd->spp, stream);
@@ -514,9 +527,6 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     Scratch h_scr;
     memset(&h_scr, 0, sizeof(h_scr));
     if (e == hipSuccess) e = hipMemcpy(&h_scr, d_scr, sizeof(Scratch), hipMemcpyDeviceToHost);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    (void)hipFree(d_scr);
     if (ra.mt) (void)hipFree(ra.mt);
     if (ra.buf) (void)hipFree(ra.buf);
     if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
@@ -551,9 +561,9 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
     a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
-    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     a.sc = s->d;
     struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
     DevBuf<Scratch> scr;
@@ -569,13 +579,16 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
     if (!s || !film_host || !rd) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
-    void *d_film = nullptr;
-    HIP_CHECK_RET(hipMalloc(&d_film, bytes), HPT_E_HIP);
-    int rc = hpt_render_device(s, cam, rd, d_film, nullptr, stats);
-    if (rc == HPT_OK && hipMemcpy(film_host, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (s->film_bytes < bytes) {                          // the device film of the host-film entry point stays with the scene
+        if (s->d_film) (void)hipFree(s->d_film);
+        s->d_film = nullptr; s->film_bytes = 0;
+        HIP_CHECK_RET(hipMalloc(&s->d_film, bytes), HPT_E_HIP);
+        s->film_bytes = bytes;
+    }
+    int rc = hpt_render_device(s, cam, rd, s->d_film, nullptr, stats);
+    if (rc == HPT_OK && hipMemcpy(film_host, s->d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
         hpt_set_error("film download failed"); rc = HPT_E_HIP;
     }
-    (void)hipFree(d_film);
     return rc;
 }
 
@@ -595,7 +608,7 @@ extern "C" int hpt_test_intersect(hpt_scene *s, const float *rays, int64_t n, in
 }
 
 extern "C" int hpt_test_bsdf(hpt_scene *s, int material, const float *in, int64_t n, float *out) {
-    if (!s || !in || !out || n < 0 || material < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
+    if (!s || !in || !out || n < 0 || material < 0 || material >= s->n_materials) { hpt_set_error("bad argument (material %d of %d)", material, s ? s->n_materials : 0); return HPT_E_INVALID; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     DevBuf<float> d_in, d_out;
     if (!d_in.alloc(16 * (size_t)n) || !d_out.alloc(12 * (size_t)n)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }

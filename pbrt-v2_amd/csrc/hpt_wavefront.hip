@@ -54,7 +54,7 @@ __device__ __forceinline__ void lane_load(LaneT &l, const float4 *st, int64_t P,
     uint32_t flags = f2u(v.x), pxy = f2u(v.y);
     l.stage = (int)(flags & 0xffu); l.specular = (flags >> 8) & 1u; l.has_mis = (flags >> 9) & 1u;
     l.has_next = (flags >> 10) & 1u; l.spec_next = (flags >> 11) & 1u; l.bounce = (int)(flags >> 16);
-    l.px = (int)(pxy & 0xffffu); l.py = (int)(pxy >> 16); l.si = f2u(v.z); l.s_end = f2u(v.w);
+    l.px = (int)(int16_t)(pxy & 0xffffu); l.py = (int)(int16_t)(pxy >> 16); l.si = f2u(v.z); l.s_end = f2u(v.w);   // px, py signed: under a wide filter the sample extent starts at negative pixels
     v = st[1 * P + slot];
     l.smp.h.pk = f2u(v.x); l.smp.dcount = f2u(v.y); l.time = v.z; l.eps = v.w;
     l.smp.h.w = rp.sampler_w; l.smp.h.i = l.si;

@@ -170,3 +170,42 @@ def sub_windows(rd):
         y0, y1 = int(np.floor(lerp(ty0, ys, ye))), int(np.floor(lerp(ty1, ys, ye)))
         out.append((x0 - xs, x1 - xs, y0 - ys, y1 - ys))
     return out
+
+
+# ---- parity at BASELINE size: crop windows of a full frame against the oracle (tests/test_gpu_fullsize.py, bench.py) ----
+CROP = 64
+
+
+def crop_windows(xres, yres, n=CROP):
+    """-> list of (name, x0, y0): corners, centre, and a window across the border of XCD bands 0 | 1"""
+    n_stx, n_sty = (xres + 31) // 32, (yres + 31) // 32
+    tiles = n_stx * n_sty
+    t1 = tiles * 1 // 8                       # first tile of band 1
+    bx, by = (t1 % n_stx) * 32, (t1 // n_stx) * 32
+    wins = [("top-left", 0, 0), ("top-right", xres - n, 0), ("bottom-left", 0, yres - n), ("bottom-right", xres - n, yres - n),
+            ("centre", (xres - n) // 2, (yres - n) // 2),
+            ("xcd-band-border", min(max(bx - n // 2, 0), xres - n), min(max(by - n // 2, 0), yres - n))]
+    return wins
+
+
+def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP):
+    """frame: the device's full film for `rd`.  Returns the worst per-crop RMSE."""
+    worst = 0.0
+    import importlib
+    film = importlib.import_module("pbrt-v2_amd.film")
+    for name, x0, y0 in crop_windows(rd.x_count, rd.y_count, n):
+        ax0, ay0 = max(x0 - 1, 0), max(y0 - 1, 0)
+        ax1, ay1 = min(x0 + n + 1, rd.x_count), min(y0 + n + 1, rd.y_count)
+        crd = abi.copy_struct(rd)
+        crd.x_start, crd.y_start, crd.x_count, crd.y_count = ax0, ay0, ax1 - ax0, ay1 - ay0
+        crd.count_work = 0
+        fo, _ = oracle.render(scene.camera, crd, flt=flt)
+        fo = fo[y0 - ay0:y0 - ay0 + n, x0 - ax0:x0 - ax0 + n]
+        fd = frame[y0:y0 + n, x0:x0 + n]
+        assert np.array_equal(fo[..., 3], fd[..., 3]), "%s: film weights differ" % name
+        err = film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fd))
+        assert err < tol, (name, err)
+        worst = max(worst, err)
+    return worst
+
+
