@@ -45,7 +45,11 @@ if k:
     derived["kernel_calls"] = int(k["Calls"])
     derived["kernel_pct_of_gpu_time"] = float(k["Percentage"])
 if "FETCH_SIZE" in pmc:
-    derived["hbm_read_bytes_per_launch"] = pmc["FETCH_SIZE"] * 1024 * 2
+    # profiles/r02_fetch_calibration.md (known-byte microbenchmarks in this kernel's access patterns): FETCH_SIZE counts a lane-scattered
+    # 64-B node fetch at x1.0 (48-B triangle records at the 64-B lines they touch) and coalesced dword scratch reads at x0.5 like the
+    # guide's 16 B/lane stream; WRITE_SIZE is x1.0.  A launch's writes are all scratch (the film is 33 MB), and what is spilled is read
+    # back once, so scratch reads ~ WRITE_SIZE, of which FETCH_SIZE saw half: read bytes = FETCH_SIZE + WRITE_SIZE / 2
+    derived["hbm_read_bytes_per_launch"] = pmc["FETCH_SIZE"] * 1024 + pmc.get("WRITE_SIZE", 0.0) * 1024 / 2
 if "WRITE_SIZE" in pmc:
     derived["hbm_write_bytes_per_launch"] = pmc["WRITE_SIZE"] * 1024
 if "hbm_read_bytes_per_launch" in derived and "hbm_write_bytes_per_launch" in derived:
@@ -94,7 +98,7 @@ if len(sys.argv) > 3:
             "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
             "scratch_bytes_per_lane": int(meta["Scratch_Size"]) if meta.get("Scratch_Size") else None,
             "kernel_avg_ms_under_rocprof": derived.get("kernel_avg_ms"),
-            "note": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-load correction; profiles/r02_fetch_calibration.md) + WRITE_SIZE KiB x1024"}
+            "note": "L2<->fabric bytes (Infinity-Cache hits included): FETCH_SIZE KiB x1024 + WRITE_SIZE KiB x1024 x 1.5 (scratch reads are counted at half: profiles/r02_fetch_calibration.md)"}
     json.dump(doc2, open(os.path.join(out_dir, "pmc_%s.json" % sys.argv[3]), "w"), indent=1)
 if False:
     json.dump({"bytes_per_launch": derived["hbm_bytes_per_launch"], "read_bytes": derived["hbm_read_bytes_per_launch"],
