@@ -37,7 +37,6 @@ struct hpt_scene {
     hpt_scene_info info;
     int n_cus;
     int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
-    int kd_mat, kd_nodes; // first measured-BRDF material and the size of its kd-tree (-1: none)
     int stack_entries;    // per-lane traversal stack entries this scene needs
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
@@ -111,8 +110,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->info.bvh_max_depth = fs.max_depth;
     s->info.device_build_ms = fs.device_build_ms; s->info.device_built = fs.device_built;
     s->stack_entries = fs.max_depth + 2;
-    // a measured BRDF: its kd walk (one row per ancestor) + the 12 rows of the wave's query queue (wave_eval_queries)
-    if (fs.kd_max_depth > 0 && s->stack_entries < fs.kd_max_depth - 1 + 12) s->stack_entries = fs.kd_max_depth - 1 + 12;   // (depth - 1 ancestor rows; a row is 1 KiB, so the kd head behind the stacks stays 8-byte aligned)
+    // a measured BRDF: the 12 rows of the wave's query queue (wave_eval_queries; the grid walk itself needs no stack)
+    if (fs.has_measured && s->stack_entries < 12) s->stack_entries = 12;
     if (s->stack_entries < 8) s->stack_entries = 8;
     if (s->stack_entries > HPT_MAX_STACK_ROWS) s->stack_entries = HPT_MAX_STACK_ROWS;
 
@@ -136,10 +135,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         else ok = false;
     }
     s->mats = 0; s->n_materials = desc->n_materials;
-    s->kd_mat = -1; s->kd_nodes = 0;
     for (int m = 0; m < desc->n_materials; ++m) {
         int k = desc->materials[m].kind;
-        if (k == HPT_MAT_MEASURED_IRREG && s->kd_mat < 0) { s->kd_mat = m; s->kd_nodes = desc->materials[m].kd_nnodes; }
         s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
                  : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
     }
@@ -335,23 +332,12 @@ template <typename T> struct DevBuf {
     bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
 };
 
-// Resident blocks per CU of configuration `cfg`, and whether the kd-tree head of the scene's measured BRDF
-// rides along in LDS: it does when its {split, bits} pairs (8 bytes a node) fit next to the traversal stacks
-// without costing a resident block.
+// Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0);
+    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows();   // [walk stack][stealing rows][cold rows]
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
-    a->kd_lds_mat = -1; a->kd_lds_nodes = 0;
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
-    if (s->kd_mat >= 0 && !getenv("HPT_NO_KD_LDS")) {
-        PathKernelArgs t = *a;
-        t.kd_lds_mat = s->kd_mat; t.kd_lds_nodes = s->kd_nodes;
-        int b1 = 0, v1 = 0;
-        if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(t), &b1, &v1) == 0 && b1 >= *bpc && b1 > 0) {
-            a->kd_lds_mat = t.kd_lds_mat; a->kd_lds_nodes = t.kd_lds_nodes;
-        }
-    }
     if (*bpc < 1) *bpc = 1;
     return 0;
 }
@@ -427,7 +413,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
@@ -560,7 +546,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (tune_forced() >= 0) return tune_forced();
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
-    a.kd_lds_mat = -1; a.kd_lds_nodes = 0; a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;

@@ -729,57 +729,69 @@ HPT_FN float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
     return (Rparl * Rparl + Rperp * Rperp) / 2.f;
 }
 
-// IrregIsotropicBRDF::f (reflection.cpp:247-272): kd-tree radius query with the reference's exact
-// post-order visiting sequence (core/kdtree.h:159-183) so the weighted sums round identically.
-// The recursion is unrolled into an explicit stack of (node, stage) pairs.
+// IrregIsotropicBRDF::f (reflection.cpp:247-272).  The reference answers it with a kd-tree radius query (core/kdtree.h:151-183):
+// the radius^2 grows .001, .002, ... until a pass finds more than two of the measured samples, and the value is the
+// exp(-100 d^2)-weighted mean of the samples of THAT pass (3.1 passes and 98 node visits per lookup on bunny.pbrt's BRDF; a
+// recursive, divergent walk with a stack per lane).  The result only depends on the final radius r_k, k = min{k : #(d2 < r_k) > 2},
+// and on which samples lie inside it — not on how they were found.
 //
-// The reference grows the radius .001, .002, ... until a pass finds more than two samples and returns
-// the sums of THAT pass (3.1 passes and 98 node visits per lookup on bunny.pbrt's BRDF).  The result
-// only depends on the final radius r_k, k = min{k : #(d2 < r_k) > 2}, and a pass at any radius visits
-// the samples in the same relative order (the order is a function of the query point alone; the radius
-// only prunes).  So the device starts at a guessed level g (a 64^3 table of the level at cell centres,
-// built at scene creation: hpt_flatten.cpp), tracks the third-smallest d2 of the pass, and sums for
-// r_g and r_(g-1) at once: k == g or g-1 ends after ONE pass with bit-identical sums, k < g-1 takes one
-// more (smaller) pass at r_k, k > g continues upwards like the reference (1.3 passes, 61 visits).
+// MI355X form: the measured samples (1 439 of them for mystique.brdf, three-dimensional points in [0,1] x [0,1] x [-1,1]) are binned
+// once, at scene creation, into a uniform 16 x 16 x 32 grid and stored cell by cell, x fastest (hpt_flatten.cpp): the samples of a
+// run of cells along x are one contiguous range.  A query at radius R visits the rows (y, z) of its box [q - R, q + R] — typically
+// 3 x 3 rows of 3 cells — reads one range per row and tests ~10 samples, without a stack, without LDS traffic and with every lane of
+// the wave in the same small loop; the walk started at a guessed level g (a 64^3 table of the level at cell centres, built with the
+// samples), sums for r_g and r_(g-1) at once and tracks the third-smallest d2, so k == g or g-1 ends after ONE pass, k < g-1 takes
+// one more (smaller) pass at r_k, k > g continues upwards like the reference.  Same samples, same weights; the sums run in grid order
+// instead of the kd-tree's post-order, i.e. the value agrees with the reference's to float rounding of a sum of ~4 terms (not bit for bit).
 struct IrregProc { f3 v; float sumWeights; f3 v2; float sumWeights2; float r2; float m1, m2, m3; };
-// Scratch stack for the kd-tree walk: the lane's LDS traversal-stack column (free while shading).
-// kd_top: optional copy of one material's {splitPos, bits} pairs in LDS (hpt_kernels_impl.h); the walk of
-// that material's tree then touches HBM / L2 only when it hands a sample to the accumulator.
-// The pointers carry the LDS address space so that the out-of-line irreg_f issues ds_read / ds_write
-// instead of flat loads (measured: flat_load + full s_waitcnt three times per step before).
 #ifdef HPT_HOST_EMU
 #define HPT_LDS
 #else
 #define HPT_LDS __attribute__((address_space(3)))
 #endif
+// A lane's LDS traversal-stack column (any lane can read any column: rows are `stride` ints apart) + the rows of the wave's query queue
 struct LaneStack {
     HPT_LDS int32_t *p; int stride;
     int qrow = 0;         // first stack row of the wave's query queue (path kernel only)
-    const HPT_LDS uint64_t *kd_top = nullptr; const hpt_material *kd_top_mat = nullptr;
 };
 #define HPT_KD_GRID 64
-// The whole query — growing-radius passes included — as a resumable walk: kd_begin() positions it, each kd_step()
-// does ONE step of the current radius pass (descend into a child, or hand the node's sample to the accumulator and pop)
-// and, when the pass ends, decides like the reference's loop (reflection.cpp:262-271) whether another pass is needed.
-// Serial callers loop until done (irreg_eval); the path kernel's wave-cooperative evaluator (hpt_kernels_impl.h) steps
-// 64 walks side by side and hands a lane the next queued query the moment its walk ends.
-// `cur` (node << 2 | stage) lives in a register, its ancestors on the lane's LDS stack column.  stage 0: first visit;
-// 1: after the first child; 2: after the second child -> hand the node's sample over.  Depth <= 24 (scene creation).
+#define HPT_BG_X 16       /* sample grid: cells along sin*sin in [0,1] */
+#define HPT_BG_Y 16       /*              dphi/pi in [0,1]            */
+#define HPT_BG_Z 32       /*              cos*cos in [-1,1]           */
+HPT_FN int bg_cell_x(float v) { int c = (int)(v * (float)HPT_BG_X); return c < 0 ? 0 : c > HPT_BG_X - 1 ? HPT_BG_X - 1 : c; }
+HPT_FN int bg_cell_y(float v) { int c = (int)(v * (float)HPT_BG_Y); return c < 0 ? 0 : c > HPT_BG_Y - 1 ? HPT_BG_Y - 1 : c; }
+HPT_FN int bg_cell_z(float v) { int c = (int)((v + 1.f) * (.5f * (float)HPT_BG_Z)); return c < 0 ? 0 : c > HPT_BG_Z - 1 ? HPT_BG_Z - 1 : c; }
+// The whole query — growing-radius passes included — as a resumable walk: kd_begin() positions it, each kd_step() advances to the
+// next row of the box when the current range is used up and tests one sample, and, when the pass ends, decides like the reference's
+// loop (reflection.cpp:262-271) whether another pass is needed.  Serial callers loop until done (irreg_eval); the path kernel's
+// wave-cooperative evaluator (hpt_kernels_impl.h) steps 64 walks side by side and hands a lane the next queued query the moment its walk ends.
 struct KdWalk {
     f3 q;                 // query point
-    uint32_t cur; int sp;
     float r; int level;   // radius^2 of this pass = .001 * 2^level
     bool last;            // this pass runs at the exact final radius (after a too-high guess)
-    bool top;             // this material's split planes are in LDS (LaneStack::kd_top)
-    const f4 *nodes; uint32_t nNodes;   // packed node records {splitPos, bits, p.x, p.y | p.z, v.r, v.g, v.b} (hpt_flatten.cpp)
+    int x0, x1, y0, y1, z1;   // cell box of the pass
+    int iy, iz;           // row being read
+    uint32_t j, jend;     // samples of that row still to test
+    const f4 *samples;    // 32-byte records {p.xyz, v.r | v.g, v.b, 0, 0} in cell order (hpt_flatten.cpp)
+    const uint32_t *cells;    // first sample of every cell, + 1 entry
     IrregProc pr;
 };
 HPT_FN void irreg_proc_reset(IrregProc *pr, float r2) {
     pr->v = S(0.f); pr->sumWeights = 0.f; pr->v2 = S(0.f); pr->sumWeights2 = 0.f; pr->r2 = r2;
     pr->m1 = pr->m2 = pr->m3 = HPT_INF;
 }
-HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack ls, KdWalk *w) {
-    w->nodes = (const f4 *)(sc.fpool + m->kd_data_off); w->nNodes = (uint32_t)m->kd_nnodes; w->top = m == ls.kd_top_mat;
+HPT_FN void kd_set_box(KdWalk *w) {
+    // every sample with d2 < r has |dx|, |dy|, |dz| < sqrt(r); the cell of a coordinate is monotonic in it, so the cells of
+    // q -+ R (R rounded up a little) bracket the cells of all those samples
+    const float R = sqrtf(w->r) * 1.00001f + 1e-6f;
+    w->x0 = bg_cell_x(fmaxf(w->q.x - R, 0.f)); w->x1 = bg_cell_x(w->q.x + R);
+    w->y0 = bg_cell_y(fmaxf(w->q.y - R, 0.f)); w->y1 = bg_cell_y(w->q.y + R);
+    const int z0 = bg_cell_z(fmaxf(w->q.z - R, -1.f)); w->z1 = bg_cell_z(w->q.z + R);
+    w->iy = w->y0 - 1; w->iz = z0; w->j = w->jend = 0u;
+}
+HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, KdWalk *w) {
+    w->samples = (const f4 *)(sc.fpool + m->kd_data_off);
+    w->cells = (const uint32_t *)(sc.fpool + m->kd_split_off);
     // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
     int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
     gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
@@ -791,56 +803,40 @@ HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack 
     float r = .001f;
     for (int i = 0; i < w->level; ++i) r *= 2.f;         // the reference's lastMaxDist2 after `level` doublings
     w->r = r; w->last = false;
-    w->cur = 0u; w->sp = 0;
     irreg_proc_reset(&w->pr, w->level > 0 ? r * .5f : 0.f);
+    kd_set_box(w);
 }
 // returns true when the query is finished: *out = IrregIsotropicBRDF::f
-template <int TIER>    // 0: tree in HBM / L2 only; 1: {split, bits} of every node in LDS
-HPT_FN bool kd_step(KdWalk *w, LaneStack ls, f3 *out) {
-    const f4 *nodes = w->nodes;
-    const uint32_t nNodes = w->nNodes;
-    const f3 p = w->q;
-    const float maxDist2 = w->r;
-    const uint32_t nodeNum = w->cur >> 2, stage = w->cur & 3u;
-    float sp_; uint32_t b;
-    if (TIER >= 1) { uint64_t t = ls.kd_top[nodeNum]; sp_ = as_float((int32_t)(uint32_t)t); b = (uint32_t)(t >> 32); }   // split | bits << 32
-    else { f4 t = nodes[2 * (int64_t)nodeNum]; sp_ = t.x; b = (uint32_t)as_int(t.y); }
-    const int axis = (int)(b & 3u);
-    {   // which child to descend into next — straight-line selects (the branchy form cost ~10 scalar branches a step):
-        // stage 0 tries the near child, then the far child if the slab reaches it; stage 1 only the far child
-        const uint32_t NONE = 0xffffffffu;
-        const uint32_t left = ((b >> 2) & 1u) ? nodeNum + 1 : NONE, right = (b >> 3) < nNodes ? (b >> 3) : NONE;
-        const float pa = comp(p, axis);
-        const float d2 = (pa - sp_) * (pa - sp_);
-        const bool leftFirst = pa <= sp_;
-        const uint32_t nearC = leftFirst ? left : right;
-        const uint32_t farC = d2 < maxDist2 ? (leftFirst ? right : left) : NONE;
-        const bool takeNear = stage == 0u && nearC != NONE;
-        const uint32_t child = takeNear ? nearC : farC;
-        if (axis != 3 && stage < 2u && child != NONE) {
-            ls.p[w->sp * ls.stride] = (int32_t)((nodeNum << 2) | (takeNear ? 1u : 2u)); ++w->sp;
-            w->cur = child << 2;
-            return false;
+HPT_FN bool kd_step(KdWalk *w, f3 *out) {
+    if (w->j >= w->jend) {                               // this row's range is used up: on to the next row of the box
+        ++w->iy;
+        if (w->iy > w->y1) { w->iy = w->y0; ++w->iz; }
+        if (w->iz <= w->z1) {
+            const uint32_t *row = w->cells + ((w->iz * HPT_BG_Y + w->iy) * HPT_BG_X);
+            w->j = row[w->x0]; w->jend = row[w->x1 + 1];
         }
     }
     IrregProc *proc = &w->pr;
-    f4 n0 = nodes[2 * (int64_t)nodeNum], n1 = nodes[2 * (int64_t)nodeNum + 1];
-    f3 np = mk3(n0.z, n0.w, n1.x);
-    float d2 = dist2(np, p);
-    if (d2 < maxDist2) { // IrregIsoProc::operator() (reflection.cpp:46-51)
-        float weight = expf(-100.f * d2);
-        f3 wv = mk3(n1.y, n1.z, n1.w) * weight;
-        proc->v = proc->v + wv;
-        proc->sumWeights += weight;
-        const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
-        proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
-        proc->sumWeights2 += in2 ? weight : 0.f;
-        // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
-        const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
-        const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
-        proc->m3 = minf(proc->m3, t2);
+    if (w->j < w->jend) {
+        const f4 n0 = w->samples[2 * (int64_t)w->j], n1 = w->samples[2 * (int64_t)w->j + 1];
+        ++w->j;
+        const float d2 = dist2(mk3(n0.x, n0.y, n0.z), w->q);
+        if (d2 < w->r) { // IrregIsoProc::operator() (reflection.cpp:46-51)
+            float weight = expf(-100.f * d2);
+            f3 wv = mk3(n0.w, n1.x, n1.y) * weight;
+            proc->v = proc->v + wv;
+            proc->sumWeights += weight;
+            const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
+            proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
+            proc->sumWeights2 += in2 ? weight : 0.f;
+            // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
+            const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
+            const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
+            proc->m3 = minf(proc->m3, t2);
+        }
+        return false;
     }
-    if (w->sp > 0) { --w->sp; w->cur = (uint32_t)ls.p[w->sp * ls.stride]; return false; }
+    if (w->iz <= w->z1) return false;                    // (an empty row: keep going)
     // ---- the pass is over ------------------------------------------------------------------------------------------
     if (w->last) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
     if (proc->m3 < w->r) {                               // more than two samples inside r: the reference stopped at k <= level
@@ -855,7 +851,7 @@ HPT_FN bool kd_step(KdWalk *w, LaneStack ls, f3 *out) {
         w->r *= 2.f; ++w->level;
         irreg_proc_reset(proc, w->r * .5f);
     }
-    w->cur = 0u; w->sp = 0;
+    kd_set_box(w);
     return false;
 }
 // The query point of IrregIsotropicBRDF::f (reflection.cpp:248-260, BRDFRemap)
@@ -870,16 +866,15 @@ HPT_FN f3 irreg_point(f3 wo, f3 wi) {
     return mk3(sini * sino, dphi / HPT_PI, cosi * coso);
 }
 // ... and the weighted average of the samples around it (reflection.cpp:261-271), one lane for itself.  Out of line.
-HPT_FN_NOINLINE f3 irreg_eval(const DScene &sc, const hpt_material *m, f3 mpt, LaneStack ls) {
+HPT_FN_NOINLINE f3 irreg_eval(const DScene &sc, const hpt_material *m, f3 mpt) {
     KdWalk w;
-    kd_begin(sc, m, mpt, ls, &w);
+    kd_begin(sc, m, mpt, &w);
     f3 out = S(0.f);
-    if (w.top) { while (!kd_step<1>(&w, ls, &out)) {} }
-    else { while (!kd_step<0>(&w, ls, &out)) {} }
+    while (!kd_step(&w, &out)) {}
     return out;
 }
-HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi, LaneStack ls) {
-    return irreg_eval(sc, m, irreg_point(wo, wi), ls);
+HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {
+    return irreg_eval(sc, m, irreg_point(wo, wi));
 }
 
 // FrCond (reflection.cpp:70-79) through FresnelConductor::Evaluate (:110-112), per RGB channel
@@ -973,7 +968,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         f3 schlick = Rs + one_minus_rs * pw;                         // SchlickFresnel (reflection.h:468-470)
         return diffuse + schlick * sc_;
     }
-    if (MATS & MATS_MEASURED) return irreg_f(sc, b.mat, wo, wi, ls);
+    if (MATS & MATS_MEASURED) return irreg_f(sc, b.mat, wo, wi);
     return S(0.f);
 }
 template <int MATS>

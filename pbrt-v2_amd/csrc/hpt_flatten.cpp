@@ -111,21 +111,33 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         if (bvh.max_depth > out->max_depth) out->max_depth = bvh.max_depth;
         tri_base += sub.size();
     }
-    // ---- measured-BRDF kd-trees -> packed 32-byte nodes ---------------------------------------
+    // ---- measured-BRDF samples -> grid-ordered 32-byte records + cell table (hpt_device.h: kd_begin / kd_step) -------
     out->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
     out->materials.assign(desc->materials, desc->materials + desc->n_materials);
     for (int m = 0; m < desc->n_materials; ++m) {
         hpt_material &ma = out->materials[(size_t)m];
         if (ma.kind != HPT_MAT_MEASURED_IRREG) continue;
-        while (out->fpool.size() % 8) out->fpool.push_back(0.f);
-        int64_t base = (int64_t)out->fpool.size();
+        out->has_measured = true;
         const float *split = desc->fpool + ma.kd_split_off, *data = desc->fpool + ma.kd_data_off;
         const int32_t *bits = desc->ipool + ma.kd_bits_off;
+        const int n_cells = HPT_BG_X * HPT_BG_Y * HPT_BG_Z;
+        std::vector<uint32_t> cell_of((size_t)ma.kd_nnodes), first((size_t)n_cells + 1, 0u);
         for (int i = 0; i < ma.kd_nnodes; ++i) {
-            float bf; memcpy(&bf, &bits[i], 4);
-            out->fpool.push_back(split[i]); out->fpool.push_back(bf);
-            for (int k = 0; k < 6; ++k) out->fpool.push_back(data[6 * i + k]);
+            const float *p = data + 6 * (size_t)i;
+            cell_of[(size_t)i] = (uint32_t)((bg_cell_z(p[2]) * HPT_BG_Y + bg_cell_y(p[1])) * HPT_BG_X + bg_cell_x(p[0]));
+            first[cell_of[(size_t)i] + 1]++;
         }
+        for (int c = 0; c < n_cells; ++c) first[(size_t)c + 1] += first[(size_t)c];
+        std::vector<uint32_t> slot(first.begin(), first.end() - 1);
+        while (out->fpool.size() % 8) out->fpool.push_back(0.f);
+        int64_t base = (int64_t)out->fpool.size();
+        out->fpool.resize(out->fpool.size() + 8 * (size_t)ma.kd_nnodes, 0.f);
+        for (int i = 0; i < ma.kd_nnodes; ++i) {       // samples of a cell keep the order of the reference's node array
+            float *r = &out->fpool[(size_t)base + 8 * (size_t)slot[cell_of[(size_t)i]]++];
+            for (int k = 0; k < 6; ++k) r[k] = data[6 * i + k];
+        }
+        int64_t cbase = (int64_t)out->fpool.size();
+        for (size_t c = 0; c < first.size(); ++c) { float w; memcpy(&w, &first[c], 4); out->fpool.push_back(w); }
         // starting-level table for irreg_f (hpt_device.h): the level k at which the reference's growing-radius
         // query (reflection.cpp:262-271) would stop for a query at each cell centre of a 64^3 grid (HPT_KD_GRID) over
         // (sin*sin, dphi/pi, cos*cos) in [0,1] x [0,1] x [-1,1]; one byte per cell, four to a pool word
@@ -148,20 +160,9 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             for (unsigned t = 0; t < nth; ++t) pool.emplace_back(work, (int)((int64_t)G * t / nth), (int)((int64_t)G * (t + 1) / nth));
             for (auto &t : pool) t.join();
         }
-        {   // depth of this tree (the device's walk keeps one stack entry per ancestor)
-            std::vector<std::pair<uint32_t, int> > todo(1, std::make_pair(0u, 1));
-            while (!todo.empty()) {
-                uint32_t n = todo.back().first; int depth = todo.back().second; todo.pop_back();
-                if (depth > out->kd_max_depth) out->kd_max_depth = depth;
-                uint32_t b = (uint32_t)bits[n];
-                if ((b & 3u) == 3u) continue;
-                if ((b >> 2) & 1u) todo.push_back(std::make_pair(n + 1, depth + 1));
-                if ((b >> 3) < (uint32_t)ma.kd_nnodes) todo.push_back(std::make_pair(b >> 3, depth + 1));
-            }
-        }
         int64_t gbase = (int64_t)out->fpool.size();
         for (size_t i = 0; i < lev.size(); i += 4) { float w; memcpy(&w, &lev[i], 4); out->fpool.push_back(w); }
-        ma.kd_data_off = base; ma.kd_split_off = HPT_KD_PACKED; ma.kd_bits_off = gbase;
+        ma.kd_data_off = base; ma.kd_split_off = cbase; ma.kd_bits_off = gbase;
     }
     out->n_tris = ntris;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

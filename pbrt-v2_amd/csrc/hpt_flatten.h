@@ -9,24 +9,22 @@
 
 namespace hpt {
 
-#define HPT_KD_PACKED (-2)
-
 struct FlatScene {
     std::vector<BvhNode64> nodes;
     std::vector<float> tri_rec;   // 12 floats per triangle, BVH leaf order
     std::vector<DMesh> meshes;
     std::vector<int32_t> inst_root;   // root node of each animated instance's BVH (-1 = no triangles)
     int32_t world_root = -1;          // root node of the world BVH (-1 = no world triangles)
-    // device copies of the float pool and the material table: measured-BRDF kd-trees are re-packed
-    // into 32-byte node records {splitPos, bits, p.xyz, v.rgb} appended to the pool (one sector per
-    // node visit instead of three scattered loads); materials[i].kd_data_off then points at the
-    // packed records (in floats, a multiple of 8), kd_split_off == HPT_KD_PACKED marks the form and
-    // kd_bits_off points at the 64^3 starting-level table of irreg_f (bytes, four to a pool word)
+    // device copies of the float pool and the material table: the samples of a measured BRDF are binned into a
+    // HPT_BG_X x HPT_BG_Y x HPT_BG_Z grid and appended to the pool cell by cell (x fastest) as 32-byte records
+    // {p.xyz, v.r | v.g, v.b, 0, 0}; materials[i].kd_data_off then points at the records (in floats, a multiple of 8),
+    // kd_split_off at the table of first samples per cell (uint32, cells + 1 entries) and kd_bits_off at the 64^3
+    // starting-level table of the query (bytes, four to a pool word) — hpt_device.h, kd_begin / kd_step
     std::vector<float> fpool;
     std::vector<hpt_material> materials;
     int64_t n_tris = 0;
     int max_depth = 0;
-    int kd_max_depth = 0;             // deepest measured-BRDF kd-tree (levels)
+    bool has_measured = false;        // some material is a measured (IrregIsotropic) BRDF
     double build_ms = 0.0;
     double device_build_ms = 0.0;     // kernel time of the device BVH builder, if it ran
     int device_built = 0;             // groups (world / instances) whose BVH the device builder made

@@ -17,17 +17,13 @@ struct PathKernelArgs {
     float *film;                    // x_count*y_count*4, zeroed before the launch
     unsigned long long *next_item;  // 8 work-queue heads (one per XCD, hpt_kernels_impl.h), zeroed before the launch
     WorkCounters *counters;         // only written by the COUNT instantiation
-    // dynamic LDS of a workgroup: [traversal stacks: stack_entries x 256 x 4 B][kd head: kd_lds_nodes x 8 B]
-    int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2, kd-tree depth + 1)
-    int32_t kd_lds_mat;             // measured-BRDF material whose kd-tree rides in LDS, or -1
-    int32_t kd_lds_nodes;
+    // dynamic LDS of a workgroup: traversal stacks, stack_entries x 256 x 4 B
+    int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2; 12 query-queue rows with a measured BRDF)
     float *inst_xf;                 // animated instances: per-path transform cache, [16 x n_instances][grid x 256] floats, or null
     int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
-    size_t b = (size_t)a.stack_entries * HPT_BLOCK * 4;
-    if (a.kd_lds_mat >= 0) b += (size_t)a.kd_lds_nodes * 8;
-    return b;
+    return (size_t)a.stack_entries * HPT_BLOCK * 4;
 }
 
 struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
@@ -41,6 +37,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
+int path_kernel_cold_rows();   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);

@@ -20,6 +20,14 @@
 
 namespace hpt {
 
+int path_kernel_cold_rows() {
+#ifdef HPT_NO_PARK
+    return 0;
+#else
+    return HPT_COLD_ROWS;
+#endif
+}
+
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelArgs a, const ReplayArgs ra) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];

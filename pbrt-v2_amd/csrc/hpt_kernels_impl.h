@@ -64,16 +64,15 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
     int next = total < 64 ? total : 64;                  // wave-uniform: first queue entry nobody has taken yet
     int slot = lane < total ? lane : -1;
     KdWalk w;
-    w.top = false;
+    w.j = w.jend = 0u; w.iz = 0; w.z1 = -1;
     if (slot >= 0)
-        kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), ls, &w);
+        kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
     for (;;) {
         if (__ballot(slot >= 0) == 0ull) break;
         if (slot >= 0) {                                 // a burst of steps between two looks at the queue
             f3 f;
             bool done = false;
-            if (w.top) { for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step<1>(&w, ls, &f); }
-            else { for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step<0>(&w, ls, &f); }
+            for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step(&w, &f);
             if (done) {
                 HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z);
                 slot = -1;
@@ -86,7 +85,7 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
                 next += __popcll(mneed);
                 if (slot < 0 && idx < total) {
                     slot = idx;
-                    kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), ls, &w);
+                    kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
                 }
             }
         }
@@ -263,26 +262,21 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
 template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
-    extern __shared__ uint64_t dyn_lds[];      // [stacks][kd head] — sized per scene (path_kernel_dyn_lds)
+    extern __shared__ uint64_t dyn_lds[];      // traversal stacks — sized per scene (path_kernel_dyn_lds)
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
     LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
-    ls.qrow = a.stack_entries - 12;            // query queue rows of wave_eval_queries (hpt_api.hip reserves them)
-    if ((MATS & MATS_MEASURED) && a.kd_lds_mat >= 0) {
-        // this workgroup's copy of the measured BRDF's kd-tree head: {splitPos, bits} of every node, so that the
-        // walk only leaves LDS when it hands a sample to the accumulator (hpt_device.h: kd_lookup)
-        uint64_t *top = dyn_lds + (size_t)a.stack_entries * (HPT_BLOCK / 2);
-        const hpt_material *km = &sc.materials[a.kd_lds_mat];
-        const f4 *kn = (const f4 *)(sc.fpool + km->kd_data_off);
-        for (int i = (int)threadIdx.x; i < a.kd_lds_nodes; i += HPT_BLOCK) {
-            f4 n0 = kn[2 * i];
-            top[i] = (uint64_t)(uint32_t)as_int(n0.x) | ((uint64_t)(uint32_t)as_int(n0.y) << 32);
-        }
-        __syncthreads();
-        ls.kd_top = (const HPT_LDS uint64_t *)top; ls.kd_top_mat = km;
-    }
+    // LDS rows of a lane's column: [walk stack][HPT_STEAL_ROWS, with stealing][HPT_COLD_ROWS] (hpt_api.hip, kernel_residency)
+#ifdef HPT_NO_PARK
+    const int top = a.stack_entries;
     Lane<LdHashSrc, INST, MATS, DL> lane;
+#else
+    const int top = a.stack_entries - HPT_COLD_ROWS;
+    Lane<LdHashSrc, INST, MATS, DL, ColdLds> lane;           // L, beta and the film sums in ten LDS rows above the stacks
+    lane.cold.c = (HPT_LDS float *)stack + top * HPT_BLOCK; lane.cold.stride = HPT_BLOCK;
+#endif
+    ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
     bool exhausted = false;
     TravState ts;                  // this lane's walk, resumable across iterations (see the traversal phase)
@@ -347,7 +341,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool tr = mine && (!DL || lane.stage != ST_SHADE);
             const bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse_steal<COUNT, INST>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, a.stack_entries - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
+            traverse_steal<COUNT, INST>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
@@ -390,7 +384,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         if (MATS & MATS_MEASURED) {
             if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
-                for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k], ls);
+                for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
         }
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
         if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;

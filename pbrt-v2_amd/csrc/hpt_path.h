@@ -170,6 +170,35 @@ struct ShadeV {
     float a3, pdf3;       // |wi.n|, pdf of the continuation direction
 };
 
+// ---- where a lane keeps its COLD state ---------------------------------------------------------------------
+// The path radiance L, the throughput beta and the film sums of the lane's pixel-chunk are touched a few times per path vertex
+// and never inside a traversal or BRDF-query loop, but as registers they are live across all of them — ten of the ~55 registers
+// of lane state the allocator has to carry (or spill to scratch: profiles/r01f_*.md) through the hot loops.
+//   ColdRegs : plain registers (parity hooks, wavefront pipeline, replay, host emulation).
+//   ColdLds  : ten rows of the lane's own LDS column above its traversal stack (the path kernel): a ds_read / ds_write per
+//              touch, conflict-free (row k of lane t at base[k * stride + t]), no scratch traffic and ten registers fewer.
+struct ColdRegs {
+    f3 L_, beta_; float f_[4];
+    HPT_MFN f3 L() const { return L_; }
+    HPT_MFN void setL(f3 v) { L_ = v; }
+    HPT_MFN f3 beta() const { return beta_; }
+    HPT_MFN void setBeta(f3 v) { beta_ = v; }
+    HPT_MFN void film_zero() { f_[0] = f_[1] = f_[2] = f_[3] = 0.f; }
+    HPT_MFN void film_add(float X, float Y, float Z, float W) { f_[0] += X; f_[1] += Y; f_[2] += Z; f_[3] += W; }
+    HPT_MFN void film_get(float *X, float *Y, float *Z, float *W) const { *X = f_[0]; *Y = f_[1]; *Z = f_[2]; *W = f_[3]; }
+};
+struct ColdLds {
+    HPT_LDS float *c; int stride;      // row k: c[k * stride]
+    HPT_MFN f3 L() const { return mk3(c[0], c[stride], c[2 * stride]); }
+    HPT_MFN void setL(f3 v) { c[0] = v.x; c[stride] = v.y; c[2 * stride] = v.z; }
+    HPT_MFN f3 beta() const { return mk3(c[3 * stride], c[4 * stride], c[5 * stride]); }
+    HPT_MFN void setBeta(f3 v) { c[3 * stride] = v.x; c[4 * stride] = v.y; c[5 * stride] = v.z; }
+    HPT_MFN void film_zero() { c[6 * stride] = 0.f; c[7 * stride] = 0.f; c[8 * stride] = 0.f; c[9 * stride] = 0.f; }
+    HPT_MFN void film_add(float X, float Y, float Z, float W) { c[6 * stride] += X; c[7 * stride] += Y; c[8 * stride] += Z; c[9 * stride] += W; }
+    HPT_MFN void film_get(float *X, float *Y, float *Z, float *W) const { *X = c[6 * stride]; *Y = c[7 * stride]; *Z = c[8 * stride]; *W = c[9 * stride]; }
+};
+#define HPT_COLD_ROWS 10
+
 // ---- lane -----------------------------------------------------------------------------------------
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.
 // MATS: BxDF families compiled in (MATS_* bits, hpt_device.h).
@@ -179,15 +208,14 @@ struct ShadeV {
 //       light — strategy "one", :82-114.  The hit is kept (camera ray + Hit, 13 registers) and its shading geometry /
 //       BSDF rebuilt for every light sample (stage ST_SHADE) instead of carrying a BSDF across the traversal phases.
 //       The specular recursion of directlighting.cpp:111-118 has nothing to sample (no specular lobe on this path).
-template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
+template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs> struct Lane {
     int stage;
     // pixel / sample bookkeeping
     int px, py;
     uint32_t si, s_end;     // current sample, end of this item's sample range
     Smp smp;
-    float fX, fY, fZ, fW;   // film accumulators of the lane's own pixel
+    Cold cold;              // L, beta (PathIntegrator::Li locals) and the film sums of the lane's own pixel-chunk
     // path state (PathIntegrator::Li locals)
-    f3 L, beta;
     int bounce;
     bool specular;
     Ray ray;                // the ray to trace in the next traversal phase
@@ -205,7 +233,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     int li, lj;
     f3 acc;                 // Ld of the current light, summed over its samples
 
-    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; fX = fY = fZ = fW = 0.f; }
+    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; }
 
     // samplerrenderer.cpp:185-206 for one camera sample
     HPT_MFN void begin_sample(const RenderParams &rp) {
@@ -218,11 +246,11 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
         time = 0.f;
         if (INST && rp.has_motion) { float t = smp.time01(rp); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
-        L = S(0.f); beta = S(1.f); bounce = 0; specular = false;
+        cold.setL(S(0.f)); cold.setBeta(S(1.f)); bounce = 0; specular = false;
         stage = ST_EXTEND;
     }
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y, uint32_t s0 = 0, uint32_t n = 0) {
-        px = x; py = y; si = s0; s_end = s0 + (n ? n : (uint32_t)rp.spp); fX = fY = fZ = fW = 0.f;
+        px = x; py = y; si = s0; s_end = s0 + (n ? n : (uint32_t)rp.spp); cold.film_zero();
         if (s_end > (uint32_t)rp.spp) s_end = (uint32_t)rp.spp;          // last chunk of an spp that is no multiple of the chunk
         smp.begin_pixel(rp, x, y);
         begin_sample(rp);
@@ -231,7 +259,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     // ImageFilm::AddSample with the box filter (film/image.cpp:77-137) + the radiance sanity
     // checks of samplerrenderer.cpp:214-228; then advance to the next sample / flush the pixel.
     HPT_MFN void finish_path(const RenderParams &rp, float *film, WorkCounters *wc) {
-        f3 Ls = L;
+        f3 Ls = cold.L();
         bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
         if (bad) { Ls = S(0.f); if (wc) wc->bad++; }
@@ -265,7 +293,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         if (y1 > rp.y_start + rp.y_count - 1) y1 = rp.y_start + rp.y_count - 1;
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x) {
-                if (x == px && y == py) { fX += X; fY += Y; fZ += Z; fW += 1.f; }
+                if (x == px && y == py) cold.film_add(X, Y, Z, 1.f);
                 else { // a sample on an exact pixel boundary also lands in the neighbour (image.cpp:82-89)
                     float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
                     film_atomic_add(f + 0, X); film_atomic_add(f + 1, Y); film_atomic_add(f + 2, Z); film_atomic_add(f + 3, 1.f);
@@ -275,6 +303,8 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         ++si;
         if (si < s_end) { begin_sample(rp); return; }
         float *f = film + 4 * ((int64_t)(py - rp.y_start) * rp.x_count + (px - rp.x_start));
+        float fX, fY, fZ, fW;
+        cold.film_get(&fX, &fY, &fZ, &fW);
         film_atomic_add(f + 0, fX); film_atomic_add(f + 1, fY); film_atomic_add(f + 2, fZ); film_atomic_add(f + 3, fW);
         stage = ST_IDLE;
         smp.end_pixel(rp);
@@ -285,15 +315,15 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
             if (sc.n_lights > 0 && rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {       // integrator.cpp:56-77
                 acc = acc + Ld;
                 const int n = dl_count(sc.lights[li], rp);
-                if (++lj == n) { L = L + sdivf(acc, (float)n); acc = S(0.f); lj = 0; ++li; }
+                if (++lj == n) { cold.setL(cold.L() + sdivf(acc, (float)n)); acc = S(0.f); lj = 0; ++li; }
                 if (li < sc.n_lights) { stage = ST_SHADE; return; }
-            } else if (sc.n_lights > 0) L = L + Ld * (float)sc.n_lights;                // integrator.cpp:110-113
+            } else if (sc.n_lights > 0) cold.setL(cold.L() + Ld * (float)sc.n_lights);                // integrator.cpp:110-113
             finish_path(rp, film, wc);
             return;
         }
-        if (sc.n_lights > 0) L = L + smul(beta, Ld * (float)sc.n_lights);  // integrator.cpp:110, path.cpp:71-80
+        if (sc.n_lights > 0) cold.setL(cold.L() + smul(cold.beta(), Ld * (float)sc.n_lights));  // integrator.cpp:110, path.cpp:71-80
         if (has_next) {
-            beta = beta_next; specular = spec_next;
+            cold.setBeta(beta_next); specular = spec_next;
             ray.o = p; ray.d = wi_next; ray.mint = eps; ray.maxt = HPT_INF; // RayDifferential(p, wi, ray, eps) path.cpp:100
             ++bounce;
             stage = ST_EXTEND;
@@ -339,9 +369,9 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         }
         // ---- ST_EXTEND: closest-hit result of a camera or continuation ray -------------------------
         if (hit.prim < 0) {
-            if (bounce == 0) L = all_lights_Le(sc, ray.d);                 // samplerrenderer.cpp:335-338
+            if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:335-338
             else if (specular)                                             // path.cpp:114-116
-                for (int i = 0; i < sc.n_lights; ++i) L = L + smul(beta, light_Le(sc, sc.lights[i], ray.d));
+                for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
             finish_path(rp, film, wc);
             return false;
         }
@@ -360,7 +390,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
         shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
         if (DL ? stage == ST_EXTEND : (bounce == 0 || specular))            // path.cpp:63-64; directlighting.cpp:90 (once per hit)
-            if (arealight >= 0) L = L + smul(beta, area_L(sc.lights[arealight], dg.nn, wo));
+            if (arealight >= 0) cold.setL(cold.L() + smul(cold.beta(), area_L(sc.lights[arealight], dg.nn, wo)));
         p = dg.p;
         f3 n = bsdf.nn;
         const bool defer = bsdf_is_measured<MATS>(bsdf);
@@ -495,7 +525,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     }
     HPT_MFN void term_next(f3 f, float a3, float pdf3) {                    // path.cpp:95-97
         has_next = !sblack(f);
-        if (has_next) beta_next = smul(beta, sdivf(f * a3, pdf3));
+        if (has_next) beta_next = smul(cold.beta(), sdivf(f * a3, pdf3));
     }
 
     // The deferred terms of the vertex, now that sv.fq[] holds the measured-BRDF values; Russian roulette; transition.
@@ -519,7 +549,7 @@ template <class Smp, bool INST, int MATS, bool DL = false> struct Lane {
     HPT_MFN void on_hit_serial(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
         ShadeV sv;
         if (!on_hit(sc, rp, hit, film, wc, ls, &sv)) return;
-        for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k], ls);
+        for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
         shade_finish(sc, rp, film, wc, sv);
     }
 };

@@ -39,9 +39,9 @@ __device__ __forceinline__ void lane_store(const LaneT &l, float4 *st, int64_t P
     uint32_t pxy = ((uint32_t)l.px & 0xffffu) | ((uint32_t)l.py << 16);
     st[0 * P + slot] = make_float4(u2f(flags), u2f(pxy), u2f(l.si), u2f(l.s_end));
     st[1 * P + slot] = make_float4(u2f(l.smp.h.pk), u2f(l.smp.dcount), l.time, l.eps);
-    st[2 * P + slot] = make_float4(l.fX, l.fY, l.fZ, l.fW);
-    st[3 * P + slot] = make_float4(l.L.x, l.L.y, l.L.z, l.beta.x);
-    st[4 * P + slot] = make_float4(l.beta.y, l.beta.z, l.p.x, l.p.y);
+    st[2 * P + slot] = make_float4(l.cold.f_[0], l.cold.f_[1], l.cold.f_[2], l.cold.f_[3]);
+    st[3 * P + slot] = make_float4(l.cold.L_.x, l.cold.L_.y, l.cold.L_.z, l.cold.beta_.x);
+    st[4 * P + slot] = make_float4(l.cold.beta_.y, l.cold.beta_.z, l.p.x, l.p.y);
     st[5 * P + slot] = make_float4(l.p.z, l.Ld.x, l.Ld.y, l.Ld.z);
     st[6 * P + slot] = make_float4(l.wi_mis.x, l.wi_mis.y, l.wi_mis.z, i2f(l.light_mis));
     st[7 * P + slot] = make_float4(l.C_mis.x, l.C_mis.y, l.C_mis.z, l.wi_next.x);
@@ -58,9 +58,9 @@ __device__ __forceinline__ void lane_load(LaneT &l, const float4 *st, int64_t P,
     v = st[1 * P + slot];
     l.smp.h.pk = f2u(v.x); l.smp.dcount = f2u(v.y); l.time = v.z; l.eps = v.w;
     l.smp.h.w = rp.sampler_w; l.smp.h.i = l.si;
-    v = st[2 * P + slot]; l.fX = v.x; l.fY = v.y; l.fZ = v.z; l.fW = v.w;
-    v = st[3 * P + slot]; l.L = mk3(v.x, v.y, v.z); l.beta.x = v.w;
-    v = st[4 * P + slot]; l.beta.y = v.x; l.beta.z = v.y; l.p.x = v.z; l.p.y = v.w;
+    v = st[2 * P + slot]; l.cold.f_[0] = v.x; l.cold.f_[1] = v.y; l.cold.f_[2] = v.z; l.cold.f_[3] = v.w;
+    v = st[3 * P + slot]; l.cold.L_ = mk3(v.x, v.y, v.z); l.cold.beta_.x = v.w;
+    v = st[4 * P + slot]; l.cold.beta_.y = v.x; l.cold.beta_.z = v.y; l.p.x = v.z; l.p.y = v.w;
     v = st[5 * P + slot]; l.p.z = v.x; l.Ld = mk3(v.y, v.z, v.w);
     v = st[6 * P + slot]; l.wi_mis = mk3(v.x, v.y, v.z); l.light_mis = f2i(v.w);
     v = st[7 * P + slot]; l.C_mis = mk3(v.x, v.y, v.z); l.wi_next.x = v.w;

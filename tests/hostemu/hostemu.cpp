@@ -212,19 +212,9 @@ extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, i
     return 0;
 }
 
-// tier: which LDS-resident parts of a measured BRDF's kd-tree the walk uses on the device (hpt_device.h: kd_lookup);
-// here they are plain host arrays built the way the kernel prologue builds them (hpt_kernels_impl.h)
 extern "C" int emu_bsdf_tier(const emu_scene *s, int material, const float *in, int64_t n, float *out, int tier) {
     const DScene &sc = s->d;
-    std::vector<uint64_t> top;
-    const hpt_material *km = &sc.materials[material];
-    if (km->kind == HPT_MAT_MEASURED_IRREG && tier >= 1) {
-        const f4 *kn = (const f4 *)(sc.fpool + km->kd_data_off);
-        for (int i = 0; i < km->kd_nnodes; ++i) {
-            f4 n0 = kn[2 * i];
-            top.push_back((uint64_t)(uint32_t)as_int(n0.x) | ((uint64_t)(uint32_t)as_int(n0.y) << 32));
-        }
-    }
+    (void)tier;
     for (int64_t i = 0; i < n; ++i) {
         const float *q = in + 16 * i; float *o = out + 12 * i;
         f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
@@ -232,7 +222,6 @@ extern "C" int emu_bsdf_tier(const emu_scene *s, int material, const float *in, 
         Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
         bsdf_add_material<MATS_ALL>(&b, &sc.materials[material]);
         int32_t stk[64]; LaneStack ls; ls.p = stk; ls.stride = 1;
-        if (!top.empty()) { ls.kd_top = top.data(); ls.kd_top_mat = km; }
         f3 f = bsdf_f<MATS_ALL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
         float pdf = bsdf_pdf<MATS_ALL>(b, wo, wi, BSDF_ALL_NOSPEC);
         f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
