@@ -128,10 +128,10 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->inst_xf = nullptr; s->inst_xf_lanes = 0;
-    if (desc->n_instances > 0) {       // 16 floats x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
+    if (desc->n_instances > 0) {       // 12 floats (3x4) x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
         s->inst_xf_lanes = (size_t)s->n_cus * 4 * HPT_BLOCK;
         void *p = nullptr;
-        if (hipMalloc(&p, sizeof(float) * 16 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
+        if (hipMalloc(&p, sizeof(float) * 12 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
         else ok = false;
     }
     s->mats = 0; s->n_materials = desc->n_materials;
@@ -335,7 +335,7 @@ template <typename T> struct DevBuf {
 // Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows();   // [walk stack][stealing rows][cold rows]
+    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats);   // [walk stack][stealing rows][cold rows]
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
     if (*bpc < 1) *bpc = 1;

@@ -78,6 +78,14 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
             return HPT_E_UNSUPPORTED;
         }
     }
+    for (int k = 0; k < d->n_instances; ++k)       // the device carries instance transforms as affine 3x4 matrices
+        for (int e = 0; e < 2; ++e) {
+            const float *m = d->instances[k].w2p_m[e], *mi = d->instances[k].w2p_minv[e];
+            if (m[12] != 0.f || m[13] != 0.f || m[14] != 0.f || m[15] != 1.f || mi[12] != 0.f || mi[13] != 0.f || mi[14] != 0.f || mi[15] != 1.f) {
+                hpt_set_error("instance %d: WorldToPrimitive is not affine (last row must be 0 0 0 1)", k);
+                return HPT_E_UNSUPPORTED;
+            }
+        }
     for (int q = 0; q < d->n_quadrics; ++q) {
         const hpt_quadric &qu = d->quadrics[q];
         if ((qu.kind != HPT_QUADRIC_SPHERE && qu.kind != HPT_QUADRIC_DISK) || qu.material < 0 ||

@@ -395,59 +395,20 @@ HPT_FN float quadric_area(const hpt_quadric &q) {
 // ---- AnimatedTransform::Interpolate on the device (core/transform.cpp:371-396) ---------------------
 // Per ray and per instance visit the reference rebuilds WorldToPrimitive at the ray's time: lerp of the
 // translation, slerp of the rotation (core/quaternion.cpp:95-107), lerp of the scale, then
-// Translate * Rotate * Scale with the scale's inverse by Gauss-Jordan (transform.cpp:76-135).  Kept
-// operation for operation so instance hits agree with the reference bit for bit.
-struct M4 { float m[16]; };
-struct Xf { M4 m, minv; };
-HPT_FN M4 m4_identity() { M4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.f : 0.f; return r; }
-HPT_FN M4 m4_mul(const M4 &a, const M4 &b) {
-    M4 r;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            r.m[4 * i + j] = a.m[4 * i + 0] * b.m[0 + j] + a.m[4 * i + 1] * b.m[4 + j] + a.m[4 * i + 2] * b.m[8 + j] + a.m[4 * i + 3] * b.m[12 + j];
-    return r;
+// Translate * Rotate * Scale.  The forward matrix (what carries rays into the instance) is kept operation for operation, so
+// instance hits agree with the reference bit for bit; the inverse (what carries the hit's geometry back) uses the analytic
+// inverse of the scale factor (m4_inverse_scale3) instead of the reference's Gauss-Jordan: equal to rounding.
+// Affine 3x4 matrices (rows 0..2 of a Matrix4x4 whose last row is (0, 0, 0, 1) — hpt_validate_desc refuses instance transforms
+// that are not): element (r, c) at m[4 r + c], so xf_vec / xf_normal index them like a full matrix.
+struct A34 { float m[12]; };
+struct Xf { A34 m, minv; };
+HPT_FN f3 xf_point_affine(const float *m, f3 p) {   // Transform::operator()(Point) with w = 1 (transform.h:192-202)
+    const float x = p.x, y = p.y, z = p.z;
+    return mk3(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]);
 }
-HPT_FN M4 m4_transpose(const M4 &a) { M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = a.m[4 * j + i]; return r; }
-HPT_FN_NOINLINE M4 m4_inverse(const M4 &in) {
-    int indxc[4], indxr[4];
-    int ipiv[4] = {0, 0, 0, 0};
-    float minv[4][4];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) minv[i][j] = in.m[4 * i + j];
-    for (int i = 0; i < 4; i++) {
-        int irow = 0, icol = 0;
-        float big = 0.f;
-        for (int j = 0; j < 4; j++) {
-            if (ipiv[j] != 1) {
-                for (int k = 0; k < 4; k++) {
-                    if (ipiv[k] == 0) {
-                        if (fabsf(minv[j][k]) >= big) { big = fabsf(minv[j][k]); irow = j; icol = k; }
-                    }
-                }
-            }
-        }
-        ++ipiv[icol];
-        if (irow != icol) for (int k = 0; k < 4; ++k) { float t = minv[irow][k]; minv[irow][k] = minv[icol][k]; minv[icol][k] = t; }
-        indxr[i] = irow; indxc[i] = icol;
-        float pivinv = 1.f / minv[icol][icol];
-        minv[icol][icol] = 1.f;
-        for (int j = 0; j < 4; j++) minv[icol][j] *= pivinv;
-        for (int j = 0; j < 4; j++) {
-            if (j != icol) {
-                float save = minv[j][icol];
-                minv[j][icol] = 0;
-                for (int k = 0; k < 4; k++) minv[j][k] -= minv[icol][k] * save;
-            }
-        }
-    }
-    for (int j = 3; j >= 0; j--) {
-        if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) { float t = minv[k][indxr[j]]; minv[k][indxr[j]] = minv[k][indxc[j]]; minv[k][indxc[j]] = t; }
-    }
-    M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = minv[i][j];
-    return r;
-}
-HPT_FN bool m4_is_identity(const M4 &a) {
+HPT_FN bool a34_is_identity(const A34 &a) {
     bool id = true;
-    for (int i = 0; i < 16; ++i) id = id && (a.m[i] == ((i % 5 == 0) ? 1.f : 0.f));
+    for (int i = 0; i < 12; ++i) id = id && (a.m[i] == ((i % 5 == 0) ? 1.f : 0.f));
     return id;
 }
 struct Quat { f3 v; float w; };
@@ -464,15 +425,20 @@ HPT_FN Quat slerp(float t, Quat q1, Quat q2) {
     Quat qperp = qnormalize(qsub(q2, qscale(q1, cosTheta)));
     return qadd(qscale(q1, cosf(thetap)), qscale(qperp, sinf(thetap)));
 }
-// want_inverse = false skips the inverse half (only .m is needed to carry a ray into the instance)
-HPT_FN_NOINLINE Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse) {
+// want_inverse = false skips the inverse half (only .m is needed to carry a ray into the instance).
+// Forward matrix: (Translate * Rotate) * Scale (transform.cpp:286-290) written out for the 3x4 part — the zero / one entries of the
+// factors only ever add exact zeros, so the products below are the reference's sums term for term and instance hits agree with the
+// reference bit for bit.  Inverse: Inverse(Scale) * (Rotate^T * Translate(-t)), with the inverse of the scale factor from its adjugate
+// (the reference runs a 4x4 Gauss-Jordan with pivot search and indexed row swaps, transform.cpp:76-135 — on a GPU a private array,
+// i.e. scratch memory by construction); the two agree to rounding and exactly for a diagonal scale.
+HPT_FN Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse) {
     Xf r;
     if (!in.actually_animated || time <= in.start_time) {
-        for (int i = 0; i < 16; ++i) { r.m.m[i] = in.w2p_m[0][i]; r.minv.m[i] = in.w2p_minv[0][i]; }
+        for (int i = 0; i < 12; ++i) { r.m.m[i] = in.w2p_m[0][i]; r.minv.m[i] = in.w2p_minv[0][i]; }
         return r;
     }
     if (time >= in.end_time) {
-        for (int i = 0; i < 16; ++i) { r.m.m[i] = in.w2p_m[1][i]; r.minv.m[i] = in.w2p_minv[1][i]; }
+        for (int i = 0; i < 12; ++i) { r.m.m[i] = in.w2p_m[1][i]; r.minv.m[i] = in.w2p_minv[1][i]; }
         return r;
     }
     float dt = (time - in.start_time) / (in.end_time - in.start_time);
@@ -481,25 +447,39 @@ HPT_FN_NOINLINE Xf anim_interpolate(const hpt_instance &in, float time, bool wan
     q0.v = mk3(in.R[0][0], in.R[0][1], in.R[0][2]); q0.w = in.R[0][3];
     q1.v = mk3(in.R[1][0], in.R[1][1], in.R[1][2]); q1.w = in.R[1][3];
     Quat q = slerp(dt, q0, q1);
-    M4 scale = m4_identity();
+    float sc[9];                                                              // lerp of the scale factors' 3x3 blocks
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
-            scale.m[4 * i + j] = (1.f - dt) * in.S[0][4 * i + j] + dt * in.S[1][4 * i + j];
-    M4 Tm = m4_identity();
-    Tm.m[3] = trans.x; Tm.m[7] = trans.y; Tm.m[11] = trans.z;
+            sc[3 * i + j] = (1.f - dt) * in.S[0][4 * i + j] + dt * in.S[1][4 * i + j];
     float xx = q.v.x * q.v.x, yy = q.v.y * q.v.y, zz = q.v.z * q.v.z;    // Quaternion::ToTransform quaternion.cpp:39-59
     float xy = q.v.x * q.v.y, xz = q.v.x * q.v.z, yz = q.v.y * q.v.z;
     float wx = q.v.x * q.w, wy = q.v.y * q.w, wz = q.v.z * q.w;
-    M4 mq = m4_identity();
-    mq.m[0] = 1.f - 2.f * (yy + zz); mq.m[1] = 2.f * (xy + wz);       mq.m[2] = 2.f * (xz - wy);
-    mq.m[4] = 2.f * (xy - wz);       mq.m[5] = 1.f - 2.f * (xx + zz); mq.m[6] = 2.f * (yz + wx);
-    mq.m[8] = 2.f * (xz + wy);       mq.m[9] = 2.f * (yz - wx);       mq.m[10] = 1.f - 2.f * (xx + yy);
-    M4 Rm = m4_transpose(mq);
-    r.m = m4_mul(m4_mul(Tm, Rm), scale);                                  // (Translate * Rotate) * Scale, transform.cpp:286-290
+    float mq[9];                                                              // its m is the TRANSPOSE of mq, its mInv is mq
+    mq[0] = 1.f - 2.f * (yy + zz); mq[1] = 2.f * (xy + wz);       mq[2] = 2.f * (xz - wy);
+    mq[3] = 2.f * (xy - wz);       mq[4] = 1.f - 2.f * (xx + zz); mq[5] = 2.f * (yz + wx);
+    mq[6] = 2.f * (xz + wy);       mq[7] = 2.f * (yz - wx);       mq[8] = 1.f - 2.f * (xx + yy);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) r.m.m[4 * i + j] = mq[i] * sc[j] + mq[3 + i] * sc[3 + j] + mq[6 + i] * sc[6 + j];   // row i of Rotate = column i of mq
+        r.m.m[4 * i + 3] = comp(trans, i);
+    }
     if (want_inverse) {
-        M4 Tinv = m4_identity();
-        Tinv.m[3] = -trans.x; Tinv.m[7] = -trans.y; Tinv.m[11] = -trans.z;
-        r.minv = m4_mul(m4_inverse(scale), m4_mul(mq, Tinv));
+        // adjugate / determinant of the scale block
+        const float a00 = sc[0], a01 = sc[1], a02 = sc[2], a10 = sc[3], a11 = sc[4], a12 = sc[5], a20 = sc[6], a21 = sc[7], a22 = sc[8];
+        const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const float inv = 1.f / (a00 * c00 + a01 * c01 + a02 * c02);
+        float si[9];
+        si[0] = c00 * inv; si[1] = (a02 * a21 - a01 * a22) * inv; si[2] = (a01 * a12 - a02 * a11) * inv;
+        si[3] = c01 * inv; si[4] = (a00 * a22 - a02 * a20) * inv; si[5] = (a02 * a10 - a00 * a12) * inv;
+        si[6] = c02 * inv; si[7] = (a01 * a20 - a00 * a21) * inv; si[8] = (a00 * a11 - a01 * a10) * inv;
+        // Rotate^T * Translate(-t) = [mq | mq * (-t)], then Inverse(Scale) in front
+        float rt[12];
+        for (int i = 0; i < 3; ++i) {
+            rt[4 * i + 0] = mq[3 * i]; rt[4 * i + 1] = mq[3 * i + 1]; rt[4 * i + 2] = mq[3 * i + 2];
+            rt[4 * i + 3] = mq[3 * i] * -trans.x + mq[3 * i + 1] * -trans.y + mq[3 * i + 2] * -trans.z;
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j)
+                r.minv.m[4 * i + j] = si[3 * i] * rt[j] + si[3 * i + 1] * rt[4 + j] + si[3 * i + 2] * rt[8 + j];
     } else r.minv = r.m;
     return r;
 }
@@ -608,7 +588,7 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
 // core/primitive.cpp:95-124): WorldToPrimitive interpolated at the ray's time carries the ray into the
 // instance's own BVH.  `ray.maxt` is shrunk to the hit distance like the reference does.
 // xf_cache (optional): this lane's column of the per-path instance-transform cache — WorldToPrimitive of every instance
-// interpolated at the path's time, 16 floats an instance, element j of instance k at xf_cache[(16 k + j) * xf_stride]
+// interpolated at the path's time, 12 floats (3x4) an instance, element j of instance k at xf_cache[(12 k + j) * xf_stride]
 // (filled by the path kernel once per camera sample; every ray of the path carries the same time, geometry.h:329-332).
 template <bool COUNT, bool INST>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
@@ -622,11 +602,11 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         const hpt_instance &in = sc.instances[k];
         float tentry;
         if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, &tentry)) continue;
-        M4 w2p;
-        if (xf_cache) { for (int j = 0; j < 16; ++j) w2p.m[j] = xf_cache[(int64_t)(16 * k + j) * xf_stride]; }
+        A34 w2p;
+        if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * k + j) * xf_stride]; }
         else w2p = anim_interpolate(in, time, false).m;
         Ray r2;
-        r2.o = xf_point(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
+        r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
         trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
         while (!t2.done()) trav_step<COUNT>(sc, t2, r2, stack, stride, cnt);
@@ -1147,7 +1127,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     const bool inInstance = INST && hit.inst >= 0;
     if (inInstance) {
         w2p = anim_interpolate(sc.instances[hit.inst], time, true);
-        ray.o = xf_point(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);
+        ray.o = xf_point_affine(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);
     }
     const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
     int v0 = idx[0], v1 = idx[1], v2 = idx[2];
@@ -1174,8 +1154,8 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     float tu = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     float tv = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
     dg_init(dg, ray_at(ray, hit.t), dpdu, dpdv, me.flip);
-    if (inInstance && !m4_is_identity(w2p.m)) {   // PrimitiveToWorld = Inverse(w2p): m = w2p.mInv, mInv = w2p.m
-        dg->p = xf_point(w2p.minv.m, dg->p);
+    if (inInstance && !a34_is_identity(w2p.m)) {   // PrimitiveToWorld = Inverse(w2p): m = w2p.mInv, mInv = w2p.m
+        dg->p = xf_point_affine(w2p.minv.m, dg->p);
         dg->nn = normalize(xf_normal(w2p.m.m, dg->nn));
         dg->dpdu = xf_vec(w2p.minv.m, dg->dpdu);
     }

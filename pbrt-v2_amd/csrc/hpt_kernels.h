@@ -19,7 +19,7 @@ struct PathKernelArgs {
     WorkCounters *counters;         // only written by the COUNT instantiation
     // dynamic LDS of a workgroup: traversal stacks, stack_entries x 256 x 4 B
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2; 12 query-queue rows with a measured BRDF)
-    float *inst_xf;                 // animated instances: per-path transform cache, [16 x n_instances][grid x 256] floats, or null
+    float *inst_xf;                 // animated instances: per-path transform cache, [12 x n_instances][grid x 256] floats, or null
     int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
@@ -37,7 +37,7 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
-int path_kernel_cold_rows();   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
+int path_kernel_cold_rows(int mats);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);

@@ -20,12 +20,9 @@
 
 namespace hpt {
 
-int path_kernel_cold_rows() {
-#ifdef HPT_NO_PARK
-    return 0;
-#else
-    return HPT_COLD_ROWS;
-#endif
+int path_kernel_cold_rows(int mats) {       // must mirror launch_path_kernel's choice of instantiation (below)
+    const int set = (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
+    return HPT_PARK_MATS(set) ? HPT_COLD_ROWS : 0;
 }
 
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------

@@ -72,7 +72,7 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
         if (slot >= 0) {                                 // a burst of steps between two looks at the queue
             f3 f;
             bool done = false;
-            for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step(&w, &f);
+            _Pragma("unroll 1") for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step(&w, &f);
             if (done) {
                 HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z);
                 slot = -1;
@@ -191,10 +191,10 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
                 float tentry;
                 if (sc.inst_root[seg] >= 0 && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
-                    M4 w2p;
-                    if (xf_cache) { for (int j = 0; j < 16; ++j) w2p.m[j] = xf_cache[(int64_t)(16 * seg + j) * xf_stride]; }
+                    A34 w2p;
+                    if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
                     else w2p = anim_interpolate(in, time, false).m;
-                    r.o = xf_point(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
+                    r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
                     trav_begin(sc, ts, r, anyhit, sc.inst_root[seg], false);
                     cur_inst = seg; sb = 0;
                 }
@@ -268,14 +268,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     const RenderParams &rp = a.rp;
     LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
     // LDS rows of a lane's column: [walk stack][HPT_STEAL_ROWS, with stealing][HPT_COLD_ROWS] (hpt_api.hip, kernel_residency)
-#ifdef HPT_NO_PARK
-    const int top = a.stack_entries;
-    Lane<LdHashSrc, INST, MATS, DL> lane;
-#else
-    const int top = a.stack_entries - HPT_COLD_ROWS;
-    Lane<LdHashSrc, INST, MATS, DL, ColdLds> lane;           // L, beta and the film sums in ten LDS rows above the stacks
-    lane.cold.c = (HPT_LDS float *)stack + top * HPT_BLOCK; lane.cold.stride = HPT_BLOCK;
-#endif
+    // Cold lane state in LDS: for the material sets with a measured BRDF (same-box A/B, profiles/r02_ab.md: bunny +3.4 %; the
+    // matte / plastic kernels gain < 1 % and a deep tree — the 1 M-triangle soup — would lose a resident workgroup to the ten rows)
+    constexpr bool PARK = HPT_PARK_MATS(MATS);
+    const int top = a.stack_entries - (PARK ? HPT_COLD_ROWS : 0);
+    Lane<LdHashSrc, INST, MATS, DL, typename ColdSel<PARK>::type> lane;
+    ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);
     ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
     bool exhausted = false;
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             xf_time = lane.time;
             for (int k = 0; k < sc.n_instances; ++k) {
                 Xf x = anim_interpolate(sc.instances[k], lane.time, false);
-                for (int j = 0; j < 16; ++j) xf_col[(int64_t)(16 * k + j) * xf_stride] = x.m.m[j];
+                for (int j = 0; j < 12; ++j) xf_col[(int64_t)(12 * k + j) * xf_stride] = x.m.m[j];
             }
         }
         Hit hit;

@@ -198,6 +198,14 @@ struct ColdLds {
     HPT_MFN void film_get(float *X, float *Y, float *Z, float *W) const { *X = c[6 * stride]; *Y = c[7 * stride]; *Z = c[8 * stride]; *W = c[9 * stride]; }
 };
 #define HPT_COLD_ROWS 10
+#ifdef HPT_NO_PARK
+#define HPT_PARK_MATS(mats) false
+#else
+#define HPT_PARK_MATS(mats) ((mats) == (MATS_PLASTIC | MATS_MEASURED))   /* the kernels of hpt_kernels_measured.hip */
+#endif
+template <bool PARK> struct ColdSel;
+template <> struct ColdSel<false> { typedef ColdRegs type; static HPT_MFN void bind(ColdRegs &, HPT_LDS float *, int) {} };
+template <> struct ColdSel<true> { typedef ColdLds type; static HPT_MFN void bind(ColdLds &c, HPT_LDS float *p, int stride) { c.c = p; c.stride = stride; } };
 
 // ---- lane -----------------------------------------------------------------------------------------
 // Smp: sample source.  LdHash (hpt_device.h) for production; MtReplay (hpt_replay.h) for parity.

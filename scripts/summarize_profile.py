@@ -25,20 +25,29 @@ for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
     stats_rows = list(csv.DictReader(open(f)))
 pmc = collections.OrderedDict()
 meta = {}
+# Only the full-frame launches count: the bench process also runs the autotune probe (a ninth of the tiles, other instantiations of
+# the same kernel template).  A full-frame launch is one that lasts at least half as long as the longest launch of the pass.
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if KERNEL not in r["Kernel_Name"]:
+        rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+        if not rows:
+            continue
+        dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        longest = max(dur(r) for r in rows)
+        for r in rows:
+            if dur(r) < 0.5 * longest:
                 continue
             pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
                                       "Accum_VGPR_Count", "SGPR_Count")}
-            meta["duration_ns_under_pmc"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            meta["kernel"] = r["Kernel_Name"][:90]
+            meta["duration_ns_under_pmc"] = dur(r)
 pmc = {k: sum(v) / len(v) for k, v in pmc.items()}     # per launch
 
-k = next((r for r in stats_rows if KERNEL in r["Name"]), None)
+ks = [r for r in stats_rows if KERNEL in r["Name"]]
+k = max(ks, key=lambda r: float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"])) if ks else None
 derived = {}
 if k:
     derived["kernel_avg_ms"] = float(k["AverageNs"]) / 1e6
