@@ -74,7 +74,7 @@ def load_workload(name, spp):
         v = np.load(os.path.join(GOLDEN, "killeroo_dl_1080p.view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         s.render.spp = spp or DEFAULT_SPP[name]
         desc = "scenes/killeroo-simple.pbrt as shipped (DirectLightingIntegrator, strategy all, 8 light samples per camera sample)"
     elif name == "soup":

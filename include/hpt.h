@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 5
+#define HPT_VERSION 6   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights) still load */
 
 enum {
     HPT_OK = 0,
@@ -50,7 +50,46 @@ enum { HPT_QUADRIC_SPHERE = 1, HPT_QUADRIC_DISK = 2 };
 
 /* Material kinds: materials/matte.cpp:42, plastic.cpp:42, measured.cpp:194 (IrregIsotropicBRDF),
  * metal.cpp:51 (Microfacet + FresnelConductor + Blinn), substrate.cpp:42 (FresnelBlend + Anisotropic) */
-enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_MAT_METAL = 4, HPT_MAT_SUBSTRATE = 5 };
+enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_MAT_METAL = 4, HPT_MAT_SUBSTRATE = 5,
+       /* materials/glass.cpp:43-61 (SpecularReflection + SpecularTransmission, FresnelDielectric(1, index)),
+        * materials/mirror.cpp:43-57 (SpecularReflection, FresnelNoOp),
+        * materials/measured.cpp:194-210 with a RegularHalfangleBRDF (MERL .binary data, core/reflection.cpp:275-300) */
+       HPT_MAT_GLASS = 6, HPT_MAT_MIRROR = 7, HPT_MAT_MEASURED_REGULAR = 8 };
+
+/* Textures (core/texture.h:44-96).  A material parameter is either the constant in its hpt_material field or —
+ * hpt_material.tex[slot] >= 0 — a texture of this table, evaluated at the hit's DifferentialGeometry like Texture::Evaluate.
+ *   CONSTANT  textures/constant.h:45-55                 value
+ *   IMAGEMAP  textures/imagemap.cpp:41-101              MIPMap::Lookup (core/mipmap.h:238-366: trilinear or EWA) of the pyramid the
+ *             reference built (MIPMap ctor, mipmap.h:105-190), through a UVMapping2D (core/texture.cpp:44-57)
+ *   SCALE     textures/scale.h:46-60                    tex1 * tex2
+ *   MIX       textures/mix.h:46-62                      (1 - amount) * tex1 + amount * tex2
+ * Other texture plugins and other mappings are outside the hot-path scope (the host wrapper refuses them). */
+enum { HPT_TEX_CONSTANT = 1, HPT_TEX_IMAGEMAP = 2, HPT_TEX_SCALE = 3, HPT_TEX_MIX = 4 };
+enum { HPT_WRAP_REPEAT = 0, HPT_WRAP_BLACK = 1, HPT_WRAP_CLAMP = 2 };   /* ImageWrap, core/mipmap.h:47-49 */
+typedef struct hpt_texture {
+    int32_t kind;
+    int32_t channels;      /* 1: Texture<float>, 3: Texture<Spectrum> (RGB) */
+    float value[3];        /* CONSTANT */
+    int32_t tex1, tex2;    /* SCALE / MIX operands (texture indices) */
+    int32_t amount;        /* MIX: float texture index */
+    /* IMAGEMAP: the MIPMap's pyramid, level after level in fpool: level l is max(1, width >> l) x max(1, height >> l) texels of
+     * `channels` floats, row-major (t * w + s), starting right after level l - 1; level 0 at pyr_off */
+    int64_t pyr_off;
+    int32_t width, height, levels;   /* level-0 resolution (a power of two after the reference's resampling), MIPMap::nLevels */
+    int32_t wrap;          /* HPT_WRAP_* */
+    int32_t do_trilinear;  /* MIPMap::doTrilinear */
+    float max_aniso;       /* MIPMap::maxAnisotropy */
+    float su, sv, du, dv;  /* UVMapping2D */
+} hpt_texture;
+/* hpt_material.tex[] slots */
+enum { HPT_TEXSLOT_KD = 0,        /* matte / plastic / substrate Kd; metal eta                 (spectrum) */
+       HPT_TEXSLOT_KS = 1,        /* plastic / substrate Ks; metal k; glass / mirror Kr        (spectrum) */
+       HPT_TEXSLOT_ROUGH = 2,     /* plastic / metal roughness; matte sigma; substrate uroughness (float) */
+       HPT_TEXSLOT_ROUGH_V = 3,   /* substrate vroughness                                          (float) */
+       HPT_TEXSLOT_BUMP = 4,      /* Material::Bump displacement (core/material.cpp:46-85)          (float) */
+       HPT_TEXSLOT_KT = 5,        /* glass Kt                                                   (spectrum) */
+       HPT_TEXSLOT_INDEX = 6,     /* glass index                                                    (float) */
+       HPT_N_TEXSLOTS = 8 };
 
 /* Light kinds: lights/point.cpp:50, lights/diffuse.cpp:69, lights/infinite.cpp:68 */
 enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3 };
@@ -67,11 +106,11 @@ typedef struct hpt_mesh {
     int64_t p_off, n_off, uv_off, idx_off;
     int32_t ntris, nverts;
     int32_t material;            /* index into materials */
-    int32_t arealight;           /* index into lights, or -1 */
+    int32_t arealight;           /* index into lights, or -1; a mesh that emits is also listed in its light's shape set */
     int32_t reverse_orientation; /* Shape::ReverseOrientation */
     int32_t swaps_handedness;    /* Shape::TransformSwapsHandedness */
     int32_t instance;            /* index into instances, or -1: mesh lives directly in the world */
-    int32_t pad;
+    int32_t alpha_tex;           /* 1 + index of the float texture TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:191-195), 0 = none */
     float o2w[16];               /* ObjectToWorld->m    */
     float o2w_inv[16];           /* ObjectToWorld->mInv */
 } hpt_mesh;
@@ -108,12 +147,11 @@ typedef struct hpt_quadric {
     float o2w_inv[16];
 } hpt_quadric;
 
-/* Material parameter record (textures are constant in the in-scope configs; the host wrapper
- * refuses non-constant textures with HPT_E_UNSUPPORTED). */
+/* Material parameter record: constants, with textures by reference (tex[]). */
 typedef struct hpt_material {
     int32_t kind;
     float kd[3];      /* matte / plastic: Kd (already Clamp()ed as in matte.cpp:53) */
-    float sigma;      /* matte: Oren-Nayar sigma (0 -> Lambertian)                   */
+    float sigma;      /* matte: Oren-Nayar sigma in degrees, already Clamp()ed to [0, 90] (matte.cpp:54); 0 -> Lambertian */
     float ks[3];      /* plastic                                                      */
     float roughness;  /* plastic: Blinn exponent = 1/roughness (plastic.cpp:60)       */
     /* measured (IrregIsotropicBRDF, core/reflection.cpp:259): KdTree<IrregIsotropicBRDFSample>
@@ -127,11 +165,19 @@ typedef struct hpt_material {
     float eta[3], k[3]; /* metal: conductor index / absorption as RGB (SPDs are converted at load, spectrum.h:428);
                            roughness above = Blinn roughness                                                  */
     float nu, nv;       /* substrate: uroughness, vroughness (Anisotropic exponents 1/nu, 1/nv); kd, ks above */
+    /* ---- version 6 ---- */
+    int32_t tex[HPT_N_TEXSLOTS];   /* texture index per parameter slot (HPT_TEXSLOT_*), -1 = the constant in the field above */
+    float kt[3];        /* glass: Kt (Kr in ks) */
+    float index;        /* glass: index of refraction */
+    /* measured, RegularHalfangleBRDF (core/reflection.cpp:275-300): regularHalfangleData as MeasuredMaterial read it
+     * (materials/measured.cpp:137-184), 3 * nThetaH * nThetaD * nPhiD floats at fpool[rh_off] */
+    int64_t rh_off;
+    int32_t rh_n_theta_h, rh_n_theta_d, rh_n_phi_d, pad2;
 } hpt_material;
 
 typedef struct hpt_light {
     int32_t kind;
-    int32_t quadric;   /* DIFFUSE_AREA: emitting quadric index (ShapeSet of one shape) */
+    int32_t quadric;   /* DIFFUSE_AREA: emitting quadric index (ShapeSet of one quadric), or -1: the shape set below */
     float pos[3];      /* POINT: world-space position (point.cpp:43)                    */
     float intensity[3];/* POINT: I ; DIFFUSE_AREA: Lemit ; INFINITE: unused             */
     float area;        /* DIFFUSE_AREA: ShapeSet::Area()                                */
@@ -146,6 +192,13 @@ typedef struct hpt_light {
                         * direct-lighting integrator, strategy "all"; 0 reads as 1; ignored by the path integrator */
     float l2w[16];     /* LightToWorld->m    */
     float l2w_inv[16]; /* LightToWorld->mInv */
+    /* ---- version 6: DIFFUSE_AREA over a ShapeSet of several shapes (core/light.cpp:114-171; quadric == -1) ----
+     * ipool[set_off + 2 i] = shape kind (0: triangle, 1: quadric), ipool[set_off + 2 i + 1] = GLOBAL triangle number (meshes in
+     * descriptor order, triangles in mesh order) or quadric index; fpool[set_area_off ..] = areas[n] (Shape::Area of every shape,
+     * = Distribution1D::func), cdf[n + 1], then funcInt — ShapeSet::areas / areaDistribution as the reference built them;
+     * `area` above is ShapeSet::sumArea */
+    int64_t set_off, set_area_off;
+    int32_t set_n, pad;
 } hpt_light;
 
 typedef struct hpt_scene_desc {
@@ -156,6 +209,7 @@ typedef struct hpt_scene_desc {
     const hpt_instance *instances; int32_t n_instances;
     const float *fpool;            int64_t n_f;
     const int32_t *ipool;          int64_t n_i;
+    const hpt_texture *textures;   int32_t n_textures;   /* version 6 */
 } hpt_scene_desc;
 
 /* PerspectiveCamera (cameras/perspective.cpp:41-49,81-138; core/camera.cpp:83-102). */

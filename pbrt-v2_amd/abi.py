@@ -9,10 +9,15 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 5
+HPT_VERSION = 6
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
+HPT_MAT_GLASS, HPT_MAT_MIRROR, HPT_MAT_MEASURED_REGULAR = 6, 7, 8
+HPT_TEX_CONSTANT, HPT_TEX_IMAGEMAP, HPT_TEX_SCALE, HPT_TEX_MIX = 1, 2, 3, 4
+HPT_WRAP_REPEAT, HPT_WRAP_BLACK, HPT_WRAP_CLAMP = 0, 1, 2
+TEXSLOT_KD, TEXSLOT_KS, TEXSLOT_ROUGH, TEXSLOT_ROUGH_V, TEXSLOT_BUMP, TEXSLOT_KT, TEXSLOT_INDEX = 0, 1, 2, 3, 4, 5, 6
+HPT_N_TEXSLOTS = 8
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER_RANDOM_MT_REPLAY = 0, 1, 2, 3
 HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
@@ -37,7 +42,7 @@ class Mesh(C.Structure):
     _fields_ = [("p_off", i64), ("n_off", i64), ("uv_off", i64), ("idx_off", i64),
                 ("ntris", i32), ("nverts", i32), ("material", i32), ("arealight", i32),
                 ("reverse_orientation", i32), ("swaps_handedness", i32),
-                ("instance", i32), ("pad", i32),
+                ("instance", i32), ("alpha_tex", i32),
                 ("o2w", M16), ("o2w_inv", M16)]
 
 
@@ -55,19 +60,55 @@ class Quadric(C.Structure):
                 ("o2w", M16), ("o2w_inv", M16)]
 
 
-class Material(C.Structure):
-    _fields_ = [("kind", i32), ("kd", f32 * 3), ("sigma", f32), ("ks", f32 * 3),
+_MATERIAL_V5 = [("kind", i32), ("kd", f32 * 3), ("sigma", f32), ("ks", f32 * 3),
                 ("roughness", f32), ("kd_split_off", i64), ("kd_bits_off", i64),
                 ("kd_data_off", i64), ("kd_nnodes", i32), ("pad", i32),
                 ("eta", f32 * 3), ("k", f32 * 3), ("nu", f32), ("nv", f32)]
+_LIGHT_V5 = [("kind", i32), ("quadric", i32), ("pos", f32 * 3), ("intensity", f32 * 3),
+             ("area", f32), ("env_w", i32), ("env_h", i32),
+             ("tex_off", i64), ("cond_func_off", i64), ("cond_cdf_off", i64),
+             ("cond_int_off", i64), ("marg_func_off", i64), ("marg_cdf_off", i64),
+             ("marg_int", f32), ("nsamples", i32), ("l2w", M16), ("l2w_inv", M16)]
+
+
+class MaterialV5(C.Structure):
+    _fields_ = _MATERIAL_V5
+
+
+class LightV5(C.Structure):
+    _fields_ = _LIGHT_V5
+
+
+class Material(C.Structure):
+    _fields_ = _MATERIAL_V5 + [("tex", i32 * HPT_N_TEXSLOTS), ("kt", f32 * 3), ("index", f32), ("rh_off", i64),
+                               ("rh_n_theta_h", i32), ("rh_n_theta_d", i32), ("rh_n_phi_d", i32), ("pad2", i32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        for k in range(HPT_N_TEXSLOTS):
+            self.tex[k] = -1
+        self.rh_off = -1
 
 
 class Light(C.Structure):
-    _fields_ = [("kind", i32), ("quadric", i32), ("pos", f32 * 3), ("intensity", f32 * 3),
-                ("area", f32), ("env_w", i32), ("env_h", i32),
-                ("tex_off", i64), ("cond_func_off", i64), ("cond_cdf_off", i64),
-                ("cond_int_off", i64), ("marg_func_off", i64), ("marg_cdf_off", i64),
-                ("marg_int", f32), ("nsamples", i32), ("l2w", M16), ("l2w_inv", M16)]
+    _fields_ = _LIGHT_V5 + [("set_off", i64), ("set_area_off", i64), ("set_n", i32), ("pad", i32)]
+
+
+class Texture(C.Structure):
+    """hpt_texture"""
+    _fields_ = [("kind", i32), ("channels", i32), ("value", f32 * 3), ("tex1", i32), ("tex2", i32), ("amount", i32),
+                ("pyr_off", i64), ("width", i32), ("height", i32), ("levels", i32), ("wrap", i32), ("do_trilinear", i32),
+                ("max_aniso", f32), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32)]
+
+
+def _upgrade(old, new_type):
+    """a version-5 record -> the version-6 record with the new fields at their 'absent' values"""
+    n = new_type()
+    C.memmove(C.addressof(n), C.addressof(old), C.sizeof(old))
+    if new_type is Light:
+        n.set_off = n.set_area_off = -1
+        n.set_n = 0
+    return n
 
 
 class SceneDesc(C.Structure):
@@ -77,7 +118,8 @@ class SceneDesc(C.Structure):
                 ("lights", C.POINTER(Light)), ("n_lights", i32),
                 ("instances", C.POINTER(Instance)), ("n_instances", i32),
                 ("fpool", C.POINTER(f32)), ("n_f", i64),
-                ("ipool", C.POINTER(i32)), ("n_i", i64)]
+                ("ipool", C.POINTER(i32)), ("n_i", i64),
+                ("textures", C.POINTER(Texture)), ("n_textures", i32)]
 
 
 class Camera(C.Structure):
@@ -187,12 +229,25 @@ class BlobHeader(C.Structure):
                 ("n_f", i64), ("n_i", i64),
                 ("cam", Camera), ("rd", RenderDesc),
                 ("sizeof_mesh", u32), ("sizeof_quadric", u32), ("sizeof_material", u32),
-                ("sizeof_light", u32), ("sizeof_instance", u32), ("pad2", u32)]
+                ("sizeof_light", u32), ("sizeof_instance", u32), ("n_textures", u32)]   # n_textures: version 6 (the word was padding before)
 
 
 ABI_SIZES = [C.sizeof(Mesh), C.sizeof(Quadric), C.sizeof(Material), C.sizeof(Light),
              C.sizeof(Camera), C.sizeof(RenderDesc), C.sizeof(Stats), C.sizeof(BlobHeader),
-             C.sizeof(Instance)]
+             C.sizeof(Instance), C.sizeof(Texture)]
+
+
+def lights_from_bytes(raw, n):
+    """the `lights` array of a *.view.npz fixture -> (Light * n); round-1 fixtures hold version-5 records"""
+    raw = bytes(raw)
+    if len(raw) == n * C.sizeof(Light):
+        return (Light * n).from_buffer_copy(raw)
+    assert len(raw) == n * C.sizeof(LightV5), "light records of unknown size"
+    old = (LightV5 * n).from_buffer_copy(raw)
+    out = (Light * max(n, 0))()
+    for i in range(n):
+        out[i] = _upgrade(old[i], Light)
+    return out
 
 
 def _arr(ctype, n):
@@ -204,7 +259,10 @@ class Scene:
     camera and the render defaults it was dumped with.  `.desc` is the hpt_scene_desc view."""
 
     def __init__(self, meshes=(), quadrics=(), materials=(), lights=(), fpool=None, ipool=None,
-                 camera=None, render=None, instances=()):
+                 camera=None, render=None, instances=(), textures=()):
+        self.textures = _arr(Texture, len(textures))
+        for i, t in enumerate(textures):
+            self.textures[i] = t
         self.meshes = _arr(Mesh, len(meshes))
         for i, m in enumerate(meshes):
             self.meshes[i] = m
@@ -235,6 +293,7 @@ class Scene:
         d.instances = C.cast(self.instances, C.POINTER(Instance)); d.n_instances = len(self.instances)
         d.fpool = self.fpool.ctypes.data_as(C.POINTER(f32)); d.n_f = self.fpool.size
         d.ipool = self.ipool.ctypes.data_as(C.POINTER(i32)); d.n_i = self.ipool.size
+        d.textures = C.cast(self.textures, C.POINTER(Texture)); d.n_textures = len(self.textures)
         return d
 
     @property
@@ -253,9 +312,10 @@ class Scene:
         h.cam, h.rd = self.camera, self.render
         h.sizeof_mesh, h.sizeof_quadric = C.sizeof(Mesh), C.sizeof(Quadric)
         h.sizeof_material, h.sizeof_light = C.sizeof(Material), C.sizeof(Light)
+        h.n_textures = len(self.textures)
         with _open(path, "wb") as f:
             f.write(bytes(h))
-            for a in (self.meshes, self.quadrics, self.materials, self.lights, self.instances):
+            for a in (self.meshes, self.quadrics, self.materials, self.lights, self.instances, self.textures):
                 f.write(bytes(a))
             f.write(self.fpool.tobytes())
             f.write(self.ipool.tobytes())
@@ -265,10 +325,12 @@ class Scene:
         with _open(path, "rb") as f:
             raw = f.read()
         h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
-        if h.magic != HPT_MAGIC or h.version != HPT_VERSION:
-            raise ValueError(f"{path}: not an HPTS v{HPT_VERSION} blob")
+        if h.magic != HPT_MAGIC or h.version not in (5, HPT_VERSION):
+            raise ValueError(f"{path}: not an HPTS v5 / v{HPT_VERSION} blob")
+        v5 = h.version == 5          # round-1 fixtures: smaller material / light records, no texture table
+        mat_t, light_t = (MaterialV5, LightV5) if v5 else (Material, Light)
         if (h.sizeof_mesh, h.sizeof_quadric, h.sizeof_material, h.sizeof_light, h.sizeof_instance) != \
-                tuple(ABI_SIZES[:4]) + (C.sizeof(Instance),):
+                (C.sizeof(Mesh), C.sizeof(Quadric), C.sizeof(mat_t), C.sizeof(light_t), C.sizeof(Instance)):
             raise ValueError(f"{path}: record sizes differ from this build of the ABI")
         off = C.sizeof(BlobHeader)
 
@@ -281,9 +343,20 @@ class Scene:
         s = Scene()
         s.meshes = take(Mesh, h.n_meshes)
         s.quadrics = take(Quadric, h.n_quadrics)
-        s.materials = take(Material, h.n_materials)
-        s.lights = take(Light, h.n_lights)
+        s.materials = take(mat_t, h.n_materials)
+        s.lights = take(light_t, h.n_lights)
         s.instances = take(Instance, h.n_instances)
+        if v5:
+            mats, lights = _arr(Material, h.n_materials), _arr(Light, h.n_lights)
+            for i in range(h.n_materials):
+                mats[i] = _upgrade(s.materials[i], Material)
+            for i in range(h.n_lights):
+                lights[i] = _upgrade(s.lights[i], Light)
+            s.materials, s.lights = mats, lights
+            for m in s.meshes:
+                m.alpha_tex = 0
+        else:
+            s.textures = take(Texture, h.n_textures)
         s.fpool = np.frombuffer(raw, dtype=np.float32, count=h.n_f, offset=off).copy(); off += 4 * h.n_f
         s.ipool = np.frombuffer(raw, dtype=np.int32, count=h.n_i, offset=off).copy(); off += 4 * h.n_i
         s.camera, s.render = h.cam, h.rd

@@ -52,6 +52,11 @@
 #include "primitive.h"
 #include "quaternion.h"
 #include "textures/constant.h"
+#include "textures/imagemap.h"
+#include "textures/scale.h"
+#include "textures/mix.h"
+#include "materials/glass.h"
+#include "materials/mirror.h"
 
 #include <map>
 #include <stdlib.h>
@@ -79,6 +84,10 @@ struct Flattener {
     std::vector<hpt_instance> instances;
     std::vector<float> fpool;
     std::vector<int32_t> ipool;
+    std::vector<hpt_texture> textures;
+    std::map<const void *, int> textureIndex;
+    std::map<const void *, int64_t> tableOffset;
+    std::vector<int64_t> meshTriBase;          // global number of every mesh's first triangle (meshes in descriptor order)
     std::map<const TriangleMesh *, int> meshIndex;
     std::map<const Shape *, int> quadricIndex;
     std::map<const Material *, int> materialIndex;
@@ -95,37 +104,108 @@ struct Flattener {
         return off;
     }
 
+
+    // ---- textures (core/texture.h): ConstantTexture, ImageTexture over a UVMapping2D, ScaleTexture, MixTexture -------------
+    // Operands are emitted before the texture that uses them (hpt_validate_desc relies on it).
+    template <typename Tmem, typename Tret> int AddImageTexture(const ImageTexture<Tmem, Tret> *it, int channels) {
+        hpt_texture r; memset(&r, 0, sizeof(r));
+        r.kind = HPT_TEX_IMAGEMAP; r.channels = channels; r.tex1 = r.tex2 = r.amount = -1;
+        const UVMapping2D *uv = dynamic_cast<const UVMapping2D *>(it->mapping);
+        if (!uv) Severe("hip renderer: only \"uv\" texture mappings are inside the hot-path scope");
+        r.su = uv->su; r.sv = uv->sv; r.du = uv->du; r.dv = uv->dv;
+        const MIPMap<Tmem> *mm = it->mipmap;
+        r.width = (int)mm->width; r.height = (int)mm->height; r.levels = (int)mm->nLevels;
+        r.wrap = mm->wrapMode == TEXTURE_REPEAT ? HPT_WRAP_REPEAT : mm->wrapMode == TEXTURE_BLACK ? HPT_WRAP_BLACK : HPT_WRAP_CLAMP;
+        r.do_trilinear = mm->doTrilinear ? 1 : 0; r.max_aniso = mm->maxAnisotropy;
+        r.pyr_off = (int64_t)fpool.size();
+        for (uint32_t l = 0; l < mm->nLevels; ++l) {
+            const BlockedArray<Tmem> &lv = *mm->pyramid[l];
+            for (uint32_t t = 0; t < lv.vSize(); ++t)
+                for (uint32_t sx = 0; sx < lv.uSize(); ++sx) PushTexel(lv(sx, t));
+        }
+        textures.push_back(r);
+        return (int)textures.size() - 1;
+    }
+    void PushTexel(float v) { fpool.push_back(v); }
+    void PushTexel(const RGBSpectrum &v) { float rgb[3]; v.ToRGB(rgb); fpool.push_back(rgb[0]); fpool.push_back(rgb[1]); fpool.push_back(rgb[2]); }
+    static void Value(float v, float out[3]) { out[0] = out[1] = out[2] = v; }
+    static void Value(const Spectrum &v, float out[3]) { v.ToRGB(out); }
+
+    int AddFloatTexture(const Texture<float> *t) { return AddTextureT<float, float>(t, 1); }
+    int AddSpectrumTexture(const Texture<Spectrum> *t) { return AddTextureT<Spectrum, RGBSpectrum>(t, 3); }
+    template <typename T, typename Tmem> int AddTextureT(const Texture<T> *t, int channels) {
+        std::map<const void *, int>::iterator it = textureIndex.find((const void *)t);
+        if (it != textureIndex.end()) return it->second;
+        int idx = -1;
+        if (const ConstantTexture<T> *c = dynamic_cast<const ConstantTexture<T> *>(t)) {
+            hpt_texture r; memset(&r, 0, sizeof(r));
+            r.kind = HPT_TEX_CONSTANT; r.channels = channels; r.tex1 = r.tex2 = r.amount = -1;
+            Value(c->value, r.value);
+            textures.push_back(r); idx = (int)textures.size() - 1;
+        } else if (const ImageTexture<Tmem, T> *im = dynamic_cast<const ImageTexture<Tmem, T> *>(t)) {
+            idx = AddImageTexture(im, channels);
+        } else if (const ScaleTexture<T, T> *sc = dynamic_cast<const ScaleTexture<T, T> *>(t)) {
+            int a = AddTextureT<T, Tmem>(sc->tex1.GetPtr(), channels), b = AddTextureT<T, Tmem>(sc->tex2.GetPtr(), channels);
+            hpt_texture r; memset(&r, 0, sizeof(r));
+            r.kind = HPT_TEX_SCALE; r.channels = channels; r.tex1 = a; r.tex2 = b; r.amount = -1;
+            textures.push_back(r); idx = (int)textures.size() - 1;
+        } else if (const MixTexture<T> *mx = dynamic_cast<const MixTexture<T> *>(t)) {
+            int a = AddTextureT<T, Tmem>(mx->tex1.GetPtr(), channels), b = AddTextureT<T, Tmem>(mx->tex2.GetPtr(), channels);
+            int am = AddFloatTexture(mx->amount.GetPtr());
+            hpt_texture r; memset(&r, 0, sizeof(r));
+            r.kind = HPT_TEX_MIX; r.channels = channels; r.tex1 = a; r.tex2 = b; r.amount = am;
+            textures.push_back(r); idx = (int)textures.size() - 1;
+        } else
+            Severe("hip renderer: texture type outside the hot-path scope (supported: constant, imagemap with uv mapping, scale, mix)");
+        textureIndex[(const void *)t] = idx;
+        return idx;
+    }
+    // A material parameter: the constant goes into the record's field, anything else into the texture table (slot index)
+    int SpectrumSlot(const Reference<Texture<Spectrum> > &tex, float k[3], bool clamp) {
+        Spectrum v;
+        if (ConstTex(tex, &v)) { if (clamp) v = v.Clamp(); v.ToRGB(k); return -1; }
+        k[0] = k[1] = k[2] = 0.f;
+        return AddSpectrumTexture(tex.GetPtr());
+    }
+    int FloatSlot(const Reference<Texture<float> > &tex, float *k) {
+        if (ConstTex(tex, k)) return -1;
+        *k = 0.f;
+        return AddFloatTexture(tex.GetPtr());
+    }
+    int BumpSlot(const Reference<Texture<float> > &tex) { return tex.GetPtr() ? AddFloatTexture(tex.GetPtr()) : -1; }
+
     int AddMaterial(const Material *m) {
         std::map<const Material *, int>::iterator it = materialIndex.find(m);
         if (it != materialIndex.end()) return it->second;
         hpt_material r;
         memset(&r, 0, sizeof(r));
-        r.kd_split_off = r.kd_bits_off = r.kd_data_off = -1;
+        r.kd_split_off = r.kd_bits_off = r.kd_data_off = r.rh_off = -1;
+        for (int k = 0; k < HPT_N_TEXSLOTS; ++k) r.tex[k] = -1;
         if (const MatteMaterial *mm = dynamic_cast<const MatteMaterial *>(m)) {
-            Spectrum kd; float sigma;
-            if (mm->bumpMap.GetPtr() || !ConstTex(mm->Kd, &kd) || !ConstTex(mm->sigma, &sigma))
-                Severe("hip renderer: matte material with non-constant textures / bump map "
-                       "is outside the hot-path scope");
             r.kind = HPT_MAT_MATTE;
-            kd = kd.Clamp();                                   // matte.cpp:53
-            kd.ToRGB(r.kd);
-            r.sigma = Clamp(sigma, 0.f, 90.f);                 // matte.cpp:54
-            if (r.sigma != 0.f)
-                Severe("hip renderer: Oren-Nayar (sigma != 0) is outside the hot-path scope");
+            r.tex[HPT_TEXSLOT_KD] = SpectrumSlot(mm->Kd, r.kd, true);                  // matte.cpp:53
+            r.tex[HPT_TEXSLOT_ROUGH] = FloatSlot(mm->sigma, &r.sigma);
+            if (r.tex[HPT_TEXSLOT_ROUGH] < 0) r.sigma = Clamp(r.sigma, 0.f, 90.f);    // matte.cpp:54
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(mm->bumpMap);
         } else if (const PlasticMaterial *pm = dynamic_cast<const PlasticMaterial *>(m)) {
-            Spectrum kd, ks; float rough;
-            if (pm->bumpMap.GetPtr() || !ConstTex(pm->Kd, &kd) || !ConstTex(pm->Ks, &ks) ||
-                !ConstTex(pm->roughness, &rough))
-                Severe("hip renderer: plastic material with non-constant textures / bump map "
-                       "is outside the hot-path scope");
             r.kind = HPT_MAT_PLASTIC;
-            kd = kd.Clamp(); kd.ToRGB(r.kd);                   // plastic.cpp:52
-            ks = ks.Clamp(); ks.ToRGB(r.ks);                   // plastic.cpp:57
-            r.roughness = rough;
+            r.tex[HPT_TEXSLOT_KD] = SpectrumSlot(pm->Kd, r.kd, true);                  // plastic.cpp:52
+            r.tex[HPT_TEXSLOT_KS] = SpectrumSlot(pm->Ks, r.ks, true);                  // plastic.cpp:57
+            r.tex[HPT_TEXSLOT_ROUGH] = FloatSlot(pm->roughness, &r.roughness);
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(pm->bumpMap);
         } else if (const MeasuredMaterial *me = dynamic_cast<const MeasuredMaterial *>(m)) {
-            if (me->bumpMap.GetPtr() || !me->thetaPhiData)
-                Severe("hip renderer: only irregular (.brdf) measured materials without bump "
-                       "maps are inside the hot-path scope");
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(me->bumpMap);
+            if (me->regularHalfangleData) {                    // RegularHalfangleBRDF (MERL .binary), measured.cpp:137-184
+                r.kind = HPT_MAT_MEASURED_REGULAR;
+                r.rh_n_theta_h = (int)me->nThetaH; r.rh_n_theta_d = (int)me->nThetaD; r.rh_n_phi_d = (int)me->nPhiD;
+                // MeasuredMaterial shares one table among the materials that name the same file (measured.cpp:139-142): so does the blob
+                std::map<const void *, int64_t>::iterator ti = tableOffset.find((const void *)me->regularHalfangleData);
+                if (ti != tableOffset.end()) r.rh_off = ti->second;
+                else {
+                    r.rh_off = PushF(me->regularHalfangleData, 3 * (size_t)me->nThetaH * me->nThetaD * me->nPhiD);
+                    tableOffset[(const void *)me->regularHalfangleData] = r.rh_off;
+                }
+            } else if (me->thetaPhiData) {
             r.kind = HPT_MAT_MEASURED_IRREG;
             const KdTree<IrregIsotropicBRDFSample> *kd = me->thetaPhiData;
             uint32_t n = kd->nNodes;
@@ -147,25 +227,34 @@ struct Flattener {
             r.kd_split_off = PushF(&split[0], n);
             r.kd_bits_off = PushI(&bits[0], n);
             r.kd_data_off = PushF(&data[0], 6 * (size_t)n);
+            } else
+                Severe("hip renderer: measured material without data");
         } else if (const MetalMaterial *mt = dynamic_cast<const MetalMaterial *>(m)) {
-            Spectrum eta, k; float rough;
-            if (mt->bumpMap.GetPtr() || !ConstTex(mt->eta, &eta) || !ConstTex(mt->k, &k) || !ConstTex(mt->roughness, &rough))
-                Severe("hip renderer: metal material with non-constant textures / bump map is outside the hot-path scope");
             r.kind = HPT_MAT_METAL;
-            eta.ToRGB(r.eta); k.ToRGB(r.k);                    // metal.cpp:64-65 (no Clamp)
-            r.roughness = rough;
+            r.tex[HPT_TEXSLOT_KD] = SpectrumSlot(mt->eta, r.eta, false);               // metal.cpp:64-65 (no Clamp)
+            r.tex[HPT_TEXSLOT_KS] = SpectrumSlot(mt->k, r.k, false);
+            r.tex[HPT_TEXSLOT_ROUGH] = FloatSlot(mt->roughness, &r.roughness);
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(mt->bumpMap);
         } else if (const SubstrateMaterial *sm = dynamic_cast<const SubstrateMaterial *>(m)) {
-            Spectrum kd, ks; float nu, nv;
-            if (sm->bumpMap.GetPtr() || !ConstTex(sm->Kd, &kd) || !ConstTex(sm->Ks, &ks) || !ConstTex(sm->nu, &nu) ||
-                !ConstTex(sm->nv, &nv))
-                Severe("hip renderer: substrate material with non-constant textures / bump map is outside the hot-path scope");
             r.kind = HPT_MAT_SUBSTRATE;
-            kd = kd.Clamp(); kd.ToRGB(r.kd);                   // substrate.cpp:50-51
-            ks = ks.Clamp(); ks.ToRGB(r.ks);
-            r.nu = nu; r.nv = nv;
+            r.tex[HPT_TEXSLOT_KD] = SpectrumSlot(sm->Kd, r.kd, true);                  // substrate.cpp:50-51
+            r.tex[HPT_TEXSLOT_KS] = SpectrumSlot(sm->Ks, r.ks, true);
+            r.tex[HPT_TEXSLOT_ROUGH] = FloatSlot(sm->nu, &r.nu);
+            r.tex[HPT_TEXSLOT_ROUGH_V] = FloatSlot(sm->nv, &r.nv);
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(sm->bumpMap);
+        } else if (const GlassMaterial *gm = dynamic_cast<const GlassMaterial *>(m)) {
+            r.kind = HPT_MAT_GLASS;
+            r.tex[HPT_TEXSLOT_KS] = SpectrumSlot(gm->Kr, r.ks, true);                  // glass.cpp:50-51
+            r.tex[HPT_TEXSLOT_KT] = SpectrumSlot(gm->Kt, r.kt, true);
+            r.tex[HPT_TEXSLOT_INDEX] = FloatSlot(gm->index, &r.index);
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(gm->bumpMap);
+        } else if (const MirrorMaterial *mi = dynamic_cast<const MirrorMaterial *>(m)) {
+            r.kind = HPT_MAT_MIRROR;
+            r.tex[HPT_TEXSLOT_KS] = SpectrumSlot(mi->Kr, r.ks, true);                  // mirror.cpp:52
+            r.tex[HPT_TEXSLOT_BUMP] = BumpSlot(mi->bumpMap);
         } else
             Severe("hip renderer: material type outside the hot-path scope "
-                   "(supported: matte, plastic, measured/.brdf, metal, substrate)");
+                   "(supported: matte, plastic, measured, metal, substrate, glass, mirror)");
         int idx = (int)materials.size();
         materials.push_back(r);
         materialIndex[m] = idx;
@@ -183,13 +272,10 @@ struct Flattener {
     void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp, int instance = -1) {
         const TriangleMesh *mesh = tri->mesh.GetPtr();
         if (meshIndex.find(mesh) != meshIndex.end()) return;
-        if (mesh->alphaTexture.GetPtr())
-            Severe("hip renderer: alpha-textured meshes are outside the hot-path scope");
         if (mesh->s)
             Severe("hip renderer: meshes with explicit tangents \"S\" are outside the hot-path scope");
-        if (gp->areaLight)
-            Severe("hip renderer: triangle-mesh emitters are outside the hot-path scope "
-                   "(sphere / disk emitters are supported)");
+        if (gp->areaLight && instance >= 0)
+            Severe("hip renderer: emitting meshes inside animated instances are outside the hot-path scope");
         hpt_mesh r;
         memset(&r, 0, sizeof(r));
         r.ntris = mesh->ntris;
@@ -199,13 +285,15 @@ struct Flattener {
         r.uv_off = mesh->uvs ? PushF(mesh->uvs, 2 * (size_t)mesh->nverts) : -1;
         r.idx_off = PushI(mesh->vertexIndex, 3 * (size_t)mesh->ntris);
         r.material = AddMaterial(gp->material.GetPtr());
-        r.arealight = -1;
+        r.arealight = LightOf(gp->areaLight);
+        r.alpha_tex = mesh->alphaTexture.GetPtr() ? 1 + AddFloatTexture(mesh->alphaTexture.GetPtr()) : 0;
         r.instance = instance;
         r.reverse_orientation = mesh->ReverseOrientation;
         r.swaps_handedness = mesh->TransformSwapsHandedness;
         CopyM(mesh->ObjectToWorld->m, r.o2w);
         CopyM(mesh->ObjectToWorld->mInv, r.o2w_inv);
         meshIndex[mesh] = (int)meshes.size();
+        meshTriBase.push_back(meshTriBase.empty() ? 0 : meshTriBase.back() + meshes.back().ntris);
         meshes.push_back(r);
     }
 
@@ -345,18 +433,41 @@ struct Flattener {
             else
                 AddQuadric(shape, gp);
         }
-        // DiffuseAreaLight -> emitting quadric (the ShapeSet holds the very Shape object of the
-        // GeometricPrimitive: core/api.cpp:1003-1009)
+        // DiffuseAreaLight -> its ShapeSet (core/light.cpp:114-139).  One quadric: the very Shape object of the GeometricPrimitive
+        // (core/api.cpp:1003-1009).  Anything else — a triangle mesh refined into its own Triangle objects, several shapes — is
+        // listed shape by shape, in the set's order, with the areas and the area distribution the reference built.
         for (uint32_t i = 0; i < scene->lights.size(); ++i) {
             const DiffuseAreaLight *dl = dynamic_cast<const DiffuseAreaLight *>(scene->lights[i]);
             if (!dl) continue;
-            if (dl->shapeSet->shapes.size() != 1)
-                Severe("hip renderer: area lights over refined shape sets are outside the scope");
-            std::map<const Shape *, int>::iterator it =
-                quadricIndex.find(dl->shapeSet->shapes[0].GetPtr());
-            if (it == quadricIndex.end())
-                Severe("hip renderer: area light shape not found among the scene's quadrics");
-            lights[i].quadric = it->second;
+            const ShapeSet *set = dl->shapeSet;
+            lights[i].set_off = lights[i].set_area_off = -1; lights[i].set_n = 0;
+            if (set->shapes.size() == 1) {
+                std::map<const Shape *, int>::iterator it = quadricIndex.find(set->shapes[0].GetPtr());
+                if (it != quadricIndex.end()) { lights[i].quadric = it->second; continue; }
+            }
+            std::vector<int> ids;
+            for (size_t k = 0; k < set->shapes.size(); ++k) {
+                const Shape *sh = set->shapes[k].GetPtr();
+                if (const Triangle *tri = dynamic_cast<const Triangle *>(sh)) {
+                    std::map<const TriangleMesh *, int>::iterator mi = meshIndex.find(tri->mesh.GetPtr());
+                    if (mi == meshIndex.end()) Severe("hip renderer: area light triangle's mesh not found in the scene");
+                    ids.push_back(0);
+                    ids.push_back((int)(meshTriBase[mi->second] + (tri->v - tri->mesh->vertexIndex) / 3));
+                } else {
+                    std::map<const Shape *, int>::iterator qi = quadricIndex.find(sh);
+                    if (qi == quadricIndex.end()) Severe("hip renderer: area light shape not found among the scene's shapes");
+                    ids.push_back(1); ids.push_back(qi->second);
+                }
+            }
+            const Distribution1D *ad = set->areaDistribution;
+            if ((size_t)ad->count != set->shapes.size() || set->areas.size() != set->shapes.size())
+                Severe("hip renderer: unexpected ShapeSet area distribution");
+            lights[i].quadric = -1;
+            lights[i].set_n = (int)set->shapes.size();
+            lights[i].set_off = PushI(&ids[0], ids.size());
+            lights[i].set_area_off = PushF(&set->areas[0], set->areas.size());
+            PushF(ad->cdf, set->shapes.size() + 1);
+            PushF(&ad->funcInt, 1);
         }
     }
 
@@ -370,6 +481,7 @@ struct Flattener {
         d.instances = instances.empty() ? NULL : &instances[0]; d.n_instances = (int)instances.size();
         d.fpool = fpool.empty() ? NULL : &fpool[0];           d.n_f = (int64_t)fpool.size();
         d.ipool = ipool.empty() ? NULL : &ipool[0];           d.n_i = (int64_t)ipool.size();
+        d.textures = textures.empty() ? NULL : &textures[0];  d.n_textures = (int)textures.size();
         return d;
     }
 };

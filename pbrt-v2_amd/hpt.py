@@ -60,7 +60,7 @@ def lib():
         L.hpt_blob_save.argtypes = [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera),
                                     C.POINTER(abi.RenderDesc)]
         L.hpt_abi_sizes.argtypes = [C.c_void_p]
-        sizes = (C.c_int32 * 9)()
+        sizes = (C.c_int32 * 10)()
         L.hpt_abi_sizes(sizes)
         if list(sizes) != abi.ABI_SIZES:
             raise HptError(f"ABI drift: libhpt.so struct sizes {list(sizes)} != abi.py {abi.ABI_SIZES}")

@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
+from tests.util import CASES, DL_CASES, FILTER_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -28,6 +28,24 @@ def test_oracle_replays_reference_image_bit_exact(cases, name):
     assert img.shape == ref.shape
     assert st[0] == rd.x_count * rd.y_count * rd.spp
     assert st[5] == 0  # no NaN / negative radiance
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
+@pytest.mark.parametrize("name", list(R2_CASES) + list(R2_VIEW_CASES))
+def test_oracle_replays_round2_reference_images_bit_exact(name):
+    """SURVEY.md §8a rows a9 / a14 / a16 / a20 and §8f-3 (tests/golden/make_golden_r2.py): Oren-Nayar (`on`); glass + mirror under the
+    path integrator (`spec`) and under DirectLightingIntegrator's SpecularReflect / SpecularTransmit recursion (`specdl`);
+    DiffuseAreaLight over triangle-mesh ShapeSets (`trilight`, `trildl`); RegularHalfangleBRDF (`merl`); image textures through
+    MIPMap EWA / trilinear lookups with ray differentials, scale / mix textures and Material::Bump (`tex`); alpha-textured
+    triangles (`alpha`); and scenes/metal.pbrt as shipped — textured, bump-mapped substrate floor, Au teapot, .exr environment map
+    (`metal`, BASELINE.json configs[4], rendered by the OpenEXR build of the reference)."""
+    s = load_case(name)
+    o = orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = o.render(s.camera, rd, nthreads=1)
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert img.shape == ref.shape and st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
 
 

@@ -46,7 +46,7 @@ def load_case(name):
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         assert len(bytes(lights)) == len(bytes(s.lights))
         s.lights = lights
         return s
@@ -55,21 +55,34 @@ def load_case(name):
         v = np.load(os.path.join(GOLDEN, "envmap_dl.view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
     if name in RANDOM_CASES or name in STRATIFIED_CASES:   # Sampler "random" / "stratified" cases: committed geometry + camera / render descriptor (sampler mode, spp) / lights
         s = abi.Scene.load(os.path.join(GOLDEN, (RANDOM_CASES.get(name) or STRATIFIED_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
+        return s
+    if name in R2_CASES:
+        s = abi.Scene.load(os.path.join(GOLDEN, R2_CASES[name]))
+        if name == "merl":       # the 17.5 MB half-angle table is rebuilt from its formula instead of being committed
+            assert all(m.rh_off == s.fpool.size for m in s.materials if m.kind == abi.HPT_MAT_MEASURED_REGULAR)
+            s.fpool = np.concatenate([s.fpool, merl_table()])
+        return s
+    if name in R2_VIEW_CASES:
+        s = abi.Scene.load(os.path.join(GOLDEN, R2_VIEW_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
     if name in FILTER_CASES or name in COMBO_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
         s = abi.Scene.load(os.path.join(GOLDEN, (FILTER_CASES.get(name) or COMBO_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
-        s.lights = (abi.Light * len(s.lights)).from_buffer_copy(v["lights"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         s.filter = abi.filter_from_array(v["filter"])
         return s
     raise KeyError(name)
@@ -94,6 +107,34 @@ RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "
 # Sampler "stratified" (same generator): 3 x 2 jittered, path; 2 x 2 jittered, direct lighting with 5 light samples; 2 x 3 unjittered,
 # path on the animated scene
 STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz", "sanim": "anim_killeroos.hpts.gz"}
+
+
+# ---- round 2 cases (tests/golden/make_golden_r2.py): Oren-Nayar, specular, triangle emitters, regular half-angle BRDF, textures, alpha
+R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hpts.gz", "merl": "merl.hpts.gz", "tex": "tex.hpts.gz",
+            "alpha": "alpha.hpts.gz", "metal": "metal.hpts.gz"}
+R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz"}     # same geometry, own camera / render descriptor / lights
+
+
+def merl_table_doubles():
+    """The synthetic MERL-layout table of the `merl` case: (3, 90 * 90 * 180) float64, channel-major like a .binary file
+    (materials/measured.cpp:137-184).  A smooth lobe in the half angle, modulated in the difference angles; values are what a
+    file would hold (the reader multiplies by 1/1500, 1.15/1500, 1.66/1500)."""
+    ih, idd, ip = np.meshgrid(np.arange(90, dtype=np.float64), np.arange(90, dtype=np.float64), np.arange(180, dtype=np.float64), indexing="ij")
+    base = 40.0 + 3000.0 * np.exp(-ih / 6.0) * (1.0 - 0.5 * idd / 90.0) + 200.0 * (1.0 + np.cos(ip * np.pi / 90.0)) * (idd / 90.0)
+    out = np.stack([base * k for k in (1.0, 0.8, 0.55)]).reshape(3, -1)
+    out[1, ::977] = -5.0          # negative entries: the reader clamps them to 0 (measured.cpp:177)
+    return np.ascontiguousarray(out)
+
+
+def merl_table():
+    """... as MeasuredMaterial stores it: float32, interleaved RGB, max(0., value * scale) evaluated in double."""
+    t = merl_table_doubles()
+    f32 = np.float32
+    scales = [f32(1.0) / f32(1500.0), f32(1.15) / f32(1500.0), f32(1.66) / f32(1500.0)]
+    out = np.zeros((t.shape[1], 3), np.float32)
+    for c in range(3):
+        out[:, c] = np.maximum(0.0, t[c] * np.float64(scales[c])).astype(np.float32)
+    return out.reshape(-1)
 
 
 def hash_rd(scene, seed=7, spp=None):
