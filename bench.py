@@ -20,6 +20,7 @@ Workloads (all 1920x1080, path maxdepth 8; lowdiscrepancy-structured sampler, bo
   anim     BASELINE.json configs[3]: scenes/anim-killeroos-moving.pbrt (2 animated instances), 128 spp/GPU
   soup     BASELINE.json configs[2]: synthetic 1M random triangles + 1 env light, 256 spp/GPU
   killeroo-dl  killeroo-simple.pbrt with the integrator it selects itself (directlighting, 8 light samples), 64 spp/GPU
+  metal    BASELINE.json configs[4]: scenes/metal.pbrt as shipped, 3840x2160, 128 spp/GPU (1024 spp over 8 GPUs)
 The default run (N = 1, no --workload) prints the headline line for bunny and, under `workloads`, the same measurement for
 killeroo, anim and soup at the spp BASELINE.json names (fewer steps each).  Geometry comes from the committed blobs
 (dumped from the reference's own parser by host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does
@@ -50,7 +51,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # soup: no reference count (its parser input is 1M triangles of synthetic text); the device's own algorithmic bytes,
 # 64 B x 265.2 BVH2 nodes + 48 B x 18.5 triangles per camera sample (bench.py --workload soup --count-work)
 ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0, "soup": 17859.0}
-DEFAULT_SPP = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "killeroo-dl": 64}
+DEFAULT_SPP = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "killeroo-dl": 64, "metal": 128}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue peak (MI355X_MICROARCH.md, wave scheduling): 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0 * 1e0      # = 1228.8 G wave-instructions / s
@@ -77,6 +78,13 @@ def load_workload(name, spp):
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         s.render.spp = spp or DEFAULT_SPP[name]
         desc = "scenes/killeroo-simple.pbrt as shipped (DirectLightingIntegrator, strategy all, 8 light samples per camera sample)"
+    elif name == "metal":     # BASELINE.json configs[4]: scenes/metal.pbrt as shipped (textured, bump-mapped substrate floor; Au teapot; .exr env map)
+        s = abi.Scene.load(os.path.join(GOLDEN, "metal.hpts.gz"))
+        v = np.load(os.path.join(GOLDEN, "metal_4k.view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.render.spp = spp or DEFAULT_SPP[name]
+        desc = "scenes/metal.pbrt as shipped (sampler + path instead of the metropolis renderer; small_env.exr for the missing uffizi map)"
     elif name == "soup":
         s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or DEFAULT_SPP[name], maxdepth=8)
         desc = "synthetic 1M random triangles + 1 env light (seed 0x5EED0001)"
@@ -247,7 +255,7 @@ def pmc_profile(workload):
 
 
 # ---- one workload, measured ----------------------------------------------------------------------------------------------
-def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch, hdist, strong=False):
+def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch, comm, strong=False):
     scene, desc = load_workload(workload, spp)
     spp_per_gpu = scene.render.spp
     rd = abi.copy_struct(scene.render)
@@ -287,7 +295,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         nonlocal last
         last = dev.render_device(scene.camera, rd, film.data_ptr(), stream)
         kernel_ms.append(last.kernel_ms)
-        return hdist.exchange_film(film, rank, world, wide_filter=flt is not None)
+        if comm is not None:       # the one film exchange of the frame, in the library: packed tiles over RCCL send / recv to rank 0 (csrc/hpt_multi.hip)
+            comm.exchange_film(rd, film.data_ptr(), stream, wide_filter=flt is not None)
+        return film
 
     for _ in range(warmup):
         step()
@@ -315,12 +325,12 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" if workload == "soup" else
         "scene blob dumped from the reference parser (tests/golden), random-free geometry",
-        "config": {"workload": "%s, 1920x1080, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
-                               % (desc, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting",
+        "config": {"workload": "%s, %dx%d, %s, %d spp per GPU (%d spp total), %s sampler seed 0, %s filter"
+                               % (desc, rd.xres, rd.yres, "path maxdepth 8" if rd.integrator == abi.HPT_INTEGRATOR_PATH else "direct lighting",
                                   rd.spp // world if strong else spp_per_gpu, rd.spp,
                                   {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)"}.get(args.sampler, "LD_HASH"),
                                   "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
-                   "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s" % (world, "gather" if flt is None else "sum-reduce"),
+                   "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s per frame in the library (hpt_comm_exchange_film: RCCL)" % (world, "gather (ncclSend / ncclRecv of packed tiles)" if flt is None else "sum-reduce (ncclReduce)"),
                    "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
                    "scene_bytes_in_hbm": int(info.total_device_bytes)},
         "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)",
@@ -384,7 +394,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    hdist = importlib.import_module("pbrt-v2_amd.dist")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -396,19 +405,26 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    comm = None
+    if world > 1:
+        def bcast(uid):                                  # torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = hpt.Comm(rank, world, local, bcast)
 
-    out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, hdist)
+    out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, comm)
     extras = []
     if default_run and not args.no_extra:
         if world == 1:
             # the other BASELINE configurations, as written (north-star scene 64 spp, configs[3] 128 spp, configs[2] 256 spp)
             for w, st, wu in (("killeroo", 3, 1), ("anim", 3, 1), ("soup", 2, 1)):
-                o, _, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, hdist)
+                o, _, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, comm)
                 extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "kernel", "setup_s", "rmse_vs_oracle", "verify", "roofline", "roofline_valu") if k in o})
                 extras[-1]["workload"] = w
         else:
             # strong scaling of the north-star frame: the fixed 256-spp 1M-triangle frame split N ways (BASELINE configs[2])
-            o, _, _ = measure(args, "soup", 0, min(2, args.steps), min(1, args.warmup), world, rank, local, dist, torch, hdist, strong=True)
+            o, _, _ = measure(args, "soup", 0, min(2, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm, strong=True)
             if rank == 0:
                 extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle") if k in o})
                 extras[-1]["workload"] = "soup (strong scaling: fixed 256-spp frame)"

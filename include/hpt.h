@@ -348,6 +348,32 @@ typedef struct hpt_filter {
 } hpt_filter;
 int hpt_scene_set_filter(hpt_scene *scene, const hpt_filter *filter);
 
+/* ---- multi-GPU (SURVEY.md §8b "gpus", §8e) ------------------------------------------------------------------------------------
+ * The path shards with no data-path collective: the scene is replicated per GPU, shard r renders the 32x32 pixel tiles t with
+ * t % n == r (shard_rank / shard_count above), and ONE exchange of film data per frame brings the frame to shard 0 — a gather of the
+ * owned tiles over RCCL send / recv (the reference's disjoint image tiles, renderers/samplerrenderer.cpp:298-307, core/sampler.cpp:55-74),
+ * or a sum-reduce of the full-frame films under a reconstruction filter wider than the box (film/image.cpp:96-136).
+ *
+ * hpt_multi: one process, one host thread per GPU — what `Renderer "hip" "integer gpus" [N]` of the pbrt plugin drives.  `devices` may
+ * name a device more than once (several shards on one GPU; their tiles then move with hipMemcpyAsync, RCCL refuses duplicate devices).
+ * hpt_multi_render ignores rd->shard_rank / shard_count; `stats` receives n_devices records (may be NULL). */
+typedef struct hpt_multi hpt_multi;
+hpt_multi *hpt_multi_create(const hpt_scene_desc *desc, const int *devices, int n_devices);
+void hpt_multi_destroy(hpt_multi *m);
+int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *filter);
+int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out);     /* the shard's scene handle (hpt_scene_tune, hpt_scene_get_info) */
+int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc *rd, float *film_xyzw_host, hpt_stats *stats);
+
+/* hpt_comm: one PROCESS per GPU (bench.py under torch.distributed.run; any launcher that can hand 128 bytes from rank 0 to the others).
+ * hpt_comm_unique_id on rank 0 (ncclGetUniqueId), hpt_comm_create everywhere (ncclCommInitRank, collective), then after every
+ * hpt_render_device of the rank's shard: hpt_comm_exchange_film on the same stream (asynchronous like an RCCL call) — afterwards rank 0's
+ * d_film_xyzw holds the whole frame.  wide_filter != 0: the scene has a filter set (sum-reduce instead of the tile gather). */
+typedef struct hpt_comm hpt_comm;
+int hpt_comm_unique_id(void *out_128_bytes);
+hpt_comm *hpt_comm_create(const void *id_128_bytes, int rank, int world, int device);
+void hpt_comm_destroy(hpt_comm *c);
+int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film_xyzw, void *stream, int wide_filter);
+
 /* ---- scene blob (serialised hpt_scene_desc + camera + render defaults); host only ------ */
 typedef struct hpt_blob hpt_blob;
 int hpt_blob_save(const char *path, const hpt_scene_desc *desc, const hpt_camera *cam,

@@ -32,6 +32,7 @@ struct hpt_scene {
     int device;
     int mats;             // MATS_* bits of the BxDF families the scene's materials need
     int n_materials;
+    bool has_specular;    // some material has a specular lobe (glass, mirror)
     DScene d;             // device pointers
     std::vector<void *> allocs;
     hpt_scene_info info;
@@ -76,6 +77,23 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
 
 extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     if (hpt_validate_desc(desc) != HPT_OK) return nullptr;
+    {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_DEPTH, no textured quadrics
+        std::vector<int> depth((size_t)desc->n_textures, 0);
+        for (int t = 0; t < desc->n_textures; ++t) {
+            const hpt_texture &tx = desc->textures[t];
+            if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX) {
+                int d = depth[(size_t)tx.tex1] > depth[(size_t)tx.tex2] ? depth[(size_t)tx.tex1] : depth[(size_t)tx.tex2];
+                if (tx.kind == HPT_TEX_MIX && depth[(size_t)tx.amount] > d) d = depth[(size_t)tx.amount];
+                depth[(size_t)t] = d + 1;
+                if (d + 1 > HPT_TEX_DEPTH) { hpt_set_error("texture %d: scale / mix textures nested deeper than %d", t, HPT_TEX_DEPTH); return nullptr; }
+            }
+        }
+        for (int q = 0; q < desc->n_quadrics; ++q) {
+            const hpt_material &ma = desc->materials[desc->quadrics[q].material];
+            for (int t = 0; t < HPT_N_TEXSLOTS; ++t)
+                if (ma.tex[t] >= 0) { hpt_set_error("quadric %d: textured materials on spheres / disks are outside the hot-path scope (triangle meshes only)", q); return nullptr; }
+        }
+    }
     int ndev = hpt_device_count();
     if (ndev <= 0) { hpt_set_error("no HIP device available (hipGetDeviceCount) — the path tracer has no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev) { hpt_set_error("device %d out of range (have %d)", device, ndev); return nullptr; }
@@ -123,10 +141,12 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.materials = upload(s, fs.materials.data(), fs.materials.size(), &ok);
     s->d.lights = upload(s, desc->lights, (size_t)desc->n_lights, &ok);
     s->d.fpool = upload(s, fs.fpool.data(), fs.fpool.size(), &ok);
-    s->d.ipool = upload(s, desc->ipool, (size_t)desc->n_i, &ok);
+    s->d.ipool = upload(s, fs.ipool.data(), fs.ipool.size(), &ok);
+    s->d.textures = upload(s, desc->textures, (size_t)desc->n_textures, &ok);
     s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
+    s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
     s->inst_xf = nullptr; s->inst_xf_lanes = 0;
     if (desc->n_instances > 0) {       // 12 floats (3x4) x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
         s->inst_xf_lanes = (size_t)s->n_cus * 4 * HPT_BLOCK;
@@ -135,11 +155,21 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         else ok = false;
     }
     s->mats = 0; s->n_materials = desc->n_materials;
+    s->has_specular = false;
+    bool ext = desc->n_textures > 0;
     for (int m = 0; m < desc->n_materials; ++m) {
-        int k = desc->materials[m].kind;
+        const hpt_material &ma = desc->materials[m];
+        const int k = ma.kind;
         s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
                  : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
+        if (k == HPT_MAT_GLASS || k == HPT_MAT_MIRROR) { ext = true; s->has_specular = true; }
+        if (k == HPT_MAT_MEASURED_REGULAR || (k == HPT_MAT_MATTE && ma.sigma != 0.f)) ext = true;
+        for (int t = 0; t < HPT_N_TEXSLOTS; ++t) if (ma.tex[t] >= 0) ext = true;
     }
+    for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0) ext = true;
+    for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
+    // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
+    if (ext) s->mats = MATS_FULL;
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
     // what every frame needs besides the film: allocated once, so that a render call neither allocates nor frees (hipFree synchronises the device)
@@ -195,6 +225,12 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
     }
     rp->cam = *cam;
+    {   // PerspectiveCamera ctor (cameras/perspective.cpp:46-48): dxCamera = RasterToCamera(1,0,0) - RasterToCamera(0,0,0), same float operations
+        const f3 o = xf_point(cam->raster_to_camera, mk3(0, 0, 0));
+        rp->dx_camera = xf_point(cam->raster_to_camera, mk3(1, 0, 0)) - o;
+        rp->dy_camera = xf_point(cam->raster_to_camera, mk3(0, 1, 0)) - o;
+        rp->diff_scale = 1.f / sqrtf((float)rd->spp);
+    }
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
@@ -426,6 +462,14 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.next_item = d_scr->next_item;
     a.counters = &d_scr->wc;
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
+    if ((s->mats & MATS_EXT) && (replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT)) {
+        hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel with a production sampler (MT_REPLAY and the wavefront pipeline cover the round-1 feature set)");
+        return HPT_E_UNSUPPORTED;
+    }
+    if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH) {
+        hpt_set_error("the direct-lighting integrator's specular recursion (core/integrator.cpp:177-258) is not on the device: glass / mirror scenes render with the path integrator");
+        return HPT_E_UNSUPPORTED;
+    }
     hipError_t e = hipSuccess;
     // configuration: pinned by HPT_TUNE, else tuned once per scene by the first job big enough to amortise the probe
     int cfg = tune_forced();

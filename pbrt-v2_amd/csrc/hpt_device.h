@@ -262,9 +262,13 @@ struct DMesh {
     int64_t n_off, uv_off, idx_off; // into fpool / ipool (n_off, uv_off: -1 = absent)
     int32_t prim_base;              // global primitive id of triangle 0
     int32_t material, arealight, flip; // flip = reverse_orientation ^ swaps_handedness
-    int32_t instance, pad;          // animated instance the mesh belongs to, or -1
+    int32_t instance, alpha_tex;    // animated instance the mesh belongs to, or -1; 1 + float texture of TriangleMesh::alphaTexture, 0 = none
     float o2w_inv[12];              // rows 0..2 of ObjectToWorld->mInv (for normals)
+    int64_t p_off;                  // vertex positions in fpool (area-light sampling addresses triangles by (mesh, triangle))
+    int32_t flip_ro, pad3;          // Shape::ReverseOrientation alone (Triangle::Sample flips its normal by it, trianglemesh.cpp:455)
 };
+#define HPT_TRI_ALPHA_BIT 0x40000000   /* set in a triangle record's mesh word when its mesh has an alpha texture */
+#define HPT_TRI_MESH_MASK 0x3fffffff
 struct DScene {
     const f4 *nodes;
     const f4 *tris;
@@ -276,6 +280,8 @@ struct DScene {
     const int32_t *ipool;
     const hpt_instance *instances;  // animated instances (TransformedPrimitive), tested after the world BVH
     const int32_t *inst_root;       // root node of each instance's own BVH (-1: empty)
+    const hpt_texture *textures;    // texture table (include/hpt.h); image pyramids in fpool
+    const float *ewa_lut;           // MIPMap::weightLut (core/mipmap.h:192-200), 128 floats computed by the host's libm
     int32_t n_tris, n_quadrics, n_lights, n_nodes, n_instances, world_root;
 };
 
@@ -541,7 +547,10 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     ts.invd = mk3(fminf(fmaxf(1.f / ray.d.x, -big), big), fminf(fmaxf(1.f / ray.d.y, -big), big), fminf(fmaxf(1.f / ray.d.z, -big), big));
 }
 
-template <bool COUNT>
+// TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:190-195, 246-276): a hit where the mesh's alpha texture evaluates to 0 is no hit
+// (defined with the textures below; only the MATS_EXT kernels instantiate the ALPHA walk)
+HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2);
+template <bool COUNT, bool ALPHA = false>
 HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
     if (ts.node >= 0) { // interior: one 64-byte node fetch, two slab tests, near child first, far child stacked
         const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
@@ -571,6 +580,7 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
             if (COUNT) cnt->tris++;
             float t, b1, b2;
             if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
+                if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
                 ts.hit.prim = (int32_t)(first + k);
                 if (ts.anyhit) { stop = true; break; }
                 ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
@@ -590,12 +600,12 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
 // xf_cache (optional): this lane's column of the per-path instance-transform cache — WorldToPrimitive of every instance
 // interpolated at the path's time, 12 floats (3x4) an instance, element j of instance k at xf_cache[(12 k + j) * xf_stride]
 // (filled by the path kernel once per camera sample; every ray of the path carries the same time, geometry.h:329-332).
-template <bool COUNT, bool INST>
+template <bool COUNT, bool INST, bool ALPHA = false>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
                      const float *xf_cache = nullptr, int64_t xf_stride = 0) {
     TravState ts;
     trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
-    while (!ts.done()) trav_step<COUNT>(sc, ts, ray, stack, stride, cnt);
+    while (!ts.done()) trav_step<COUNT, ALPHA>(sc, ts, ray, stack, stride, cnt);
     *hit = ts.hit;
     if (anyhit && hit->prim >= 0) return true;
     if (INST) for (int k = 0; k < sc.n_instances; ++k) {
@@ -609,7 +619,7 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
         trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
-        while (!t2.done()) trav_step<COUNT>(sc, t2, r2, stack, stride, cnt);
+        while (!t2.done()) trav_step<COUNT, ALPHA>(sc, t2, r2, stack, stride, cnt);
         if (t2.hit.prim >= 0) {
             *hit = t2.hit; hit->inst = k;
             ray.maxt = r2.maxt;
@@ -622,12 +632,19 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
 // ---- shading geometry + BSDF -------------------------------------------------------------------
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16,
        BSDF_ALL = 31, BSDF_ALL_NOSPEC = 15 };
-enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFACET_COND = 4, BX_FRESNELBLEND = 5 };
+enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFACET_COND = 4, BX_FRESNELBLEND = 5,
+       BX_OREN_NAYAR = 6,   // exponent = A, ey = B (reflection.h:371-378)
+       BX_SPEC_REFL = 7,    // R; exponent = index of the FresnelDielectric(1, index), 0 = FresnelNoOp
+       BX_SPEC_TRANS = 8,   // R = T; exponent = index (etai = 1, etat = index)
+       BX_REGULAR = 9 };    // RegularHalfangleBRDF over mat->rh_*
 
 // Material feature bits: the path kernel is instantiated per set of BxDF families a scene can need,
 // so a scene of matte + plastic surfaces does not carry the registers and code of the measured-BRDF
 // kd-tree walk, the conductor Fresnel or the anisotropic substrate (hpt_kernels_*.hip).
-enum { MATS_PLASTIC = 1, MATS_MEASURED = 2, MATS_METAL = 4, MATS_SUBSTRATE = 8, MATS_ALL = 15 };
+// MATS_EXT: everything round 2 added — Oren-Nayar, specular lobes (glass, mirror), the regular half-angle BRDF, textures with ray
+// differentials and bump mapping, alpha-textured triangles, triangle-mesh emitters.  Its own kernel set (hpt_kernels_ext.hip): the
+// scenes that need none of it keep the lean kernels.
+enum { MATS_PLASTIC = 1, MATS_MEASURED = 2, MATS_METAL = 4, MATS_SUBSTRATE = 8, MATS_ALL = 15, MATS_EXT = 16, MATS_FULL = 31 };
 
 // BSDF value type (replaces the arena-allocated BSDF + BxDF objects of core/reflection.h:150-191)
 struct Bsdf {
@@ -641,7 +658,11 @@ struct Bsdf {
     const hpt_material *mat;
     HPT_MFN int kind(int i) const { return i == 0 ? kind0 : kind1; }
     HPT_MFN f3 R(int i) const { return i == 0 ? R0 : R1; }
-    HPT_MFN int type(int i) const { return kind(i) == BX_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE) : (BSDF_REFLECTION | BSDF_GLOSSY); }
+    HPT_MFN int type(int i) const {
+        const int k = kind(i);
+        return (k == BX_LAMBERT || k == BX_OREN_NAYAR) ? (BSDF_REFLECTION | BSDF_DIFFUSE) : k == BX_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
+             : k == BX_SPEC_TRANS ? (BSDF_TRANSMISSION | BSDF_SPECULAR) : (BSDF_REFLECTION | BSDF_GLOSSY);
+    }
     HPT_MFN f3 w2l(f3 v) const { return mk3(dot(v, sn), dot(v, tn), dot(v, nn)); }
     HPT_MFN f3 l2w(f3 v) const {
         return mk3(sn.x * v.x + tn.x * v.y + nn.x * v.z, sn.y * v.x + tn.y * v.y + nn.y * v.z, sn.z * v.x + tn.z * v.y + nn.z * v.z);
@@ -903,10 +924,52 @@ HPT_FN void aniso_sample(float ex, float ey, f3 wo, f3 *wi, float u1, float u2, 
     *pdf = aniso_pdf_wh(ex, ey, wo, wh);
 }
 HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy);
+HPT_FN float cos_phi(f3 w) { float st = sin_theta(w); if (st == 0.f) return 1.f; return clampf(w.x / st, -1.f, 1.f); }   // reflection.h:86-90
+HPT_FN float sin_phi(f3 w) { float st = sin_theta(w); if (st == 0.f) return 0.f; return clampf(w.y / st, -1.f, 1.f); }   // :93-97
+// RegularHalfangleBRDF::f (core/reflection.cpp:275-308): a table lookup in half-angle / difference-angle coordinates
+HPT_FN f3 regular_halfangle_f(const DScene &sc, const hpt_material *m, f3 WO, f3 WI) {
+    f3 wo = WO, wi = WI;
+    f3 wh = wo + wi;
+    if (wh.z < 0.f) { wo = -wo; wi = -wi; wh = -wh; }
+    if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return S(0.f);
+    wh = normalize(wh);
+    float whTheta = spherical_theta(wh);
+    float whCosPhi = cos_phi(wh), whSinPhi = sin_phi(wh);
+    float whCosTheta = wh.z, whSinTheta = sin_theta(wh);
+    f3 whx = mk3(whCosPhi * whCosTheta, whSinPhi * whCosTheta, -whSinTheta);
+    f3 why = mk3(-whSinPhi, whCosPhi, 0);
+    f3 wd = mk3(dot(wi, whx), dot(wi, why), dot(wi, wh));
+    float wdTheta = spherical_theta(wd), wdPhi = spherical_phi(wd);
+    if (wdPhi > HPT_PI) wdPhi -= HPT_PI;
+    const int nH = m->rh_n_theta_h, nD = m->rh_n_theta_d, nP = m->rh_n_phi_d;
+    int ih = (int)(sqrtf(maxf(0.f, whTheta / (HPT_PI / 2.f))) / 1.f * nH); ih = ih < 0 ? 0 : ih > nH - 1 ? nH - 1 : ih;
+    int id = (int)(wdTheta / (HPT_PI / 2.f) * nD); id = id < 0 ? 0 : id > nD - 1 ? nD - 1 : id;
+    int ip = (int)(wdPhi / HPT_PI * nP); ip = ip < 0 ? 0 : ip > nP - 1 ? nP - 1 : ip;
+    const float *v = sc.fpool + m->rh_off + 3 * (int64_t)(ip + nP * (id + ih * nD));
+    return mk3(v[0], v[1], v[2]);
+}
 template <int MATS>
 HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack ls) {
     int kind = b.kind(i);
     if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
+    if (MATS & MATS_EXT) {
+        if (kind == BX_SPEC_REFL || kind == BX_SPEC_TRANS) return S(0.f);   // reflection.h:313-315, 340-342
+        if (kind == BX_REGULAR) return regular_halfangle_f(sc, b.mat, wo, wi);
+        if (kind == BX_OREN_NAYAR) {                                  // OrenNayar::f, reflection.cpp:178-201
+            float sinthetai = sin_theta(wi), sinthetao = sin_theta(wo);
+            float maxcos = 0.f;
+            if ((double)sinthetai > 1e-4 && (double)sinthetao > 1e-4) {
+                float sinphii = sin_phi(wi), cosphii = cos_phi(wi);
+                float sinphio = sin_phi(wo), cosphio = cos_phi(wo);
+                float dcos = cosphii * cosphio + sinphii * sinphio;
+                maxcos = maxf(0.f, dcos);
+            }
+            float sinalpha, tanbeta;
+            if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sinalpha = sinthetao; tanbeta = sinthetai / abs_cos_theta(wi); }
+            else { sinalpha = sinthetai; tanbeta = sinthetao / abs_cos_theta(wo); }
+            return (b.R(i) * HPT_INV_PI) * (b.exponent + b.ey * maxcos * sinalpha * tanbeta);
+        }
+    }
     if ((MATS & MATS_PLASTIC) && kind == BX_MICROFACET) {            // :211-222
         float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
         if (cosThetaI == 0.f || cosThetaO == 0.f) return S(0.f);
@@ -953,6 +1016,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
 }
 template <int MATS>
 HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
+    if ((MATS & MATS_EXT) && (b.kind(i) == BX_SPEC_REFL || b.kind(i) == BX_SPEC_TRANS)) return 0.f;   // reflection.h:318-320, 345-347
     if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Pdf (reflection.cpp:465-468)
         if (!same_hemisphere(wo, wi)) return 0.f;
         return .5f * (abs_cos_theta(wi) * HPT_INV_PI + aniso_pdf_wh(b.exponent, b.ey, wo, normalize(wo + wi)));
@@ -986,8 +1050,32 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
 // BSDF::Sample_f (reflection.cpp:555-566) discards that value for every non-specular BxDF and re-evaluates f
 // over all matching lobes — and none of the BxDFs on this path is specular — so the value is not computed here
 // (for the measured BRDF it would be a second kd-tree query per sample).
+// (a SPECULAR lobe is the exception: its Sample_f value is the one BSDF::Sample_f returns — *fspec)
 template <int MATS>
-HPT_FN void bxdf_sample_dir(const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf) {
+HPT_FN void bxdf_sample_dir(const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, f3 *fspec) {
+    if ((MATS & MATS_EXT) && b.kind(i) == BX_SPEC_REFL) {           // SpecularReflection::Sample_f, reflection.cpp:138-145
+        *wi = mk3(-wo.x, -wo.y, wo.z);
+        *pdf = 1.f;
+        const float F = b.exponent > 0.f ? fresnel_dielectric(wo.z, 1.f, b.exponent) : 1.f;    // FresnelDielectric(1, ior) / FresnelNoOp
+        *fspec = sdivf(smul(S(F), b.R(i)), abs_cos_theta(*wi));
+        return;
+    }
+    if ((MATS & MATS_EXT) && b.kind(i) == BX_SPEC_TRANS) {          // SpecularTransmission::Sample_f, reflection.cpp:148-170
+        const bool entering = wo.z > 0.f;
+        float ei = 1.f, et = b.exponent;
+        if (!entering) { float t = ei; ei = et; et = t; }
+        const float sini2 = sin_theta2(wo);
+        const float eta = ei / et;
+        const float sint2 = eta * eta * sini2;
+        if (sint2 >= 1.f) { *fspec = S(0.f); return; }               // total internal reflection (pdf stays 0)
+        float cost = sqrtf(maxf(0.f, 1.f - sint2));
+        if (entering) cost = -cost;
+        *wi = mk3(eta * -wo.x, eta * -wo.y, cost);
+        *pdf = 1.f;
+        const float F = fresnel_dielectric(wo.z, 1.f, b.exponent);
+        *fspec = sdivf(smul(S(1.f - F), b.R(i)), abs_cos_theta(*wi));
+        return;
+    }
     if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Sample_f (reflection.cpp:446-462)
         if (u1 < .5f) {
             u1 = 2.f * u1;
@@ -1046,7 +1134,7 @@ HPT_FN float bsdf_pdf(const Bsdf &b, f3 woW, f3 wiW, int flags) {
 // pdf averaged over the matching lobes, sampled type; false = the reference returns black here.
 template <int MATS>
 HPT_FN bool bsdf_sample_dir(const Bsdf &b, f3 woW, f3 *wo_l, f3 *wi_l, f3 *wiW, float u1, float u2, float uComp, float *pdf,
-                            int flags, int *sampledType) {
+                            int flags, int *sampledType, f3 *fspec = nullptr) {
     int matching = 0;
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags)) ++matching;
     if (matching == 0) { *pdf = 0.f; *sampledType = 0; return false; }
@@ -1056,7 +1144,9 @@ HPT_FN bool bsdf_sample_dir(const Bsdf &b, f3 woW, f3 *wo_l, f3 *wi_l, f3 *wiW, 
     for (int i = 0; i < b.n; ++i) if (bx_match(b, i, flags) && count-- == 0) { sel = i; break; }
     f3 wo = b.w2l(woW), wi = S(0.f);
     *pdf = 0.f;
-    bxdf_sample_dir<MATS>(b, sel, wo, &wi, u1, u2, pdf);
+    f3 fs = S(0.f);
+    bxdf_sample_dir<MATS>(b, sel, wo, &wi, u1, u2, pdf, &fs);
+    if (fspec) *fspec = fs;
     if (*pdf == 0.f) { *sampledType = 0; return false; }
     int stype = b.type(sel);
     *sampledType = stype;
@@ -1080,8 +1170,9 @@ HPT_FN f3 bsdf_f_local(const DScene &sc, const Bsdf &b, f3 wo, f3 wi, f3 woW, f3
 template <int MATS>
 HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, float u1, float u2, float uComp, float *pdf,
                         int flags, int *sampledType, LaneStack ls) {
-    f3 wo, wi;
-    if (!bsdf_sample_dir<MATS>(b, woW, &wo, &wi, wiW, u1, u2, uComp, pdf, flags, sampledType)) return S(0.f);
+    f3 wo, wi, fs;
+    if (!bsdf_sample_dir<MATS>(b, woW, &wo, &wi, wiW, u1, u2, uComp, pdf, flags, sampledType, &fs)) return S(0.f);
+    if ((MATS & MATS_EXT) && (*sampledType & BSDF_SPECULAR)) return fs;             // reflection.cpp:555: a specular lobe's own value
     return bsdf_f_local<MATS>(sc, b, wo, wi, woW, *wiW, flags, ls);
 }
 // A BSDF made of the measured lobe alone (materials/measured.cpp:121-131): its f() is a kd-tree query, which the
@@ -1095,6 +1186,261 @@ HPT_FN bool bsdf_query_point(const Bsdf &b, f3 wo, f3 wi, f3 woW, f3 wiW, int fl
     if (!bx_match(b, 0, flags)) return false;
     *q = irreg_point(wo, wi);
     return true;
+}
+
+// ---- textures (MATS_EXT kernels only) ------------------------------------------------------------------------------
+// The full DifferentialGeometry of core/diffgeom.h: what texture lookups (u, v and their screen-space derivatives) and bump mapping
+// (dpdv, dndu, dndv) need on top of the {p, nn, dpdu} the untextured kernels carry.
+struct DGeomX { f3 p, nn, dpdu, dpdv, dndu, dndv, dpdx, dpdy; float u, v, dudx, dvdx, dudy, dvdy; };
+HPT_FN int mod_i(int a, int b);
+struct TexV { float c[3]; };
+// MIPMap<T>::Texel (core/mipmap.h:204-223).  Level l of a pyramid starts right after level l - 1 (include/hpt.h).
+HPT_FN void mip_level(const hpt_texture &t, int level, int64_t *off, int *w, int *h) {
+    int64_t o = t.pyr_off; int ww = t.width, hh = t.height;
+    for (int l = 0; l < level; ++l) { o += (int64_t)ww * hh * t.channels; ww = ww > 1 ? ww / 2 : 1; hh = hh > 1 ? hh / 2 : 1; }
+    *off = o; *w = ww; *h = hh;
+}
+HPT_FN TexV mip_texel(const DScene &sc, const hpt_texture &t, int64_t off, int w, int h, int si, int ti) {
+    TexV r; r.c[0] = r.c[1] = r.c[2] = 0.f;
+    if (t.wrap == HPT_WRAP_REPEAT) { si = mod_i(si, w); ti = mod_i(ti, h); }
+    else if (t.wrap == HPT_WRAP_CLAMP) { si = si < 0 ? 0 : si > w - 1 ? w - 1 : si; ti = ti < 0 ? 0 : ti > h - 1 ? h - 1 : ti; }
+    else if (si < 0 || si >= w || ti < 0 || ti >= h) return r;
+    const float *px = sc.fpool + off + ((int64_t)ti * w + si) * t.channels;
+    r.c[0] = px[0];
+    if (t.channels == 3) { r.c[1] = px[1]; r.c[2] = px[2]; }
+    return r;
+}
+HPT_FN TexV mip_triangle(const DScene &sc, const hpt_texture &t, int level, float s, float tt) {     // :258-269
+    level = level < 0 ? 0 : level > t.levels - 1 ? t.levels - 1 : level;
+    int64_t off; int w, h;
+    mip_level(t, level, &off, &w, &h);
+    s = s * w - 0.5f;
+    tt = tt * h - 0.5f;
+    const int s0 = (int)floorf(s), t0 = (int)floorf(tt);
+    const float ds = s - s0, dt = tt - t0;
+    const TexV a = mip_texel(sc, t, off, w, h, s0, t0), b = mip_texel(sc, t, off, w, h, s0, t0 + 1);
+    const TexV c = mip_texel(sc, t, off, w, h, s0 + 1, t0), d = mip_texel(sc, t, off, w, h, s0 + 1, t0 + 1);
+    TexV r;
+    for (int k = 0; k < 3; ++k) r.c[k] = (((1.f - ds) * (1.f - dt)) * a.c[k] + ((1.f - ds) * dt) * b.c[k]) + (ds * (1.f - dt)) * c.c[k] + (ds * dt) * d.c[k];
+    return r;
+}
+HPT_FN float log2_pbrt(float x) { const float invLog2 = 1.f / logf(2.f); return logf(x) * invLog2; }    // pbrt.h:255-258
+HPT_FN TexV mip_ewa(const DScene &sc, const hpt_texture &t, int level, float s, float tt, float ds0, float dt0, float ds1, float dt1) {   // :317-366
+    int64_t off; int w, h;
+    if (level >= t.levels) { mip_level(t, t.levels - 1, &off, &w, &h); return mip_texel(sc, t, off, w, h, 0, 0); }
+    mip_level(t, level, &off, &w, &h);
+    s = s * w - 0.5f;
+    tt = tt * h - 0.5f;
+    ds0 *= w; dt0 *= h; ds1 *= w; dt1 *= h;
+    float A = dt0 * dt0 + dt1 * dt1 + 1;
+    float B = -2.f * (ds0 * dt0 + ds1 * dt1);
+    float C = ds0 * ds0 + ds1 * ds1 + 1;
+    const float invF = 1.f / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    const float det = -B * B + 4.f * A * C;
+    const float invDet = 1.f / det;
+    const float uSqrt = sqrtf(det * C), vSqrt = sqrtf(A * det);
+    const int s0 = (int)ceilf(s - 2.f * invDet * uSqrt), s1 = (int)floorf(s + 2.f * invDet * uSqrt);
+    const int t0 = (int)ceilf(tt - 2.f * invDet * vSqrt), t1 = (int)floorf(tt + 2.f * invDet * vSqrt);
+    TexV sum; sum.c[0] = sum.c[1] = sum.c[2] = 0.f;
+    float sumWts = 0.f;
+    for (int it = t0; it <= t1; ++it) {
+        const float tc = it - tt;
+        for (int is = s0; is <= s1; ++is) {
+            const float ss = is - s;
+            const float r2 = A * ss * ss + B * ss * tc + C * tc * tc;
+            if (r2 < 1.f) {
+                int li = (int)(r2 * 128); if (li > 127) li = 127;
+                const float weight = sc.ewa_lut[li];
+                const TexV tx = mip_texel(sc, t, off, w, h, is, it);
+                for (int k = 0; k < 3; ++k) sum.c[k] += tx.c[k] * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    for (int k = 0; k < 3; ++k) sum.c[k] = sum.c[k] / sumWts;
+    return sum;
+}
+// MIPMap::Lookup(s, t, ds0, dt0, ds1, dt1) (core/mipmap.h:272-314) and the trilinear Lookup(s, t, width) (:238-255)
+HPT_FN TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s, float tt, float ds0, float dt0, float ds1, float dt1) {
+    if (t.do_trilinear) {
+        const float width = 2.f * maxf(maxf(fabsf(ds0), fabsf(dt0)), maxf(fabsf(ds1), fabsf(dt1)));
+        const float level = t.levels - 1 + log2_pbrt(maxf(width, 1e-8f));
+        if (level < 0) return mip_triangle(sc, t, 0, s, tt);
+        if (level >= t.levels - 1) { int64_t off; int w, h; mip_level(t, t.levels - 1, &off, &w, &h); return mip_texel(sc, t, off, w, h, 0, 0); }
+        const int iLevel = (int)floorf(level);
+        const float delta = level - iLevel;
+        const TexV a = mip_triangle(sc, t, iLevel, s, tt), b = mip_triangle(sc, t, iLevel + 1, s, tt);
+        TexV r; for (int k = 0; k < 3; ++k) r.c[k] = (1.f - delta) * a.c[k] + delta * b.c[k];
+        return r;
+    }
+    if (ds0 * ds0 + dt0 * dt0 < ds1 * ds1 + dt1 * dt1) { float x = ds0; ds0 = ds1; ds1 = x; x = dt0; dt0 = dt1; dt1 = x; }
+    const float majorLength = sqrtf(ds0 * ds0 + dt0 * dt0);
+    float minorLength = sqrtf(ds1 * ds1 + dt1 * dt1);
+    if (minorLength * t.max_aniso < majorLength && minorLength > 0.f) {
+        const float scale = majorLength / (minorLength * t.max_aniso);
+        ds1 *= scale; dt1 *= scale; minorLength *= scale;
+    }
+    if (minorLength == 0.f) return mip_triangle(sc, t, 0, s, tt);
+    const float lod = maxf(0.f, t.levels - 1.f + log2_pbrt(minorLength));
+    const int ilod = (int)floorf(lod);
+    const float d = lod - ilod;
+    const TexV a = mip_ewa(sc, t, ilod, s, tt, ds0, dt0, ds1, dt1), b = mip_ewa(sc, t, ilod + 1, s, tt, ds0, dt0, ds1, dt1);
+    TexV r; for (int k = 0; k < 3; ++k) r.c[k] = (1.f - d) * a.c[k] + d * b.c[k];
+    return r;
+}
+// Texture<T>::Evaluate(dg): constant, image map through a UVMapping2D (textures/imagemap.cpp:94-101, core/texture.cpp:88-98), scale
+// (textures/scale.h:51-53), mix (textures/mix.h:51-55).  Operands precede a texture in the table (hpt_validate_desc), and the scene is
+// refused above HPT_TEX_DEPTH levels of nesting (hpt_api.hip), so the recursion is a template of bounded depth, not a device call stack.
+#define HPT_TEX_DEPTH 3
+template <int DEPTH>
+HPT_FN TexV tex_eval(const DScene &sc, int id, const DGeomX &dg) {
+    const hpt_texture &t = sc.textures[id];
+    TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
+    if (t.kind == HPT_TEX_CONSTANT) return r;
+    if (t.kind == HPT_TEX_IMAGEMAP)
+        return mip_lookup(sc, t, t.su * dg.u + t.du, t.sv * dg.v + t.dv, t.su * dg.dudx, t.sv * dg.dvdx, t.su * dg.dudy, t.sv * dg.dvdy);
+    if (DEPTH > 0) {
+        TexV a = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex1, dg), b = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex2, dg);
+        if (sc.textures[t.tex1].channels < t.channels) a.c[1] = a.c[2] = a.c[0];   // a float operand of a spectrum texture acts on every channel
+        if (sc.textures[t.tex2].channels < t.channels) b.c[1] = b.c[2] = b.c[0];
+        if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k]; return r; }
+        const float amt = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
+        for (int k = 0; k < 3; ++k) r.c[k] = (1.f - amt) * a.c[k] + amt * b.c[k];
+    }
+    return r;
+}
+HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_eval<HPT_TEX_DEPTH>(sc, id, dg).c[0]; }
+HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_eval<HPT_TEX_DEPTH>(sc, id, dg); return mk3(v.c[0], v.c[1], v.c[2]); }
+
+HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2) {
+    const DMesh &me = sc.meshes[mesh_word & HPT_TRI_MESH_MASK];
+    const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
+    float uv[3][2];
+    if (me.uv_off >= 0) {
+        const float *U = sc.fpool + me.uv_off;
+        for (int k = 0; k < 3; ++k) { uv[k][0] = U[2 * idx[k]]; uv[k][1] = U[2 * idx[k] + 1]; }
+    } else { uv[0][0] = 0.f; uv[0][1] = 0.f; uv[1][0] = 1.f; uv[1][1] = 0.f; uv[2][0] = 1.f; uv[2][1] = 1.f; }
+    const float b0 = 1 - b1 - b2;
+    DGeomX dg;
+    dg.u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+    dg.v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+    dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.f;          // dgLocal: a fresh DifferentialGeometry has no screen-space derivatives (diffgeom.cpp:50)
+    return tex_float(sc, me.alpha_tex - 1, dg) != 0.f;
+}
+
+// A ray's differentials (RayDifferential, core/geometry.h:322-381): only camera rays have them on this path
+struct RayDiff { bool has; f3 rxo, ryo, rxd, ryd; };
+HPT_FN bool solve2x2(float A00, float A01, float A10, float A11, float B0, float B1, float *x0, float *x1) {   // core/transform.cpp:39-49
+    const float det = A00 * A11 - A01 * A10;
+    if (fabsf(det) < 1e-10f) return false;
+    *x0 = (A11 * B0 - A01 * B1) / det;
+    *x1 = (A00 * B1 - A10 * B0) / det;
+    return !(*x0 != *x0 || *x1 != *x1);
+}
+// DifferentialGeometry::ComputeDifferentials (core/diffgeom.cpp:58-113)
+HPT_FN void compute_differentials(DGeomX *dg, const RayDiff &rd) {
+    dg->dudx = dg->dvdx = dg->dudy = dg->dvdy = 0.f;
+    dg->dpdx = dg->dpdy = S(0.f);
+    if (!rd.has) return;
+    const float d = -dot(dg->nn, dg->p);
+    const float tx = -(dot(dg->nn, rd.rxo) + d) / dot(dg->nn, rd.rxd);
+    if (tx != tx) return;
+    const f3 px = rd.rxo + rd.rxd * tx;
+    const float ty = -(dot(dg->nn, rd.ryo) + d) / dot(dg->nn, rd.ryd);
+    if (ty != ty) return;
+    const f3 py = rd.ryo + rd.ryd * ty;
+    dg->dpdx = px - dg->p;
+    dg->dpdy = py - dg->p;
+    int a0, a1;
+    if (fabsf(dg->nn.x) > fabsf(dg->nn.y) && fabsf(dg->nn.x) > fabsf(dg->nn.z)) { a0 = 1; a1 = 2; }
+    else if (fabsf(dg->nn.y) > fabsf(dg->nn.z)) { a0 = 0; a1 = 2; }
+    else { a0 = 0; a1 = 1; }
+    const float A00 = comp(dg->dpdu, a0), A01 = comp(dg->dpdv, a0), A10 = comp(dg->dpdu, a1), A11 = comp(dg->dpdv, a1);
+    const float Bx0 = comp(px, a0) - comp(dg->p, a0), Bx1 = comp(px, a1) - comp(dg->p, a1);
+    const float By0 = comp(py, a0) - comp(dg->p, a0), By1 = comp(py, a1) - comp(dg->p, a1);
+    if (!solve2x2(A00, A01, A10, A11, Bx0, Bx1, &dg->dudx, &dg->dvdx)) { dg->dudx = 0.f; dg->dvdx = 0.f; }
+    if (!solve2x2(A00, A01, A10, A11, By0, By1, &dg->dudy, &dg->dvdy)) { dg->dudy = 0.f; dg->dvdy = 0.f; }
+}
+// Material::Bump (core/material.cpp:46-85)
+HPT_FN void bump_geometry(const DScene &sc, int tex, f3 ngeom, const DGeomX &dgs, int flip, DGeomX *out) {
+    DGeomX e = dgs;
+    float du = .5f * (fabsf(dgs.dudx) + fabsf(dgs.dudy));
+    if (du == 0.f) du = .01f;
+    e.p = dgs.p + dgs.dpdu * du;
+    e.u = dgs.u + du;
+    e.nn = normalize(cross(dgs.dpdu, dgs.dpdv) + dgs.dndu * du);
+    const float uDisplace = tex_float(sc, tex, e);
+    float dv = .5f * (fabsf(dgs.dvdx) + fabsf(dgs.dvdy));
+    if (dv == 0.f) dv = .01f;
+    e.p = dgs.p + dgs.dpdv * dv;
+    e.u = dgs.u;
+    e.v = dgs.v + dv;
+    e.nn = normalize(cross(dgs.dpdu, dgs.dpdv) + dgs.dndv * dv);
+    const float vDisplace = tex_float(sc, tex, e);
+    const float displace = tex_float(sc, tex, dgs);
+    *out = dgs;
+    out->dpdu = (dgs.dpdu + dgs.nn * ((uDisplace - displace) / du)) + dgs.dndu * displace;
+    out->dpdv = (dgs.dpdv + dgs.nn * ((vDisplace - displace) / dv)) + dgs.dndv * displace;
+    out->nn = normalize(cross(out->dpdu, out->dpdv));
+    if (flip) out->nn = out->nn * -1.f;
+    if (dot(out->nn, ngeom) < 0.f) out->nn = -out->nn;          // Faceforward, geometry.h:594-596
+}
+// Material::GetBSDF with every parameter a Texture::Evaluate(dgs): the record's constant or the texture of its slot
+// (matte.cpp:42-63, plastic.cpp:42-66, measured.cpp:194-210, metal.cpp:51-68, substrate.cpp:42-58, glass.cpp:41-57, mirror.cpp:44-57)
+HPT_FN f3 mat_rgb(const DScene &sc, const hpt_material *m, int slot, const float *k, const DGeomX &dgs, bool clamp) {
+    if (m->tex[slot] < 0) return mk3(k[0], k[1], k[2]);      // (constants arrive Clamp()ed where the material clamps)
+    const f3 v = tex_rgb(sc, m->tex[slot], dgs);
+    return clamp ? sclamp0(v) : v;
+}
+HPT_FN float mat_float(const DScene &sc, const hpt_material *m, int slot, float k, const DGeomX &dgs) {
+    return m->tex[slot] < 0 ? k : tex_float(sc, m->tex[slot], dgs);
+}
+HPT_FN float blinn_exponent(float roughness) { float e = 1.f / roughness; if (e > 10000.f || e != e) e = 10000.f; return e; }   // reflection.h:424
+HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material *m, const DGeomX &dgs) {
+    b->mat = m;
+    if (m->kind == HPT_MAT_MATTE) {
+        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true);
+        const float sig = clampf(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->sigma, dgs), 0.f, 90.f);
+        if (!sblack(kd)) {
+            if (sig == 0.f) bsdf_push(b, BX_LAMBERT, kd);
+            else {                                                  // OrenNayar ctor, reflection.h:371-378
+                const float sigma = (HPT_PI / 180.f) * sig, sigma2 = sigma * sigma;
+                b->exponent = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                b->ey = 0.45f * sigma2 / (sigma2 + 0.09f);
+                bsdf_push(b, BX_OREN_NAYAR, kd);
+            }
+        }
+    } else if (m->kind == HPT_MAT_PLASTIC) {
+        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
+        if (!sblack(ks)) { b->exponent = blinn_exponent(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs)); bsdf_push(b, BX_MICROFACET, ks); }
+    } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
+        bsdf_push(b, BX_IRREG, S(0.f));
+    } else if (m->kind == HPT_MAT_MEASURED_REGULAR) {
+        bsdf_push(b, BX_REGULAR, S(0.f));
+    } else if (m->kind == HPT_MAT_METAL) {
+        b->exponent = blinn_exponent(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs));
+        bsdf_push(b, BX_MICROFACET_COND, mat_rgb(sc, m, HPT_TEXSLOT_KD, m->eta, dgs, false));
+        b->R1 = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->k, dgs, false);
+    } else if (m->kind == HPT_MAT_SUBSTRATE) {
+        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        const float u = mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->nu, dgs), v = mat_float(sc, m, HPT_TEXSLOT_ROUGH_V, m->nv, dgs);
+        if (!sblack(kd) || !sblack(ks)) {
+            b->exponent = blinn_exponent(u); b->ey = blinn_exponent(v);     // Anisotropic ctor (reflection.h:439-443): the same clamp
+            bsdf_push(b, BX_FRESNELBLEND, kd);
+            b->R1 = ks;
+        }
+    } else if (m->kind == HPT_MAT_GLASS) {
+        b->exponent = mat_float(sc, m, HPT_TEXSLOT_INDEX, m->index, dgs);
+        const f3 R = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true), T = mat_rgb(sc, m, HPT_TEXSLOT_KT, m->kt, dgs, true);
+        if (!sblack(R)) bsdf_push(b, BX_SPEC_REFL, R);
+        if (!sblack(T)) bsdf_push(b, BX_SPEC_TRANS, T);
+    } else if (m->kind == HPT_MAT_MIRROR) {
+        const f3 R = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        b->exponent = 0.f;                                          // FresnelNoOp
+        if (!sblack(R)) bsdf_push(b, BX_SPEC_REFL, R);
+    }
 }
 
 // Hit -> DifferentialGeometry -> shading geometry -> BSDF:
@@ -1119,7 +1465,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
     f4 a = tp[0], bb = tp[1], c = tp[2];
     f3 p1 = mk3(a.x, a.y, a.z), p2 = mk3(bb.x, bb.y, bb.z), p3 = mk3(c.x, c.y, c.z);
-    const DMesh &me = sc.meshes[as_int(a.w)];
+    const DMesh &me = sc.meshes[as_int(a.w) & HPT_TRI_MESH_MASK];
     int tri = as_int(bb.w);
     // hit inside an animated instance: redo the geometry in the instance's space with the transformed
     // ray, then carry p / nn / dpdu back to the world (core/primitive.cpp:104-117)
@@ -1195,6 +1541,115 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     }
     bsdf_frame(b, ns_nn, ns_dpdu, dg->nn);
     bsdf_add_material<MATS>(b, &sc.materials[me.material]);
+}
+
+// The same chain for the MATS_EXT kernels: the full DifferentialGeometry (u, v, dpdv, ray differentials of camera rays), dndu / dndv of
+// the interpolated normal (trianglemesh.cpp:334-355), Material::Bump and texture-valued material parameters.  Also reports the
+// geometric normal dg.nn (emitter facing test) — out of line: one copy for the extension, shadow-ray-free paths of the kernel.
+template <bool INST>
+HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float time, const Hit &hit, const RayDiff &rdiff, Bsdf *b, DGeom *dgo,
+                                     float *rayEps, int *arealight) {
+    Ray ray = wray;
+    DGeomX dg;
+    dg.dndu = dg.dndv = S(0.f);
+    const hpt_material *mat;
+    int flip;
+    DGeomX dgs;
+    if (hit.prim >= sc.n_tris) {
+        const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+        float t; DGeom d3;
+        quadric_intersect(q, ray, &t, &d3);           // (textures on quadrics are refused at scene creation: u, v, dpdv are not needed)
+        dg.p = d3.p; dg.nn = d3.nn; dg.dpdu = d3.dpdu; dg.dpdv = cross(d3.nn, d3.dpdu); dg.u = dg.v = 0.f;
+        compute_differentials(&dg, rdiff);
+        *rayEps = 5e-4f * hit.t;
+        *arealight = q.arealight;
+        mat = &sc.materials[q.material];
+        flip = q.reverse_orientation ^ q.swaps_handedness;
+        dgs = dg;
+    } else {
+        const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+        f4 a = tp[0], bb = tp[1], c = tp[2];
+        f3 p1 = mk3(a.x, a.y, a.z), p2 = mk3(bb.x, bb.y, bb.z), p3 = mk3(c.x, c.y, c.z);
+        const DMesh &me = sc.meshes[as_int(a.w) & HPT_TRI_MESH_MASK];
+        const int tri = as_int(bb.w);
+        Xf w2p;
+        const bool inInstance = INST && hit.inst >= 0;
+        if (inInstance) {
+            w2p = anim_interpolate(sc.instances[hit.inst], time, true);
+            ray.o = xf_point_affine(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);
+        }
+        const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
+        const int v0 = idx[0], v1 = idx[1], v2 = idx[2];
+        float uv[3][2];
+        if (me.uv_off >= 0) {
+            const float *U = sc.fpool + me.uv_off;
+            uv[0][0] = U[2 * v0]; uv[0][1] = U[2 * v0 + 1]; uv[1][0] = U[2 * v1]; uv[1][1] = U[2 * v1 + 1];
+            uv[2][0] = U[2 * v2]; uv[2][1] = U[2 * v2 + 1];
+        } else { uv[0][0] = 0.f; uv[0][1] = 0.f; uv[1][0] = 1.f; uv[1][1] = 0.f; uv[2][0] = 1.f; uv[2][1] = 1.f; }
+        const f3 e1 = p2 - p1, e2 = p3 - p1;
+        const float du1 = uv[0][0] - uv[2][0], du2 = uv[1][0] - uv[2][0];
+        const float dv1 = uv[0][1] - uv[2][1], dv2 = uv[1][1] - uv[2][1];
+        const f3 dp1 = p1 - p3, dp2 = p2 - p3;
+        const float determinant = du1 * dv2 - dv1 * du2;
+        f3 dpdu, dpdv;
+        if (determinant == 0.f) coordinate_system(normalize(cross(e2, e1)), &dpdu, &dpdv);
+        else {
+            const float invdet = 1.f / determinant;
+            dpdu = (dp1 * dv2 - dp2 * dv1) * invdet;
+            dpdv = (dp1 * (-du2) + dp2 * du1) * invdet;
+        }
+        const float b1 = hit.b1, b2 = hit.b2, b0 = 1 - b1 - b2;
+        dg.u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+        dg.v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+        flip = me.flip;
+        dg.p = ray_at(ray, hit.t); dg.dpdu = dpdu; dg.dpdv = dpdv;
+        dg.nn = normalize(cross(dpdu, dpdv));
+        if (flip) dg.nn = dg.nn * -1.f;
+        if (inInstance && !a34_is_identity(w2p.m)) {
+            dg.p = xf_point_affine(w2p.minv.m, dg.p);
+            dg.nn = normalize(xf_normal(w2p.m.m, dg.nn));
+            dg.dpdu = xf_vec(w2p.minv.m, dg.dpdu);
+            dg.dpdv = xf_vec(w2p.minv.m, dg.dpdv);
+        }
+        compute_differentials(&dg, rdiff);
+        *rayEps = 1e-3f * hit.t;
+        *arealight = me.arealight;
+        mat = &sc.materials[me.material];
+        dgs = dg;
+        if (me.n_off >= 0) {
+            float A00 = uv[1][0] - uv[0][0], A01 = uv[2][0] - uv[0][0], A10 = uv[1][1] - uv[0][1], A11 = uv[2][1] - uv[0][1];
+            float bb0, bb1 = 0.f, bb2 = 0.f;
+            if (!solve2x2(A00, A01, A10, A11, dg.u - uv[0][0], dg.v - uv[0][1], &bb1, &bb2)) bb0 = bb1 = bb2 = 1.f / 3.f;
+            else bb0 = 1.f - bb1 - bb2;
+            const float *N = sc.fpool + me.n_off;
+            const f3 n0 = mk3(N[3 * v0], N[3 * v0 + 1], N[3 * v0 + 2]);
+            const f3 n1 = mk3(N[3 * v1], N[3 * v1 + 1], N[3 * v1 + 2]);
+            const f3 n2 = mk3(N[3 * v2], N[3 * v2 + 1], N[3 * v2 + 2]);
+            const f3 nsum = (n0 * bb0 + n1 * bb1) + n2 * bb2;
+            float minv[12];
+            for (int k = 0; k < 12; ++k) minv[k] = inInstance ? w2p.m.m[k] : me.o2w_inv[k];
+            const f3 ns = normalize(xf_normal(minv, nsum));
+            f3 ss = normalize(dg.dpdu);
+            f3 ts = cross(ss, ns);
+            if (len2(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+            else coordinate_system(ns, &ss, &ts);
+            f3 dndu = S(0.f), dndv = S(0.f);
+            if (determinant != 0.f) {
+                const float invdet = 1.f / determinant;
+                const f3 dn1 = n0 - n2, dn2 = n1 - n2;
+                dndu = (dn1 * dv2 - dn2 * dv1) * invdet;
+                dndv = (dn1 * (-du2) + dn2 * du1) * invdet;
+            }
+            dgs.dpdu = ss; dgs.dpdv = ts;
+            dgs.nn = normalize(cross(ss, ts));
+            if (flip) dgs.nn = dgs.nn * -1.f;
+            dgs.dndu = xf_normal(minv, dndu); dgs.dndv = xf_normal(minv, dndv);
+        }
+    }
+    if (mat->tex[HPT_TEXSLOT_BUMP] >= 0) { DGeomX db; bump_geometry(sc, mat->tex[HPT_TEXSLOT_BUMP], dg.nn, dgs, flip, &db); dgs = db; }
+    dgo->p = dgs.p; dgo->nn = dg.nn; dgo->dpdu = dgs.dpdu;
+    bsdf_frame(b, dgs.nn, dgs.dpdu, dg.nn);
+    bsdf_add_material_ext(b, sc, mat, dgs);
 }
 
 // ---- lights ---------------------------------------------------------------------------------------
@@ -1287,7 +1742,61 @@ HPT_FN float quadric_pdf(const hpt_quadric &q, f3 p, f3 wi) { // Sphere::Pdf (sp
     if (pdf == HPT_INF || pdf == -HPT_INF) pdf = 0.f;
     return pdf;
 }
+// A triangle of an area light's shape set, addressed as (mesh, triangle in mesh) — hpt_flatten.cpp rewrites the set that way
+HPT_FN void set_tri_verts(const DScene &sc, int mesh, int tri, f3 *p1, f3 *p2, f3 *p3) {
+    const DMesh &me = sc.meshes[mesh];
+    const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
+    const float *P = sc.fpool + me.p_off;
+    *p1 = mk3(P[3 * idx[0]], P[3 * idx[0] + 1], P[3 * idx[0] + 2]);
+    *p2 = mk3(P[3 * idx[1]], P[3 * idx[1] + 1], P[3 * idx[1] + 2]);
+    *p3 = mk3(P[3 * idx[2]], P[3 * idx[2] + 1], P[3 * idx[2] + 2]);
+}
+// geometric normal of a triangle as Triangle::Intersect builds it: Normalize(Cross(dpdu, dpdv)) from the uv parameterisation, flipped
+// by orientation (trianglemesh.cpp:162-201, diffgeom.cpp:40-55)
+HPT_FN f3 tri_dg_normal(const DScene &sc, const DMesh &me, int tri, f3 p1, f3 p2, f3 p3) {
+    const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
+    float uv[3][2];
+    if (me.uv_off >= 0) {
+        const float *U = sc.fpool + me.uv_off;
+        for (int k = 0; k < 3; ++k) { uv[k][0] = U[2 * idx[k]]; uv[k][1] = U[2 * idx[k] + 1]; }
+    } else { uv[0][0] = 0.f; uv[0][1] = 0.f; uv[1][0] = 1.f; uv[1][1] = 0.f; uv[2][0] = 1.f; uv[2][1] = 1.f; }
+    const float du1 = uv[0][0] - uv[2][0], du2 = uv[1][0] - uv[2][0];
+    const float dv1 = uv[0][1] - uv[2][1], dv2 = uv[1][1] - uv[2][1];
+    const f3 dp1 = p1 - p3, dp2 = p2 - p3;
+    const float determinant = du1 * dv2 - dv1 * du2;
+    f3 dpdu, dpdv;
+    if (determinant == 0.f) coordinate_system(normalize(cross(p3 - p1, p2 - p1)), &dpdu, &dpdv);
+    else {
+        const float invdet = 1.f / determinant;
+        dpdu = (dp1 * dv2 - dp2 * dv1) * invdet;
+        dpdv = (dp1 * (-du2) + dp2 * du1) * invdet;
+    }
+    f3 nn = normalize(cross(dpdu, dpdv));
+    if (me.flip) nn = nn * -1.f;
+    return nn;
+}
+// Shape::Pdf(p, wi) for a triangle (core/shape.cpp:86-99): ray / triangle, then dist^2 / (|n . -wi| * Area)
+HPT_FN float set_tri_pdf(const DScene &sc, int mesh, int tri, float area, f3 p, f3 wi) {
+    f3 p1, p2, p3;
+    set_tri_verts(sc, mesh, tri, &p1, &p2, &p3);
+    Ray ray; ray.o = p; ray.d = wi; ray.mint = 1e-3f; ray.maxt = HPT_INF;
+    float t, b1, b2;
+    if (!tri_test(p1, p2, p3, ray, &t, &b1, &b2)) return 0.f;
+    const f3 nn = tri_dg_normal(sc, sc.meshes[mesh], tri, p1, p2, p3);
+    float pdf = dist2(p, ray_at(ray, t)) / (absdot(nn, -wi) * area);
+    if (pdf == HPT_INF || pdf == -HPT_INF) pdf = 0.f;
+    return pdf;
+}
+HPT_FN float quadric_pdf(const hpt_quadric &q, f3 p, f3 wi);
 HPT_FN_LIGHT float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
+    if (l.kind == HPT_LIGHT_DIFFUSE_AREA && l.quadric < 0) {       // ShapeSet::Pdf (core/light.cpp:157-162) over several shapes
+        const int32_t *ss = sc.ipool + l.set_off;
+        const float *areas = sc.fpool + l.set_area_off;
+        float pdf = 0.f;
+        for (int i = 0; i < l.set_n; ++i)
+            pdf += areas[i] * (ss[2 * i] < 0 ? quadric_pdf(sc.quadrics[ss[2 * i + 1]], p, wi) : set_tri_pdf(sc, ss[2 * i], ss[2 * i + 1], areas[i], p, wi));
+        return pdf / l.area;
+    }
     if (l.kind == HPT_LIGHT_DIFFUSE_AREA) { // ShapeSet::Pdf (core/light.cpp:157-162), one shape
         float pdf = 0.f;
         pdf += l.area * quadric_pdf(sc.quadrics[l.quadric], p, wi);
@@ -1312,7 +1821,7 @@ HPT_FN_LIGHT float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) 
 }
 // Light::Sample_L(p, pEpsilon, ls, ...) : point.cpp:50-57, diffuse.cpp:69-81, infinite.cpp:195-221.
 // Outputs wi, pdf and the shadow ray of the VisibilityTester (core/light.h:87-96).
-HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow) {
+HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow, float uComp = 0.f) {
     if (l.kind == HPT_LIGHT_POINT) {
         f3 lp = mk3(l.pos[0], l.pos[1], l.pos[2]);
         *wi = normalize(lp - p);
@@ -1322,8 +1831,25 @@ HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float
         return sdivf(mk3(l.intensity[0], l.intensity[1], l.intensity[2]), dist2(lp, p));
     }
     if (l.kind == HPT_LIGHT_DIFFUSE_AREA) {
-        const hpt_quadric &q = sc.quadrics[l.quadric];
-        f3 ns; f3 ps = quadric_sample(q, p, u0, u1, &ns);
+        f3 ns, ps;
+        if (l.quadric >= 0) ps = quadric_sample(sc.quadrics[l.quadric], p, u0, u1, &ns);
+        else {     // ShapeSet::Sample(p, ls, Ns) (core/light.cpp:143-147): Distribution1D::SampleDiscrete (montecarlo.h:99-107), then the shape's own Sample
+            const int32_t *ss = sc.ipool + l.set_off;
+            const float *cdf = sc.fpool + l.set_area_off + l.set_n;
+            int lo = 0, hi = l.set_n + 1;
+            while (lo < hi) { int mid = (lo + hi) / 2; if (uComp < cdf[mid]) hi = mid; else lo = mid + 1; }
+            int sn = lo - 1; if (sn < 0) sn = 0;
+            if (sn > l.set_n - 1) sn = l.set_n - 1;
+            if (ss[2 * sn] < 0) ps = quadric_sample(sc.quadrics[ss[2 * sn + 1]], p, u0, u1, &ns);
+            else {     // Triangle::Sample (trianglemesh.cpp:444-457) + UniformSampleTriangle (montecarlo.cpp:351-355)
+                f3 p1, p2, p3;
+                set_tri_verts(sc, ss[2 * sn], ss[2 * sn + 1], &p1, &p2, &p3);
+                const float su1 = sqrtf(u0), b1 = 1.f - su1, b2 = u1 * su1;
+                ps = (p1 * b1 + p2 * b2) + p3 * (1.f - b1 - b2);
+                ns = normalize(cross(p2 - p1, p3 - p1));
+                if (sc.meshes[ss[2 * sn]].flip_ro) ns = ns * -1.f;
+            }
+        }
         *wi = normalize(ps - p);
         *pdf = light_pdf(sc, l, p, *wi);
         float d = len(p - ps);
@@ -1367,6 +1893,40 @@ HPT_FN void camera_ray(const hpt_camera &cam, float imageX, float imageY, float 
     }
     ray->o = xf_point(cam.camera_to_world, ray->o);
     ray->d = xf_vec(cam.camera_to_world, ray->d);
+}
+
+// Ray differentials of a camera ray (cameras/perspective.cpp:105-131) after ray.ScaleDifferentials(1 / sqrt(spp))
+// (renderers/samplerrenderer.cpp:190, core/geometry.h:370-375).  dxc / dyc: PerspectiveCamera::dxCamera, dyCamera (ctor, :46-48);
+// `ray` is the world-space camera ray camera_ray() made from the same sample.
+HPT_FN void camera_ray_differentials(const hpt_camera &cam, f3 dxc, f3 dyc, float scale, float imageX, float imageY, float lensU, float lensV,
+                                     const Ray &ray, RayDiff *rd) {
+    const f3 Pcamera = xf_point(cam.raster_to_camera, mk3(imageX, imageY, 0));
+    f3 rxo = S(0.f), ryo = S(0.f), rxd, ryd;
+    if (cam.lens_radius > 0.f) {
+        float lu, lv;
+        concentric_sample_disk(lensU, lensV, &lu, &lv);
+        lu *= cam.lens_radius; lv *= cam.lens_radius;
+        const f3 dx = normalize(Pcamera + dxc);
+        float ft = cam.focal_distance / dx.z;
+        f3 pFocus = dx * ft;
+        rxo = mk3(lu, lv, 0.f);
+        rxd = normalize(pFocus - rxo);
+        const f3 dy = normalize(Pcamera + dyc);
+        ft = cam.focal_distance / dy.z;
+        pFocus = dy * ft;
+        ryo = mk3(lu, lv, 0.f);
+        ryd = normalize(pFocus - ryo);
+    } else {
+        rxd = normalize(Pcamera + dxc);
+        ryd = normalize(Pcamera + dyc);
+    }
+    rxo = xf_point(cam.camera_to_world, rxo); ryo = xf_point(cam.camera_to_world, ryo);
+    rxd = xf_vec(cam.camera_to_world, rxd); ryd = xf_vec(cam.camera_to_world, ryd);
+    rd->has = true;
+    rd->rxo = ray.o + (rxo - ray.o) * scale;
+    rd->ryo = ray.o + (ryo - ray.o) * scale;
+    rd->rxd = ray.d + (rxd - ray.d) * scale;
+    rd->ryd = ray.d + (ryd - ray.d) * scale;
 }
 
 } // namespace hpt

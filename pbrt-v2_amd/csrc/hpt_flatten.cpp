@@ -2,6 +2,7 @@
 #include "hpt_flatten.h"
 
 #include <chrono>
+#include <cmath>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -47,7 +48,8 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         dm.n_off = me.n_off; dm.uv_off = me.uv_off; dm.idx_off = me.idx_off;
         dm.prim_base = (int32_t)base; dm.material = me.material; dm.arealight = me.arealight;
         dm.flip = me.reverse_orientation ^ me.swaps_handedness;
-        dm.instance = me.instance; dm.pad = 0;
+        dm.instance = me.instance; dm.alpha_tex = me.alpha_tex;
+        dm.p_off = me.p_off; dm.flip_ro = me.reverse_orientation; dm.pad3 = 0;
         for (int k = 0; k < 12; ++k) dm.o2w_inv[k] = me.o2w_inv[k];
         const float *P = desc->fpool + me.p_off;
         const int32_t *idx = desc->ipool + me.idx_off;
@@ -104,7 +106,8 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             uint32_t s0 = src[bvh.order[i]];
             float *r = &out->tri_rec[12 * (tri_base + i)];
             for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[s0].v[k][0]; r[4 * k + 1] = in[s0].v[k][1]; r[4 * k + 2] = in[s0].v[k][2]; }
-            memcpy(&r[3], &tri_mesh[s0], 4);
+            int32_t mesh_word = tri_mesh[s0] | (desc->meshes[tri_mesh[s0]].alpha_tex > 0 ? HPT_TRI_ALPHA_BIT : 0);
+            memcpy(&r[3], &mesh_word, 4);
             memcpy(&r[7], &tri_idx[s0], 4);
         }
         if (g < 0) out->world_root = node_base; else out->inst_root[(size_t)g] = node_base;
@@ -163,6 +166,29 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         int64_t gbase = (int64_t)out->fpool.size();
         for (size_t i = 0; i < lev.size(); i += 4) { float w; memcpy(&w, &lev[i], 4); out->fpool.push_back(w); }
         ma.kd_data_off = base; ma.kd_split_off = cbase; ma.kd_bits_off = gbase;
+    }
+    // ---- area lights over shape sets: (kind, global triangle number | quadric) -> (mesh | -1, triangle in mesh | quadric) ----------
+    out->ipool.assign(desc->ipool, desc->ipool + desc->n_i);
+    for (int l = 0; l < desc->n_lights; ++l) {
+        const hpt_light &li = desc->lights[l];
+        if (li.kind != HPT_LIGHT_DIFFUSE_AREA || li.quadric >= 0) continue;
+        for (int i = 0; i < li.set_n; ++i) {
+            int32_t *e = &out->ipool[(size_t)li.set_off + 2 * (size_t)i];
+            if (e[0] == 1) { e[0] = -1; continue; }
+            int64_t g = e[1], mb = 0;
+            for (int m = 0; m < desc->n_meshes; ++m) {
+                if (g < mb + desc->meshes[m].ntris) { e[0] = m; e[1] = (int32_t)(g - mb); break; }
+                mb += desc->meshes[m].ntris;
+            }
+        }
+    }
+    // ---- MIPMap::weightLut (core/mipmap.h:192-200) with the HOST's expf: the table the reference's lookups use -----------------------
+    while (out->fpool.size() % 4) out->fpool.push_back(0.f);
+    out->ewa_lut_off = (int64_t)out->fpool.size();
+    for (int i = 0; i < 128; ++i) {
+        float alpha = 2;
+        float r2 = float(i) / float(128 - 1);
+        out->fpool.push_back(expf(-alpha * r2) - expf(-alpha));
     }
     out->n_tris = ntris;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

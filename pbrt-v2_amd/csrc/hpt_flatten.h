@@ -21,6 +21,8 @@ struct FlatScene {
     // kd_split_off at the table of first samples per cell (uint32, cells + 1 entries) and kd_bits_off at the 64^3
     // starting-level table of the query (bytes, four to a pool word) — hpt_device.h, kd_begin / kd_step
     std::vector<float> fpool;
+    std::vector<int32_t> ipool;       // device copy of the int pool: shape sets of area lights rewritten to (mesh, triangle in mesh)
+    int64_t ewa_lut_off = 0;          // MIPMap::weightLut in fpool
     std::vector<hpt_material> materials;
     int64_t n_tris = 0;
     int max_depth = 0;

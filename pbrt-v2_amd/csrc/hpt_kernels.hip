@@ -21,7 +21,7 @@
 namespace hpt {
 
 int path_kernel_cold_rows(int mats) {       // must mirror launch_path_kernel's choice of instantiation (below)
-    const int set = (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
+    const int set = (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
     return HPT_PARK_MATS(set) ? HPT_COLD_ROWS : 0;
 }
 
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
     const float *r = rays + 8 * i;
     Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
     Hit hit; TravCounters tc = {0, 0};
-    bool h = traverse<false, true>(sc, ray, 0.f, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
+    bool h = traverse<false, true, true>(sc, ray, 0.f, anyhit != 0, &hit, lds_stack + threadIdx.x, HPT_BLOCK, &tc);
     float *o = out_hit + 4 * i;
     if (anyhit) { out_prim[i] = h ? 0 : -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
     if (!h) { out_prim[i] = -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
     if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[1] = 0.f; o[2] = 0.f; o[3] = 5e-4f * hit.t; return; }
     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
-    int mesh = as_int(tp[0].w), tri = as_int(tp[1].w);
+    int mesh = as_int(tp[0].w) & HPT_TRI_MESH_MASK, tri = as_int(tp[1].w);
     out_prim[i] = sc.meshes[mesh].prim_base + tri;
     o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
 }
@@ -164,11 +164,16 @@ __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, 
     f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
     f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
     Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
-    bsdf_add_material<MATS_ALL>(&b, &sc.materials[material]);
-    f3 f = bsdf_f<MATS_ALL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
-    float pdf = bsdf_pdf<MATS_ALL>(b, wo, wi, BSDF_ALL_NOSPEC);
+    {   // the parameters through the extension's evaluator (textures, if any, are looked up at (u, v) = (u1, u2) of the input row, no differentials)
+        DGeomX dgs;
+        dgs.p = S(0.f); dgs.nn = nn; dgs.dpdu = dpdu; dgs.dpdv = cross(nn, dpdu); dgs.dndu = dgs.dndv = dgs.dpdx = dgs.dpdy = S(0.f);
+        dgs.u = q[6]; dgs.v = q[7]; dgs.dudx = dgs.dvdx = dgs.dudy = dgs.dvdy = 0.f;
+        bsdf_add_material_ext(&b, sc, &sc.materials[material], dgs);
+    }
+    f3 f = bsdf_f<MATS_FULL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
+    float pdf = bsdf_pdf<MATS_FULL>(b, wo, wi, BSDF_ALL_NOSPEC);
     f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-    f3 sf = bsdf_sample_f<MATS_ALL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
+    f3 sf = bsdf_sample_f<MATS_FULL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL, &stype, ls);   // BSDF_ALL: specular lobes can be sampled
     o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
     o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
 }
@@ -189,13 +194,16 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 // ---- launchers ----------------------------------------------------------------------------------------
 hipError_t launch_path_basic(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_measured(const PathKernelArgs &, int, bool, int, hipStream_t);
+hipError_t launch_path_ext(const PathKernelArgs &, int, bool, int, hipStream_t);
 hipError_t launch_path_all(const PathKernelArgs &, int, bool, int, hipStream_t);
 int occupancy_basic(bool, int, bool, size_t, int *, int *);
 int occupancy_measured(bool, int, bool, size_t, int *, int *);
+int occupancy_ext(bool, int, bool, size_t, int *, int *);
 int occupancy_all(bool, int, bool, size_t, int *, int *);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
 static int pick_variant(int mats) {
+    if (mats & MATS_EXT) return 3;
     if ((mats & ~MATS_PLASTIC) == 0) return 0;
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
     return 2;
@@ -204,6 +212,7 @@ int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds,
     switch (pick_variant(mats)) {
         case 0: return occupancy_basic(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
         case 1: return occupancy_measured(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 3: return occupancy_ext(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
         default: return occupancy_all(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
     }
 }
@@ -211,6 +220,7 @@ hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks
     switch (pick_variant(mats)) {
         case 0: return launch_path_basic(a, grid_blocks, count, cfg, stream);
         case 1: return launch_path_measured(a, grid_blocks, count, cfg, stream);
+        case 3: return launch_path_ext(a, grid_blocks, count, cfg, stream);
         default: return launch_path_all(a, grid_blocks, count, cfg, stream);
     }
 }

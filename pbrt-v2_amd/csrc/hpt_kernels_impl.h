@@ -133,7 +133,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // the other, the tree of every instance whose motion bounds the (shrinking) ray still crosses, each in the instance's own space at
 // the ray's time (xf_cache: the per-path transform cache, or null -> anim_interpolate).  Helpers only ever walk the subtree they were
 // given, in whatever space the donor was in, and publish the instance number with the hit.
-template <bool COUNT, bool INST>
+template <bool COUNT, bool INST, bool ALPHA>
 __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
                                                TravCounters *cnt, const float *xf_cache, int64_t xf_stride) {
     const int lane = lane_id();
@@ -155,7 +155,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     for (;;) {
         const bool busy = ts.node != HPT_TRAV_EMPTY;
         const bool any_busy = __ballot(busy || seg < n_inst) != 0ull;
-        if (busy) trav_step<COUNT>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+        if (busy) trav_step<COUNT, ALPHA>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
         // (after every step — measured: every 16 / 8 / 4 / 2 / 1 steps = 612 / 660 / 708 / 775 / 800 Msamples/s on killeroo —
         //  but only the parts that have something to do: a publish when some lane found a hit, a steal when some lane idles)
         const bool found = ts.hit.prim >= 0;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool tr = mine && (!DL || lane.stage != ST_SHADE);
             const bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse_steal<COUNT, INST>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
+            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 if (!DL || lane.stage != ST_SHADE) {
                     bool anyhit = lane.stage == ST_SHADOW;
                     if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
-                    traverse<COUNT, INST>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc, xf_col, xf_stride);
+                    traverse<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc, xf_col, xf_stride);
                 }
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 const unsigned long long bm = __ballot(busy);
                 if (bm == 0ull) break;
                 if (EE > 0 && __popcll(bm) < EE && __ballot(tracing && !busy) != 0ull) break;
-                if (busy) trav_step<COUNT>(sc, ts, lane.ray, stack, HPT_BLOCK, &tc);
+                if (busy) trav_step<COUNT, (MATS & MATS_EXT) != 0>(sc, ts, lane.ray, stack, HPT_BLOCK, &tc);
             }
             if (tracing && ts.done() && mine) {
                 tracing = false;
@@ -408,7 +408,16 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_STEAL(c) ((c) >= 5)
-#define HPT_CFG_KERNEL(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, HPT_CFG_STEAL(C)>
+// HPT_LEAN_SET (defined by a translation unit before this header): build configurations 0, 5 and 6 only — 1 and 2 run as 0, 3 as 5, 4 as 6.
+// The extension set's kernels are several times the size of the others (texture filtering, bump mapping, shape-set lights); the free-running
+// and plain lock-step schedules have not won a scene since subtree stealing (profiles/r01_ab.md) and are not worth their compile time there.
+#ifdef HPT_LEAN_SET
+#define HPT_CFG_ALIAS(c) ((c) == 3 ? 5 : (c) == 4 ? 6 : (c) <= 2 ? 0 : (c))
+#else
+#define HPT_CFG_ALIAS(c) (c)
+#endif
+#define HPT_CFG_KERNEL_(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, HPT_CFG_STEAL(C)>
+#define HPT_CFG_KERNEL(MATS, INST, C) HPT_CFG_KERNEL_(MATS, INST, HPT_CFG_ALIAS(C))
 // the direct-lighting integrator: lock step + subtree stealing, HPT_DL_WAVES waves/SIMD
 #ifndef HPT_DL_WAVES
 #define HPT_DL_WAVES 3   /* measured on killeroo-simple.pbrt as shipped: 4 / 3 / 2 waves per SIMD = 374 / 461 / 384 M camera samples/s (lane utilisation is 69 % there: the spills cost more than the fourth wave hides) */

@@ -1,0 +1,356 @@
+// hpt_multi.hip — multi-GPU behind the C ABI (SURVEY.md §8b "gpus", §8e; include/hpt.h).
+//
+// The path shards with NO data-path collective: the scene is replicated in every GPU's HBM, shard r renders the 32x32 super-tiles t
+// with t % n == r (hpt_render_desc.shard_rank / shard_count — the enumeration the kernel's work queue walks), and the only
+// communication is ONE exchange of film data per frame:
+//   * default box filter: a GATHER of the tiles each shard owns to shard 0 — each shard packs its tiles (16 KiB apiece) into a
+//     contiguous buffer (hpt_pack_tiles_kernel), the root posts one ncclRecv per peer / every peer one ncclSend inside one
+//     ncclGroupStart / ncclGroupEnd (point-to-point over xGMI; the film crosses the links exactly once: 33 MB at 1080p), the root scatters
+//     the tiles into the frame (hpt_unpack_tiles_kernel);
+//   * a reconstruction filter wider than the box (hpt_scene_set_filter): samples reach pixels of neighbouring tiles, every shard's film
+//     holds partial sums over the whole frame, and the exchange is one ncclReduce(sum) of the full-frame films to shard 0.
+// Two forms share this code:
+//   hpt_comm  : one PROCESS per GPU (bench.py under torch.distributed.run, which only carries the 128-byte ncclUniqueId and the timing
+//               barrier): ncclCommInitRank;
+//   hpt_multi : one process, one host THREAD per GPU (the pbrt plugin, `Renderer "hip" "integer gpus" [N]`): ncclCommInitAll.
+// RCCL is reached through dlopen("librccl.so.1") — the copy already in the process (PyTorch ships one) or ROCm's — so that libhpt.so has no
+// link-time dependency on a second RCCL.  RCCL refuses two ranks on one device ("Duplicate GPU detected"); hpt_multi_create therefore
+// accepts a device list with repeats (several shards on one GPU, e.g. {0, 0}) and moves their tiles with hipMemcpyAsync instead — the
+// single-GPU test path of the sharding, packing and threading; RCCL itself then runs with a communicator of one rank.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hpt_internal.h"
+#include "hpt_kernels.h"
+
+namespace {
+
+// ---- the few RCCL entry points this file needs (rccl.h declarations, resolved at run time) --------------------------------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat32 = 7 };   // ncclDataType_t
+enum { ncclSum = 0 };       // ncclRedOp_t
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (r.lib) {
+#define SYM(field, name) *(void **)(&r.field) = dlsym(r.lib, name)
+            SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+            SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+            SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(Reduce, "ncclReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.Reduce) r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+#define NCCL_OK(expr) do { int rc_ = (expr); if (rc_ != ncclSuccess) { hpt_set_error("%s failed: %s", #expr, rccl()->GetErrorString ? rccl()->GetErrorString(rc_) : "RCCL error"); return HPT_E_HIP; } } while (0)
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { hpt_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return HPT_E_HIP; } } while (0)
+
+// ---- tiles <-> packed buffer -------------------------------------------------------------------------------------------------------
+// Shard `rank` of `count` owns the 32x32 super-tiles t = rank, rank + count, ... of the n_stx x n_sty grid over the film; its k-th tile
+// sits at floats [k * 4096, (k + 1) * 4096) of the packed buffer (pixels row-major inside the tile, pixels beyond the film's edge unused).
+__global__ void hpt_pack_tiles_kernel(const float4 *film, float4 *packed, int x_count, int y_count, int n_stx, int n_tiles, int rank, int count) {
+    const int k = blockIdx.x;                         // local tile
+    const int t = k * count + rank;
+    if (t >= n_tiles) return;
+    const int x0 = (t % n_stx) * 32, y0 = (t / n_stx) * 32;
+    for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
+        const int x = x0 + (p & 31), y = y0 + (p >> 5);
+        packed[(size_t)k * 1024 + p] = (x < x_count && y < y_count) ? film[(size_t)y * x_count + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__global__ void hpt_unpack_tiles_kernel(float4 *film, const float4 *packed, int x_count, int y_count, int n_stx, int n_tiles, int rank, int count) {
+    const int k = blockIdx.x;
+    const int t = k * count + rank;
+    if (t >= n_tiles) return;
+    const int x0 = (t % n_stx) * 32, y0 = (t / n_stx) * 32;
+    for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
+        const int x = x0 + (p & 31), y = y0 + (p >> 5);
+        if (x < x_count && y < y_count) film[(size_t)y * x_count + x] = packed[(size_t)k * 1024 + p];
+    }
+}
+inline int local_tiles(int n_tiles, int rank, int count) { return (n_tiles - rank + count - 1) / count; }
+
+} // namespace
+
+// ---- one process per GPU -----------------------------------------------------------------------------------------------------------------
+struct hpt_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    float4 *packed = nullptr; size_t packed_tiles = 0;      // send buffer (peers) / receive buffer for all peers' tiles (root)
+};
+
+extern "C" int hpt_comm_unique_id(void *out128) {
+    if (!out128) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    Rccl *r = rccl();
+    if (!r) { hpt_set_error("RCCL (librccl.so.1) is not available in this process"); return HPT_E_NODEVICE; }
+    ncclUniqueId id;
+    NCCL_OK(r->GetUniqueId(&id));
+    memcpy(out128, &id, sizeof(id));
+    return HPT_OK;
+}
+
+extern "C" hpt_comm *hpt_comm_create(const void *id128, int rank, int world, int device) {
+    Rccl *r = rccl();
+    if (!r) { hpt_set_error("RCCL (librccl.so.1) is not available in this process"); return nullptr; }
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { hpt_set_error("bad communicator arguments"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { hpt_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    hpt_comm *c = new hpt_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    int rc = r->CommInitRank(&c->comm, world, id, rank);
+    if (rc != ncclSuccess) { hpt_set_error("ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); delete c; return nullptr; }
+    return c;
+}
+
+extern "C" void hpt_comm_destroy(hpt_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->packed) (void)hipFree(c->packed);
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    delete c;
+}
+
+// The end-of-frame film exchange on `stream` (the stream the shard was rendered on; asynchronous, like an RCCL call).
+// d_film: this rank's x_count * y_count * 4 floats; on rank 0 it holds the whole frame afterwards.
+extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film, void *stream_v, int wide_filter) {
+    if (!c || !rd || !d_film) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    if (c->world == 1) return HPT_OK;
+    Rccl *r = rccl();
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_OK(hipSetDevice(c->device));
+    const size_t n_floats = (size_t)rd->x_count * rd->y_count * 4;
+    if (wide_filter) {                                   // partial sums over the whole frame: one sum-reduce to rank 0
+        NCCL_OK(r->Reduce(d_film, d_film, n_floats, ncclFloat32, ncclSum, 0, c->comm, stream));
+        return HPT_OK;
+    }
+    const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
+    const size_t need = c->rank == 0 ? (size_t)n_tiles : (size_t)local_tiles(n_tiles, c->rank, c->world);
+    if (c->packed_tiles < need) {
+        if (c->packed) (void)hipFree(c->packed);
+        c->packed = nullptr; c->packed_tiles = 0;
+        HIP_OK(hipMalloc((void **)&c->packed, need * 1024 * sizeof(float4)));
+        c->packed_tiles = need;
+    }
+    if (c->rank != 0) {
+        const int mine = local_tiles(n_tiles, c->rank, c->world);
+        if (mine > 0) hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, stream, (const float4 *)d_film, c->packed, rd->x_count, rd->y_count, n_stx, n_tiles, c->rank, c->world);
+        NCCL_OK(r->GroupStart());
+        if (mine > 0) NCCL_OK(r->Send(c->packed, (size_t)mine * 4096, ncclFloat32, 0, c->comm, stream));
+        NCCL_OK(r->GroupEnd());
+        return HPT_OK;
+    }
+    NCCL_OK(r->GroupStart());
+    size_t off = 0;
+    for (int p = 1; p < c->world; ++p) {
+        const int n = local_tiles(n_tiles, p, c->world);
+        if (n > 0) NCCL_OK(r->Recv(c->packed + off * 1024, (size_t)n * 4096, ncclFloat32, p, c->comm, stream));
+        off += (size_t)n;
+    }
+    NCCL_OK(r->GroupEnd());
+    off = 0;
+    for (int p = 1; p < c->world; ++p) {
+        const int n = local_tiles(n_tiles, p, c->world);
+        if (n > 0) hipLaunchKernelGGL(hpt_unpack_tiles_kernel, dim3(n), dim3(256), 0, stream, (float4 *)d_film, c->packed + off * 1024, rd->x_count, rd->y_count, n_stx, n_tiles, p, c->world);
+        off += (size_t)n;
+    }
+    HIP_OK(hipGetLastError());
+    return HPT_OK;
+}
+
+// ---- one process, one host thread per GPU -----------------------------------------------------------------------------------------------------
+struct hpt_multi {
+    int n = 0;
+    std::vector<int> devices;
+    std::vector<hpt_scene *> scenes;
+    std::vector<void *> films;          // per shard: full-frame device film
+    std::vector<hipStream_t> streams;
+    std::vector<float4 *> packed;       // per shard: its packed tiles ON THE ROOT'S DEVICE side of the transfer (peer path) / send buffer (RCCL path)
+    std::vector<float4 *> recv;         // RCCL path: root's receive buffers
+    std::vector<ncclComm_t> comms;      // RCCL path (distinct devices); empty: peer-copy path
+    size_t film_bytes = 0, tiles_cap = 0;
+    bool wide = false;
+};
+
+extern "C" void hpt_multi_destroy(hpt_multi *m) {
+    if (!m) return;
+    for (int i = 0; i < m->n; ++i) {
+        (void)hipSetDevice(m->devices[(size_t)i]);
+        if (i < (int)m->films.size() && m->films[(size_t)i]) (void)hipFree(m->films[(size_t)i]);
+        if (i < (int)m->packed.size() && m->packed[(size_t)i]) (void)hipFree(m->packed[(size_t)i]);
+        if (i < (int)m->recv.size() && m->recv[(size_t)i]) (void)hipFree(m->recv[(size_t)i]);
+        if (i < (int)m->streams.size() && m->streams[(size_t)i]) (void)hipStreamDestroy(m->streams[(size_t)i]);
+        if (i < (int)m->comms.size() && m->comms[(size_t)i] && rccl()) (void)rccl()->CommDestroy(m->comms[(size_t)i]);
+        if (i < (int)m->scenes.size() && m->scenes[(size_t)i]) hpt_scene_destroy(m->scenes[(size_t)i]);
+    }
+    delete m;
+}
+
+extern "C" hpt_multi *hpt_multi_create(const hpt_scene_desc *desc, const int *devices, int n_devices) {
+    if (!desc || !devices || n_devices < 1 || n_devices > 64) { hpt_set_error("bad device list"); return nullptr; }
+    hpt_multi *m = new hpt_multi();
+    m->n = n_devices;
+    m->devices.assign(devices, devices + n_devices);
+    m->scenes.assign((size_t)n_devices, nullptr); m->films.assign((size_t)n_devices, nullptr); m->streams.assign((size_t)n_devices, nullptr);
+    m->packed.assign((size_t)n_devices, nullptr); m->recv.assign((size_t)n_devices, nullptr);
+    // the scene is replicated: one hpt_scene per shard, built concurrently (BVH build on the host is per scene; uploads overlap)
+    std::vector<std::thread> th;
+    std::vector<std::string> errs((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i)
+        th.emplace_back([&, i]() {
+            m->scenes[(size_t)i] = hpt_scene_create(desc, devices[i]);
+            if (!m->scenes[(size_t)i]) errs[(size_t)i] = hpt_last_error();                 // (the error text is thread-local)
+            else if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreate(&m->streams[(size_t)i]) != hipSuccess) errs[(size_t)i] = "hipStreamCreate failed";
+        });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n_devices; ++i)
+        if (!errs[(size_t)i].empty()) { hpt_set_error("shard %d (device %d): %s", i, devices[i], errs[(size_t)i].c_str()); hpt_multi_destroy(m); return nullptr; }
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) distinct = false;
+    const char *force = getenv("HPT_GATHER");                // "peer": hipMemcpyAsync between devices instead of RCCL
+    if (n_devices > 1 && distinct && !(force && !strcmp(force, "peer"))) {
+        Rccl *r = rccl();
+        if (!r) { hpt_set_error("RCCL (librccl.so.1) is not available (HPT_GATHER=peer gathers with hipMemcpyPeerAsync)"); hpt_multi_destroy(m); return nullptr; }
+        m->comms.assign((size_t)n_devices, nullptr);
+        int rc = r->CommInitAll(m->comms.data(), n_devices, devices);
+        if (rc != ncclSuccess) { hpt_set_error("ncclCommInitAll failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); m->comms.clear(); hpt_multi_destroy(m); return nullptr; }
+    } else if (n_devices > 1) {
+        for (int i = 1; i < n_devices; ++i) {                // peer path: let the root's device read / write the others' memory
+            if (devices[i] == devices[0]) continue;
+            (void)hipSetDevice(devices[0]); (void)hipDeviceEnablePeerAccess(devices[i], 0);
+            (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[0], 0);
+        }
+        (void)hipGetLastError();
+    }
+    return m;
+}
+
+extern "C" int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *f) {
+    if (!m) { hpt_set_error("null handle"); return HPT_E_INVALID; }
+    for (int i = 0; i < m->n; ++i) { int rc = hpt_scene_set_filter(m->scenes[(size_t)i], f); if (rc != HPT_OK) return rc; }
+    m->wide = f != nullptr;
+    return HPT_OK;
+}
+
+extern "C" int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out) {
+    if (!m || !out || shard < 0 || shard >= m->n) { hpt_set_error("bad shard"); return HPT_E_INVALID; }
+    *out = m->scenes[(size_t)shard];
+    return HPT_OK;
+}
+
+// One frame: every shard renders its tiles on its own device (one host thread each), then the film exchange; the frame lands in
+// film_xyzw_host (rank 0's film).  stats: n_devices records (may be null).  rd->shard_rank / shard_count are ignored.
+extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc *rd, float *film_host, hpt_stats *stats) {
+    if (!m || !cam || !rd || !film_host) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    const int n = m->n;
+    const size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
+    const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
+    const bool use_rccl = !m->comms.empty();
+    // buffers (grown on demand, kept with the handle)
+    if (m->film_bytes < bytes || m->tiles_cap < (size_t)n_tiles) {
+        for (int i = 0; i < n; ++i) {
+            HIP_OK(hipSetDevice(m->devices[(size_t)i]));
+            if (m->films[(size_t)i]) (void)hipFree(m->films[(size_t)i]);
+            if (m->packed[(size_t)i]) (void)hipFree(m->packed[(size_t)i]);
+            if (m->recv[(size_t)i]) (void)hipFree(m->recv[(size_t)i]);
+            m->films[(size_t)i] = nullptr; m->packed[(size_t)i] = nullptr; m->recv[(size_t)i] = nullptr;
+            HIP_OK(hipMalloc(&m->films[(size_t)i], bytes));
+            const size_t mine = (size_t)local_tiles(n_tiles, i, n);
+            if (i > 0 && mine > 0) HIP_OK(hipMalloc((void **)&m->packed[(size_t)i], mine * 1024 * sizeof(float4)));
+            if (i > 0 && mine > 0) { HIP_OK(hipSetDevice(m->devices[0])); HIP_OK(hipMalloc((void **)&m->recv[(size_t)i], mine * 1024 * sizeof(float4))); }
+        }
+        m->film_bytes = bytes; m->tiles_cap = (size_t)n_tiles;
+    }
+    std::vector<int> rcs((size_t)n, HPT_OK);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<hpt_stats> st((size_t)n);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i]() {
+            hpt_render_desc r = *rd;
+            r.shard_rank = i; r.shard_count = n;
+            int rc = hpt_render_device(m->scenes[(size_t)i], cam, &r, m->films[(size_t)i], m->streams[(size_t)i], &st[(size_t)i]);
+            if (rc == HPT_OK && i > 0 && !m->wide && m->packed[(size_t)i]) {
+                const int mine = local_tiles(n_tiles, i, n);
+                hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, m->streams[(size_t)i], (const float4 *)m->films[(size_t)i], m->packed[(size_t)i],
+                                   rd->x_count, rd->y_count, n_stx, n_tiles, i, n);
+                if (hipStreamSynchronize(m->streams[(size_t)i]) != hipSuccess) rc = HPT_E_HIP;
+            }
+            rcs[(size_t)i] = rc;
+            if (rc != HPT_OK) errs[(size_t)i] = hpt_last_error();
+        });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; ++i) if (rcs[(size_t)i] != HPT_OK) { hpt_set_error("shard %d: %s", i, errs[(size_t)i].c_str()); return rcs[(size_t)i]; }
+    if (stats) for (int i = 0; i < n; ++i) stats[i] = st[(size_t)i];
+    // ---- film exchange to shard 0 ---------------------------------------------------------------------------------------------------
+    if (n > 1) {
+        if (m->wide) {                 // sum of partial films
+            if (use_rccl) {
+                Rccl *r = rccl();
+                NCCL_OK(r->GroupStart());
+                for (int i = 0; i < n; ++i) NCCL_OK(r->Reduce(m->films[(size_t)i], m->films[(size_t)i], bytes / 4, ncclFloat32, ncclSum, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
+                NCCL_OK(r->GroupEnd());
+            } else {
+                hpt_set_error("wide-filter film reduction across shards needs RCCL (distinct devices)");
+                return HPT_E_UNSUPPORTED;
+            }
+        } else {
+            if (use_rccl) {
+                Rccl *r = rccl();
+                NCCL_OK(r->GroupStart());
+                for (int i = 1; i < n; ++i) {
+                    const int mine = local_tiles(n_tiles, i, n);
+                    if (mine <= 0) continue;
+                    NCCL_OK(r->Send(m->packed[(size_t)i], (size_t)mine * 4096, ncclFloat32, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
+                    NCCL_OK(r->Recv(m->recv[(size_t)i], (size_t)mine * 4096, ncclFloat32, i, m->comms[0], m->streams[0]));
+                }
+                NCCL_OK(r->GroupEnd());
+            } else {
+                HIP_OK(hipSetDevice(m->devices[0]));
+                for (int i = 1; i < n; ++i) {
+                    const int mine = local_tiles(n_tiles, i, n);
+                    if (mine <= 0) continue;
+                    if (m->devices[(size_t)i] == m->devices[0]) HIP_OK(hipMemcpyAsync(m->recv[(size_t)i], m->packed[(size_t)i], (size_t)mine * 1024 * sizeof(float4), hipMemcpyDeviceToDevice, m->streams[0]));
+                    else HIP_OK(hipMemcpyPeerAsync(m->recv[(size_t)i], m->devices[0], m->packed[(size_t)i], m->devices[(size_t)i], (size_t)mine * 1024 * sizeof(float4), m->streams[0]));
+                }
+            }
+            HIP_OK(hipSetDevice(m->devices[0]));
+            for (int i = 1; i < n; ++i) {
+                const int mine = local_tiles(n_tiles, i, n);
+                if (mine > 0) hipLaunchKernelGGL(hpt_unpack_tiles_kernel, dim3(mine), dim3(256), 0, m->streams[0], (float4 *)m->films[0], m->recv[(size_t)i], rd->x_count, rd->y_count, n_stx, n_tiles, i, n);
+            }
+        }
+        for (int i = 0; i < n; ++i) { HIP_OK(hipSetDevice(m->devices[(size_t)i])); HIP_OK(hipStreamSynchronize(m->streams[(size_t)i])); }
+    }
+    HIP_OK(hipSetDevice(m->devices[0]));
+    HIP_OK(hipMemcpy(film_host, m->films[0], bytes, hipMemcpyDeviceToHost));
+    return HPT_OK;
+}

@@ -49,6 +49,8 @@ struct RenderParams {
     int32_t sampler_kind;      // 0 low discrepancy, 1 random, 2 stratified
     int32_t strat_n, strat_jitter;                 // stratified: spp, jitter
     float strat_fxs, strat_dx, strat_dy, strat_dt; // (float)xsamples, 1.f / xsamples, 1.f / ysamples, 1.f / spp
+    f3 dx_camera, dy_camera;   // PerspectiveCamera::dxCamera / dyCamera (cameras/perspective.cpp:46-48): camera-ray differentials (MATS_EXT kernels)
+    float diff_scale;          // 1 / sqrt(samplesPerPixel): ray.ScaleDifferentials (renderers/samplerrenderer.cpp:190)
     int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
@@ -369,6 +371,12 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                         quadric_intersect(q, ray, &t, &dg);
                         sees = dot(dg.nn, -wi_mis) > 0.f;       // Intersection::Le -> DiffuseAreaLight::L
                     }
+                } else if (MATS & MATS_EXT) {                   // a triangle of an emitting mesh
+                    const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+                    const f4 a = tp[0], bb = tp[1], c = tp[2];
+                    const DMesh &me = sc.meshes[as_int(a.w) & HPT_TRI_MESH_MASK];
+                    if (me.arealight == light_mis)
+                        sees = dot(tri_dg_normal(sc, me, as_int(bb.w), mk3(a.x, a.y, a.z), mk3(bb.x, bb.y, bb.z), mk3(c.x, c.y, c.z)), -wi_mis) > 0.f;
                 }
             } else sees = sc.lights[light_mis].kind == HPT_LIGHT_INFINITE; // light->Le(ray), integrator.cpp:166
             if (sees) Ld = Ld + C_mis;
@@ -395,7 +403,18 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // reference's (all array / rng draws of the vertex happen here, the Russian-roulette draw in shade_finish).
     HPT_MFN void shade_prepare(const DScene &sc, const RenderParams &rp, const Hit &hit, LaneStack ls, ShadeV *sv) {
         Bsdf bsdf; DGeom dg; int arealight;
-        shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
+        if (MATS & MATS_EXT) {
+            // the camera ray is the only one with differentials (geometry.h:351-361): rebuilt from its sample at the first hit
+            RayDiff rdiff; rdiff.has = false;
+            if (DL ? true : bounce == 0) {
+                float ia, ib, lu = 0.f, lv = 0.f;
+                smp.image(rp, &ia, &ib);
+                if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
+                camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, ray, &rdiff);
+            }
+            shade_geometry_ext<INST>(sc, ray, time, hit, rdiff, &bsdf, &dg, &eps, &arealight);
+        } else
+            shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
         f3 wo = -ray.d;
         if (DL ? stage == ST_EXTEND : (bounce == 0 || specular))            // path.cpp:63-64; directlighting.cpp:90 (once per hit)
             if (arealight >= 0) cold.setL(cold.L() + smul(cold.beta(), area_L(sc.lights[arealight], dg.nn, wo)));
@@ -423,7 +442,6 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                 ln = smp.draw();
                 ls0 = smp.draw(); ls1 = smp.draw(); ls2 = smp.draw();
             }
-            (void)ls2;
             int lightNum = (int)floorf(ln * sc.n_lights);
             if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
             if (DL && lightPick >= 0) lightNum = lightPick;
@@ -431,7 +449,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             const bool isDelta = light.kind == HPT_LIGHT_POINT;
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
-            f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow);
+            f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
             if (lightPdf > 0.f && !sblack(Li)) {
                 if (defer) {
                     sv->has[0] = bsdf_query_point(bsdf, bsdf.w2l(wo), bsdf.w2l(wi), wo, wi, BSDF_ALL_NOSPEC, &sv->fq[0]);
@@ -491,11 +509,12 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             float ps0, ps1, ps2;
             if (useArrays) { smp.two(3 * bounce + 2, &ps0, &ps1); ps2 = smp.one(4 * bounce + 3); }
             else { ps0 = smp.draw(); ps1 = smp.draw(); ps2 = smp.draw(); }
-            f3 wi, wo_l, wi_l; float pdf; int flags;
-            if (bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags)) {
+            f3 wi, wo_l, wi_l, fspec; float pdf; int flags;
+            if (bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, &fspec)) {
                 wi_next = wi;
                 spec_next = (flags & BSDF_SPECULAR) != 0;
-                if (defer) {
+                if ((MATS & MATS_EXT) && spec_next) term_next(fspec, absdot(wi, n), pdf);       // a specular lobe's Sample_f value (reflection.cpp:555)
+                else if (defer) {
                     sv->has[2] = bsdf_query_point(bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, &sv->fq[2]);
                     sv->a3 = absdot(wi, n); sv->pdf3 = pdf;
                 } else term_next(bsdf_f_local<MATS>(sc, bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, ls), absdot(wi, n), pdf);

@@ -495,6 +495,9 @@ HipPathRenderer::HipPathRenderer(Sampler *s, Camera *c, SurfaceIntegrator *si,
     surfaceIntegrator = si;
     volumeIntegrator = vi;
     device = params.FindOneInt("device", 0);
+    gpus = params.FindOneInt("gpus", 1);
+    if (const char *e = getenv("HPT_GPUS")) gpus = atoi(e);
+    if (gpus < 1) gpus = 1;
     seed = (unsigned)params.FindOneInt("seed", 0);
     std::string sm = params.FindOneString("sampler", "ldhash");
     if (sm == "ldhash") samplerMode = HPT_SAMPLER_LD_HASH;
@@ -587,17 +590,38 @@ void HipPathRenderer::Render(const Scene *scene) {
         return;
     }
 
-    hpt_scene *hs = hpt_scene_create(&desc, device);
-    if (!hs) Severe("hip renderer: %s", hpt_last_error());
-    if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
     std::vector<float> xyzw(4 * (size_t)rd.x_count * rd.y_count);
     hpt_stats st;
+    memset(&st, 0, sizeof(st));
     ProgressReporter reporter(1, "Rendering (HIP)");
-    if (hpt_render(hs, &cam, &rd, &xyzw[0], &st) != HPT_OK)
-        Severe("hip renderer: %s", hpt_last_error());
+    if (gpus > 1) {
+        // `gpus` — one host thread per device inside the library, pixel tiles round-robin, one film gather over RCCL
+        std::vector<int> devs;
+        for (int i = 0; i < gpus; ++i) devs.push_back(device + i);
+        if (const char *e = getenv("HPT_GPU_LIST")) {               // explicit list, repeats allowed ("0,0": two shards on one GPU)
+            devs.clear();
+            for (const char *p = e; *p;) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        }
+        hpt_multi *hm = hpt_multi_create(&desc, &devs[0], (int)devs.size());
+        if (!hm) Severe("hip renderer: %s", hpt_last_error());
+        if (!defaultBox && hpt_multi_set_filter(hm, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        std::vector<hpt_stats> sts(devs.size());
+        if (hpt_multi_render(hm, &cam, &rd, &xyzw[0], &sts[0]) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        hpt_multi_destroy(hm);
+        for (size_t i = 0; i < sts.size(); ++i) {
+            st.camera_samples += sts[i].camera_samples; st.bad_samples += sts[i].bad_samples;
+            if (sts[i].kernel_ms > st.kernel_ms) st.kernel_ms = sts[i].kernel_ms;
+        }
+    } else {
+        hpt_scene *hs = hpt_scene_create(&desc, device);
+        if (!hs) Severe("hip renderer: %s", hpt_last_error());
+        if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        if (hpt_render(hs, &cam, &rd, &xyzw[0], &st) != HPT_OK)
+            Severe("hip renderer: %s", hpt_last_error());
+        hpt_scene_destroy(hs);
+    }
     reporter.Update();
     reporter.Done();
-    hpt_scene_destroy(hs);
     if (st.bad_samples)
         Error("hip renderer: %llu camera samples had NaN / negative / infinite luminance and "
               "were set to black", (unsigned long long)st.bad_samples);
@@ -615,13 +639,26 @@ void HipPathRenderer::Render(const Scene *scene) {
     camera->film->WriteImage();
 }
 
-Spectrum HipPathRenderer::Li(const Scene *, const RayDifferential &, const Sample *, RNG &,
-                             MemoryArena &, Intersection *, Spectrum *) const {
-    Severe("HipPathRenderer::Li: per-ray host callbacks are not part of the device path");
-    return Spectrum(0.f);
+// Renderer::Li / Transmittance (core/renderer.h:47-53): what the reference's integrators call back into for a ray of their own
+// (SpecularReflect / SpecularTransmit, core/integrator.cpp:177-258; irradiance caching, photon mapping ...).  Nothing on the device path
+// calls them — the kernel owns the whole per-sample loop — but the interface is honoured for host-side callers: the same evaluation
+// SamplerRenderer::Li performs (renderers/samplerrenderer.cpp:320-342), with the plugins this renderer owns, on the CPU.
+Spectrum HipPathRenderer::Li(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng,
+                             MemoryArena &arena, Intersection *isect, Spectrum *T) const {
+    Spectrum localT;
+    if (!T) T = &localT;
+    Intersection localIsect;
+    if (!isect) isect = &localIsect;
+    Spectrum Li = 0.f;
+    if (scene->Intersect(ray, isect))
+        Li = surfaceIntegrator->Li(scene, this, ray, *isect, sample, rng, arena);
+    else
+        for (uint32_t i = 0; i < scene->lights.size(); ++i) Li += scene->lights[i]->Le(ray);
+    Spectrum Lvi = volumeIntegrator->Li(scene, this, ray, sample, rng, T, arena);
+    return *T * Li + Lvi;
 }
 
-Spectrum HipPathRenderer::Transmittance(const Scene *, const RayDifferential &, const Sample *,
-                                        RNG &, MemoryArena &) const {
-    return Spectrum(1.f);
+Spectrum HipPathRenderer::Transmittance(const Scene *scene, const RayDifferential &ray, const Sample *sample,
+                                        RNG &rng, MemoryArena &arena) const {
+    return volumeIntegrator->Transmittance(scene, this, ray, sample, rng, arena);
 }

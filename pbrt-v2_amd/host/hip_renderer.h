@@ -31,6 +31,7 @@ private:
     SurfaceIntegrator *surfaceIntegrator;
     VolumeIntegrator *volumeIntegrator;
     int device;        // "integer device"  [0]
+    int gpus;          // "integer gpus"    [1]: the frame's pixel tiles sharded over devices device .. device + gpus - 1 (hpt_multi, include/hpt.h)
     int samplerMode;   // "string sampler"  ["ldhash" | "mtreplay"]
     unsigned seed;     // "integer seed"    [0]
     std::string dumpPath; // "string dumpscene" [""] or env HPT_DUMP_SCENE: write blob, do not render

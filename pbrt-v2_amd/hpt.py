@@ -21,6 +21,8 @@ EXPORTS = [
     "hpt_scene_get_info", "hpt_render", "hpt_render_device", "hpt_scene_tune", "hpt_scene_set_filter", "hpt_blob_save", "hpt_blob_load",
     "hpt_blob_scene", "hpt_blob_camera", "hpt_blob_render", "hpt_blob_free",
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
+    "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
+    "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
 ]
 
 
@@ -59,6 +61,17 @@ def lib():
         L.hpt_test_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
         L.hpt_blob_save.argtypes = [C.c_char_p, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera),
                                     C.POINTER(abi.RenderDesc)]
+        L.hpt_multi_create.restype = C.c_void_p
+        L.hpt_multi_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_int), C.c_int]
+        L.hpt_multi_destroy.argtypes = [C.c_void_p]
+        L.hpt_multi_set_filter.argtypes = [C.c_void_p, C.POINTER(abi.Filter)]
+        L.hpt_multi_scene.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.hpt_multi_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
+        L.hpt_comm_unique_id.argtypes = [C.c_void_p]
+        L.hpt_comm_create.restype = C.c_void_p
+        L.hpt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.hpt_comm_destroy.argtypes = [C.c_void_p]
+        L.hpt_comm_exchange_film.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int]
         L.hpt_abi_sizes.argtypes = [C.c_void_p]
         sizes = (C.c_int32 * 10)()
         L.hpt_abi_sizes(sizes)
@@ -146,6 +159,76 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+class MultiScene:
+    """hpt_multi handle: the scene replicated on `devices` (repeats allowed), one host thread per shard, film exchange in the library
+    (RCCL send / recv between distinct devices, hipMemcpyAsync between shards of one device)."""
+
+    def __init__(self, scene, devices):
+        self.scene, self.devices = scene, list(devices)
+        d = scene.desc
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self.h = lib().hpt_multi_create(C.byref(d), arr, len(self.devices))
+        if not self.h:
+            raise HptError(f"hpt_multi_create failed: {last_error()}")
+
+    def set_filter(self, flt):
+        _check(lib().hpt_multi_set_filter(self.h, C.byref(flt) if flt is not None else None))
+
+    def tune(self, cam, rd):
+        """Pick the kernel configuration on every shard's scene handle (scene preparation)."""
+        out = []
+        for i in range(len(self.devices)):
+            h = C.c_void_p()
+            _check(lib().hpt_multi_scene(self.h, i, C.byref(h)))
+            rc = lib().hpt_scene_tune(h, C.byref(cam), C.byref(rd))
+            if rc < 0:
+                _check(rc)
+            out.append(rc)
+        return out
+
+    def render(self, cam, rd):
+        """-> (film (H, W, 4) of the whole frame, [Stats per shard])"""
+        film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
+        st = (abi.Stats * len(self.devices))()
+        _check(lib().hpt_multi_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, C.byref(st)))
+        return film, list(st)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hpt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """hpt_comm: the film exchange of the one-process-per-GPU form.  `bcast(bytes_or_None) -> bytes` carries rank 0's 128-byte
+    ncclUniqueId to every rank (torch.distributed.broadcast_object_list in bench.py)."""
+
+    def __init__(self, rank, world, device, bcast):
+        uid = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _check(lib().hpt_comm_unique_id(buf))
+            uid = buf.raw
+        uid = bcast(uid)
+        self.h = lib().hpt_comm_create(C.c_char_p(uid), rank, world, device)
+        if not self.h:
+            raise HptError(f"hpt_comm_create failed: {last_error()}")
+
+    def exchange_film(self, rd, d_film_ptr, stream=None, wide_filter=False):
+        _check(lib().hpt_comm_exchange_film(self.h, C.byref(rd), C.c_void_p(d_film_ptr), C.c_void_p(stream or 0), 1 if wide_filter else 0))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hpt_comm_destroy(self.h)
+            self.h = None
 
 
 def sampler(rd, x, y):

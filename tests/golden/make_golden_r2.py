@@ -207,5 +207,27 @@ def main():
             print("%10d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 
 
+
+
+def metal_4k_view():
+    """camera + render descriptor of BASELINE.json configs[4] as written — metal.pbrt at 3840x2160, 128 spp per GPU (1024 over 8 GPUs), path
+    maxdepth 8 — for `bench.py --workload metal`; geometry / textures are metal.hpts.gz."""
+    import re
+    text = open(os.path.join(REF, "metal.pbrt")).read()
+    text = re.sub(r'Renderer "metropolis"[^\n]*\n[^\n]*\n', 'SurfaceIntegrator "path" "integer maxdepth" [8]\n', text)
+    text = text.replace('"integer xresolution" [400] "integer yresolution" [400]', '"integer xresolution" [3840] "integer yresolution" [2160] "string filename" "x.pfm"')
+    text = text.replace('"integer pixelsamples" [4]', '"integer pixelsamples" [128]')
+    text = text.replace("textures/uffizi_latlong.exr", os.path.join(HERE, "small_env.exr"))
+    text = text.replace('"textures/lines.exr"', '"%s/textures/lines.exr"' % REF).replace('"spds/', '"%s/spds/' % REF).replace('Include "geometry/', 'Include "%s/geometry/' % REF)
+    with tempfile.TemporaryDirectory() as tmp:
+        sp, blob = os.path.join(tmp, "m.pbrt"), os.path.join(tmp, "m.hpts")
+        open(sp, "w").write(text)
+        subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", sp], cwd=tmp, env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+        v, g = abi.Scene.load(blob), abi.Scene.load(os.path.join(HERE, "metal.hpts.gz"))
+        assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool)
+        np.savez(os.path.join(HERE, "metal_4k.view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8), render=np.frombuffer(bytes(v.render), dtype=np.uint8))
+
+
 if __name__ == "__main__":
     main()
+    metal_4k_view()

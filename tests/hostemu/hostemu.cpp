@@ -22,7 +22,7 @@ using namespace hpt;
 struct emu_scene {
     FlatScene fs;
     std::vector<hpt_quadric> quadrics; std::vector<hpt_material> materials; std::vector<hpt_light> lights;
-    std::vector<float> fpool; std::vector<int32_t> ipool; std::vector<hpt_instance> instances;
+    std::vector<float> fpool; std::vector<int32_t> ipool; std::vector<hpt_instance> instances; std::vector<hpt_texture> textures;
     DScene d;
 };
 
@@ -33,7 +33,8 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->materials = s->fs.materials;
     s->lights.assign(desc->lights, desc->lights + desc->n_lights);
     s->fpool = s->fs.fpool;
-    s->ipool.assign(desc->ipool, desc->ipool + desc->n_i);
+    s->ipool = s->fs.ipool;          // (shape sets rewritten by flatten_scene)
+    s->textures.assign(desc->textures, desc->textures + desc->n_textures);
     memset(&s->d, 0, sizeof(s->d));
     s->d.nodes = (const f4 *)s->fs.nodes.data();
     s->d.tris = (const f4 *)s->fs.tri_rec.data();
@@ -45,6 +46,7 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->instances.assign(desc->instances, desc->instances + desc->n_instances);
     s->d.instances = s->instances.data(); s->d.inst_root = s->fs.inst_root.data();
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
+    s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
     return s;
 }
 extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
@@ -65,6 +67,12 @@ static void gather_film(const RenderParams &rp, float *film) {
 
 static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderParams *rp) {
     rp->cam = *cam;
+    {   // as fill_params of csrc/hpt_api.hip
+        const f3 o = xf_point(cam->raster_to_camera, mk3(0, 0, 0));
+        rp->dx_camera = xf_point(cam->raster_to_camera, mk3(1, 0, 0)) - o;
+        rp->dy_camera = xf_point(cam->raster_to_camera, mk3(0, 1, 0)) - o;
+        rp->diff_scale = 1.f / sqrtf((float)rd->spp);
+    }
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
@@ -126,7 +134,7 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
             if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashSrc, true, MATS_ALL, DL> lane; lane.init();
+            Lane<LdHashSrc, true, MATS_FULL, DL> lane; lane.init();
             lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 Hit hit;
@@ -134,7 +142,7 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
                 if (!DL || lane.stage != ST_SHADE) {
                     bool anyhit = lane.stage == ST_SHADOW;
                     if (anyhit) wc.shadow++; else wc.closest++;
-                    traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                    traverse<true, true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 }
                 { LaneStack ls; ls.p = stack; ls.stride = 1; lane.on_hit_serial(s->d, rp, hit, film, &wc, ls); }
             }
@@ -199,7 +207,7 @@ extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, i
         const float *r = rays + 8 * i;
         Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
         Hit hit; TravCounters tc = {0, 0}; int32_t stack[64];
-        bool h = traverse<false, true>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
+        bool h = traverse<false, true, true>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
         float *o = out_hit + 4 * i;
         o[0] = o[1] = o[2] = o[3] = 0.f;
         if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
@@ -220,12 +228,15 @@ extern "C" int emu_bsdf_tier(const emu_scene *s, int material, const float *in, 
         f3 wo = mk3(q[0], q[1], q[2]), wi = mk3(q[3], q[4], q[5]);
         f3 nn = mk3(q[9], q[10], q[11]), dpdu = mk3(q[12], q[13], q[14]);
         Bsdf b; bsdf_frame(&b, nn, dpdu, nn * q[15]);
-        bsdf_add_material<MATS_ALL>(&b, &sc.materials[material]);
+        {   DGeomX dgs;
+            dgs.p = S(0.f); dgs.nn = nn; dgs.dpdu = dpdu; dgs.dpdv = cross(nn, dpdu); dgs.dndu = dgs.dndv = dgs.dpdx = dgs.dpdy = S(0.f);
+            dgs.u = q[6]; dgs.v = q[7]; dgs.dudx = dgs.dvdx = dgs.dudy = dgs.dvdy = 0.f;
+            bsdf_add_material_ext(&b, sc, &sc.materials[material], dgs); }
         int32_t stk[64]; LaneStack ls; ls.p = stk; ls.stride = 1;
-        f3 f = bsdf_f<MATS_ALL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
-        float pdf = bsdf_pdf<MATS_ALL>(b, wo, wi, BSDF_ALL_NOSPEC);
+        f3 f = bsdf_f<MATS_FULL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
+        float pdf = bsdf_pdf<MATS_FULL>(b, wo, wi, BSDF_ALL_NOSPEC);
         f3 swi = S(0.f); float spdf = 0.f; int stype = 0;
-        f3 sf = bsdf_sample_f<MATS_ALL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL_NOSPEC, &stype, ls);
+        f3 sf = bsdf_sample_f<MATS_FULL>(sc, b, wo, &swi, q[6], q[7], q[8], &spdf, BSDF_ALL, &stype, ls);
         o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
         o[4] = swi.x; o[5] = swi.y; o[6] = swi.z; o[7] = sf.x; o[8] = sf.y; o[9] = sf.z; o[10] = spdf; o[11] = (float)stype;
     }
