@@ -225,10 +225,19 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
     }
     rp->cam = *cam;
-    {   // PerspectiveCamera ctor (cameras/perspective.cpp:46-48): dxCamera = RasterToCamera(1,0,0) - RasterToCamera(0,0,0), same float operations
-        const f3 o = xf_point(cam->raster_to_camera, mk3(0, 0, 0));
-        rp->dx_camera = xf_point(cam->raster_to_camera, mk3(1, 0, 0)) - o;
-        rp->dy_camera = xf_point(cam->raster_to_camera, mk3(0, 1, 0)) - o;
+    {   // PerspectiveCamera ctor (cameras/perspective.cpp:46-48): dxCamera = RasterToCamera(1,0,0) - RasterToCamera(0,0,0) — Transform::operator()
+        // (Point) written out on the host (core/transform.h:192-202), the float operations of the reference
+        const float *m = cam->raster_to_camera;
+        auto pt = [m](float x, float y, float z, float out[3]) {
+            float xp = m[0] * x + m[1] * y + m[2] * z + m[3], yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+            float zp = m[8] * x + m[9] * y + m[10] * z + m[11], wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+            if (wp != 1.f) { float inv = 1.f / wp; xp *= inv; yp *= inv; zp *= inv; }
+            out[0] = xp; out[1] = yp; out[2] = zp;
+        };
+        float o[3], px[3], py[3];
+        pt(0, 0, 0, o); pt(1, 0, 0, px); pt(0, 1, 0, py);
+        rp->dx_camera.x = px[0] - o[0]; rp->dx_camera.y = px[1] - o[1]; rp->dx_camera.z = px[2] - o[2];
+        rp->dy_camera.x = py[0] - o[0]; rp->dy_camera.y = py[1] - o[1]; rp->dy_camera.z = py[2] - o[2];
         rp->diff_scale = 1.f / sqrtf((float)rd->spp);
     }
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;

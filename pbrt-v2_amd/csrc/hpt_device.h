@@ -1262,7 +1262,7 @@ HPT_FN TexV mip_ewa(const DScene &sc, const hpt_texture &t, int level, float s, 
     return sum;
 }
 // MIPMap::Lookup(s, t, ds0, dt0, ds1, dt1) (core/mipmap.h:272-314) and the trilinear Lookup(s, t, width) (:238-255)
-HPT_FN TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s, float tt, float ds0, float dt0, float ds1, float dt1) {
+HPT_FN_NOINLINE TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s, float tt, float ds0, float dt0, float ds1, float dt1) {
     if (t.do_trilinear) {
         const float width = 2.f * maxf(maxf(fabsf(ds0), fabsf(dt0)), maxf(fabsf(ds1), fabsf(dt1)));
         const float level = t.levels - 1 + log2_pbrt(maxf(width, 1e-8f));
@@ -1291,10 +1291,11 @@ HPT_FN TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s, float tt
 }
 // Texture<T>::Evaluate(dg): constant, image map through a UVMapping2D (textures/imagemap.cpp:94-101, core/texture.cpp:88-98), scale
 // (textures/scale.h:51-53), mix (textures/mix.h:51-55).  Operands precede a texture in the table (hpt_validate_desc), and the scene is
-// refused above HPT_TEX_DEPTH levels of nesting (hpt_api.hip), so the recursion is a template of bounded depth, not a device call stack.
+// refused above HPT_TEX_DEPTH levels of nesting (hpt_api.hip), so the recursion is a template of bounded depth (out-of-line functions, one
+// per level: inlined, the filtering code would be copied into every operand of every call site).
 #define HPT_TEX_DEPTH 3
 template <int DEPTH>
-HPT_FN TexV tex_eval(const DScene &sc, int id, const DGeomX &dg) {
+HPT_FN_NOINLINE TexV tex_eval(const DScene &sc, int id, const DGeomX &dg) {
     const hpt_texture &t = sc.textures[id];
     TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
     if (t.kind == HPT_TEX_CONSTANT) return r;
