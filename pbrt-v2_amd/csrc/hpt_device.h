@@ -1789,8 +1789,10 @@ HPT_FN float set_tri_pdf(const DScene &sc, int mesh, int tri, float area, f3 p, 
     return pdf;
 }
 HPT_FN float quadric_pdf(const hpt_quadric &q, f3 p, f3 wi);
+// EXT: the MATS_EXT kernels — the only ones that carry the code for area lights over shape sets (triangle-mesh emitters)
+template <bool EXT>
 HPT_FN_LIGHT float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) {
-    if (l.kind == HPT_LIGHT_DIFFUSE_AREA && l.quadric < 0) {       // ShapeSet::Pdf (core/light.cpp:157-162) over several shapes
+    if (EXT && l.kind == HPT_LIGHT_DIFFUSE_AREA && l.quadric < 0) {       // ShapeSet::Pdf (core/light.cpp:157-162) over several shapes
         const int32_t *ss = sc.ipool + l.set_off;
         const float *areas = sc.fpool + l.set_area_off;
         float pdf = 0.f;
@@ -1822,6 +1824,7 @@ HPT_FN_LIGHT float light_pdf(const DScene &sc, const hpt_light &l, f3 p, f3 wi) 
 }
 // Light::Sample_L(p, pEpsilon, ls, ...) : point.cpp:50-57, diffuse.cpp:69-81, infinite.cpp:195-221.
 // Outputs wi, pdf and the shadow ray of the VisibilityTester (core/light.h:87-96).
+template <bool EXT>
 HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float pEps, float u0, float u1, f3 *wi, float *pdf, Ray *shadow, float uComp = 0.f) {
     if (l.kind == HPT_LIGHT_POINT) {
         f3 lp = mk3(l.pos[0], l.pos[1], l.pos[2]);
@@ -1833,7 +1836,7 @@ HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float
     }
     if (l.kind == HPT_LIGHT_DIFFUSE_AREA) {
         f3 ns, ps;
-        if (l.quadric >= 0) ps = quadric_sample(sc.quadrics[l.quadric], p, u0, u1, &ns);
+        if (!EXT || l.quadric >= 0) ps = quadric_sample(sc.quadrics[l.quadric], p, u0, u1, &ns);
         else {     // ShapeSet::Sample(p, ls, Ns) (core/light.cpp:143-147): Distribution1D::SampleDiscrete (montecarlo.h:99-107), then the shape's own Sample
             const int32_t *ss = sc.ipool + l.set_off;
             const float *cdf = sc.fpool + l.set_area_off + l.set_n;
@@ -1852,7 +1855,7 @@ HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float
             }
         }
         *wi = normalize(ps - p);
-        *pdf = light_pdf(sc, l, p, *wi);
+        *pdf = light_pdf<EXT>(sc, l, p, *wi);
         float d = len(p - ps);
         shadow->o = p; shadow->d = vdiv(ps - p, d); shadow->mint = pEps; shadow->maxt = d * (1.f - 1e-3f);
         return area_L(l, ns, -*wi);

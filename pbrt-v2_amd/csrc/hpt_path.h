@@ -449,7 +449,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             const bool isDelta = light.kind == HPT_LIGHT_POINT;
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
-            f3 Li = light_sample_L(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
+            f3 Li = light_sample_L<(MATS & MATS_EXT) != 0>(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
             if (lightPdf > 0.f && !sblack(Li)) {
                 if (defer) {
                     sv->has[0] = bsdf_query_point(bsdf, bsdf.w2l(wo), bsdf.w2l(wi), wo, wi, BSDF_ALL_NOSPEC, &sv->fq[0]);
@@ -483,7 +483,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                     float weight = 1.f;
                     bool ok = true;
                     if (!(sampledType & BSDF_SPECULAR)) {
-                        lightPdf = light_pdf(sc, light, p, wi);
+                        lightPdf = light_pdf<(MATS & MATS_EXT) != 0>(sc, light, p, wi);
                         if (lightPdf == 0.f) ok = false;
                         else weight = power_heuristic(1, bsdfPdf, 1, lightPdf);
                     }
