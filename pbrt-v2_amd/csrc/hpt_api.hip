@@ -42,6 +42,7 @@ struct hpt_scene {
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
+    float *dl_stack; size_t dl_stack_floats;       // direct lighting over specular surfaces: the recursion's per-lane ray stacks (grown on demand)
     void *d_film; size_t film_bytes;               // device film of hpt_render (host-film entry point), grown on demand
     void *d_scr; hipEvent_t ev0, ev1;              // per-frame scratch (work-queue heads + counters) and timing events, created once
     float *sbuf; size_t sbuf_floats;             // two-pass film: per-sample records of the last filtered render (grown on demand)         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
@@ -70,6 +71,7 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
     if (s->sbuf) (void)hipFree(s->sbuf);
     if (s->d_scr) (void)hipFree(s->d_scr);
     if (s->d_film) (void)hipFree(s->d_film);
+    if (s->dl_stack) (void)hipFree(s->dl_stack);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -102,7 +104,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->device = device;
     s->tune_cfg = -1;
     s->sbuf = nullptr; s->sbuf_floats = 0;
-    s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0;
+    s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0; s->dl_stack = nullptr; s->dl_stack_floats = 0;
     s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
@@ -116,9 +118,21 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     // HPT_BVH_BUILD=lbvh: build the trees on the device (hpt_bvh_gpu.hip).  An LBVH is not depth-bounded: the path
     // kernel sizes its LDS stacks per scene (up to HPT_MAX_STACK_ROWS), the fixed-stack kernels (replay, wavefront,
     // parity hooks) refuse deeper trees.
+    // Default (no HPT_BVH_BUILD): the device builder for large scenes — from HPT_BVH_DEVICE_MIN triangles (400 000) on, where its
+    // tree traces as fast as the host's binned-SAH tree (1 M-triangle soup: 240 vs 237 Msamples/s, profiles/r01_ab.md) and the build
+    // drops from 0.7 s to 12 ms of kernels; a group whose LBVH is deeper than 30 levels (no LDS rows left for subtree stealing at
+    // four workgroups per CU) still gets the depth-bounded host tree.  Small scenes (cache resident, 30-50 ms host build) keep SAH:
+    // its leaves are better (bunny 507 vs 458, killeroo 685 vs 538 Msamples/s).  HPT_BVH_BUILD=sah / lbvh pins the choice.
     BvhDeviceBuildFn dev_build = nullptr;
-    if (const char *e = getenv("HPT_BVH_BUILD")) if (!strcmp(e, "lbvh")) dev_build = build_bvh_lbvh_gpu;
-    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs, dev_build, HPT_MAX_STACK_ROWS - 2) != HPT_OK) { delete s; return nullptr; }
+    int dev_depth = HPT_MAX_STACK_ROWS - 2;
+    int64_t total_tris = 0;
+    for (int m = 0; m < desc->n_meshes; ++m) total_tris += desc->meshes[m].ntris;
+    int64_t dev_min = 400000;
+    if (const char *e = getenv("HPT_BVH_DEVICE_MIN")) dev_min = atoll(e);
+    const char *bb = getenv("HPT_BVH_BUILD");
+    if (bb && !strcmp(bb, "lbvh")) dev_build = build_bvh_lbvh_gpu;
+    else if (!(bb && !strcmp(bb, "sah")) && total_tris >= dev_min) { dev_build = build_bvh_lbvh_gpu; dev_depth = 30; }
+    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs, dev_build, dev_depth) != HPT_OK) { delete s; return nullptr; }
     if (fs.max_depth + 2 > HPT_MAX_STACK_ROWS) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
     s->device_build_ms = fs.device_build_ms; s->device_built = fs.device_built;
     const int64_t ntris = fs.n_tris;
@@ -458,7 +472,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
@@ -475,8 +489,8 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel with a production sampler (MT_REPLAY and the wavefront pipeline cover the round-1 feature set)");
         return HPT_E_UNSUPPORTED;
     }
-    if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH) {
-        hpt_set_error("the direct-lighting integrator's specular recursion (core/integrator.cpp:177-258) is not on the device: glass / mirror scenes render with the path integrator");
+    if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH && rd->maxdepth > 16) {
+        hpt_set_error("direct lighting over specular surfaces: maxdepth %d exceeds the 16 levels the recursion's ray stack is sized for", rd->maxdepth);
         return HPT_E_UNSUPPORTED;
     }
     hipError_t e = hipSuccess;
@@ -514,6 +528,17 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if ((replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT) && s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) {
         hpt_set_error("BVH depth %d: the replay / wavefront kernels have a fixed %d-row traversal stack (build the scene with the host SAH builder)", s->info.bvh_max_depth, HPT_STACK_DEPTH);
         return HPT_E_UNSUPPORTED;
+    }
+    if (dl && s->has_specular && e == hipSuccess) {      // SpecularReflect / SpecularTransmit recursion: a stack of pending rays per lane, in HBM
+        a.dl_cap = rd->maxdepth + 1;
+        const size_t need = (size_t)(a.dl_cap + 1) * HPT_DLS_FLOATS * (size_t)grid * HPT_BLOCK;
+        if (s->dl_stack_floats < need) {
+            if (s->dl_stack) (void)hipFree(s->dl_stack);
+            s->dl_stack = nullptr; s->dl_stack_floats = 0;
+            e = hipMalloc((void **)&s->dl_stack, need * sizeof(float));
+            if (e == hipSuccess) s->dl_stack_floats = need;
+        }
+        a.dl_stack = s->dl_stack;
     }
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) a.rp.sbuf_xyzw = a.rp.sbuf_pos = nullptr;   // the wavefront pipeline keeps the one-pass (atomic) splat
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
@@ -599,7 +624,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (tune_forced() >= 0) return tune_forced();
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
-    a.dl = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
@@ -620,6 +645,7 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
     size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
     if (s->film_bytes < bytes) {                          // the device film of the host-film entry point stays with the scene
         if (s->d_film) (void)hipFree(s->d_film);
+    if (s->dl_stack) (void)hipFree(s->dl_stack);
         s->d_film = nullptr; s->film_bytes = 0;
         HIP_CHECK_RET(hipMalloc(&s->d_film, bytes), HPT_E_HIP);
         s->film_bytes = bytes;

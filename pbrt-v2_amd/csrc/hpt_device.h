@@ -1549,7 +1549,7 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
 // geometric normal dg.nn (emitter facing test) — out of line: one copy for the extension, shadow-ray-free paths of the kernel.
 template <bool INST>
 HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float time, const Hit &hit, const RayDiff &rdiff, Bsdf *b, DGeom *dgo,
-                                     float *rayEps, int *arealight) {
+                                     float *rayEps, int *arealight, DGeomX *dgs_out = nullptr) {
     Ray ray = wray;
     DGeomX dg;
     dg.dndu = dg.dndv = S(0.f);
@@ -1649,8 +1649,40 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
     }
     if (mat->tex[HPT_TEXSLOT_BUMP] >= 0) { DGeomX db; bump_geometry(sc, mat->tex[HPT_TEXSLOT_BUMP], dg.nn, dgs, flip, &db); dgs = db; }
     dgo->p = dgs.p; dgo->nn = dg.nn; dgo->dpdu = dgs.dpdu;
+    if (dgs_out) *dgs_out = dgs;
     bsdf_frame(b, dgs.nn, dgs.dpdu, dg.nn);
     bsdf_add_material_ext(b, sc, mat, dgs);
+}
+// Ray differentials of the rays SpecularReflect / SpecularTransmit spawn (core/integrator.cpp:190-207, 229-250): rd of the incoming ray,
+// dgs / n of the shading geometry, wo = -ray.d, wi the specular direction, eta = the BSDF's index of refraction
+HPT_FN void specular_differentials(const RayDiff &rd, f3 rayd_unused, const DGeomX &dgs, f3 p, f3 n, f3 wo, f3 wi, bool reflect, float bsdf_eta, RayDiff *out) {
+    (void)rayd_unused;
+    out->has = rd.has;
+    out->rxo = out->ryo = out->rxd = out->ryd = S(0.f);
+    if (!rd.has) return;
+    out->rxo = p + dgs.dpdx;
+    out->ryo = p + dgs.dpdy;
+    const f3 dndx = dgs.dndu * dgs.dudx + dgs.dndv * dgs.dvdx;
+    const f3 dndy = dgs.dndu * dgs.dudy + dgs.dndv * dgs.dvdy;
+    if (reflect) {
+        const f3 dwodx = (-rd.rxd) - wo, dwody = (-rd.ryd) - wo;
+        const float dDNdx = dot(dwodx, n) + dot(wo, dndx);
+        const float dDNdy = dot(dwody, n) + dot(wo, dndy);
+        out->rxd = (wi - dwodx) + (dndx * dot(wo, n) + n * dDNdx) * 2.f;
+        out->ryd = (wi - dwody) + (dndy * dot(wo, n) + n * dDNdy) * 2.f;
+    } else {
+        float eta = bsdf_eta;
+        const f3 w = -wo;
+        if (dot(w, n) < 0) eta = 1.f / eta;
+        const f3 dwdx = rd.rxd - w, dwdy = rd.ryd - w;
+        const float dDNdx = dot(dwdx, n) + dot(w, dndx);
+        const float dDNdy = dot(dwdy, n) + dot(w, dndy);
+        const float mu = eta * dot(w, n) - dot(wi, n);
+        const float dmudx = (eta - (eta * eta * dot(w, n)) / dot(wi, n)) * dDNdx;
+        const float dmudy = (eta - (eta * eta * dot(w, n)) / dot(wi, n)) * dDNdy;
+        out->rxd = (wi + dwdx * eta) - (dndx * mu + n * dmudx);
+        out->ryd = (wi + dwdy * eta) - (dndy * mu + n * dmudy);
+    }
 }
 
 // ---- lights ---------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ struct PathKernelArgs {
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2; 12 query-queue rows with a measured BRDF)
     float *inst_xf;                 // animated instances: per-path transform cache, [12 x n_instances][grid x 256] floats, or null
     int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
+    float *dl_stack;                // direct lighting over specular surfaces: per-lane stack of pending specular rays, [(dl_cap + 1) x HPT_DLS_FLOATS][grid x 256] floats, or null
+    int32_t dl_cap;                 // its capacity in rays (maxdepth + 1)
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
     return (size_t)a.stack_entries * HPT_BLOCK * 4;

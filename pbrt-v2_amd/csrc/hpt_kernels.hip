@@ -14,6 +14,8 @@
 // address 64 consecutive banks (conflict-free ds_read/ds_write_b32).
 // No MFMA anywhere: the workload is divergent pointer chasing, not a contraction.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 
 #include "hpt_kernels_impl.h"
 #include "hpt_replay.h"
@@ -135,6 +137,72 @@ __global__ __launch_bounds__(256) void hpt_film_gather_kernel(const RenderParams
     f[0] = aX; f[1] = aY; f[2] = aZ; f[3] = aW;
 }
 
+// The same second pass, LDS-staged (the default since round 2).  A workgroup owns 16 x 16 film pixels, one per lane.  The records that can
+// reach them lie in (16 + 2 ry) rows of (16 + 2 rx) pixels of the sample extent; a row's records are ONE contiguous array, which the
+// workgroup copies into LDS in slabs of g source pixels (coalesced 16-byte + 8-byte loads, every record read once per workgroup it can
+// reach: (20 / 16)^2 = 1.56x for a 2-pixel filter) and then every lane walks ITS OWN window — the source pixels within the filter radius
+// of its pixel, all their samples — straight out of LDS: no cross-lane broadcast, every live lane tests a record it can actually use
+// (the broadcast form above spends 9 v_readlane + ~20 VALU per record for all 64 lanes and finds 16 of them in reach: 20 % lane
+// utilisation, profiles/r01f_bunny_gaussian_gather.md).  A pixel's records sit (spp + 1) slots apart, so that the 16 pixels of a row — which
+// walk 16 different source pixels in step — hit different LDS banks.  Summation order: rows, source pixels, sample index — the order of
+// film_gather_pixel (hpt_path.h), so the film is bit-identical to it, to the broadcast kernel, and from run to run.
+__global__ __launch_bounds__(256) void hpt_film_gather_lds_kernel(const RenderParams rp, float *film, int g) {
+    extern __shared__ float4 dyn_rec[];                      // [g][spp + 1] {X, Y, Z, w}, then [g][spp + 1] {imageX, imageY}
+    __shared__ float s_tab[256];
+    s_tab[threadIdx.x] = rp.ftable[threadIdx.x];
+    const int spp = rp.spp, pitch = spp + 1;
+    float2 *lds_pos = (float2 *)(dyn_rec + (size_t)g * pitch);
+    const int bx0 = rp.x_start + (int)blockIdx.x * 16, by0 = rp.y_start + (int)blockIdx.y * 16;
+    const int x = bx0 + (int)(threadIdx.x & 15), y = by0 + (int)(threadIdx.x >> 4);
+    const bool live = x < rp.x_start + rp.x_count && y < rp.y_start + rp.y_count;
+    const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
+    int qx0 = bx0 - rx, qx1 = bx0 + 15 + rx, qy0 = by0 - ry, qy1 = by0 + 15 + ry;
+    if (qx0 < rp.sx_start) qx0 = rp.sx_start;
+    if (qx1 > rp.sx_start + rp.sx_count - 1) qx1 = rp.sx_start + rp.sx_count - 1;
+    if (qy0 < rp.sy_start) qy0 = rp.sy_start;
+    if (qy1 > rp.sy_start + rp.sy_count - 1) qy1 = rp.sy_start + rp.sy_count - 1;
+    float aX = 0.f, aY = 0.f, aZ = 0.f, aW = 0.f;
+    for (int qy = qy0; qy <= qy1; ++qy) {
+        const bool row_in_reach = live && qy >= y - ry && qy <= y + ry;
+        for (int qg = qx0; qg <= qx1; qg += g) {
+            const int n = qx1 - qg + 1 < g ? qx1 - qg + 1 : g;
+            const int64_t base = ((int64_t)(qy - rp.sy_start) * rp.sx_count + (qg - rp.sx_start)) * spp;
+            const float4 *rec = (const float4 *)rp.sbuf_xyzw + base;
+            const float2 *pos = (const float2 *)rp.sbuf_pos + base;
+            __syncthreads();                                   // (the previous slab is no longer read; also orders s_tab)
+            for (int p = 0; p < n; ++p)
+                for (int k = (int)threadIdx.x; k < spp; k += 256) {
+                    dyn_rec[p * pitch + k] = rec[(int64_t)p * spp + k];
+                    lds_pos[p * pitch + k] = pos[(int64_t)p * spp + k];
+                }
+            __syncthreads();
+            if (!row_in_reach) continue;
+            int wx0 = x - rx, wx1 = x + rx;
+            if (wx0 < qg) wx0 = qg;
+            if (wx1 > qg + n - 1) wx1 = qg + n - 1;
+            for (int qx = wx0; qx <= wx1; ++qx) {
+                const float4 *r4 = dyn_rec + (qx - qg) * pitch;
+                const float2 *p2 = lds_pos + (qx - qg) * pitch;
+                for (int k = 0; k < spp; ++k) {
+                    const float4 r = r4[k];
+                    if (r.w == 0.f) continue;                  // not rendered by this shard
+                    const float2 ps = p2[k];
+                    const float dimageX = ps.x - 0.5f, dimageY = ps.y - 0.5f;
+                    if (x < (int)ceilf(dimageX - rp.fxw) || x > (int)floorf(dimageX + rp.fxw)) continue;
+                    if (y < (int)ceilf(dimageY - rp.fyw) || y > (int)floorf(dimageY + rp.fyw)) continue;
+                    int ix = (int)floorf(fabsf((x - dimageX) * rp.finvx * 16.f)); if (ix > 15) ix = 15;
+                    int iy = (int)floorf(fabsf((y - dimageY) * rp.finvy * 16.f)); if (iy > 15) iy = 15;
+                    const float wt = s_tab[iy * 16 + ix];
+                    aX += wt * r.x; aY += wt * r.y; aZ += wt * r.z; aW += wt;
+                }
+            }
+        }
+    }
+    if (!live) return;
+    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+    f[0] = aX; f[1] = aY; f[2] = aZ; f[3] = aW;
+}
+
 // ---- function-level parity kernels (same device functions, array in / array out) --------------------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene sc, const float *rays, int64_t n, int anyhit,
                                                                   float *out_hit, int32_t *out_prim) {
@@ -231,7 +299,17 @@ hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, h
 }
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream) {
     dim3 grid((unsigned)((rp.x_count + 15) / 16), (unsigned)((rp.y_count + 15) / 16));
-    hipLaunchKernelGGL(hpt_film_gather_kernel, grid, dim3(256), 0, stream, rp, film);
+    // LDS-staged gather: slabs of g source pixels (24 bytes x (spp + 1) each) in up to 48 KB; a pixel with more samples than fit (spp > 2047),
+    // or HPT_GATHER_KERNEL=bcast, takes the wave-broadcast kernel
+    const size_t per_px = (size_t)(rp.spp + 1) * 24, budget = 48 * 1024;
+    const char *force = getenv("HPT_GATHER_KERNEL");
+    if (per_px <= budget && !(force && !strcmp(force, "bcast"))) {
+        int g = (int)(budget / per_px);
+        const int seg = 16 + 2 * (int)floorf(rp.fxw + 0.5f);
+        if (g > seg) g = seg;
+        hipLaunchKernelGGL(hpt_film_gather_lds_kernel, grid, dim3(256), (size_t)g * per_px, stream, rp, film, g);
+    } else
+        hipLaunchKernelGGL(hpt_film_gather_kernel, grid, dim3(256), 0, stream, rp, film);
     return hipGetLastError();
 }
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {

@@ -200,6 +200,7 @@ struct ColdLds {
     HPT_MFN void film_get(float *X, float *Y, float *Z, float *W) const { *X = c[6 * stride]; *Y = c[7 * stride]; *Z = c[8 * stride]; *W = c[9 * stride]; }
 };
 #define HPT_COLD_ROWS 10
+#define HPT_DLS_FLOATS 24     /* one pending ray of the direct-lighting specular recursion: o, d, beta, epsilon, depth, has-differentials, 4 x 3 differentials */
 #ifdef HPT_NO_PARK
 #define HPT_PARK_MATS(mats) false
 #else
@@ -242,8 +243,15 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     Ray cam; Hit chit;
     int li, lj;
     f3 acc;                 // Ld of the current light, summed over its samples
+    // direct lighting with specular surfaces (MATS_EXT): the SpecularReflect / SpecularTransmit recursion of directlighting.cpp:111-118,
+    // core/integrator.cpp:177-258 unrolled into a depth-first walk over an explicit stack of pending rays in HBM (dls: this lane's
+    // column, element k of entry e at dls[(e * HPT_DLS_FLOATS + k) * dls_stride]; the entry after the last holds the current ray's
+    // differentials).  Li is linear in the radiance of the spawned rays, so a node adds beta * (Le + direct lighting) with beta = the
+    // product of f * |wi.n| / pdf along its branch; the same Sample serves every node, as in the reference.
+    int depth, nsp, dls_cap;
+    float *dls; int64_t dls_stride;
 
-    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; }
+    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; }
 
     // samplerrenderer.cpp:185-206 for one camera sample
     HPT_MFN void begin_sample(const RenderParams &rp) {
@@ -256,7 +264,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
         time = 0.f;
         if (INST && rp.has_motion) { float t = smp.time01(rp); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
-        cold.setL(S(0.f)); cold.setBeta(S(1.f)); bounce = 0; specular = false;
+        cold.setL(S(0.f)); cold.setBeta(S(1.f)); bounce = 0; specular = false; depth = 0; nsp = 0;
         stage = ST_EXTEND;
     }
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y, uint32_t s0 = 0, uint32_t n = 0) {
@@ -325,10 +333,10 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             if (sc.n_lights > 0 && rp.integrator == HPT_INTEGRATOR_DIRECT_ALL) {       // integrator.cpp:56-77
                 acc = acc + Ld;
                 const int n = dl_count(sc.lights[li], rp);
-                if (++lj == n) { cold.setL(cold.L() + sdivf(acc, (float)n)); acc = S(0.f); lj = 0; ++li; }
+                if (++lj == n) { cold.setL(cold.L() + node_weight(sdivf(acc, (float)n))); acc = S(0.f); lj = 0; ++li; }
                 if (li < sc.n_lights) { stage = ST_SHADE; return; }
-            } else if (sc.n_lights > 0) cold.setL(cold.L() + Ld * (float)sc.n_lights);                // integrator.cpp:110-113
-            finish_path(rp, film, wc);
+            } else if (sc.n_lights > 0) cold.setL(cold.L() + node_weight(Ld * (float)sc.n_lights));                // integrator.cpp:110-113
+            node_done(sc, rp, film, wc, true);
             return;
         }
         if (sc.n_lights > 0) cold.setL(cold.L() + smul(cold.beta(), Ld * (float)sc.n_lights));  // integrator.cpp:110, path.cpp:71-80
@@ -344,6 +352,71 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             ray.o = p; ray.d = wi_mis; ray.mint = eps; ray.maxt = HPT_INF; // integrator.cpp:160
             stage = ST_MIS;
         } else after_mis(sc, rp, film, wc);
+    }
+
+    static constexpr bool DL_REC = DL && (MATS & MATS_EXT) != 0;
+    HPT_MFN f3 node_weight(f3 v) const { return DL_REC ? smul(cold.beta(), v) : v; }
+    // differentials of the ray the current vertex was reached by: the camera ray's, rebuilt from its sample (path: first hit only,
+    // geometry.h:351-361); under the direct-lighting recursion the spawned ray's, kept in the lane's HBM column
+    HPT_MFN void current_differentials(const RenderParams &rp, const Ray &r, RayDiff *rd) {
+        rd->has = false;
+        if (DL_REC && depth > 0) {
+            if (!dls) return;
+            const float *c = dls + (int64_t)dls_cap * HPT_DLS_FLOATS * dls_stride;
+            rd->has = c[0] != 0.f;
+            if (!rd->has) return;
+            float v[12];
+            for (int k = 0; k < 12; ++k) v[k] = c[(int64_t)(1 + k) * dls_stride];
+            rd->rxo = mk3(v[0], v[1], v[2]); rd->ryo = mk3(v[3], v[4], v[5]); rd->rxd = mk3(v[6], v[7], v[8]); rd->ryd = mk3(v[9], v[10], v[11]);
+            return;
+        }
+        if (DL ? true : bounce == 0) {
+            float ia, ib, lu = 0.f, lv = 0.f;
+            smp.image(rp, &ia, &ib);
+            if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
+            camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, r, rd);
+        }
+    }
+    // A node of the direct-lighting recursion is finished (all its light samples taken, or its ray escaped): spawn its specular rays,
+    // continue with the next pending one, or — nothing pending — hand the camera sample to the film.
+    HPT_MFN void node_done(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc, bool was_hit) {
+        if (DL_REC && dls) {
+            if (was_hit && depth + 1 < rp.maxdepth) {
+                RayDiff rdiff; current_differentials(rp, cam, &rdiff);
+                Bsdf bsdf; DGeom dg; DGeomX dgs; int al; float e;
+                shade_geometry_ext<INST>(sc, cam, time, chit, rdiff, &bsdf, &dg, &e, &al, &dgs);
+                const f3 wo = -cam.d, n = bsdf.nn, pp = dg.p;
+                const f3 W = cold.beta();
+                for (int pass = 1; pass >= 0; --pass) {              // transmission pushed first: reflection is evaluated first, as in the reference
+                    f3 wo_l, wi_l, wi, fs; float pdf; int st;
+                    if (!bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, .5f, .5f, .5f, &pdf, (pass == 0 ? BSDF_REFLECTION : BSDF_TRANSMISSION) | BSDF_SPECULAR, &st, &fs)) continue;
+                    if (!(pdf > 0.f) || sblack(fs) || absdot(wi, n) == 0.f || nsp >= dls_cap) continue;
+                    RayDiff cd;
+                    specular_differentials(rdiff, cam.d, dgs, pp, n, wo, wi, pass == 0, bsdf.exponent, &cd);
+                    const f3 Wc = smul(W, sdivf(fs * absdot(wi, n), pdf));
+                    float *s = dls + (int64_t)nsp * HPT_DLS_FLOATS * dls_stride;
+                    const float v[HPT_DLS_FLOATS] = {pp.x, pp.y, pp.z, wi.x, wi.y, wi.z, Wc.x, Wc.y, Wc.z, e, (float)(depth + 1), cd.has ? 1.f : 0.f,
+                                                     cd.rxo.x, cd.rxo.y, cd.rxo.z, cd.ryo.x, cd.ryo.y, cd.ryo.z, cd.rxd.x, cd.rxd.y, cd.rxd.z, cd.ryd.x, cd.ryd.y, cd.ryd.z};
+                    for (int k = 0; k < HPT_DLS_FLOATS; ++k) s[(int64_t)k * dls_stride] = (cd.has || k < 12) ? v[k] : 0.f;
+                    ++nsp;
+                }
+            }
+            if (nsp > 0) {
+                --nsp;
+                const float *s = dls + (int64_t)nsp * HPT_DLS_FLOATS * dls_stride;
+                float v[HPT_DLS_FLOATS];
+                for (int k = 0; k < HPT_DLS_FLOATS; ++k) v[k] = s[(int64_t)k * dls_stride];
+                ray.o = mk3(v[0], v[1], v[2]); ray.d = mk3(v[3], v[4], v[5]); ray.mint = v[9]; ray.maxt = HPT_INF;
+                cold.setBeta(mk3(v[6], v[7], v[8]));
+                depth = (int)v[10];
+                float *c = dls + (int64_t)dls_cap * HPT_DLS_FLOATS * dls_stride;       // the ray's differentials: current-node slot
+                c[0] = v[11];
+                for (int k = 0; k < 12; ++k) c[(int64_t)(1 + k) * dls_stride] = v[12 + k];
+                stage = ST_EXTEND;
+                return;
+            }
+        }
+        finish_path(rp, film, wc);
     }
 
     // Called with the result of the traversal phase for this lane's pending ray.  Shadow / MIS results and
@@ -385,6 +458,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         }
         // ---- ST_EXTEND: closest-hit result of a camera or continuation ray -------------------------
         if (hit.prim < 0) {
+            if (DL_REC && depth > 0) { cold.setL(cold.L() + smul(cold.beta(), all_lights_Le(sc, ray.d))); node_done(sc, rp, film, wc, false); return false; }
             if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:335-338
             else if (specular)                                             // path.cpp:114-116
                 for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
@@ -405,13 +479,8 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         Bsdf bsdf; DGeom dg; int arealight;
         if (MATS & MATS_EXT) {
             // the camera ray is the only one with differentials (geometry.h:351-361): rebuilt from its sample at the first hit
-            RayDiff rdiff; rdiff.has = false;
-            if (DL ? true : bounce == 0) {
-                float ia, ib, lu = 0.f, lv = 0.f;
-                smp.image(rp, &ia, &ib);
-                if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
-                camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, ray, &rdiff);
-            }
+            RayDiff rdiff;
+            current_differentials(rp, ray, &rdiff);
             shade_geometry_ext<INST>(sc, ray, time, hit, rdiff, &bsdf, &dg, &eps, &arealight);
         } else
             shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);

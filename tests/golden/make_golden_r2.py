@@ -10,6 +10,7 @@
             formula — tests/util.py merl_table — so only geometry travels)
   tex       ImageTexture (Spectrum + float) through MIPMap EWA and trilinear lookups with camera-ray differentials, ScaleTexture,
             MixTexture, float roughness texture, Material::Bump on a flat quad and on a mesh with vertex normals
+  mirtex    a textured floor seen in a mirror and through a glass solid under DirectLightingIntegrator: differentials of the specular rays
   alpha     TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:191-195, 246-276): a cut-out quad between light and floor
   metal     scenes/metal.pbrt as shipped (BASELINE.json configs[4]) with the metropolis Renderer line replaced by sampler + path and
             the missing uffizi map replaced by tests/golden/small_env.exr: textured, bump-mapped substrate floor (lines.exr) + Au teapot
@@ -186,6 +187,14 @@ def main():
                + WALL % 'Material "plastic" "texture Kd" "tinted" "color Ks" [.3 .3 .3] "texture roughness" "rough"'
                + OCTA % ('Material "matte" "texture Kd" "mixed" "texture bumpmap" "bumpy"', 0.3, 0.9, 0.6) + "WorldEnd\n")
         run("tex", tex, tmp).save(os.path.join(HERE, "tex.hpts.gz"))
+        # ---- mirtex: textured surfaces seen THROUGH specular bounces under direct lighting: the ray differentials of SpecularReflect /
+        # SpecularTransmit (core/integrator.cpp:190-207, 229-250) drive the EWA lookups at the deeper hits
+        mirtex = (HEAD % dict(out="%OUT%", spp=4, integrator='SurfaceIntegrator "directlighting" "integer maxdepth" [4]') + POINT % (30, 30, 30, 1, 4, 4)
+                  + SPHERE_LIGHT % (10, 10, 10, 2, -2, 3, 1.5, 0.4) + texdefs
+                  + FLOOR % 'Material "matte" "texture Kd" "pat"'
+                  + 'AttributeBegin\nMaterial "mirror" "color Kr" [.9 .9 .9]\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -3  4 0 -3  4 4 -2.2  -4 4 -2.2] "float uv" [0 0 1 0 1 1 0 1]\nAttributeEnd\n'
+                  + OCTA % ('Material "glass" "float index" [1.5]', 0.3, 0.9, 0.6) + "WorldEnd\n")
+        run("mirtex", mirtex, tmp).save(os.path.join(HERE, "mirtex.hpts.gz"))
         # ---- alpha: cut-out quad ----------------------------------------------------------------------------------------------------
         alpha = (HEAD % dict(out="%OUT%", spp=8, integrator=PATH % 4) + SPHERE_LIGHT % (30, 30, 28, 1, 0, 3.6, 0.5, 0.3)
                  + 'Texture "mask" "float" "imagemap" "string filename" "%s" "string wrap" ["clamp"]\n' % ALPHA
@@ -203,7 +212,7 @@ def main():
         text = text.replace('"textures/lines.exr"', '"%s/textures/lines.exr"' % REF).replace('"spds/', '"%s/spds/' % REF).replace('Include "geometry/', 'Include "%s/geometry/' % REF)
         run("metal", text, tmp, exe=PBRT_EXR).save(os.path.join(HERE, "metal.hpts.gz"))
     for f in sorted(os.listdir(HERE)):
-        if any(f.startswith(p) for p in ("on.", "spec", "tril", "merl", "tex", "alpha", "metal")):
+        if any(f.startswith(p) for p in ("on.", "spec", "tril", "merl", "tex", "alpha", "metal", "mirtex")):
             print("%10d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 
 

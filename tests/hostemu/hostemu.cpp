@@ -135,6 +135,8 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
             int x, y; uint32_t s0;
             if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
             Lane<LdHashSrc, true, MATS_FULL, DL> lane; lane.init();
+            std::vector<float> dls((size_t)(rd->maxdepth + 2) * HPT_DLS_FLOATS, 0.f);
+            if (DL) { lane.dls = dls.data(); lane.dls_stride = 1; lane.dls_cap = rd->maxdepth + 1; }
             lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 Hit hit;

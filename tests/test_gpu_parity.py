@@ -668,7 +668,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "trilight", "trildl", "merl", "tex", "alpha", "metal"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)
@@ -676,7 +676,9 @@ def test_round2_features_match_oracle_sample_for_sample(name):
     """SURVEY.md §8a rows a9 / a14 / a16 / a20 and §8f-3 on the device (MATS_EXT kernel set, hpt_kernels_ext.hip): Oren-Nayar; glass and
     mirror (specular bounces of the path integrator); DiffuseAreaLight over triangle-mesh ShapeSets (path and direct lighting);
     RegularHalfangleBRDF; ImageTexture through MIPMap EWA / trilinear with camera-ray differentials, scale / mix textures, bump mapping;
-    alpha-textured triangles; scenes/metal.pbrt as shipped.  Each case's oracle is pinned bit-identical to the reference binary
+    alpha-textured triangles; scenes/metal.pbrt as shipped; glass + mirror under DirectLightingIntegrator — the SpecularReflect /
+    SpecularTransmit recursion as a depth-first walk over a per-lane ray stack in HBM (`specdl`), with textures filtered through the
+    specular rays' differentials (`mirtex`).  Each case's oracle is pinned bit-identical to the reference binary
     (tests/test_oracle_pin.py).  Bar: film weights identical, per-pixel RMSE < 1e-3 (north-star tolerance; ~1e-6 in practice)."""
     s = load_case(name)
     rd = hash_rd(s, seed=3)
@@ -723,18 +725,19 @@ def test_round2_bsdfs_match_oracle(name, material):
 
 
 def test_scope_limits_of_the_extension_are_refused_loudly():
-    """Glass / mirror under the direct-lighting integrator (its specular recursion is oracle-only so far) and the parity pipelines
-    (MT_REPLAY, wavefront) on an extension scene return HPT_E_UNSUPPORTED instead of rendering something else."""
-    s = load_case("specdl")
-    d = hpt.DeviceScene(s)
-    with pytest.raises(hpt.HptError, match="specular recursion"):
-        d.render(s.camera, hash_rd(s, seed=1))
+    """The parity pipelines (MT_REPLAY, wavefront) cover the round-1 feature set: on an extension scene they return HPT_E_UNSUPPORTED
+    instead of rendering something else; so does a direct-lighting recursion deeper than its ray stack is sized for."""
     s = load_case("spec")
     d = hpt.DeviceScene(s)
     rd = hash_rd(s, seed=1)
     rd.pipeline = abi.HPT_PIPELINE_WAVEFRONT
     with pytest.raises(hpt.HptError, match="persistent kernel"):
         d.render(s.camera, rd)
+    s = load_case("specdl")
+    rd = hash_rd(s, seed=1)
+    rd.maxdepth = 40
+    with pytest.raises(hpt.HptError, match="16 levels"):
+        hpt.DeviceScene(s).render(s.camera, rd)
 
 
 def test_shards_partition_the_image(cases, dev):

@@ -99,7 +99,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "trilight", "trildl", "merl", "tex", "alpha", "metal"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,
@@ -114,7 +114,7 @@ def test_round2_features_render_matches_oracle(name):
     assert abs(int(so[1]) - int(se[1])) <= 4 and abs(int(so[2]) - int(se[2])) <= 4
     assert np.array_equal(fo[..., 3], fe[..., 3])
     io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
-    assert differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-6
+    assert differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-6     # (specdl / mirtex: the recursion's products are taken in another order)
 
 
 @pytest.mark.parametrize("name,material", [("on", 1), ("on", 2), ("spec", 1), ("spec", 2), ("spec", 4), ("merl", 0), ("tex", 2), ("tex", 3)])
