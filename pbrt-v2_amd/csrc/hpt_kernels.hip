@@ -137,31 +137,63 @@ __global__ __launch_bounds__(256) void hpt_film_gather_kernel(const RenderParams
     f[0] = aX; f[1] = aY; f[2] = aZ; f[3] = aW;
 }
 
-// The same second pass, LDS-staged (the default since round 2).  A workgroup owns 16 x 16 film pixels, one per lane.  The records that can
-// reach them lie in (16 + 2 ry) rows of (16 + 2 rx) pixels of the sample extent; a row's records are ONE contiguous array, which the
-// workgroup copies into LDS in slabs of g source pixels (coalesced 16-byte + 8-byte loads, every record read once per workgroup it can
-// reach: (20 / 16)^2 = 1.56x for a 2-pixel filter) and then every lane walks ITS OWN window — the source pixels within the filter radius
-// of its pixel, all their samples — straight out of LDS: no cross-lane broadcast, every live lane tests a record it can actually use
-// (the broadcast form above spends 9 v_readlane + ~20 VALU per record for all 64 lanes and finds 16 of them in reach: 20 % lane
-// utilisation, profiles/r01f_bunny_gaussian_gather.md).  A pixel's records sit (spp + 1) slots apart, so that the 16 pixels of a row — which
-// walk 16 different source pixels in step — hit different LDS banks.  Summation order: rows, source pixels, sample index — the order of
-// film_gather_pixel (hpt_path.h), so the film is bit-identical to it, to the broadcast kernel, and from run to run.
+// The same second pass, LDS-staged (the default since round 2).  A workgroup owns BW x (256 / BW) film pixels, one per lane.  The records that
+// can reach them lie in (BH + 2 ry) rows of (BW + 2 rx) pixels of the sample extent; a row's records are ONE contiguous array, which the
+// workgroup copies into LDS in slabs of g source pixels (coalesced 16-byte + 8-byte loads, all 256 threads) and then every lane walks ITS OWN
+// window — the source pixels within the filter radius of its pixel, all their samples — straight out of LDS: no cross-lane broadcast
+// (the broadcast form above spends 9 v_readlane + ~20 VALU per record for all 64 lanes and finds 16 of them in reach: 20 % lane utilisation,
+// profiles/r01f_bunny_gaussian_gather.md).
+//   LDS record: float4 {X, Y, Z, E} + float2 {dimageX, dimageY} (24 bytes).  E packs the record's pixel extent — the reference's
+// x0 = Ceil2Int(dimageX - xWidth) .. x1 = Floor2Int(dimageX + xWidth), y0 .. y1 (film/image.cpp:77-84), computed ONCE when the record is staged —
+// as four bytes {x0, 127 - x1, y0, 127 - y1} relative to the workgroup's origin (bx0 - rx - 1, by0 - ry - 1) and clamped to 0..127; a lane holds
+// L = {x, 127 - x, y, 127 - y} | 0x80808080 for its pixel, and  (L - E) & 0x80808080 == 0x80808080  (no byte borrows: every byte of L is >= 0x80,
+// every byte of E < 0x80) says x0 <= x <= x1 and y0 <= y <= y1 in three VALU instructions.  A record this shard did not render (w == 0) is staged
+// with E = 0x7f7f7f7f, which no pixel passes.  A pixel's records sit (spp + 1) slots apart, so the lanes of a pixel row — which walk BW different
+// source pixels in step — hit different banks with both the b128 and the b64 read (MI355X_MICROARCH.md, LDS lane groups).
+//   Per record the lane's work is straight-line: the table index is computed and the weight LOADED for every record and then selected to +0
+// when the record is out of reach, which leaves the sums unchanged bit for bit (radiance values are finite: samplerrenderer.cpp:214-228 zeroes
+// the others).  (x - dimageX) * invWidth * 16 is computed as (x - dimageX) * (invWidth * 16): scaling by 16 commutes with rounding.  Records go
+// eight at a time, loads first, so their LDS latency overlaps.
+//   Summation order: rows, source pixels, sample index — the order of film_gather_pixel (hpt_path.h), so the film is bit-identical to it, to the
+// broadcast kernel, and from run to run.
+template <int BW>
 __global__ __launch_bounds__(256) void hpt_film_gather_lds_kernel(const RenderParams rp, float *film, int g) {
-    extern __shared__ float4 dyn_rec[];                      // [g][spp + 1] {X, Y, Z, w}, then [g][spp + 1] {imageX, imageY}
-    __shared__ float s_tab[256];
-    s_tab[threadIdx.x] = rp.ftable[threadIdx.x];
+    constexpr int BH = 256 / BW;
+    extern __shared__ float4 dyn_rec[];                      // [g][spp + 1] {X, Y, Z, E}, then [g][spp + 1] {dimageX, dimageY}
+    // the 16 x 16 weight table, rows 32 dwords apart with the row's 16 weights twice: a lane reads the copy its pixel row's parity picks, so the
+    // two pixel rows that share a 32-lane LDS access group use disjoint banks whatever their iy (which differ by a multiple of 16 / yWidth: with
+    // one copy they collide two-way on every record, profiles/r02h_gather_pmc.md)
+    __shared__ float s_tab[512];
+    s_tab[(threadIdx.x >> 4) * 32 + (threadIdx.x & 15)] = s_tab[(threadIdx.x >> 4) * 32 + 16 + (threadIdx.x & 15)] = rp.ftable[threadIdx.x];
     const int spp = rp.spp, pitch = spp + 1;
-    float2 *lds_pos = (float2 *)(dyn_rec + (size_t)g * pitch);
-    const int bx0 = rp.x_start + (int)blockIdx.x * 16, by0 = rp.y_start + (int)blockIdx.y * 16;
-    const int x = bx0 + (int)(threadIdx.x & 15), y = by0 + (int)(threadIdx.x >> 4);
+    float2 *lds_d = (float2 *)(dyn_rec + (size_t)g * pitch);
+    const int bx0 = rp.x_start + (int)blockIdx.x * BW, by0 = rp.y_start + (int)blockIdx.y * BH;
+    const int x = bx0 + (int)(threadIdx.x % BW), y = by0 + (int)(threadIdx.x / BW);
+    const float fx = (float)x, fy = (float)y;
     const bool live = x < rp.x_start + rp.x_count && y < rp.y_start + rp.y_count;
     const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
-    int qx0 = bx0 - rx, qx1 = bx0 + 15 + rx, qy0 = by0 - ry, qy1 = by0 + 15 + ry;
+    const int ox = bx0 - rx - 1, oy = by0 - ry - 1;          // extents are stored relative to this
+    const uint32_t L = ((uint32_t)(x - ox) | (uint32_t)(127 - (x - ox)) << 8 | (uint32_t)(y - oy) << 16 | (uint32_t)(127 - (y - oy)) << 24) | 0x80808080u;
+    int qx0 = bx0 - rx, qx1 = bx0 + BW - 1 + rx, qy0 = by0 - ry, qy1 = by0 + BH - 1 + ry;
     if (qx0 < rp.sx_start) qx0 = rp.sx_start;
     if (qx1 > rp.sx_start + rp.sx_count - 1) qx1 = rp.sx_start + rp.sx_count - 1;
     if (qy0 < rp.sy_start) qy0 = rp.sy_start;
     if (qy1 > rp.sy_start + rp.sy_count - 1) qy1 = rp.sy_start + rp.sy_count - 1;
+    const float fxw = rp.fxw, fyw = rp.fyw, finvx16 = rp.finvx * 16.f, finvy16 = rp.finvy * 16.f;
+    // thread t stages records t, t + 256, ... of a slab: (source pixel, sample) advance by (256 / spp, 256 % spp) with a carry
+    const int step_p = 256 / spp, step_k = 256 - step_p * spp;
+    const int p_first = (int)threadIdx.x / spp, k_first = (int)threadIdx.x - p_first * spp;
     float aX = 0.f, aY = 0.f, aZ = 0.f, aW = 0.f;
+    const float *tab = s_tab + 16 * ((threadIdx.x / BW) & 1);
+    auto clamp7 = [](int v) -> uint32_t { return (uint32_t)(v < 0 ? 0 : v > 127 ? 127 : v); };
+    // one record: the weight it carries to this lane's pixel (0 if out of reach)
+    auto weight = [&](const float4 &r, const float2 &d) -> float {
+        const bool in = ((L - __float_as_uint(r.w)) & 0x80808080u) == 0x80808080u;
+        unsigned ix = (unsigned)(int)floorf(fabsf((fx - d.x) * finvx16)); ix = ix > 15u ? 15u : ix;
+        unsigned iy = (unsigned)(int)floorf(fabsf((fy - d.y) * finvy16)); iy = iy > 15u ? 15u : iy;
+        const float t = tab[iy * 32u + ix];
+        return in ? t : 0.f;
+    };
     for (int qy = qy0; qy <= qy1; ++qy) {
         const bool row_in_reach = live && qy >= y - ry && qy <= y + ry;
         for (int qg = qx0; qg <= qx1; qg += g) {
@@ -170,11 +202,23 @@ __global__ __launch_bounds__(256) void hpt_film_gather_lds_kernel(const RenderPa
             const float4 *rec = (const float4 *)rp.sbuf_xyzw + base;
             const float2 *pos = (const float2 *)rp.sbuf_pos + base;
             __syncthreads();                                   // (the previous slab is no longer read; also orders s_tab)
-            for (int p = 0; p < n; ++p)
-                for (int k = (int)threadIdx.x; k < spp; k += 256) {
-                    dyn_rec[p * pitch + k] = rec[(int64_t)p * spp + k];
-                    lds_pos[p * pitch + k] = pos[(int64_t)p * spp + k];
+            {
+                int p = p_first, k = k_first;
+                for (int i = (int)threadIdx.x; i < n * spp; i += 256) {
+                    float4 r = rec[i];
+                    const float2 ps = pos[i];
+                    const float dimageX = ps.x - 0.5f, dimageY = ps.y - 0.5f;
+                    uint32_t e = 0x7f7f7f7fu;
+                    if (r.w != 0.f)
+                        e = clamp7((int)ceilf(dimageX - fxw) - ox) | (127u - clamp7((int)floorf(dimageX + fxw) - ox)) << 8 |
+                            clamp7((int)ceilf(dimageY - fyw) - oy) << 16 | (127u - clamp7((int)floorf(dimageY + fyw) - oy)) << 24;
+                    r.w = __uint_as_float(e);
+                    dyn_rec[p * pitch + k] = r;
+                    lds_d[p * pitch + k] = make_float2(dimageX, dimageY);
+                    p += step_p; k += step_k;
+                    if (k >= spp) { k -= spp; ++p; }
                 }
+            }
             __syncthreads();
             if (!row_in_reach) continue;
             int wx0 = x - rx, wx1 = x + rx;
@@ -182,18 +226,135 @@ __global__ __launch_bounds__(256) void hpt_film_gather_lds_kernel(const RenderPa
             if (wx1 > qg + n - 1) wx1 = qg + n - 1;
             for (int qx = wx0; qx <= wx1; ++qx) {
                 const float4 *r4 = dyn_rec + (qx - qg) * pitch;
-                const float2 *p2 = lds_pos + (qx - qg) * pitch;
-                for (int k = 0; k < spp; ++k) {
-                    const float4 r = r4[k];
-                    if (r.w == 0.f) continue;                  // not rendered by this shard
-                    const float2 ps = p2[k];
-                    const float dimageX = ps.x - 0.5f, dimageY = ps.y - 0.5f;
-                    if (x < (int)ceilf(dimageX - rp.fxw) || x > (int)floorf(dimageX + rp.fxw)) continue;
-                    if (y < (int)ceilf(dimageY - rp.fyw) || y > (int)floorf(dimageY + rp.fyw)) continue;
-                    int ix = (int)floorf(fabsf((x - dimageX) * rp.finvx * 16.f)); if (ix > 15) ix = 15;
-                    int iy = (int)floorf(fabsf((y - dimageY) * rp.finvy * 16.f)); if (iy > 15) iy = 15;
-                    const float wt = s_tab[iy * 16 + ix];
-                    aX += wt * r.x; aY += wt * r.y; aZ += wt * r.z; aW += wt;
+                const float2 *d2 = lds_d + (qx - qg) * pitch;
+                int k = 0;
+                for (; k + 8 <= spp; k += 8) {
+                    float4 r[8]; float2 d[8]; float w[8];
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) { r[j] = r4[k + j]; d[j] = d2[k + j]; }
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = weight(r[j], d[j]);
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) { aX += w[j] * r[j].x; aY += w[j] * r[j].y; aZ += w[j] * r[j].z; aW += w[j]; }
+                }
+                for (; k + 4 <= spp; k += 4) {
+                    const float4 r0 = r4[k], r1 = r4[k + 1], r2 = r4[k + 2], r3 = r4[k + 3];
+                    const float2 d0 = d2[k], d1 = d2[k + 1], d2_ = d2[k + 2], d3 = d2[k + 3];
+                    const float w0 = weight(r0, d0), w1 = weight(r1, d1), w2 = weight(r2, d2_), w3 = weight(r3, d3);
+                    aX += w0 * r0.x; aY += w0 * r0.y; aZ += w0 * r0.z; aW += w0;
+                    aX += w1 * r1.x; aY += w1 * r1.y; aZ += w1 * r1.z; aW += w1;
+                    aX += w2 * r2.x; aY += w2 * r2.y; aZ += w2 * r2.z; aW += w2;
+                    aX += w3 * r3.x; aY += w3 * r3.y; aZ += w3 * r3.z; aW += w3;
+                }
+                for (; k < spp; ++k) {
+                    const float4 r0 = r4[k];
+                    const float w0 = weight(r0, d2[k]);
+                    aX += w0 * r0.x; aY += w0 * r0.y; aZ += w0 * r0.z; aW += w0;
+                }
+            }
+        }
+    }
+    if (!live) return;
+    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+    f[0] = aX; f[1] = aY; f[2] = aZ; f[3] = aW;
+}
+
+// The gather for filters of radius <= 2 pixels (the defaults of every reference filter but sinc: filters/*.cpp), with the per-record arithmetic
+// moved out of the lanes.  A record of source pixel q can only reach the pixels q - r .. q + r, per axis; WHICH of them it reaches and with which
+// table column / row is a property of the record, not of the lane that reads it, so it is worked out once when the record is staged: per axis
+// 2 r + 1 five-bit codes, code = min(Floor2Int(|x - dimageX| * invWidth * 16), 15) where x0 <= x <= x1 (film/image.cpp:77-93) and 16 where
+// not, packed into one dword.  The LDS weight table has a zero row and a zero column for code 16, so a lane's work per record is: two bit-field
+// extracts (shift = 5 x its pixel's offset from the source pixel), one address, one table read, the four multiply-adds — about 9 VALU
+// instructions instead of 22 (profiles/r02h_gather_pmc.md: the kernel above is VALU- and latency-bound, not LDS-bound).
+//   LDS record: float4 {X, Y, Z, codesX} + dword codesY (20 bytes); a record this shard did not render has codesX = all 16.  Table rows are 64
+// dwords apart and a lane reads columns 17 * (its pixel row's parity) + code, so the two pixel rows of a 32-lane access group use (almost)
+// disjoint banks.  Order of summation as above: the film is bit-identical to film_gather_pixel's.
+template <int BW>
+__global__ __launch_bounds__(256) void hpt_film_gather_idx_kernel(const RenderParams rp, float *film, int g) {
+    constexpr int BH = 256 / BW;
+    extern __shared__ float4 dyn_rec[];                      // [g][spp + 1] {X, Y, Z, codesX}, then [g][spp + 1] codesY
+    __shared__ float s_tab[17 * 64];
+    for (int i = (int)threadIdx.x; i < 17 * 64; i += 256) {
+        const int cy = i >> 6, c = i & 63, cx = c < 17 ? c : c - 17;
+        s_tab[i] = (cy < 16 && c < 34 && cx < 16) ? rp.ftable[cy * 16 + cx] : 0.f;
+    }
+    const int spp = rp.spp, pitch = spp + 1;
+    uint32_t *lds_cy = (uint32_t *)(dyn_rec + (size_t)g * pitch);
+    const int bx0 = rp.x_start + (int)blockIdx.x * BW, by0 = rp.y_start + (int)blockIdx.y * BH;
+    const int x = bx0 + (int)(threadIdx.x % BW), y = by0 + (int)(threadIdx.x / BW);
+    const bool live = x < rp.x_start + rp.x_count && y < rp.y_start + rp.y_count;
+    const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
+    int qx0 = bx0 - rx, qx1 = bx0 + BW - 1 + rx, qy0 = by0 - ry, qy1 = by0 + BH - 1 + ry;
+    if (qx0 < rp.sx_start) qx0 = rp.sx_start;
+    if (qx1 > rp.sx_start + rp.sx_count - 1) qx1 = rp.sx_start + rp.sx_count - 1;
+    if (qy0 < rp.sy_start) qy0 = rp.sy_start;
+    if (qy1 > rp.sy_start + rp.sy_count - 1) qy1 = rp.sy_start + rp.sy_count - 1;
+    const float fxw = rp.fxw, fyw = rp.fyw, finvx16 = rp.finvx * 16.f, finvy16 = rp.finvy * 16.f;
+    const int step_p = 256 / spp, step_k = 256 - step_p * spp;
+    const int p_first = (int)threadIdx.x / spp, k_first = (int)threadIdx.x - p_first * spp;
+    const char *tab = (const char *)s_tab + 4 * 17 * ((threadIdx.x / BW) & 1);
+    // the 2 r + 1 codes of one axis: q the record's source pixel, d its dimage coordinate
+    auto codes = [](int q, int r, float d, float w, float inv16) -> uint32_t {
+        uint32_t c = 0;
+        for (int o = 0; o <= 2 * r; ++o) {
+            const float t = (float)(q - r + o);
+            uint32_t i = (uint32_t)(int)floorf(fabsf((t - d) * inv16)); i = i > 15u ? 15u : i;
+            if (!(t >= d - w && t <= d + w)) i = 16u;            // (for integer t:  t >= ceil(a) <=> t >= a,  t <= floor(b) <=> t <= b)
+            c |= i << (5 * o);
+        }
+        return c;
+    };
+    float aX = 0.f, aY = 0.f, aZ = 0.f, aW = 0.f;
+    for (int qy = qy0; qy <= qy1; ++qy) {
+        const bool row_in_reach = live && qy >= y - ry && qy <= y + ry;
+        const uint32_t shy = (uint32_t)(5 * (y - qy + ry));
+        for (int qg = qx0; qg <= qx1; qg += g) {
+            const int n = qx1 - qg + 1 < g ? qx1 - qg + 1 : g;
+            const int64_t base = ((int64_t)(qy - rp.sy_start) * rp.sx_count + (qg - rp.sx_start)) * spp;
+            const float4 *rec = (const float4 *)rp.sbuf_xyzw + base;
+            const float2 *pos = (const float2 *)rp.sbuf_pos + base;
+            __syncthreads();                                   // (the previous slab is no longer read; also orders s_tab)
+            {
+                int p = p_first, k = k_first;
+                for (int i = (int)threadIdx.x; i < n * spp; i += 256) {
+                    float4 r = rec[i];
+                    const float2 ps = pos[i];
+                    uint32_t cx = 16u | 16u << 5 | 16u << 10 | 16u << 15 | 16u << 20;
+                    if (r.w != 0.f) cx = codes(qg + p, rx, ps.x - 0.5f, fxw, finvx16);
+                    r.w = __uint_as_float(cx);
+                    dyn_rec[p * pitch + k] = r;
+                    lds_cy[p * pitch + k] = codes(qy, ry, ps.y - 0.5f, fyw, finvy16);
+                    p += step_p; k += step_k;
+                    if (k >= spp) { k -= spp; ++p; }
+                }
+            }
+            __syncthreads();
+            if (!row_in_reach) continue;
+            int wx0 = x - rx, wx1 = x + rx;
+            if (wx0 < qg) wx0 = qg;
+            if (wx1 > qg + n - 1) wx1 = qg + n - 1;
+            for (int qx = wx0; qx <= wx1; ++qx) {
+                const float4 *r4 = dyn_rec + (qx - qg) * pitch;
+                const uint32_t *c1 = lds_cy + (qx - qg) * pitch;
+                const uint32_t shx = (uint32_t)(5 * (x - qx + rx));
+                auto weight = [&](const float4 &r, uint32_t cy) -> float {
+                    const uint32_t ex = (__float_as_uint(r.w) >> shx) & 31u, ey = (cy >> shy) & 31u;
+                    return *(const float *)(tab + (ey << 8 | ex << 2));
+                };
+                int k = 0;
+                for (; k + 8 <= spp; k += 8) {
+                    float4 r[8]; uint32_t c[8]; float w[8];
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) { r[j] = r4[k + j]; c[j] = c1[k + j]; }
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = weight(r[j], c[j]);
+                    #pragma unroll
+                    for (int j = 0; j < 8; ++j) { aX += w[j] * r[j].x; aY += w[j] * r[j].y; aZ += w[j] * r[j].z; aW += w[j]; }
+                }
+                for (; k < spp; ++k) {
+                    const float4 r0 = r4[k];
+                    const float w0 = weight(r0, c1[k]);
+                    aX += w0 * r0.x; aY += w0 * r0.y; aZ += w0 * r0.z; aW += w0;
                 }
             }
         }
@@ -298,18 +459,30 @@ hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, h
     return hipGetLastError();
 }
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream) {
-    dim3 grid((unsigned)((rp.x_count + 15) / 16), (unsigned)((rp.y_count + 15) / 16));
-    // LDS-staged gather: slabs of g source pixels (24 bytes x (spp + 1) each) in up to 48 KB; a pixel with more samples than fit (spp > 2047),
-    // or HPT_GATHER_KERNEL=bcast, takes the wave-broadcast kernel
-    const size_t per_px = (size_t)(rp.spp + 1) * 24, budget = 48 * 1024;
+    // LDS-staged gather: slabs of g source pixels in up to 48 KB of LDS.  Filters of radius <= 2 pixels take the pre-indexed kernel (20 bytes x
+    // (spp + 1) per source pixel), wider ones the extent-byte kernel (24 bytes; radius <= 40); a pixel with more samples than fit (spp > 2047)
+    // or HPT_GATHER_KERNEL=bcast takes the wave-broadcast kernel.  HPT_GATHER_KERNEL=lds forces the extent-byte kernel, lds32 its 32 x 8 pixel
+    // workgroup shape (5 of every 6 lane rows busy per source row instead of 5 of 8, but the 32 + 2 rx pixel slab costs occupancy: slower,
+    // profiles/r02g_gather.md).
     const char *force = getenv("HPT_GATHER_KERNEL");
-    if (per_px <= budget && !(force && !strcmp(force, "bcast"))) {
+    const int rx = (int)floorf(rp.fxw + 0.5f), ry = (int)floorf(rp.fyw + 0.5f);
+    const bool f_bcast = force && !strcmp(force, "bcast"), f_lds = force && !strncmp(force, "lds", 3), wide = force && !strcmp(force, "lds32");
+    const size_t budget = 48 * 1024;
+    const bool idx = rx <= 2 && ry <= 2 && !f_lds;
+    const size_t per_px = (size_t)(rp.spp + 1) * (idx ? 20 : 24);
+    if (per_px <= budget && rx <= 40 && ry <= 40 && !f_bcast) {
         int g = (int)(budget / per_px);
-        const int seg = 16 + 2 * (int)floorf(rp.fxw + 0.5f);
+        const int bw = wide ? 32 : 16, seg = bw + 2 * rx;
         if (g > seg) g = seg;
-        hipLaunchKernelGGL(hpt_film_gather_lds_kernel, grid, dim3(256), (size_t)g * per_px, stream, rp, film, g);
-    } else
+        dim3 grid((unsigned)((rp.x_count + bw - 1) / bw), (unsigned)((rp.y_count + 256 / bw - 1) / (256 / bw)));
+        const size_t lds = ((size_t)g * per_px + 15) & ~(size_t)15;
+        if (idx) hipLaunchKernelGGL(hpt_film_gather_idx_kernel<16>, grid, dim3(256), lds, stream, rp, film, g);
+        else if (wide) hipLaunchKernelGGL(hpt_film_gather_lds_kernel<32>, grid, dim3(256), lds, stream, rp, film, g);
+        else hipLaunchKernelGGL(hpt_film_gather_lds_kernel<16>, grid, dim3(256), lds, stream, rp, film, g);
+    } else {
+        dim3 grid((unsigned)((rp.x_count + 15) / 16), (unsigned)((rp.y_count + 15) / 16));
         hipLaunchKernelGGL(hpt_film_gather_kernel, grid, dim3(256), 0, stream, rp, film);
+    }
     return hipGetLastError();
 }
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {
