@@ -26,6 +26,12 @@ using namespace hpt;
         }                                                                                   \
     } while (0)
 
+// PathKernelArgs::retrace_*: HPT_RETRACE_MIN (lanes, default 8; 65 = never) and HPT_RETRACE_MAX (extra walks per round, default 4)
+static void retrace_defaults(hpt::PathKernelArgs *a) {
+    const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
+    a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
+    if (a->retrace_min < 1) a->retrace_min = 1;
+}
 struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; };   // one work-queue head per XCD
 
 struct hpt_scene {
@@ -473,6 +479,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
     a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    retrace_defaults(&a);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
@@ -594,6 +601,10 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (ra.mt) (void)hipFree(ra.mt);
     if (ra.buf) (void)hipFree(ra.buf);
     if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    if (getenv("HPT_PHASE_TIMERS"))   // a -DHPT_PHASE_TIMERS kernel build leaves wave clocks per loop section in the work counters
+        fprintf(stderr, "hpt phase clocks (refill, extension walk, shadow+MIS walk, on_hit, BRDF queries, shade_finish): %llu %llu %llu %llu %llu %llu  kernel %.3f ms cfg %d\n",
+                (unsigned long long)h_scr.wc.samples, (unsigned long long)h_scr.wc.closest, (unsigned long long)h_scr.wc.shadow, (unsigned long long)h_scr.wc.nodes,
+                (unsigned long long)h_scr.wc.tris, (unsigned long long)h_scr.wc.bad, ms, cfg);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
@@ -625,6 +636,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
     a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    retrace_defaults(&a);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;

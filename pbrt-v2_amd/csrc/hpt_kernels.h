@@ -23,6 +23,9 @@ struct PathKernelArgs {
     int32_t dl;                     // 1: the direct-lighting instantiation (rp.integrator says which strategy)
     float *dl_stack;                // direct lighting over specular surfaces: per-lane stack of pending specular rays, [(dl_cap + 1) x HPT_DLS_FLOATS][grid x 256] floats, or null
     int32_t dl_cap;                 // its capacity in rays (maxdepth + 1)
+    // lock step + stealing: when at least retrace_min lanes' extension rays escaped, those lanes finish their path, take their next camera ray
+    // and the wave walks again (at most retrace_max times per round) before it shades, so the shading block runs with more of its lanes
+    int32_t retrace_min, retrace_max;
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
     return (size_t)a.stack_entries * HPT_BLOCK * 4;

@@ -294,7 +294,21 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     const int64_t xf_stride = (int64_t)gridDim.x * HPT_BLOCK;
     float *xf_col = (INST && a.inst_xf) ? a.inst_xf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x : nullptr;
     float xf_time = -HPT_INF;
+#ifdef HPT_PHASE_TIMERS   /* debug build (make variants VARIANTS="pt=-DHPT_PHASE_TIMERS"): wave clocks per loop section, into the work counters */
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) lane.spt[i] = 0;
+#define HPT_PT(i) { const unsigned long long pt_n = __builtin_readcyclecounter(); pt[i] += pt_n - pt_t; pt_t = pt_n; }
+#else
+#define HPT_PT(i)
+#endif
+    // lock step + stealing (path integrator): an extension hit waiting for its shading while the wave walks again for the lanes whose
+    // rays escaped (PathKernelArgs::retrace_min)
+    constexpr bool RETRACE = STEAL && PHASED && !DL;
+    Hit pend; bool has_pend = false; int retraced = 0;
+    pend.prim = -1; pend.t = 0.f; pend.b1 = 0.f; pend.b2 = 0.f; pend.inst = -1;
     for (;;) {
+        // ---- camera samples completed in the last round: to the film, next sample (the one place finish_path is compiled in) ----
+        lane.flush(rp, a.film, COUNT ? &wc : nullptr);
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
         // Eight queue heads, one per XCD: the dispatcher is observed to put workgroup b on XCD b % 8 (a speed assumption only),
         // each XCD has its own 4 MiB L2, and head k hands out the k-th eighth of the frame's 32x32 tiles (all their sample
@@ -337,12 +351,30 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             while (__ballot(my_phase == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
+        HPT_PT(0)
         if (STEAL && PHASED) {
             // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
-            const bool tr = mine && (!DL || lane.stage != ST_SHADE);
+            const bool tr = mine && (!DL || lane.stage != ST_SHADE) && !(RETRACE && has_pend);
             const bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
             traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
+            if (RETRACE && phase == ST_EXTEND) {
+                // Extension rays that escaped end their paths without shading.  If there are enough of them, they take their next camera
+                // ray now (flush at the top of the loop; idle lanes pull new work there too) and the wave walks once more — the lanes that
+                // did hit keep their Hit and help as subtree thieves — so that the shading block below runs with more of the wave.
+                const bool miss = tr && hit.prim < 0;
+                if (retraced < a.retrace_max && __popcll(__ballot(miss)) >= a.retrace_min) {
+                    if (miss) lane.extend_miss(sc, rp, a.film, COUNT ? &wc : nullptr);
+                    else if (tr) { pend = hit; has_pend = true; }
+                    ++retraced;
+                    continue;                                  // (the phase stays ST_EXTEND)
+                }
+                if (has_pend) { hit = pend; has_pend = false; }
+                retraced = 0;
+            }
+#ifdef HPT_PHASE_TIMERS
+            if (phase == ST_EXTEND) HPT_PT(1) else HPT_PT(2)
+#endif
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
@@ -381,15 +413,30 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
         }
+        HPT_PT(3)
         // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
         if (MATS & MATS_MEASURED) {
             if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
                 for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
         }
+        HPT_PT(4)
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
+        HPT_PT(5)
         if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
     }
+#ifdef HPT_PHASE_TIMERS
+#if HPT_PHASE_TIMERS == 2   /* the sections of shade_prepare instead, summed over LANES (geometry, light sample, f + pdf, MIS sample, continuation) */
+    for (int i = 0; i < 6; ++i) pt[i] = lane.spt[i];
+    if (true) {
+#else
+    if ((threadIdx.x & 63) == 0) {
+#endif
+        atomicAdd((unsigned long long *)&a.counters->samples, pt[0]); atomicAdd((unsigned long long *)&a.counters->closest, pt[1]);
+        atomicAdd((unsigned long long *)&a.counters->shadow, pt[2]); atomicAdd((unsigned long long *)&a.counters->nodes, pt[3]);
+        atomicAdd((unsigned long long *)&a.counters->tris, pt[4]); atomicAdd((unsigned long long *)&a.counters->bad, pt[5]);
+    }
+#endif
     if (COUNT) {
         wc.nodes = tc.nodes; wc.tris = tc.tris;
         atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)wc.samples);

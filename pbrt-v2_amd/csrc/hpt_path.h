@@ -250,8 +250,13 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // product of f * |wi.n| / pdf along its branch; the same Sample serves every node, as in the reference.
     int depth, nsp, dls_cap;
     float *dls; int64_t dls_stride;
+    // The camera sample is complete: its radiance goes to the film and the lane starts its next sample — finish_path(), which the callers of
+    // on_hit() / shade_finish() run ONCE per round through flush() instead of the four places of the state machine that can end a path
+    // (each an inlined copy of the film update and the camera-ray set-up: the path kernels are 30-50 k instructions).
+    bool fin;
 
-    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; }
+    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; fin = false; }
+    HPT_MFN void flush(const RenderParams &rp, float *film, WorkCounters *wc) { if (fin) { fin = false; finish_path(rp, film, wc); } }
 
     // samplerrenderer.cpp:185-206 for one camera sample
     HPT_MFN void begin_sample(const RenderParams &rp) {
@@ -345,7 +350,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             ray.o = p; ray.d = wi_next; ray.mint = eps; ray.maxt = HPT_INF; // RayDifferential(p, wi, ray, eps) path.cpp:100
             ++bounce;
             stage = ST_EXTEND;
-        } else finish_path(rp, film, wc);
+        } else fin = true;
     }
     HPT_MFN void after_shadow(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
         if (has_mis) {
@@ -416,13 +421,30 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                 return;
             }
         }
-        finish_path(rp, film, wc);
+        fin = true;
+    }
+
+    // The extension ray escaped: the radiance it sees (samplerrenderer.cpp:335-338, path.cpp:114-116); the path is complete.
+    HPT_MFN void extend_miss(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
+        if (DL_REC && depth > 0) { cold.setL(cold.L() + smul(cold.beta(), all_lights_Le(sc, ray.d))); node_done(sc, rp, film, wc, false); return; }
+        if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:335-338
+        else if (specular)                                             // path.cpp:114-116
+            for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
+        fin = true;
     }
 
     // Called with the result of the traversal phase for this lane's pending ray.  Shadow / MIS results and
     // misses are finished here (returns false).  An extension HIT is only prepared: the caller resolves the
     // BSDF values that are still kd-tree queries (sv->has[], measured BRDF) — wave-cooperatively in the path
     // kernel, serially elsewhere (on_hit_serial) — and then calls shade_finish().
+#ifdef HPT_PHASE_TIMERS
+    unsigned long long spt[8], spt_t;
+#define HPT_SPT0 spt_t = __builtin_readcyclecounter();
+#define HPT_SPT(i) { const unsigned long long n_ = __builtin_readcyclecounter(); spt[i] += n_ - spt_t; spt_t = n_; }
+#else
+#define HPT_SPT0
+#define HPT_SPT(i)
+#endif
     HPT_MFN bool on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls, ShadeV *sv) {
         if (DL && stage == ST_SHADE) {       // next light sample of the kept camera hit (no ray was traced)
             ray = cam;
@@ -457,14 +479,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             return false;
         }
         // ---- ST_EXTEND: closest-hit result of a camera or continuation ray -------------------------
-        if (hit.prim < 0) {
-            if (DL_REC && depth > 0) { cold.setL(cold.L() + smul(cold.beta(), all_lights_Le(sc, ray.d))); node_done(sc, rp, film, wc, false); return false; }
-            if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:335-338
-            else if (specular)                                             // path.cpp:114-116
-                for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
-            finish_path(rp, film, wc);
-            return false;
-        }
+        if (hit.prim < 0) { extend_miss(sc, rp, film, wc); return false; }
         if (DL) { cam = ray; chit = hit; li = 0; lj = 0; acc = S(0.f); }
         shade_prepare(sc, rp, hit, ls, sv);
         return true;
@@ -477,6 +492,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // reference's (all array / rng draws of the vertex happen here, the Russian-roulette draw in shade_finish).
     HPT_MFN void shade_prepare(const DScene &sc, const RenderParams &rp, const Hit &hit, LaneStack ls, ShadeV *sv) {
         Bsdf bsdf; DGeom dg; int arealight;
+        HPT_SPT0
         if (MATS & MATS_EXT) {
             // the camera ray is the only one with differentials (geometry.h:351-361): rebuilt from its sample at the first hit
             RayDiff rdiff;
@@ -484,6 +500,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             shade_geometry_ext<INST>(sc, ray, time, hit, rdiff, &bsdf, &dg, &eps, &arealight);
         } else
             shade_geometry<INST, MATS>(sc, ray, time, hit, &bsdf, &dg, &eps, &arealight);
+        HPT_SPT(1)
         f3 wo = -ray.d;
         if (DL ? stage == ST_EXTEND : (bounce == 0 || specular))            // path.cpp:63-64; directlighting.cpp:90 (once per hit)
             if (arealight >= 0) cold.setL(cold.L() + smul(cold.beta(), area_L(sc.lights[arealight], dg.nn, wo)));
@@ -519,6 +536,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
             f3 Li = light_sample_L<(MATS & MATS_EXT) != 0>(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
+            HPT_SPT(2)
             if (lightPdf > 0.f && !sblack(Li)) {
                 if (defer) {
                     sv->has[0] = bsdf_query_point(bsdf, bsdf.w2l(wo), bsdf.w2l(wi), wo, wi, BSDF_ALL_NOSPEC, &sv->fq[0]);
@@ -540,6 +558,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                     }
                 }
             }
+            HPT_SPT(3)
             if (!DL) {                                                      // (see above: fetched late)
                 if (useArrays) { smp.two(3 * bounce + 1, &bs0, &bs1); bs2 = smp.one(4 * bounce + 2); }
                 else { bs0 = smp.draw(); bs1 = smp.draw(); bs2 = smp.draw(); }
@@ -573,6 +592,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                 }
             }
         }
+        HPT_SPT(4)
         // continuation (path.cpp:83-110): beta' = beta * f * |wi.n| / pdf
         if (!DL) {
             float ps0, ps1, ps2;
@@ -589,6 +609,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                 } else term_next(bsdf_f_local<MATS>(sc, bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, ls), absdot(wi, n), pdf);
             }
         }
+        HPT_SPT(5)
     }
 
     // Sample values of the direct-lighting integrator for light sample (li, lj) — layout of RequestSamples,
@@ -644,9 +665,11 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // on_hit with the pending measured-BRDF queries evaluated by this lane itself, one after the other
     HPT_MFN void on_hit_serial(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
         ShadeV sv;
-        if (!on_hit(sc, rp, hit, film, wc, ls, &sv)) return;
-        for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
-        shade_finish(sc, rp, film, wc, sv);
+        if (on_hit(sc, rp, hit, film, wc, ls, &sv)) {
+            for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
+            shade_finish(sc, rp, film, wc, sv);
+        }
+        flush(rp, film, wc);
     }
 };
 

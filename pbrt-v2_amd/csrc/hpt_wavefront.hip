@@ -66,6 +66,7 @@ __device__ __forceinline__ void lane_load(LaneT &l, const float4 *st, int64_t P,
     v = st[7 * P + slot]; l.C_mis = mk3(v.x, v.y, v.z); l.wi_next.x = v.w;
     v = st[8 * P + slot]; l.wi_next.y = v.x; l.wi_next.z = v.y; l.beta_next.x = v.z; l.beta_next.y = v.w;
     v = st[9 * P + slot]; l.beta_next.z = v.x;
+    l.fin = false;     // (on_hit_serial flushes a completed sample before the state is stored)
 }
 
 __device__ __forceinline__ int wf_lane_id() { return (int)__lane_id(); }
