@@ -384,9 +384,41 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
     o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
 }
 
-__global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, int64_t n, float *out) {
+// wave_check (HPT_BSDF_WAVE_CHECK=1, measured BRDFs): every lane also sends three query points built from its input row through the path kernel's
+// wave-cooperative evaluator (wave_eval_queries: 192 queries per wave, so lanes take new queries while others are mid-walk) and the row's
+// output becomes {max |wave - serial| over the three, the three serial values' first components, ...}: must be 0.
+__global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, int64_t n, float *out, int wave_check) {
     __shared__ int32_t lds_stack[HPT_STACK_DEPTH * 64];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wave_check) {
+        LaneStack ls; ls.p = (HPT_LDS int32_t *)(lds_stack + threadIdx.x); ls.stride = 64; ls.qrow = 0;
+        const bool live = i < n && sc.materials[material].kind == HPT_MAT_MEASURED_IRREG;
+        ShadeV sv; sv.mat = material; sv.has_shadow = false;
+        f3 ser[3];
+        for (int k = 0; k < 3; ++k) {
+            sv.has[k] = live; sv.fq[k] = S(0.f); ser[k] = S(0.f);
+            if (live) {
+                const float *q = in + 16 * i;
+                f3 wo = normalize(mk3(q[0], q[1], q[2])), wi = normalize(mk3(q[3], q[4], q[5]));
+                if (k == 1) wi = normalize(mk3(q[6] - .5f, q[7] - .5f, q[8]));
+                if (k == 2) wo = normalize(mk3(q[7] - .5f, q[6] - .5f, q[8] + .1f));
+                sv.fq[k] = irreg_point(wo, wi);
+                ser[k] = irreg_eval(sc, &sc.materials[material], sv.fq[k]);
+            }
+        }
+        wave_eval_queries(sc, ls, sv, live);
+        if (i < n) {
+            float *o = out + 12 * i, d = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                const f3 e = sv.fq[k] - ser[k];
+                d = fmaxf(d, fmaxf(fabsf(e.x), fmaxf(fabsf(e.y), fabsf(e.z))));
+                if (!(e.x == e.x && e.y == e.y && e.z == e.z)) d = HPT_INF;
+                o[1 + 3 * k] = ser[k].x; o[2 + 3 * k] = sv.fq[k].x; o[3 + 3 * k] = 0.f;
+            }
+            o[0] = d; o[10] = 0.f; o[11] = 0.f;
+        }
+        return;
+    }
     if (i >= n) return;
     LaneStack ls; ls.p = (HPT_LDS int32_t *)(lds_stack + threadIdx.x); ls.stride = 64;
     const float *q = in + 16 * i; float *o = out + 12 * i;
@@ -492,7 +524,8 @@ hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int 
 }
 hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s) {
     int grid = (int)((n + 63) / 64);
-    if (grid > 0) hipLaunchKernelGGL(hpt_bsdf_kernel, dim3(grid), dim3(64), 0, s, sc, material, in, n, out);
+    const char *wc = getenv("HPT_BSDF_WAVE_CHECK");
+    if (grid > 0) hipLaunchKernelGGL(hpt_bsdf_kernel, dim3(grid), dim3(64), 0, s, sc, material, in, n, out, wc && atoi(wc) ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_sampler(const RenderParams &rp, int x, int y, float *out, hipStream_t s) {

@@ -64,7 +64,7 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
     int next = total < 64 ? total : 64;                  // wave-uniform: first queue entry nobody has taken yet
     int slot = lane < total ? lane : -1;
     KdWalk w;
-    w.j = w.jend = 0u; w.iz = 0; w.z1 = -1;
+    w.j = w.jend = 0u; w.iy = w.iz = 0; w.y0 = w.y1 = w.z1 = -1; w.x0 = w.x1 = 0; w.samples = nullptr; w.cells = nullptr;
     if (slot >= 0)
         kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
     for (;;) {
@@ -96,6 +96,10 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
     const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2);
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), total = n0 + n1 + n2;
     if (total == 0) return;
+#if defined(HPT_KD_DBG) && HPT_KD_DBG == 5
+    if (shaded) for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
+    return;
+#endif
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int o0 = __popcll(m0 & lt), o1 = n0 + __popcll(m1 & lt), o2 = n0 + n1 + __popcll(m2 & lt);

@@ -88,6 +88,21 @@ def test_bsdf_matches_oracle(cases, dev, ora, name, material):
     assert np.isclose(a[:, vals], b[:, vals], rtol=2e-5, atol=1e-7).mean() > 0.97
 
 
+def test_wave_cooperative_brdf_queries_equal_the_serial_walk(cases, dev, monkeypatch):
+    """wave_eval_queries (the path kernel's evaluator of measured-BRDF values: 192 queries per wave in an LDS queue, lanes take the next
+    query the moment their walk ends) returns exactly what irreg_eval returns for the same query points: HPT_BSDF_WAVE_CHECK makes the
+    bsdf hook kernel run both and report max |wave - serial| per row."""
+    s = cases["b8"]
+    mats = [i for i, m in enumerate(s.materials) if m.kind == abi.HPT_MAT_MEASURED_IRREG]
+    assert mats
+    monkeypatch.setenv("HPT_BSDF_WAVE_CHECK", "1")
+    inp = bsdf_inputs(64 * 48, seed=9)
+    inp[:, 2] = np.abs(inp[:, 2]); inp[:, 5] = np.abs(inp[:, 5])
+    out = dev["b8"].bsdf(mats[0], inp)
+    assert (out[:, 1] > 0).mean() > 0.5          # the serial values are real BRDF values
+    assert np.array_equal(out[:, 0], np.zeros(len(out), np.float32)), float(out[:, 0].max())
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_render_matches_oracle_sample_for_sample(cases, dev, ora, name):
     s = cases[name]
