@@ -365,8 +365,12 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         # wave-instructions per camera sample from the committed PMC pass x this run's samples / this run's kernel time
         ipl = prof["valu_wave_instructions_per_launch"] / prof["samples_per_launch"] * per_launch_samples
         ach = ipl / (k_ms * 1e-3) / 1e9
+        # peak: one wave64 instruction per SIMD every 2 clocks — what v_fma/mul/add_f32, v_add_u32, v_and_b32, v_cndmask reach; v_min/max_f32,
+        # v_cmp, conversions, shifts and all f64 take 4 (profiles/r02j_valu_rate.md), so frac_at_4_clocks (every instruction priced at 4
+        # clocks) is the other bracket: the slab test this kernel mostly executes is 24 two-clock + 25 four-clock instructions per node
         out["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 2), "peak": VALU_PEAK_GINST, "unit": "Gwave-inst/s",
-                                "frac": round(ach / VALU_PEAK_GINST, 4), "lane_utilisation": prof.get("valu_lane_utilisation"),
+                                "frac": round(ach / VALU_PEAK_GINST, 4), "frac_at_4_clocks": round(2.0 * ach / VALU_PEAK_GINST, 4),
+                                "lane_utilisation": prof.get("valu_lane_utilisation"),
                                 "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"), "source": prof.get("source")}
     return out, scene, flt
 

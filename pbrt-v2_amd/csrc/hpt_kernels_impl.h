@@ -371,6 +371,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                     if (miss) lane.extend_miss(sc, rp, a.film, COUNT ? &wc : nullptr);
                     else if (tr) { pend = hit; has_pend = true; }
                     ++retraced;
+                    HPT_PT(1)
                     continue;                                  // (the phase stays ST_EXTEND)
                 }
                 if (has_pend) { hit = pend; has_pend = false; }

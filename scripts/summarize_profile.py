@@ -50,9 +50,17 @@ ks = [r for r in stats_rows if KERNEL in r["Name"]]
 k = max(ks, key=lambda r: float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"])) if ks else None
 derived = {}
 if k:
-    derived["kernel_avg_ms"] = float(k["AverageNs"]) / 1e6
+    derived["kernel_avg_ms_all_launches"] = float(k["AverageNs"]) / 1e6      # (the --stats row: autotune probe launches of the same instantiation included)
     derived["kernel_calls"] = int(k["Calls"])
     derived["kernel_pct_of_gpu_time"] = float(k["Percentage"])
+    # the figure bench.py's HIP events must agree with: the FULL-FRAME launches of that kernel in the kernel trace (a launch at least
+    # half as long as the longest; the probe launches render a ninth of the tiles at <= 64 spp)
+    for f in glob.glob(os.path.join(src, "trace", "*kernel_trace.csv")):
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if r["Kernel_Name"] == k["Name"]]
+        full = [d for d in durs if d >= 0.5 * max(durs)] if durs else []
+        if full:
+            derived["kernel_avg_ms"] = sum(full) / len(full) / 1e6
+            derived["kernel_full_frame_launches"] = len(full)
 if "FETCH_SIZE" in pmc:
     # profiles/r02_fetch_calibration.md (known-byte microbenchmarks in this kernel's access patterns): FETCH_SIZE counts a lane-scattered
     # 64-B node fetch at x1.0 (48-B triangle records at the 64-B lines they touch) and coalesced dword scratch reads at x0.5 like the

@@ -683,7 +683,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)

@@ -99,7 +99,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,

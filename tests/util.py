@@ -112,7 +112,7 @@ STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz
 # ---- round 2 cases (tests/golden/make_golden_r2.py): Oren-Nayar, specular, triangle emitters, regular half-angle BRDF, textures, alpha
 R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hpts.gz", "merl": "merl.hpts.gz", "tex": "tex.hpts.gz",
             "alpha": "alpha.hpts.gz", "metal": "metal.hpts.gz", "mirtex": "mirtex.hpts.gz"}
-R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz"}     # same geometry, own camera / render descriptor / lights
+R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
 def merl_table_doubles():
