@@ -31,6 +31,8 @@ static void retrace_defaults(hpt::PathKernelArgs *a) {
     const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
     a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
     if (a->retrace_min < 1) a->retrace_min = 1;
+    const char *lq = getenv("HPT_LEAF_Q"), *bq = getenv("HPT_LEAF_BLOCK_Q");     // eighths of the busy lanes (0: the leaf half runs every step, as before round 2)
+    a->leaf_q = lq ? atoi(lq) : 4; a->block_q = bq ? atoi(bq) : 8;
 }
 struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; };   // one work-queue head per XCD
 

@@ -496,7 +496,11 @@ HPT_FN Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse
 // by entry distance, far child on a per-lane stack.  `stack` points at this lane's slot 0 and
 // consecutive entries are `stride` ints apart (LDS: stride = block size, so the 64 lanes of a
 // wave hit 64 different banks).
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
+struct TravCounters { uint32_t nodes, tris; unsigned long long leaf_clocks = 0, step_clocks = 0; uint32_t leaf_lanes = 0, steps = 0; };
+#else
 struct TravCounters { uint32_t nodes, tris; };
+#endif
 
 // Ray / box overlap for the device's own BVH (not the reference's tree, so only conservativeness matters:
 // a box the ray touches must never be rejected; the triangle tests decide the hit).  min/max form of the slab
@@ -550,47 +554,71 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
 // TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:190-195, 246-276): a hit where the mesh's alpha texture evaluates to 0 is no hit
 // (defined with the textures below; only the MATS_EXT kernels instantiate the ALPHA walk)
 HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2);
+// The two halves of a step, separately callable (the lock-step + stealing walk of the path kernel batches the leaf half: hpt_kernels_impl.h).
+// trav_node: ts.node >= 0 — one 64-byte node fetch, two slab tests, near child first, far child stacked; leaves ts.node at the next interior
+// node, at a leaf code, or — nothing hit, nothing stacked — HPT_TRAV_EMPTY.
+template <bool COUNT>
+HPT_FN void trav_node(const DScene &sc, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
+    const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
+    f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (COUNT) cnt->nodes++;
+    float t0, t1;
+    bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
+    bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
+    const int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
+    // near child first, far child stacked — selects instead of a four-way branch
+    const bool both = h0 && h1, swap = t1 < t0;
+    if (both) { stack[ts.sp * stride] = swap ? c0 : c1; ++ts.sp; }
+    int32_t next = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
+    if (!(h0 || h1)) {
+        next = HPT_TRAV_EMPTY;
+        if (ts.sp > 0) { --ts.sp; next = stack[ts.sp * stride]; }
+    }
+    ts.node = next;
+}
+HPT_FN bool trav_is_leaf(int32_t node) { return node < 0 && node != HPT_TRAV_EMPTY; }
+HPT_FN void trav_pop(TravState &ts, const int32_t *stack, int stride) {
+    if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
+    else ts.node = HPT_TRAV_EMPTY;
+}
+// trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
+// any-hit ray is done (occluded).
+template <bool COUNT, bool ALPHA>
+HPT_FN bool trav_leaf(const DScene &sc, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
+    const uint32_t code = (uint32_t)~leaf;
+    const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+    for (uint32_t k = 0; k < count; ++k) {
+        const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
+        f4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) cnt->tris++;
+        float t, b1, b2;
+        if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
+            if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
+            ts.hit.prim = (int32_t)(first + k);
+            if (ts.anyhit) return true;
+            ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
+            ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
+        }
+    }
+    return false;
+}
 template <bool COUNT, bool ALPHA = false>
 HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
-    if (ts.node >= 0) { // interior: one 64-byte node fetch, two slab tests, near child first, far child stacked
-        const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
-        f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (COUNT) cnt->nodes++;
-        float t0, t1;
-        bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
-        bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
-        const int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
-        // near child first, far child stacked — selects instead of a four-way branch
-        const bool both = h0 && h1, swap = t1 < t0;
-        if (both) { stack[ts.sp * stride] = swap ? c0 : c1; ++ts.sp; }
-        int32_t next = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
-        if (!(h0 || h1)) {
-            next = HPT_TRAV_EMPTY;
-            if (ts.sp > 0) { --ts.sp; next = stack[ts.sp * stride]; }
-        }
-        ts.node = next;
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
+    const unsigned long long st0_ = __builtin_readcyclecounter();
+#endif
+    if (ts.node >= 0) trav_node<COUNT>(sc, ts, ray, stack, stride, cnt);
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* debug build: how much of a step is the leaf part, and how many lanes take it */
+    const unsigned long long lt0_ = __builtin_readcyclecounter();
+    cnt->leaf_lanes += trav_is_leaf(ts.node) ? 1u : 0u; cnt->steps++;
+#endif
+    if (trav_is_leaf(ts.node)) { // leaf, then pop
+        if (trav_leaf<COUNT, ALPHA>(sc, ts, ray, ts.node, cnt)) ts.node = HPT_TRAV_EMPTY;
+        else trav_pop(ts, stack, stride);
     }
-    if (ts.node < 0 && ts.node != HPT_TRAV_EMPTY) { // leaf: <= 8 pre-gathered 48-byte triangle records, then pop
-        uint32_t code = (uint32_t)~ts.node;
-        uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-        bool stop = false;
-        for (uint32_t k = 0; k < count; ++k) {
-            const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
-            f4 a = tp[0], b = tp[1], c = tp[2];
-            if (COUNT) cnt->tris++;
-            float t, b1, b2;
-            if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
-                if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
-                ts.hit.prim = (int32_t)(first + k);
-                if (ts.anyhit) { stop = true; break; }
-                ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
-                ray.maxt = t; // GeometricPrimitive::Intersect shrinks the ray (core/primitive.cpp:174)
-            }
-        }
-        if (stop) ts.node = HPT_TRAV_EMPTY;
-        else if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
-        else ts.node = HPT_TRAV_EMPTY;
-    }
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
+    { const unsigned long long n_ = __builtin_readcyclecounter(); cnt->leaf_clocks += n_ - lt0_; cnt->step_clocks += n_ - st0_; }
+#endif
 }
 
 // One ray, start to finish, on this lane: the world BVH (+ quadrics), then every animated instance

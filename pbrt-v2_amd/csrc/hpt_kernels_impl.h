@@ -139,7 +139,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // given, in whatever space the donor was in, and publish the instance number with the hit.
 template <bool COUNT, bool INST, bool ALPHA>
 __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
-                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride) {
+                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
@@ -156,10 +156,43 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     HPT_AUX(aux + 1, lane) = as_int(r.maxt);                        // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 4, lane) = -1;
     HPT_WAVE_SYNC();
+    // Leaf batching.  Measured (profiles/r02i_phase_clocks.md): the leaf half of a step — the triangle tests, double-precision cross
+    // products and all — takes 51-56 % of the step's time with 5-12 % of the lanes in it; whenever ANY lane reaches a leaf the whole wave
+    // pays for it.  So a lane that reaches a leaf PARKS it (pend) and walks on with the next stacked subtree, and the wave runs the leaf
+    // half only when enough lanes hold one: at least leaf_q eighths of the busy lanes, or block_q eighths of them can do nothing else
+    // (their next node is a leaf too, or their walk is over), or nobody can walk.  Testing a leaf later only delays the shrinking of
+    // the ray (a few more nodes visited); the nearest hit is the same up to exact ties.
+    int32_t pend = HPT_TRAV_EMPTY;
     for (;;) {
-        const bool busy = ts.node != HPT_TRAV_EMPTY;
-        const bool any_busy = __ballot(busy || seg < n_inst) != 0ull;
-        if (busy) trav_step<COUNT, ALPHA>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+        const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
+        const unsigned long long mbusy = __ballot(busy);
+        const bool any_busy = (mbusy | __ballot(seg < n_inst)) != 0ull;
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* every lane: wave clocks of the node half / of the leaf half, iterations, leaf phases, lanes in them */
+        const unsigned long long w0_ = __builtin_readcyclecounter();
+        cnt->steps++;
+#endif
+        if (ts.node >= 0) trav_node<COUNT>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node)) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
+        const unsigned long long w1_ = __builtin_readcyclecounter();
+        cnt->step_clocks += w1_ - w0_;
+#endif
+        {
+            const bool has = pend != HPT_TRAV_EMPTY;
+            const unsigned long long mh = __ballot(has);
+            if (mh != 0ull) {
+                const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
+                if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
+                    if (has) {
+                        if (trav_leaf<COUNT, ALPHA>(sc, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
+                        pend = HPT_TRAV_EMPTY;
+                    }
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
+                    cnt->leaf_clocks += __builtin_readcyclecounter() - w1_; cnt->leaf_lanes += (unsigned)nh; cnt->tris++;
+#endif
+                }
+            }
+        }
         // (after every step — measured: every 16 / 8 / 4 / 2 / 1 steps = 612 / 660 / 708 / 775 / 800 Msamples/s on killeroo —
         //  but only the parts that have something to do: a publish when some lane found a hit, a steal when some lane idles)
         const bool found = ts.hit.prim >= 0;
@@ -177,13 +210,13 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 if (INST) HPT_AUX(aux + 5, owner) = cur_inst;
             }
             ts.hit.prim = -1;                                           // published (or beaten)
-            if (ts.node != HPT_TRAV_EMPTY) {
-                if (ts.anyhit) { if (shared == 0) ts.node = HPT_TRAV_EMPTY; }   // somebody found an occluder
+            if (ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY) {
+                if (ts.anyhit) { if (shared == 0) { ts.node = HPT_TRAV_EMPTY; pend = HPT_TRAV_EMPTY; } }   // somebody found an occluder
                 else r.maxt = fminf(r.maxt, as_float(shared));
             }
             if (!any_busy) break;                                       // (the last publish has just happened)
         }
-        if (INST && ts.node == HPT_TRAV_EMPTY && seg < n_inst) {
+        if (INST && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && seg < n_inst) {
             // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
             const int shared = HPT_AUX(aux + 1, lane);                  // (seg < n_inst only on the owner: owner == lane)
             ++seg;
@@ -206,7 +239,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         }
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
-        const bool idle = !still && seg >= n_inst;
+        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_inst;
         const bool donor = still && ts.sp >= 1;
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool tr = mine && (!DL || lane.stage != ST_SHADE) && !(RETRACE && has_pend);
             const bool anyhit = lane.stage == ST_SHADOW;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride);
+            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride, a.leaf_q, a.block_q);
             if (RETRACE && phase == ST_EXTEND) {
                 // Extension rays that escaped end their paths without shading.  If there are enough of them, they take their next camera
                 // ray now (flush at the top of the loop; idle lanes pull new work there too) and the wave walks once more — the lanes that
@@ -431,7 +464,10 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
     }
 #ifdef HPT_PHASE_TIMERS
-#if HPT_PHASE_TIMERS == 2   /* the sections of shade_prepare instead, summed over LANES (geometry, light sample, f + pdf, MIS sample, continuation) */
+#if HPT_PHASE_TIMERS == 3   /* the walk: lane-summed clocks of whole steps / of their leaf parts, steps, steps that were at a leaf */
+    pt[0] = 0; pt[1] = tc.steps; pt[2] = tc.leaf_lanes; pt[3] = tc.step_clocks; pt[4] = tc.leaf_clocks; pt[5] = tc.tris;   // (tris: leaf phases seen)
+    if (true) {
+#elif HPT_PHASE_TIMERS == 2   /* the sections of shade_prepare instead, summed over LANES (geometry, light sample, f + pdf, MIS sample, continuation) */
     for (int i = 0; i < 6; ++i) pt[i] = lane.spt[i];
     if (true) {
 #else
