@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 abi = importlib.import_module("pbrt-v2_amd.abi")
 hpt = importlib.import_module("pbrt-v2_amd.hpt")
 scenes = importlib.import_module("pbrt-v2_amd.scenes")
+_EXCHANGE = {}       # "fallback": why the multi-GPU film exchange went through torch.distributed instead of hpt_comm (main)
 film_mod = importlib.import_module("pbrt-v2_amd.film")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -256,6 +257,7 @@ def pmc_profile(workload):
 
 # ---- one workload, measured ----------------------------------------------------------------------------------------------
 def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch, comm, strong=False):
+    dist_mod = importlib.import_module("pbrt-v2_amd.dist") if (world > 1 and comm is None) else None
     scene, desc = load_workload(workload, spp)
     spp_per_gpu = scene.render.spp
     rd = abi.copy_struct(scene.render)
@@ -297,6 +299,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         kernel_ms.append(last.kernel_ms)
         if comm is not None:       # the one film exchange of the frame, in the library: packed tiles over RCCL send / recv to rank 0 (csrc/hpt_multi.hip)
             comm.exchange_film(rd, film.data_ptr(), stream, wide_filter=flt is not None)
+        elif world > 1:            # fallback (see main): the same exchange through torch.distributed
+            g = dist_mod.exchange_film(film, rank, world, wide_filter=flt is not None)
+            return g if g is not None else film
         return film
 
     for _ in range(warmup):
@@ -330,7 +335,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                                   rd.spp // world if strong else spp_per_gpu, rd.spp,
                                   {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)"}.get(args.sampler, "LD_HASH"),
                                   "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
-                   "sharding": "32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s per frame in the library (hpt_comm_exchange_film: RCCL)" % (world, "gather (ncclSend / ncclRecv of packed tiles)" if flt is None else "sum-reduce (ncclReduce)"),
+                   "sharding": ("32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s per frame in the library (hpt_comm_exchange_film: RCCL)" % (world, "gather (ncclSend / ncclRecv of packed tiles)" if flt is None else "sum-reduce (ncclReduce)"))
+                               if (comm is not None or world == 1) else
+                               ("32x32 pixel tiles round-robin over %d GPU(s), scene replicated, film exchange through torch.distributed (pbrt-v2_amd/dist.py) — FALLBACK: %s" % (world, _EXCHANGE.get("fallback"))),
                    "prims": int(info.n_tris + info.n_quadrics), "bvh_nodes_64B": int(info.n_bvh_nodes),
                    "scene_bytes_in_hbm": int(info.total_device_bytes)},
         "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)",
@@ -415,7 +422,21 @@ def main():
             box = [uid]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        comm = hpt.Comm(rank, world, local, bcast)
+        # The library's exchange (hpt_comm over RCCL) has only ever run with a communicator of one rank on the one-GPU development box.
+        # If it cannot be set up on every rank, the frame is exchanged by pbrt-v2_amd/dist.py instead (the same tile gather through
+        # torch.distributed's RCCL backend) and the JSON line says so ("film_exchange").
+        err = None
+        try:
+            comm = hpt.Comm(rank, world, local, bcast)
+        except Exception as e:                           # noqa: BLE001 — any failure of the set-up takes the fallback
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            _EXCHANGE["fallback"] = err or "hpt_comm_create failed on another rank"
 
     out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, comm)
     extras = []
