@@ -322,9 +322,15 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
-    // a pixel's samples are split into items of `chunk` samples: keeps items small next to the job
-    // (short tail, even load when a shard owns few pixels); <= 64 spp is one item, summed in order
+    // A pixel's samples are split into work items of `chunk` samples.  A LARGE job (>= 32 M camera samples in this shard) takes ONE sample per
+    // item: lanes then pull work at the granularity of a path, so the samples of cheap pixels (sky: one ray) are consumed by whichever lane is
+    // free instead of tying a lane to 64 escaping rays in a row while its neighbours shade — measured at 1080p with 64 / 8 / 1 samples per
+    // item: bunny 1161 / 1272 / 1514, killeroo 971 / 1043 / 1128, anim 737 / 751 / 823, soup 264 / 272 / 296 Msamples/s (profiles/r02_ab.md).
+    // The price: every sample adds itself to its film pixel with four float atomics (0.5 G per 1080p / 64 spp frame — nothing next to the
+    // rays), so the float sums of a pixel are no longer formed in sample order: the film is reproducible to rounding (~1e-7 relative), the
+    // weights exactly.  Small jobs (the parity tests) keep one item per pixel up to 64 spp, summed in order.  HPT_CHUNK=<power of two> overrides.
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
+    if (local * 1024 * (int64_t)rd->spp >= ((int64_t)32 << 20)) rp->chunk = 1;
     if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
     rp->items_per_pass = local * 1024;
     rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);   // the last chunk of a non-power-of-two spp is short (Lane::begin_pixel)
@@ -440,7 +446,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
         if (round == 1 && prd.spp <= 16) break;
         if (fill_params(cam, &prd, &a.rp, s) != HPT_OK) { e = hipErrorInvalidValue; break; }
         a.rp.has_motion = inst ? 1 : 0;
-        if (a.rp.chunk > 4) { a.rp.chunk = 4; a.rp.n_items = a.rp.items_per_pass * ((prd.spp + 3) / 4); }
+        if (!getenv("HPT_CHUNK")) { a.rp.chunk = 1; a.rp.n_items = a.rp.items_per_pass * (int64_t)prd.spp; }   // the job this probe stands for is a large one: one sample per item
         for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
             if (!in_race[cfg]) continue;
             int bpc = 0, vg = 0;

@@ -1,5 +1,5 @@
 """Parity at BASELINE size: the frames bench.py times — 1920x1080 at the spp BASELINE.json names — rendered through the
-C ABI exactly as bench.py renders them (autotuned kernel configuration, 64-sample work items in several passes, the eight
+C ABI exactly as bench.py renders them (autotuned kernel configuration, one camera sample per work item (large jobs), the eight
 per-XCD queue heads) and compared with the oracle on crop windows at FULL spp.
 
 The production sampler is stateless per (pixel, sample), so the oracle can render any crop window of the same frame
@@ -57,7 +57,7 @@ def test_bench_frame_matches_oracle_on_crops_at_full_spp(name, spp):
     print("%s %d spp, configuration %d: worst crop RMSE vs oracle %.3g" % (name, spp, st.tune_cfg, worst))
 
 
-def test_every_kernel_configuration_renders_the_bench_frame_bit_identically(monkeypatch):
+def test_every_kernel_configuration_renders_the_same_bench_frame(monkeypatch):
     """bunny 1080p / 64 spp under each of the seven tuning configurations: one film (the crops of the
     test above therefore hold for whichever configuration the autotuner picks on a given box)."""
     s = bench_workload("bunny", 64)
@@ -72,15 +72,33 @@ def test_every_kernel_configuration_renders_the_bench_frame_bit_identically(monk
             ref = f
         else:
             assert np.array_equal(f[..., 3], ref[..., 3])
-            # bit-identical except where a closest hit lies exactly on an edge two triangles share (the walk's visiting order /
-            # the stealing walk's publishing order decides which of the two owns it) and where two boundary spills of float
-            # atomics meet in one pixel: a handful of the 2 M pixels
-            assert (f == ref).all(axis=2).mean() > 0.9999
-            assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(ref)) < 1e-4
+            # The same samples, sample for sample.  A job of this size runs with one camera sample per work item (hpt_api.hip, fill_params):
+            # every sample adds itself to its pixel with float atomics, so a pixel's 64 terms arrive in a different order from run to run
+            # and the sums agree to float rounding, not bit for bit (with HPT_CHUNK=64 — one item per pixel, summed in sample order — the
+            # films are bit-identical except for a handful of pixels whose closest hit lies exactly on an edge two triangles share).
+            rgb_f, rgb_r = film.xyzw_to_rgb(f), film.xyzw_to_rgb(ref)
+            assert film.rmse(rgb_f, rgb_r) < 1e-5
+            assert np.isclose(rgb_f, rgb_r, rtol=2e-5, atol=1e-6).all(axis=2).mean() > 0.9999
+
+
+def test_one_item_per_pixel_is_summed_in_sample_order(monkeypatch):
+    """HPT_CHUNK=64 (the work-item size of small jobs): a pixel's samples are summed by one lane in sample order — two renders of the
+    bench frame are bit-identical, and agree with the default one-sample items to float rounding."""
+    s = bench_workload("bunny", 64)
+    rd = abi.copy_struct(s.render)
+    dev = hpt.DeviceScene(s)
+    monkeypatch.setenv("HPT_TUNE", "5")
+    fa, _ = dev.render(s.camera, rd)                       # default: one sample per item (float atomics)
+    monkeypatch.setenv("HPT_CHUNK", "64")
+    fb, _ = dev.render(s.camera, rd)
+    fc, _ = dev.render(s.camera, rd)
+    assert np.array_equal(fb[..., 3], fa[..., 3]) and np.array_equal(fb[..., 3], fc[..., 3])
+    assert (fb == fc).all(axis=2).mean() > 0.9999          # (exact-tie pixels aside)
+    assert film.rmse(film.xyzw_to_rgb(fa), film.xyzw_to_rgb(fb)) < 1e-5
 
 
 def test_soup_1m_triangles_256_spp_matches_oracle_on_crops():
-    """BASELINE configs[2] as written: 1 M random triangles + 1 env light, 1920x1080, 256 spp (four passes of 64-sample
+    """BASELINE configs[2] as written: 1 M random triangles + 1 env light, 1920x1080, 256 spp (256 passes of one-sample
     work items), path maxdepth 8 — a 155 MB scene whose BVH is deeper than anything the small cases reach."""
     s = scenes.synthetic_soup(n_tris=1_000_000, spp=256, maxdepth=8)
     rd = abi.copy_struct(s.render)
