@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU call P4: under one-sample work items — re-walk off, single queue head, direct lighting with 8 heads
+# GPU call P5: phase population threshold (HPT_PHASE_MIN)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r02p; mkdir -p $O
@@ -9,11 +9,11 @@ run() { tag=$1; shift
     echo "$tag $w: $(python -c "import json; d=json.loads(open('$O/${tag}_$w.log').read().strip().splitlines()[-1]); print(d['value'], d['kernel']['avg_ms'], d['kernel']['tune_cfg'][:1])" 2>&1 | tail -1)"
   done
 }
-WL="bunny killeroo anim soup"
-run base A=1
-run rt_off HPT_RETRACE_MIN=65 HPT_RETRACE_MAX=0
-run onehead HPT_XCD_QUEUE=0
-WL="killeroo-dl"
-run dl_base A=1
-run dl_8heads HPT_XCD_QUEUE=1
-run dl_chunk64 HPT_CHUNK=64
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "render_matches or configurations" 2>&1 | tail -1
+HPT_PHASE_MIN=16 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "render_matches or configurations" 2>&1 | tail -1
+WL="bunny killeroo anim soup killeroo-dl"
+run pm0 HPT_PHASE_MIN=0
+run pm8 HPT_PHASE_MIN=8
+run pm16 HPT_PHASE_MIN=16
+run pm32 HPT_PHASE_MIN=32
+run pm48 HPT_PHASE_MIN=48
