@@ -196,14 +196,24 @@ def end_to_end_pbrt_hip(workload, scene):
     with tempfile.TemporaryDirectory() as tmp:
         sf = os.path.join(tmp, "s.pbrt")
         open(sf, "w").write(ref_scene_text(workload, rd.xres, rd.yres, rd.spp, rd.maxdepth, os.path.join(tmp, "o.pfm"), renderer="hip"))
-        t = time.time()
-        p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        dt = time.time() - t
-        if p.returncode != 0 or not os.path.exists(os.path.join(tmp, "o.pfm")):
-            return {"error": p.stderr.decode(errors="replace")[-300:]}
+        # The first process that loads ROCm's own HIP runtime on a fresh box pages it in from the image (measured: 156 s once, against
+        # 0.7-1.2 s — this bench process runs on torch's bundled runtime and does not warm it).  So the command runs twice: the first
+        # wall time is reported as cold_wall_s, the second is the figure; a first run beyond 240 s is given up on.
+        runs = []
+        for _ in range(2):
+            t = time.time()
+            try:
+                p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            except subprocess.TimeoutExpired:
+                return {"error": "pbrt_hip did not finish within 240 s (cold start of the HIP runtime on a fresh box?)", "runs_s": runs}
+            runs.append(time.time() - t)
+            if p.returncode != 0 or not os.path.exists(os.path.join(tmp, "o.pfm")):
+                return {"error": p.stderr.decode(errors="replace")[-300:]}
+            os.remove(os.path.join(tmp, "o.pfm"))
+        dt = runs[-1]
     n = rd.xres * rd.yres * rd.spp
-    return {"wall_s": round(dt, 3), "msamples_per_s_inclusive": round(n / dt / 1e6, 2),
-            "what": "pbrt_hip --quiet %s (%dx%d, %d spp): process start, parse, pbrt scene construction, flatten, BVH build + upload, "
+    return {"wall_s": round(dt, 3), "cold_wall_s": round(runs[0], 3), "msamples_per_s_inclusive": round(n / dt / 1e6, 2),
+            "what": "pbrt_hip --quiet %s (%dx%d, %d spp), second of two runs: process start, parse, pbrt scene construction, flatten, BVH build + upload, "
                     "autotune probe, render, film D2H, WriteImage (.pfm)" % (REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.spp)}
 
 
