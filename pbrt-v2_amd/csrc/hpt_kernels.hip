@@ -453,16 +453,16 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
-hipError_t launch_path_basic(const PathKernelArgs &, int, bool, int, hipStream_t);
-hipError_t launch_path_measured(const PathKernelArgs &, int, bool, int, hipStream_t);
-hipError_t launch_path_ext(const PathKernelArgs &, int, bool, int, hipStream_t);
-hipError_t launch_path_all(const PathKernelArgs &, int, bool, int, hipStream_t);
-int occupancy_basic(bool, int, bool, size_t, int *, int *);
-int occupancy_measured(bool, int, bool, size_t, int *, int *);
-int occupancy_ext(bool, int, bool, size_t, int *, int *);
-int occupancy_all(bool, int, bool, size_t, int *, int *);
+#define HPT_DECL_SET(NAME)                                                              \
+    hipError_t launch_path_##NAME(const PathKernelArgs &, int, bool, int, hipStream_t);     \
+    hipError_t launch_path_##NAME##_i(const PathKernelArgs &, int, bool, int, hipStream_t); \
+    int occupancy_##NAME(int, bool, size_t, int *, int *);                                  \
+    int occupancy_##NAME##_i(int, bool, size_t, int *, int *);
+HPT_DECL_SET(basic) HPT_DECL_SET(measured) HPT_DECL_SET(ext) HPT_DECL_SET(all)
+#undef HPT_DECL_SET
 
-// smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present)
+// smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present); every set exists without
+// (hpt_kernels_<set>.hip) and with (hpt_kernels_<set>_i.hip) animated instances
 static int pick_variant(int mats) {
     if (mats & MATS_EXT) return 3;
     if ((mats & ~MATS_PLASTIC) == 0) return 0;
@@ -471,18 +471,19 @@ static int pick_variant(int mats) {
 }
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
     switch (pick_variant(mats)) {
-        case 0: return occupancy_basic(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        case 1: return occupancy_measured(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        case 3: return occupancy_ext(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        default: return occupancy_all(inst, cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 0: return inst ? occupancy_basic_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_basic(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 1: return inst ? occupancy_measured_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_measured(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 3: return inst ? occupancy_ext_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_ext(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        default: return inst ? occupancy_all_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_all(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
     }
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {
+    const bool inst = a.sc.n_instances > 0;
     switch (pick_variant(mats)) {
-        case 0: return launch_path_basic(a, grid_blocks, count, cfg, stream);
-        case 1: return launch_path_measured(a, grid_blocks, count, cfg, stream);
-        case 3: return launch_path_ext(a, grid_blocks, count, cfg, stream);
-        default: return launch_path_all(a, grid_blocks, count, cfg, stream);
+        case 0: return inst ? launch_path_basic_i(a, grid_blocks, count, cfg, stream) : launch_path_basic(a, grid_blocks, count, cfg, stream);
+        case 1: return inst ? launch_path_measured_i(a, grid_blocks, count, cfg, stream) : launch_path_measured(a, grid_blocks, count, cfg, stream);
+        case 3: return inst ? launch_path_ext_i(a, grid_blocks, count, cfg, stream) : launch_path_ext(a, grid_blocks, count, cfg, stream);
+        default: return inst ? launch_path_all_i(a, grid_blocks, count, cfg, stream) : launch_path_all(a, grid_blocks, count, cfg, stream);
     }
 }
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {

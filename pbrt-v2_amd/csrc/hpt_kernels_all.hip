@@ -1,5 +1,5 @@
-// hpt_kernels_all.hip — path kernel instantiated for the material set MATS_ALL (see hpt_kernels_impl.h).
+// hpt_kernels_all.hip — path kernel instantiated (scenes WITHOUT animated instances; hpt_kernels_all_i.hip: with) for the material set MATS_ALL (see hpt_kernels_impl.h).
 #include "hpt_kernels_impl.h"
 namespace hpt {
-HPT_DEFINE_PATH_LAUNCHER(all, MATS_ALL)
+HPT_DEFINE_PATH_LAUNCHER(all, MATS_ALL, false)
 }

@@ -1,8 +1,8 @@
-// hpt_kernels_ext.hip — path kernel instantiated (scenes WITHOUT animated instances; hpt_kernels_ext_i.hip: with) for the material set MATS_FULL: every BxDF family plus what round 2 added (Oren-Nayar,
+// hpt_kernels_ext_i.hip — path kernel instantiated (scenes WITH animated instances) for the material set MATS_FULL: every BxDF family plus what round 2 added (Oren-Nayar,
 // specular lobes, the regular half-angle BRDF, textures with ray differentials and bump mapping, alpha-textured triangles, triangle-mesh
 // emitters).  Scenes that use none of it run the leaner sets (hpt_kernels_{basic,measured,all}.hip).  See hpt_kernels_impl.h.
 #define HPT_LEAN_SET 1
 #include "hpt_kernels_impl.h"
 namespace hpt {
-HPT_DEFINE_PATH_LAUNCHER(ext, MATS_FULL, false)
+HPT_DEFINE_PATH_LAUNCHER(ext_i, MATS_FULL, true)
 }

@@ -515,48 +515,44 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #endif
 #define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true>
 
-// Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS.  The instrumented (COUNT)
-// build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
-#define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS)                                                                        \
-    template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, bool inst, size_t dyn_lds, hipStream_t s) { \
-        if (inst) hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, true, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
-        else hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, false, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
+// Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS and for scenes with (INSTV = true) or without animated
+// instances — one translation unit each (hpt_kernels_<set>.hip, hpt_kernels_<set>_i.hip): the two halves want different compiler
+// settings (the Makefile schedules the instance-free kernels with -amdgpu-sched-strategy=max-ilp: bunny +2.6 %, soup +2.5 %, killeroo
+// +1 %; the instanced kernels, at their register limit, lose 6 % with it — profiles/r02_ab.md) and build in parallel.  The
+// instrumented (COUNT) build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
+#define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS, INSTV)                                                                 \
+    template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, size_t dyn_lds, hipStream_t s) { \
+        hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, INSTV, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);             \
         return hipGetLastError();                                                                                   \
     }                                                                                                               \
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
         const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
-        const bool inst = a.sc.n_instances > 0;                                                                     \
         if (a.dl) {                                                                                                 \
-            if (inst && count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, true, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);        \
-            else if (inst) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, true, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);           \
-            else if (count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, false, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
-            else hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, false, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);                    \
+            if (count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
+            else hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, INSTV, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);               \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (count) {                                                                                                \
-            if (inst) hipLaunchKernelGGL((hpt_path_kernel<true, true, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);  \
-            else hipLaunchKernelGGL((hpt_path_kernel<true, false, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
+            hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
-        if (inst && cfg == 1) cfg = 0;                                                                              \
+        if (INSTV && cfg == 1) cfg = 0;                                                                             \
         switch (cfg) {                                                                                              \
-            case 1: return launch_cfg_##NAME<1>(a, grid, inst, dyn_lds, s);                                                  \
-            case 2: return launch_cfg_##NAME<2>(a, grid, inst, dyn_lds, s);                                                  \
-            case 3: return launch_cfg_##NAME<3>(a, grid, inst, dyn_lds, s);                                                  \
-            case 4: return launch_cfg_##NAME<4>(a, grid, inst, dyn_lds, s);                                                  \
-            case 5: return launch_cfg_##NAME<5>(a, grid, inst, dyn_lds, s);                                                  \
-            case 6: return launch_cfg_##NAME<6>(a, grid, inst, dyn_lds, s);                                                  \
-            default: return launch_cfg_##NAME<0>(a, grid, inst, dyn_lds, s);                                                 \
+            case 1: return launch_cfg_##NAME<1>(a, grid, dyn_lds, s);                                                        \
+            case 2: return launch_cfg_##NAME<2>(a, grid, dyn_lds, s);                                                        \
+            case 3: return launch_cfg_##NAME<3>(a, grid, dyn_lds, s);                                                        \
+            case 4: return launch_cfg_##NAME<4>(a, grid, dyn_lds, s);                                                        \
+            case 5: return launch_cfg_##NAME<5>(a, grid, dyn_lds, s);                                                        \
+            case 6: return launch_cfg_##NAME<6>(a, grid, dyn_lds, s);                                                        \
+            default: return launch_cfg_##NAME<0>(a, grid, dyn_lds, s);                                                       \
         }                                                                                                           \
     }                                                                                                               \
-    template <int CFG> static const void *fn_cfg_##NAME(bool inst) {                                                \
-        return inst ? (const void *)HPT_CFG_KERNEL(MATS, true, CFG) : (const void *)HPT_CFG_KERNEL(MATS, false, CFG); \
-    }                                                                                                               \
-    int occupancy_##NAME(bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                             \
-        if (inst && cfg == 1) cfg = 0;                                                                              \
-        const void *fn = cfg == 1 ? fn_cfg_##NAME<1>(inst) : cfg == 2 ? fn_cfg_##NAME<2>(inst) : cfg == 3 ? fn_cfg_##NAME<3>(inst) \
-                       : cfg == 4 ? fn_cfg_##NAME<4>(inst) : cfg == 5 ? fn_cfg_##NAME<5>(inst) : cfg == 6 ? fn_cfg_##NAME<6>(inst) : fn_cfg_##NAME<0>(inst); \
-        if (dl) fn = inst ? (const void *)HPT_DL_KERNEL(MATS, true, false) : (const void *)HPT_DL_KERNEL(MATS, false, false);      \
+    template <int CFG> static const void *fn_cfg_##NAME() { return (const void *)HPT_CFG_KERNEL(MATS, INSTV, CFG); } \
+    int occupancy_##NAME(int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                         \
+        if (INSTV && cfg == 1) cfg = 0;                                                                             \
+        const void *fn = cfg == 1 ? fn_cfg_##NAME<1>() : cfg == 2 ? fn_cfg_##NAME<2>() : cfg == 3 ? fn_cfg_##NAME<3>() \
+                       : cfg == 4 ? fn_cfg_##NAME<4>() : cfg == 5 ? fn_cfg_##NAME<5>() : cfg == 6 ? fn_cfg_##NAME<6>() : fn_cfg_##NAME<0>(); \
+        if (dl) fn = (const void *)HPT_DL_KERNEL(MATS, INSTV, false);                                               \
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \
