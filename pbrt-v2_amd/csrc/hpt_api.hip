@@ -26,14 +26,6 @@ using namespace hpt;
         }                                                                                   \
     } while (0)
 
-// PathKernelArgs::retrace_*: HPT_RETRACE_MIN (lanes, default 8; 65 = never) and HPT_RETRACE_MAX (extra walks per round, default 4)
-static void retrace_defaults(hpt::PathKernelArgs *a) {
-    const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
-    a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
-    if (a->retrace_min < 1) a->retrace_min = 1;
-    const char *lq = getenv("HPT_LEAF_Q"), *bq = getenv("HPT_LEAF_BLOCK_Q");     // eighths of the busy lanes (0: the leaf half runs every step, as before round 2)
-    a->leaf_q = lq ? atoi(lq) : 4; a->block_q = bq ? atoi(bq) : 8;
-}
 struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; };   // one work-queue head per XCD
 
 struct hpt_scene {
@@ -55,6 +47,18 @@ struct hpt_scene {
     void *d_scr; hipEvent_t ev0, ev1;              // per-frame scratch (work-queue heads + counters) and timing events, created once
     float *sbuf; size_t sbuf_floats;             // two-pass film: per-sample records of the last filtered render (grown on demand)         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
 };
+
+// PathKernelArgs::retrace_*: HPT_RETRACE_MIN (lanes, default 8; 65 = never) and HPT_RETRACE_MAX (extra walks per round, default 4)
+static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
+    const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
+    a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
+    if (a->retrace_min < 1) a->retrace_min = 1;
+    const char *lq = getenv("HPT_LEAF_Q"), *bq = getenv("HPT_LEAF_BLOCK_Q");     // eighths of the busy lanes (0: the leaf half runs every step, as before round 2)
+    // a BVH that does not fit the caches (> 64 MB of nodes + triangle records: the 1 M-triangle soup) prefers earlier leaf phases — its node
+    // steps wait for HBM, parked leaves pile up behind them — : same-box 2/1 against 4/8: soup 303 vs 296, the 7 MB scenes 1483 vs 1514 (bunny)
+    const bool big = s && s->info.bvh_bytes + s->info.tri_bytes > ((int64_t)64 << 20);
+    a->leaf_q = lq ? atoi(lq) : big ? 2 : 4; a->block_q = bq ? atoi(bq) : big ? 1 : 8;
+}
 
 extern "C" int hpt_device_count(void) {
     int n = 0;
@@ -489,7 +493,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
     a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
-    retrace_defaults(&a);
+    retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
@@ -646,7 +650,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
     a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
-    retrace_defaults(&a);
+    retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
