@@ -81,10 +81,15 @@ def test_bsdf_matches_oracle(cases, dev, ora, name, material):
     # f, pdf, sampled f and pdf: relative; the Blinn lobe (exponent 40 on the shiny killeroo)
     # amplifies an ulp of the half-vector by its exponent
     vals = [0, 1, 2, 3, 7, 8, 9, 10]
-    # the anisotropic lobe raises cos(theta_h) to (ex*x^2 + ey*y^2)/(1 - cos^2): exponents in the
-    # thousands near the pole, where one ulp of the half vector is amplified accordingly
-    rtol = 2e-2 if name == "ms" and material >= 1 else 5e-4
-    assert np.allclose(a[:, vals], b[:, vals], rtol=rtol, atol=1e-6, equal_nan=True), np.abs(a - b).max()
+    close = np.isclose(a[:, vals], b[:, vals], rtol=5e-4, atol=1e-6, equal_nan=True)
+    if name == "ms" and material == 1:
+        # the anisotropic metal lobe raises cos(theta_h) to (ex*x^2 + ey*y^2)/(1 - cos^2): exponents in the thousands near the pole, where one
+        # ulp of the half vector is amplified accordingly.  Measured (scripts/check_aniso_error.py): 99.99 % of the values within 2.2e-5, the
+        # worst of 32 000 at 1.6e-2 — so: all but one in ten thousand within 5e-4, the stragglers within 2 %
+        assert close.mean() > 0.9999, close.mean()
+        assert np.allclose(a[:, vals], b[:, vals], rtol=2e-2, atol=1e-6, equal_nan=True), np.abs(a - b).max()
+    else:
+        assert close.all(), np.abs(a - b).max()
     assert np.isclose(a[:, vals], b[:, vals], rtol=2e-5, atol=1e-7).mean() > 0.97
 
 
