@@ -365,7 +365,7 @@ static int render_wavefront(hpt_scene *s, PathKernelArgs &pa, const hpt_render_d
     if (e == hipSuccess) e = hipMemsetAsync(a.state, 0, sizeof(float4) * 10 * (size_t)P, stream);
     if (e == hipSuccess) e = hipMemsetAsync(a.qcount, 0, sizeof(int) * 4, stream);
     int bpc = 1, vgprs = 0;
-    if (e == hipSuccess && wf_trace_occupancy(s->d.n_instances > 0, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && wf_trace_occupancy(s->d.n_instances > 0, s->info.bvh_max_depth, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int *h_q = nullptr;
@@ -382,7 +382,7 @@ static int render_wavefront(hpt_scene *s, PathKernelArgs &pa, const hpt_render_d
         for (int k = 0; k < check_every && e == hipSuccess; ++k, ++iters) {
             a.parity = (int)(iters & 1);
             e = wf_launch_advance(s->mats, a, count, stream);
-            if (e == hipSuccess) e = wf_launch_trace(a, grid, count, stream);
+            if (e == hipSuccess) e = wf_launch_trace(a, grid, count, s->info.bvh_max_depth, stream);
         }
         // the queue length of the last advance tells whether anything is still in flight
         if (e == hipSuccess) e = hipMemcpyAsync(h_q, a.qcount, sizeof(int) * 4, hipMemcpyDeviceToHost, stream);
@@ -546,10 +546,6 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
     if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
     a.inst_xf = (s->inst_xf && (size_t)grid * HPT_BLOCK <= s->inst_xf_lanes && !getenv("HPT_NO_XF_CACHE")) ? s->inst_xf : nullptr;
-    if ((replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT) && s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) {
-        hpt_set_error("BVH depth %d: the replay / wavefront kernels have a fixed %d-row traversal stack (build the scene with the host SAH builder)", s->info.bvh_max_depth, HPT_STACK_DEPTH);
-        return HPT_E_UNSUPPORTED;
-    }
     if (dl && s->has_specular && e == hipSuccess) {      // SpecularReflect / SpecularTransmit recursion: a stack of pending rays per lane, in HBM
         a.dl_cap = rd->maxdepth + 1;
         const size_t need = (size_t)(a.dl_cap + 1) * HPT_DLS_FLOATS * (size_t)grid * HPT_BLOCK;
@@ -603,7 +599,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
     // two-pass film: w = 0 marks a sample this shard does not render; then the path kernel parks its samples, the gather sums them
     if (e == hipSuccess && a.rp.sbuf_xyzw) e = hipMemsetAsync(a.rp.sbuf_xyzw, 0, sizeof(float) * 4 * (size_t)a.rp.sx_count * a.rp.sy_count * (size_t)rd->spp, stream);
-    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
+    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, s->info.bvh_max_depth, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
     if (e == hipSuccess && a.rp.sbuf_xyzw) e = launch_film_gather(a.rp, a.film, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);
@@ -686,12 +682,11 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
 // ---- parity hooks -------------------------------------------------------------------------------------
 extern "C" int hpt_test_intersect(hpt_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim) {
     if (!s || !rays || !out_hit || !out_prim || n < 0) { hpt_set_error("bad argument"); return HPT_E_INVALID; }
-    if (s->info.bvh_max_depth + 2 > HPT_STACK_DEPTH) { hpt_set_error("BVH depth %d exceeds the parity hook's fixed traversal stack", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     DevBuf<float> d_rays, d_hit; DevBuf<int32_t> d_prim;
     if (!d_rays.alloc(8 * (size_t)n) || !d_hit.alloc(4 * (size_t)n) || !d_prim.alloc((size_t)n)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
     HIP_CHECK_RET(hipMemcpy(d_rays.p, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice), HPT_E_HIP);
-    HIP_CHECK_RET(launch_intersect(s->d, d_rays.p, n, anyhit, d_hit.p, d_prim.p, nullptr), HPT_E_HIP);
+    HIP_CHECK_RET(launch_intersect(s->d, d_rays.p, n, anyhit, d_hit.p, d_prim.p, s->info.bvh_max_depth, nullptr), HPT_E_HIP);
     HIP_CHECK_RET(hipDeviceSynchronize(), HPT_E_HIP);
     HIP_CHECK_RET(hipMemcpy(out_hit, d_hit.p, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost), HPT_E_HIP);
     HIP_CHECK_RET(hipMemcpy(out_prim, d_prim.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost), HPT_E_HIP);

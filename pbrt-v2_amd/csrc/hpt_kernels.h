@@ -41,6 +41,10 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
     int32_t ntasks;
 };
 
+// The replay, wavefront-trace and intersect-hook kernels keep one traversal stack column per lane in dynamic LDS: BVH depth + 2 rows, at least
+// HPT_STACK_DEPTH (the depth bound of the host SAH builder), at most HPT_MAX_STACK_ROWS (what flatten_scene accepts from the device builder)
+inline int fixed_stack_rows(int bvh_depth) { return bvh_depth + 2 > HPT_STACK_DEPTH ? bvh_depth + 2 : HPT_STACK_DEPTH; }
+inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows(bvh_depth) * HPT_BLOCK * sizeof(int32_t); }
 #define HPT_MAX_STACK_ROWS 40   /* dynamic LDS stack rows of the path kernel: 40 KiB a workgroup = 4 workgroups per CU */
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
@@ -48,10 +52,10 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 int path_kernel_cold_rows(int mats);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
-hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream);
+hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream);   // second pass of the two-pass film (table filters)
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
-                            int32_t *out_prim, hipStream_t s);
+                            int32_t *out_prim, int bvh_depth, hipStream_t s);
 hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s);
 hipError_t launch_sampler(const RenderParams &rp, int x, int y, float *out, hipStream_t s);
 

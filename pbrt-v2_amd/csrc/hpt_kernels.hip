@@ -29,7 +29,7 @@ int path_kernel_cold_rows(int mats) {       // must mirror launch_path_kernel's 
 
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelArgs a, const ReplayArgs ra) {
-    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    extern __shared__ int32_t lds_stack[];      // fixed_stack_rows(BVH depth) x HPT_BLOCK ints (launch_replay_kernel)
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void hpt_film_gather_idx_kernel(const RenderPa
 // ---- function-level parity kernels (same device functions, array in / array out) --------------------
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene sc, const float *rays, int64_t n, int anyhit,
                                                                   float *out_hit, int32_t *out_prim) {
-    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    extern __shared__ int32_t lds_stack[];      // fixed_stack_rows(BVH depth) x HPT_BLOCK ints (launch_intersect)
     int64_t i = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *r = rays + 8 * i;
@@ -486,9 +486,9 @@ hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks
         default: return inst ? launch_path_all_i(a, grid_blocks, count, cfg, stream) : launch_path_all(a, grid_blocks, count, cfg, stream);
     }
 }
-hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, hipStream_t stream) {
+hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream) {
     int grid = (int)(ra.nlanes / HPT_BLOCK);
-    hipLaunchKernelGGL(hpt_replay_kernel, dim3(grid), dim3(HPT_BLOCK), 0, stream, a, ra);
+    hipLaunchKernelGGL(hpt_replay_kernel, dim3(grid), dim3(HPT_BLOCK), fixed_stack_bytes(bvh_depth), stream, a, ra);
     return hipGetLastError();
 }
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream) {
@@ -518,9 +518,9 @@ hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t s
     }
     return hipGetLastError();
 }
-hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, hipStream_t s) {
+hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit, int32_t *out_prim, int bvh_depth, hipStream_t s) {
     int grid = (int)((n + HPT_BLOCK - 1) / HPT_BLOCK);
-    if (grid > 0) hipLaunchKernelGGL(hpt_intersect_kernel, dim3(grid), dim3(HPT_BLOCK), 0, s, sc, rays, n, anyhit, out_hit, out_prim);
+    if (grid > 0) hipLaunchKernelGGL(hpt_intersect_kernel, dim3(grid), dim3(HPT_BLOCK), fixed_stack_bytes(bvh_depth), s, sc, rays, n, anyhit, out_hit, out_prim);
     return hipGetLastError();
 }
 hipError_t launch_bsdf(const DScene &sc, int material, const float *in, int64_t n, float *out, hipStream_t s) {

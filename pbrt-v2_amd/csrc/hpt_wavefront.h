@@ -28,8 +28,8 @@ struct WfArgs {
 };
 
 hipError_t wf_launch_advance(int mats, const WfArgs &a, bool count, hipStream_t s);
-hipError_t wf_launch_trace(const WfArgs &a, int grid, bool count, hipStream_t s);
-int wf_trace_occupancy(bool inst, int *blocks_per_cu, int *vgprs);
+hipError_t wf_launch_trace(const WfArgs &a, int grid, bool count, int bvh_depth, hipStream_t s);
+int wf_trace_occupancy(bool inst, int bvh_depth, int *blocks_per_cu, int *vgprs);
 
 } // namespace hpt
 #endif

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void wf_advance_kernel(const WfArgs a) {
 // ---- trace: persistent waves drain the compacted ray queue -------------------------------------------
 template <bool COUNT, bool INST>
 __global__ __launch_bounds__(HPT_BLOCK, HPT_WF_TRACE_WAVES) void wf_trace_kernel(const WfArgs a) {
-    __shared__ int32_t lds_stack[HPT_STACK_DEPTH * HPT_BLOCK];
+    extern __shared__ int32_t lds_stack[];      // fixed_stack_rows(BVH depth) x HPT_BLOCK ints (wf_launch_trace)
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
     const int64_t P = a.P;
@@ -201,18 +201,20 @@ hipError_t wf_launch_advance(int mats, const WfArgs &a, bool count, hipStream_t 
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return launch_advance_m<MATS_PLASTIC | MATS_MEASURED>(a, count, s);
     return launch_advance_m<MATS_ALL>(a, count, s);
 }
-hipError_t wf_launch_trace(const WfArgs &a, int grid, bool count, hipStream_t s) {
+hipError_t wf_launch_trace(const WfArgs &a, int grid, bool count, int bvh_depth, hipStream_t s) {
     const bool inst = a.sc.n_instances > 0;
-    if (count && inst) hipLaunchKernelGGL((wf_trace_kernel<true, true>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
-    else if (count) hipLaunchKernelGGL((wf_trace_kernel<true, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
-    else if (inst) hipLaunchKernelGGL((wf_trace_kernel<false, true>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((wf_trace_kernel<false, false>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
+    const size_t lds = fixed_stack_bytes(bvh_depth);
+    if (count && inst) hipLaunchKernelGGL((wf_trace_kernel<true, true>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);
+    else if (count) hipLaunchKernelGGL((wf_trace_kernel<true, false>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);
+    else if (inst) hipLaunchKernelGGL((wf_trace_kernel<false, true>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((wf_trace_kernel<false, false>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);
     return hipGetLastError();
 }
-int wf_trace_occupancy(bool inst, int *blocks_per_cu, int *vgprs) {
+int wf_trace_occupancy(bool inst, int bvh_depth, int *blocks_per_cu, int *vgprs) {
     int nb = 0;
-    hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_trace_kernel<false, true>, HPT_BLOCK, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_trace_kernel<false, false>, HPT_BLOCK, 0);
+    const size_t lds = fixed_stack_bytes(bvh_depth);
+    hipError_t e = inst ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_trace_kernel<false, true>, HPT_BLOCK, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_trace_kernel<false, false>, HPT_BLOCK, lds);
     if (e != hipSuccess) return -1;
     hipFuncAttributes fa;
     const void *fn = inst ? (const void *)wf_trace_kernel<false, true> : (const void *)wf_trace_kernel<false, false>;

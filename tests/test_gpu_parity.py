@@ -361,14 +361,20 @@ def test_gpu_built_bvh_finds_the_same_hits_and_film(cases, dev, ora, name, monke
     assert st.bad_samples == 0
     assert np.array_equal(f_gpu[..., 3], f_host[..., 3])
     assert film.rmse(film.xyzw_to_rgb(f_gpu), film.xyzw_to_rgb(f_host)) < 1e-4     # ties between equal-t hits may differ
-    if info.bvh_max_depth + 2 <= 26:   # the parity hook has a fixed 26-row stack
-        rays = random_rays(s, 20000, seed=3)
-        hg, pg = d.intersect(rays)
-        ho, po = ora[name].intersect(rays)
-        same = (pg >= 0) == (po >= 0)
-        assert same.mean() > 0.9995
-        both = (pg >= 0) & (po >= 0)
-        assert np.array_equal(hg[both][:, 0], ho[both][:, 0])
+    # the intersect hook, the wavefront trace kernel and the replay kernel size their LDS stacks from the tree's depth too (a device-built
+    # tree is not depth-bounded: killeroo's is 35 deep against the host builder's bound of 24)
+    rays = random_rays(s, 20000, seed=3)
+    hg, pg = d.intersect(rays)
+    ho, po = ora[name].intersect(rays)
+    same = (pg >= 0) == (po >= 0)
+    assert same.mean() > 0.9995
+    both = (pg >= 0) & (po >= 0)
+    assert np.array_equal(hg[both][:, 0], ho[both][:, 0])
+    rd_w = hash_rd(s, seed=6)
+    rd_w.pipeline = abi.HPT_PIPELINE_WAVEFRONT
+    f_wf, st_wf = d.render(s.camera, rd_w)
+    assert st_wf.bad_samples == 0 and np.array_equal(f_wf[..., 3], f_host[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(f_wf), film.xyzw_to_rgb(f_host)) < 1e-4
 
 
 def test_pbrt_binary_with_the_hip_renderer_end_to_end(tmp_path):
