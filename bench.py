@@ -47,19 +47,20 @@ _EXCHANGE = {}       # "fallback": why the multi-GPU film exchange went through 
 film_mod = importlib.import_module("pbrt-v2_amd.film")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# algorithmic traversal bytes per camera sample of the REFERENCE algorithm
-# (32 B x BVH nodes visited + 48 B x triangles tested, measured on the instrumented reference)
-# soup: no reference count (its parser input is 1M triangles of synthetic text); the device's own algorithmic bytes,
-# 64 B x 265.2 BVH2 nodes + 48 B x 18.5 triangles per camera sample (bench.py --workload soup --count-work)
-ALGO_BYTES_PER_SAMPLE = {"bunny": 2180.0, "killeroo": 3570.0, "anim": 3000.0, "soup": 17859.0}
-DEFAULT_SPP = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "killeroo-dl": 64, "metal": 128}
+# the roofline numerator is the algorithmic traversal traffic of the REFERENCE algorithm, 32 B x BVH nodes visited +
+# 48 B x triangles tested per camera sample (accelerators/bvh.cpp:403-454 over its 32-byte LinearBVHNodes).  It is MEASURED IN THIS RUN
+# (reference_work below): the oracle — whose BVH is the reference's own build, pinned bit-identical to the reference binary — counts
+# nodes and triangle tests over a 1-spp sweep of the same frame (2179 / 3566 / 3008 B per sample on bunny / killeroo / anim: the
+# figures SURVEY §8d measured on the instrumented reference; 17.8 KB on the 1 M-triangle soup).  No constants.
+DEFAULT_SPP = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "soup4m": 64, "killeroo-dl": 64, "metal": 128}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue peak (MI355X_MICROARCH.md, wave scheduling): 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0 * 1e0      # = 1228.8 G wave-instructions / s
 TUNE_NAMES = ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases",
               "3 waves/SIMD, lock-step phases", "4 waves/SIMD, lock-step phases, subtree stealing",
               "3 waves/SIMD, lock-step phases, subtree stealing"]
-REF_SCENE_FILE = {"bunny": "bunny.pbrt", "killeroo": "killeroo-simple.pbrt", "anim": "anim-killeroos-moving.pbrt"}
+REF_SCENE_FILE = {"bunny": "bunny.pbrt", "killeroo": "killeroo-simple.pbrt", "anim": "anim-killeroos-moving.pbrt", "metal": "metal.pbrt"}
+_CALIB = {}          # achieved-peak HBM bandwidth of device 0 (hpt_calib_hbm_triad), measured once per process
 
 
 def load_workload(name, spp):
@@ -80,15 +81,18 @@ def load_workload(name, spp):
         s.render.spp = spp or DEFAULT_SPP[name]
         desc = "scenes/killeroo-simple.pbrt as shipped (DirectLightingIntegrator, strategy all, 8 light samples per camera sample)"
     elif name == "metal":     # BASELINE.json configs[4]: scenes/metal.pbrt as shipped (textured, bump-mapped substrate floor; Au teapot; .exr env map)
-        s = abi.Scene.load(os.path.join(GOLDEN, "metal.hpts.gz"))
-        v = np.load(os.path.join(GOLDEN, "metal_4k.view.npz"))
+        s = abi.Scene.load(os.path.join(GOLDEN, "metalg.hpts.gz"))      # tests/golden/make_golden_r3.py
+        v = np.load(os.path.join(GOLDEN, "metalg_4k.view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.render.spp = spp or DEFAULT_SPP[name]
-        desc = "scenes/metal.pbrt as shipped (sampler + path instead of the metropolis renderer; small_env.exr for the missing uffizi map)"
+        desc = "scenes/metal.pbrt as shipped (sampler + path instead of the metropolis renderer; textures/grace_latlong.exr, 1000x500, for the missing uffizi map)"
     elif name == "soup":
         s = scenes.synthetic_soup(n_tris=1_000_000, spp=spp or DEFAULT_SPP[name], maxdepth=8)
         desc = "synthetic 1M random triangles + 1 env light (seed 0x5EED0001)"
+    elif name == "soup4m":    # the HBM point: 4 M triangles = 704 MB of nodes + triangle records, 2.7x the 256 MiB Infinity Cache
+        s = scenes.synthetic_soup(n_tris=4_000_000, spp=spp or DEFAULT_SPP[name], maxdepth=8)
+        desc = "synthetic 4M random triangles + 1 env light (seed 0x5EED0001; the configs[2] generator at 4x the count: scene data beyond the Infinity Cache)"
     else:
         raise SystemExit("unknown workload " + name)
     s.render.sampler_mode, s.render.seed = abi.HPT_SAMPLER_LD_HASH, 0
@@ -140,7 +144,14 @@ def ref_scene_text(workload, xres, yres, spp, maxdepth, out_file, renderer=None)
     import re
     sd = os.path.join(ROOT, "oracle", "_ref", "scenes")
     text = open(os.path.join(sd, REF_SCENE_FILE[workload])).read()
-    if workload == "bunny":     # bunny.pbrt sets only the Film; sampler and integrator come from the api defaults
+    if workload == "metal":     # as tests/golden/make_golden_r3.py: sampler + path for the metropolis line, grace_latlong.exr for the missing uffizi map
+        text = re.sub(r'Renderer "metropolis"[^\n]*\n[^\n]*\n', 'SurfaceIntegrator "path" "integer maxdepth" [%d]\n' % maxdepth, text)
+        text = text.replace('"integer xresolution" [400] "integer yresolution" [400]',
+                            '"integer xresolution" [%d] "integer yresolution" [%d] "string filename" "%s"' % (xres, yres, out_file))
+        text = text.replace('"integer pixelsamples" [4]', '"integer pixelsamples" [%d]' % spp)
+        text = text.replace("textures/uffizi_latlong.exr", "%s/textures/grace_latlong.exr" % sd)
+        text = text.replace('"textures/lines.exr"', '"%s/textures/lines.exr"' % sd).replace('"spds/', '"%s/spds/' % sd)
+    elif workload == "bunny":     # bunny.pbrt sets only the Film; sampler and integrator come from the api defaults
         text = text.split("\n", 2)[2]
         text = ('Film "image" "integer xresolution" [%d] "integer yresolution" [%d] "string filename" "%s"\n'
                 'Sampler "lowdiscrepancy" "integer pixelsamples" [%d]\nSurfaceIntegrator "path" "integer maxdepth" [%d]\n'
@@ -164,13 +175,13 @@ def cpu_baseline_reference(workload, scene):
     """pbrt-v2's OWN multithreaded CPU path (oracle/_ref/pbrt = the reference compiled from /root/reference/src by
     oracle/Makefile) on the same scene file, same frame, on this host's cores: two-point fit t(spp_b) - t(spp_a) so that
     parsing and the BVH build drop out.  None when the binary / scene files did not travel."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+    exe = os.path.join(ROOT, "oracle", "_ref", "pbrt_exr" if workload == "metal" else "pbrt")   # metal.pbrt reads .exr maps: the reference built with its vendored OpenEXR
     if workload not in REF_SCENE_FILE or not os.path.exists(exe) or \
             not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "scenes", REF_SCENE_FILE[workload])):
         return None
     cores = usable_cores()
     rd = scene.render
-    a, b = 2, 16
+    a, b = (2, 16) if rd.xres * rd.yres <= 1920 * 1080 else (1, 4)     # ~10-30 s of CPU work
     ts = {}
     with tempfile.TemporaryDirectory() as tmp:
         for spp in (a, b):
@@ -181,8 +192,8 @@ def cpu_baseline_reference(workload, scene):
             ts[spp] = time.time() - t
     rate = (b - a) * rd.xres * rd.yres / max(ts[b] - ts[a], 1e-9)
     return {"value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
-            "sample": "pbrt-v2 itself (oracle/_ref/pbrt --ncores %d) on %s at %dx%d, path maxdepth %d: (%d - %d) spp / (%.2f s - %.2f s) — "
-                      "two-point fit, parse + BVH build cancel" % (cores, REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.maxdepth, b, a, ts[b], ts[a])}
+            "sample": "pbrt-v2 itself (oracle/_ref/%s --ncores %d) on %s at %dx%d, path maxdepth %d: (%d - %d) spp / (%.2f s - %.2f s) — "
+                      "two-point fit, parse + BVH build cancel" % (os.path.basename(exe), cores, REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.maxdepth, b, a, ts[b], ts[a])}
 
 
 def end_to_end_pbrt_hip(workload, scene):
@@ -218,10 +229,11 @@ def end_to_end_pbrt_hip(workload, scene):
 
 
 # ---- verification of the timed film ----------------------------------------------------------------------------------
-def verify_film(scene, rd, full, flt, n_crop=64):
-    """full: the (gathered) film of the LAST timed step, host numpy (H, W, 4).  Weight sums + oracle crops."""
+def verify_film(scene, rd, full, flt, n_crop=64, n_content=18):
+    """full: the (gathered) film of the LAST timed step, host numpy (H, W, 4).  Weight sums + oracle crops at full spp: the six fixed
+    windows (corners, centre, across two XCD bands) and the n_content windows of the frame with the highest luminance variance."""
     from oracle import orc  # the checker
-    from tests.util import crop_windows
+    from tests.util import content_windows, crop_windows
     out = {}
     samples = rd.x_count * rd.y_count * rd.spp
     wsum = float(full[..., 3].astype(np.float64).sum())
@@ -233,7 +245,8 @@ def verify_film(scene, rd, full, flt, n_crop=64):
             raise SystemExit("bench: the timed film holds weight %.0f for %d camera samples" % (wsum, samples))
     o = orc.OracleScene(scene)
     worst, t0 = 0.0, time.time()
-    for name, x0, y0 in crop_windows(rd.x_count, rd.y_count, n_crop):
+    wins = crop_windows(rd.x_count, rd.y_count, n_crop) + content_windows(full, n_content, n_crop)
+    for name, x0, y0 in wins:
         apron = 1 if flt is None else 0
         ax0, ay0 = max(x0 - apron, 0), max(y0 - apron, 0)
         ax1, ay1 = min(x0 + n_crop + apron, rd.x_count), min(y0 + n_crop + apron, rd.y_count)
@@ -248,10 +261,92 @@ def verify_film(scene, rd, full, flt, n_crop=64):
         err = film_mod.rmse(film_mod.xyzw_to_rgb(fo), film_mod.xyzw_to_rgb(fd))
         worst = max(worst, err)
     out["rmse_vs_oracle"] = worst
-    out["crops"] = "%d windows of %dx%d px at %d spp (corners, centre, across two XCD bands), oracle %.1f s" % (6, n_crop, n_crop, rd.spp, time.time() - t0)
+    out["crops"] = "%d windows of %dx%d px at %d spp (corners, centre, across two XCD bands + the %d of highest luminance variance), oracle %.1f s" \
+        % (len(wins), n_crop, n_crop, rd.spp, n_content, time.time() - t0)
     out["tolerance"] = 1e-3
     if not worst < 1e-3:
         raise SystemExit("bench: per-pixel RMSE of the timed film against the oracle is %.3g (tolerance 1e-3)" % worst)
+    return out
+
+
+def reference_work(scene, rd):
+    """The roofline numerator, measured in this run: BVH nodes visited and triangles tested per camera sample by the REFERENCE algorithm
+    on the reference's own tree (the oracle restates BVHAccel's build and Intersect / IntersectP, accelerators/bvh.cpp:153-503, and is pinned
+    bit-identical to the reference binary), over a 1-spp sweep of the whole frame with the production sampler."""
+    from oracle import orc  # checker / instrumented reference only
+    crd = abi.copy_struct(rd)
+    crd.spp, crd.shard_rank, crd.shard_count, crd.count_work = 1, 0, 1, 0
+    crd.sampler_mode = abi.HPT_SAMPLER_LD_HASH
+    t0 = time.time()
+    _, st = orc.OracleScene(scene).render(scene.camera, crd, nthreads=usable_cores())
+    n = float(st[0])
+    return {"nodes32_per_sample": round(st[3] / n, 3), "tris_per_sample": round(st[4] / n, 3),
+            "closest_rays_per_sample": round(st[1] / n, 4), "shadow_rays_per_sample": round(st[2] / n, 4),
+            "bytes_per_sample": round((32.0 * st[3] + 48.0 * st[4]) / n, 1),
+            "what": "32 B x nodes + 48 B x triangle tests of BVHAccel::Intersect / IntersectP on the reference's tree (oracle counters), "
+                    "%dx%d at 1 spp, %.1f s" % (crd.x_count, crd.y_count, time.time() - t0)}
+
+
+def achieved_peak(local):
+    """hpt_calib_hbm_triad: float4 triad over 3 x 1 GiB on this rank's device, best of 5 (report the achieved peak too)."""
+    if "gbs" not in _CALIB:
+        try:
+            _CALIB["gbs"] = round(hpt.hbm_triad(local, 1 << 30, 5), 1)
+        except Exception as e:                               # noqa: BLE001 — calibration only
+            _CALIB["gbs"], _CALIB["error"] = None, str(e)
+    return _CALIB["gbs"]
+
+
+# ---- hardware counters of THIS run ---------------------------------------------------------------------------------------------
+PMC_PASSES = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")]
+
+
+def pmc_live(workload, spp, timeout_s=240):
+    """HBM-side bytes and VALU figures of the path kernel, collected NOW: one rocprofv3 --kernel-trace --pmc pass per counter group
+    (separate passes, kernel trace only — MI355X_MICROARCH.md's HBM recipe) around a child `bench.py --workload W --steps 1` of the same
+    frame.  FETCH_SIZE / WRITE_SIZE are KiB; corrections as profiles/r02_fetch_calibration.md measured them for this kernel's access
+    patterns (lane-scattered 64-B node fetches x1.0, coalesced scratch reloads counted at half, writes x1.0, all of them scratch):
+    read bytes = FETCH_SIZE + WRITE_SIZE / 2.  Returns {} with "error" when rocprofv3 is unavailable or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    vals, meta, t0 = {}, {}, time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for i, grp in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0",
+                   "--no-cpu-baseline", "--no-verify", "--no-extra", "--no-pmc", "--no-work"]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {"error": "rocprofv3 --pmc %s timed out after %d s" % (" ".join(grp), timeout_s)}
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if "hpt_path_kernel" in r["Kernel_Name"]]
+            if p.returncode != 0 or not rows:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d rows; %s" % (" ".join(grp), p.returncode, len(rows), p.stderr.decode(errors="replace")[-200:])}
+            dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])     # noqa: E731
+            longest = max(dur(r) for r in rows)
+            for r in rows:                                  # the full-frame launch only (the autotune probe runs the same template)
+                if dur(r) >= 0.5 * longest:
+                    vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                    meta = {"scratch_bytes_per_lane": int(r["Scratch_Size"]), "vgprs": int(r["VGPR_Count"]), "kernel_ms_under_pmc": round(dur(r) / 1e6, 3)}
+    v = {k: sum(x) / len(x) for k, x in vals.items()}
+    out = {"source": "rocprofv3 --kernel-trace --pmc, %d passes inside this bench run (%.0f s)" % (len(PMC_PASSES), time.time() - t0)}
+    out.update(meta)
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out["write_bytes"] = v["WRITE_SIZE"] * 1024.0
+        out["read_bytes"] = v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0 / 2.0
+        out["bytes_per_launch"] = out["read_bytes"] + out["write_bytes"]
+    if "SQ_INSTS_VALU" in v:
+        out["valu_wave_instructions_per_launch"] = v["SQ_INSTS_VALU"]
+    if v.get("SQ_ACTIVE_INST_VALU"):
+        out["valu_lane_utilisation"] = round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
     return out
 
 
@@ -362,25 +457,68 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
     if not args.no_verify:
         out["verify"] = verify_film(scene, rd, full_h, flt)
         out["rmse_vs_oracle"] = out["verify"]["rmse_vs_oracle"]
-    bps = ALGO_BYTES_PER_SAMPLE.get(workload)
+    # ---- film D2H included (SURVEY.md §8d's metric ends at "film resident on host"): a few more frames, each followed by the copy ----
+    if world == 1 and not args.no_work:
+        host = torch.empty((rd.y_count, rd.x_count, 4), dtype=torch.float32).pin_memory()
+        torch.cuda.synchronize()
+        n_d2h = min(steps, 3)
+        t0 = time.perf_counter()
+        for _ in range(n_d2h):
+            step()
+            host.copy_(film, non_blocking=True)
+            torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        out["value_incl_d2h"] = round(rd.x_count * rd.y_count * rd.spp * n_d2h / dt2 / 1e6, 3)
+    # ---- work per camera sample, measured in this run: the device's own count on the tree it walks (instrumented kernel build, one
+    # frame at <= 8 spp) beside the reference algorithm's count on the reference's tree (oracle counters) ----
+    work = {}
+    if not args.no_work and args.pipeline == "persistent":
+        rdc = abi.copy_struct(rd)
+        rdc.count_work, rdc.spp = 1, min(rd.spp, 8)
+        if abi.sampler_kind(rdc.sampler_mode) == abi.HPT_SAMPLER_STRATIFIED_HASH:
+            rdc.sampler_mode = abi.HPT_SAMPLER_LD_HASH       # (8 spp need not be xsamples x ysamples; the work per sample is the same)
+        c = dev.render_device(scene.camera, rdc, film.data_ptr(), stream)
+        n = float(c.camera_samples)
+        work["device"] = {"nodes64_per_sample": round(c.nodes_visited / n, 3), "tris_per_sample": round(c.tris_tested / n, 3),
+                          "closest_rays_per_sample": round(c.closest_rays / n, 4), "shadow_rays_per_sample": round(c.shadow_rays / n, 4),
+                          "bytes_per_sample": round((64.0 * c.nodes_visited + 48.0 * c.tris_tested) / n, 1),
+                          "what": "64 B x BVH2 node fetches + 48 B x triangle records of hpt_path_kernel on the tree this run walks "
+                                  "(%s, depth %d), instrumented build, %d spp" % ("device LBVH" if info.device_built else "host SAH", info.bvh_max_depth, rdc.spp)}
     if args.count_work:
-        out["work"] = {"closest_rays_per_sample": last.closest_rays / per_launch_samples,
-                       "shadow_rays_per_sample": last.shadow_rays / per_launch_samples,
-                       "nodes64_per_sample": last.nodes_visited / per_launch_samples,
-                       "tris_per_sample": last.tris_tested / per_launch_samples,
-                       "device_bytes_per_sample": (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples}
-    if bps is None and args.count_work:
-        bps = (64 * last.nodes_visited + 48 * last.tris_tested) / per_launch_samples
-    prof = pmc_profile(workload)
+        n = float(per_launch_samples)
+        work["device_timed_frame"] = {"nodes64_per_sample": last.nodes_visited / n, "tris_per_sample": last.tris_tested / n,
+                                      "closest_rays_per_sample": last.closest_rays / n, "shadow_rays_per_sample": last.shadow_rays / n}
+    bps = None
+    if not args.no_work:
+        work["reference"] = reference_work(scene, rd)
+        bps = work["reference"]["bytes_per_sample"]
+    if work:
+        out["work"] = work
+    prof = {}
+    if args.pmc and world == 1:
+        prof = pmc_live(workload, spp_per_gpu)
+        if prof.get("error"):
+            out["pmc_error"] = prof["error"]
+    if not prof.get("bytes_per_launch"):
+        committed = pmc_profile(workload)
+        if committed:
+            committed = dict(committed, source="COMMITTED file %s (not measured in this run)" % committed.get("source"))
+        prof = committed or prof
     if bps is not None:
         achieved = bps * per_launch_samples / (k_ms * 1e-3) / 1e9
+        scale = per_launch_samples / float(prof["samples_per_launch"]) if prof.get("samples_per_launch") else 1.0
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": prof.get("bytes_per_launch"),
-                           "algorithmic_bytes_per_sample": bps}
-    if prof.get("valu_wave_instructions_per_launch") and prof.get("samples_per_launch"):
+                           "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "traffic": (prof["bytes_per_launch"] * scale) if prof.get("bytes_per_launch") else None,
+                           "traffic_source": prof.get("source"), "traffic_write_bytes": (prof["write_bytes"] * scale) if prof.get("write_bytes") else None,
+                           "algorithmic_bytes_per_sample": bps, "achieved_peak": achieved_peak(local),
+                           "scene_bytes_in_hbm": int(info.total_device_bytes),
+                           "numerator": "reference algorithm on the reference's tree, counted by the oracle in this run (work.reference)"}
+        if out["roofline"]["achieved_peak"]:
+            out["roofline"]["frac_of_achieved_peak"] = round(achieved / out["roofline"]["achieved_peak"], 5)
+    if prof.get("valu_wave_instructions_per_launch"):
         # second roofline for the cache-resident scenes (7 MB of scene data never leaves L2 / Infinity Cache): VALU issue.
-        # wave-instructions per camera sample from the committed PMC pass x this run's samples / this run's kernel time
-        ipl = prof["valu_wave_instructions_per_launch"] / prof["samples_per_launch"] * per_launch_samples
+        ipl = prof["valu_wave_instructions_per_launch"] * (per_launch_samples / float(prof["samples_per_launch"]) if prof.get("samples_per_launch") else 1.0)
         ach = ipl / (k_ms * 1e-3) / 1e9
         # peak: one wave64 instruction per SIMD every 2 clocks — what v_fma/mul/add_f32, v_add_u32, v_and_b32, v_cndmask reach; v_min/max_f32,
         # v_cmp, conversions, shifts and all f64 take 4 (profiles/r02j_valu_rate.md), so frac_at_4_clocks (every instruction priced at 4
@@ -407,11 +545,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed film")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only (no killeroo / anim / soup lines, no pbrt_hip end-to-end run)")
-    ap.add_argument("--count-work", action="store_true", help="instrumented kernel: report rays / nodes / tris")
+    ap.add_argument("--count-work", action="store_true", help="instrumented kernel for the TIMED frames too: report rays / nodes / tris of the timed frame")
+    ap.add_argument("--no-work", action="store_true", help="skip the work counters (device count_work frame, oracle node / triangle counters) and with them the roofline")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=None, help="collect FETCH_SIZE / WRITE_SIZE / VALU counters of this workload now (rocprofv3 --pmc child runs); default: on for the headline workload of the default run")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false")
     args = ap.parse_args()
     default_run = args.workload is None and args.filter == "box" and args.sampler == "lowdiscrepancy" and \
         args.pipeline == "persistent" and not args.count_work and not args.spp
     workload = args.workload or "bunny"
+    want_pmc = args.pmc if args.pmc is not None else (default_run and not args.no_extra and int(os.environ.get("WORLD_SIZE", "1")) == 1)
 
     import torch
     import torch.distributed as dist
@@ -448,15 +590,21 @@ def main():
             comm = None
             _EXCHANGE["fallback"] = err or "hpt_comm_create failed on another rank"
 
+    args.pmc = want_pmc
     out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, comm)
+    args.pmc = False                                     # the counters are collected for the headline workload only
     extras = []
     if default_run and not args.no_extra:
         if world == 1:
-            # the other BASELINE configurations, as written (north-star scene 64 spp, configs[3] 128 spp, configs[2] 256 spp)
-            for w, st, wu in (("killeroo", 3, 1), ("anim", 3, 1), ("soup", 2, 1)):
-                o, _, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, comm)
-                extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "kernel", "setup_s", "rmse_vs_oracle", "verify", "roofline", "roofline_valu") if k in o})
+            # the other BASELINE configurations, as written (north-star scene 64 spp, configs[3] 128 spp, configs[2] 256 spp, configs[4]
+            # metal.pbrt at 4K with 128 spp per GPU) and the HBM point (4 M triangles: scene data 2.7x the Infinity Cache)
+            for w, st, wu in (("killeroo", 10, 2), ("anim", 5, 1), ("soup", 3, 1), ("metal", 2, 1), ("soup4m", 2, 1)):
+                o, sc_w, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, comm)
+                extras.append({k: o[k] for k in ("value", "value_incl_d2h", "unit", "steps", "ms_per_step", "config", "kernel", "setup_s", "rmse_vs_oracle", "verify", "work", "roofline", "roofline_valu") if k in o})
                 extras[-1]["workload"] = w
+                if w == "metal" and not args.no_cpu_baseline:   # configs[4]'s own CPU line: pbrt-v2 (OpenEXR build) on metal.pbrt at 4K
+                    ref = cpu_baseline_reference(w, sc_w)
+                    extras[-1]["cpu_baseline"] = ref or cpu_baseline_port(sc_w)
         else:
             # strong scaling of the north-star frame: the fixed 256-spp 1M-triangle frame split N ways (BASELINE configs[2])
             o, _, _ = measure(args, "soup", 0, min(2, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm, strong=True)

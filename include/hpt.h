@@ -401,6 +401,11 @@ int hpt_test_bsdf(hpt_scene *scene, int material, const float *in, int64_t n, fl
  * per sample = 5 (imageX,imageY,lensU,lensV,time) + 14 one-D + 18 two-D. */
 int hpt_test_sampler(const hpt_render_desc *rd, int x, int y, float *out /* spp*37 */);
 
+/* ---- calibration: the achieved-peak HBM bandwidth of `device` ("verify with a stream-triad microbench and report
+ * achieved-peak too").  float4 triad a = b + s * c over three arrays of bytes_per_array each (pass >= 1 GiB: far beyond the 256 MiB
+ * Infinity Cache), best of `reps` launches; *gb_per_s = 3 * bytes_per_array / time.  bench.py reports it as roofline.achieved_peak. */
+int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps, double *gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
+    rp->bad_counter = nullptr;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
     rp->random_sampler = random_sampler ? 1 : 0;
@@ -414,7 +415,7 @@ template <typename T> struct DevBuf {
 // Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats);   // [walk stack][stealing rows][cold rows]
+    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);   // [walk stack][stealing rows][cold rows]
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
     if (*bpc < 1) *bpc = 1;
@@ -505,6 +506,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     Scratch *d_scr = (Scratch *)s->d_scr;                // (one render at a time per scene handle)
     a.next_item = d_scr->next_item;
     a.counters = &d_scr->wc;
+    a.rp.bad_counter = (unsigned long long *)&d_scr->wc.bad;   // the production kernels count bad radiance values there (one atomic on the rare path)
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
     if ((s->mats & MATS_EXT) && (replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT)) {
         hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel with a production sampler (MT_REPLAY and the wavefront pipeline cover the round-1 feature set)");
@@ -580,8 +582,9 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
             }
             if (rd->count_work) {
                 stats->camera_samples = h_scr2.wc.samples; stats->closest_rays = h_scr2.wc.closest; stats->shadow_rays = h_scr2.wc.shadow;
-                stats->nodes_visited = h_scr2.wc.nodes; stats->tris_tested = h_scr2.wc.tris; stats->bad_samples = h_scr2.wc.bad;
+                stats->nodes_visited = h_scr2.wc.nodes; stats->tris_tested = h_scr2.wc.tris;
             }
+            stats->bad_samples = h_scr2.wc.bad;
             stats->grid_blocks = (uint32_t)wgrid; stats->block_threads = HPT_BLOCK;
             stats->resident_waves = (uint32_t)(wbpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)wvg;
         }
@@ -631,8 +634,9 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         if (rd->count_work || replay) {
             stats->camera_samples = h_scr.wc.samples;
             stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
-            stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris; stats->bad_samples = h_scr.wc.bad;
+            stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris;
         }
+        if (!getenv("HPT_PHASE_TIMERS")) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:214-228: the host plugin reports them)
         stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
         stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs;
         stats->tune_cfg = replay ? 0u : (uint32_t)cfg;
@@ -667,7 +671,6 @@ extern "C" int hpt_render(hpt_scene *s, const hpt_camera *cam, const hpt_render_
     size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
     if (s->film_bytes < bytes) {                          // the device film of the host-film entry point stays with the scene
         if (s->d_film) (void)hipFree(s->d_film);
-    if (s->dl_stack) (void)hipFree(s->dl_stack);
         s->d_film = nullptr; s->film_bytes = 0;
         HIP_CHECK_RET(hipMalloc(&s->d_film, bytes), HPT_E_HIP);
         s->film_bytes = bytes;

@@ -73,6 +73,9 @@ static int64_t pyramid_floats(int64_t w, int64_t h, int levels, int channels) {
     return n;
 }
 
+// [off, off + n) inside a pool of `total` elements — without forming off + n (both come from an untrusted file)
+static bool in_pool(int64_t off, int64_t n, int64_t total) { return off >= 0 && n >= 0 && off <= total && n <= total - off; }
+
 int hpt_validate_desc(const hpt_scene_desc *d) {
     if (!d) { hpt_set_error("null scene descriptor"); return HPT_E_INVALID; }
     if (d->n_meshes < 0 || d->n_quadrics < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_instances < 0 ||
@@ -84,7 +87,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
         if (tx.kind == HPT_TEX_CONSTANT) {
         } else if (tx.kind == HPT_TEX_IMAGEMAP) {
             if (tx.width <= 0 || tx.height <= 0 || (tx.width & (tx.width - 1)) || (tx.height & (tx.height - 1)) || tx.levels <= 0 || tx.levels > 32 ||
-                tx.pyr_off < 0 || tx.pyr_off + pyramid_floats(tx.width, tx.height, tx.levels, tx.channels) > d->n_f ||
+                tx.pyr_off < 0 || tx.pyr_off > d->n_f || pyramid_floats(tx.width, tx.height, tx.levels, tx.channels) > d->n_f - tx.pyr_off ||   // (no sum of untrusted int64s: it could wrap)
                 tx.wrap < HPT_WRAP_REPEAT || tx.wrap > HPT_WRAP_CLAMP) {
                 hpt_set_error("texture %d: image pyramid out of range / not a power of two", t);
                 return HPT_E_INVALID;
@@ -107,9 +110,9 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
     for (int m = 0; m < d->n_meshes; ++m) {
         const hpt_mesh &me = d->meshes[m];
         if (me.ntris < 0 || me.nverts < 0 || me.p_off < 0 || me.idx_off < 0 ||
-            me.p_off + 3ll * me.nverts > d->n_f || me.idx_off + 3ll * me.ntris > d->n_i ||
-            (me.n_off >= 0 && me.n_off + 3ll * me.nverts > d->n_f) ||
-            (me.uv_off >= 0 && me.uv_off + 2ll * me.nverts > d->n_f) ||
+            me.p_off > d->n_f || 3ll * me.nverts > d->n_f - me.p_off || me.idx_off > d->n_i || 3ll * me.ntris > d->n_i - me.idx_off ||
+            (me.n_off >= 0 && (me.n_off > d->n_f || 3ll * me.nverts > d->n_f - me.n_off)) ||
+            (me.uv_off >= 0 && (me.uv_off > d->n_f || 2ll * me.nverts > d->n_f - me.uv_off)) ||
             me.material < 0 || me.material >= d->n_materials || me.arealight < -1 || me.arealight >= d->n_lights ||
             me.instance < -1 || me.instance >= d->n_instances) {
             hpt_set_error("mesh %d: offsets/indices out of range", m);
@@ -160,15 +163,19 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
         if (ma.kind == HPT_MAT_MATTE || ma.kind == HPT_MAT_PLASTIC || ma.kind == HPT_MAT_METAL || ma.kind == HPT_MAT_SUBSTRATE ||
             ma.kind == HPT_MAT_GLASS || ma.kind == HPT_MAT_MIRROR) {
         } else if (ma.kind == HPT_MAT_MEASURED_REGULAR) {
-            const int64_t n = (int64_t)ma.rh_n_theta_h * ma.rh_n_theta_d * ma.rh_n_phi_d;
-            if (ma.rh_n_theta_h <= 0 || ma.rh_n_theta_d <= 0 || ma.rh_n_phi_d <= 0 || ma.rh_off < 0 || ma.rh_off + 3 * n > d->n_f) {
+            // every factor bounded before the product (each <= 2^20: the product fits 2^60; the device indexes the table in 32-bit, so the
+            // whole table must stay below 2^31 floats), and no sum of untrusted int64s
+            const bool dims_ok = ma.rh_n_theta_h > 0 && ma.rh_n_theta_d > 0 && ma.rh_n_phi_d > 0 &&
+                                 ma.rh_n_theta_h <= (1 << 20) && ma.rh_n_theta_d <= (1 << 20) && ma.rh_n_phi_d <= (1 << 20);
+            const int64_t n = dims_ok ? (int64_t)ma.rh_n_theta_h * ma.rh_n_theta_d * ma.rh_n_phi_d : 0;
+            if (!dims_ok || n > (((int64_t)1 << 31) - 1) / 3 || ma.rh_off < 0 || ma.rh_off > d->n_f || 3 * n > d->n_f - ma.rh_off) {
                 hpt_set_error("material %d: regular half-angle table out of range", m);
                 return HPT_E_INVALID;
             }
         } else if (ma.kind == HPT_MAT_MEASURED_IRREG) {
             if (ma.kd_nnodes <= 0 || ma.kd_split_off < 0 || ma.kd_bits_off < 0 || ma.kd_data_off < 0 ||
-                ma.kd_split_off + ma.kd_nnodes > d->n_f || ma.kd_bits_off + ma.kd_nnodes > d->n_i ||
-                ma.kd_data_off + 6ll * ma.kd_nnodes > d->n_f) {
+                ma.kd_split_off > d->n_f || ma.kd_nnodes > d->n_f - ma.kd_split_off || ma.kd_bits_off > d->n_i || ma.kd_nnodes > d->n_i - ma.kd_bits_off ||
+                ma.kd_data_off > d->n_f || 6ll * ma.kd_nnodes > d->n_f - ma.kd_data_off) {
                 hpt_set_error("material %d: kd-tree offsets out of range", m);
                 return HPT_E_INVALID;
             }
@@ -202,8 +209,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                     return HPT_E_INVALID;
                 }
             } else {    // ShapeSet of several shapes
-                if (li.set_n <= 0 || li.set_off < 0 || li.set_off + 2ll * li.set_n > d->n_i || li.set_area_off < 0 ||
-                    li.set_area_off + 2ll * li.set_n + 2 > d->n_f) {
+                if (li.set_n <= 0 || !in_pool(li.set_off, 2ll * li.set_n, d->n_i) || !in_pool(li.set_area_off, 2ll * li.set_n + 2, d->n_f)) {
                     hpt_set_error("light %d: shape set out of range", l);
                     return HPT_E_INVALID;
                 }
@@ -222,13 +228,22 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                     if (!ok) { hpt_set_error("light %d: shape %d of its set does not refer back to the light", l, i); return HPT_E_INVALID; }
                 }
             }
+            {   // every emitting shape must be sampled by its light: a quadric emitter belongs to a one-quadric light or to the set, and the
+                // triangles of an emitting mesh are all in the set (the device adds Le at their hits and weighs it against Light::Pdf —
+                // emitters the light never samples would bias the estimate)
+                int64_t set_tris = 0, mesh_tris = 0;
+                if (li.quadric < 0) { const int32_t *ss = d->ipool + li.set_off; for (int i = 0; i < li.set_n; ++i) set_tris += ss[2 * i] == 0; }
+                for (int m = 0; m < d->n_meshes; ++m) if (d->meshes[m].arealight == l) mesh_tris += d->meshes[m].ntris;
+                if (mesh_tris != set_tris) {
+                    hpt_set_error("light %d: %lld triangles of emitting meshes refer to it, its shape set holds %lld", l, (long long)mesh_tris, (long long)set_tris);
+                    return HPT_E_INVALID;
+                }
+            }
         } else if (li.kind == HPT_LIGHT_INFINITE) {
             int64_t w = li.env_w, h = li.env_h;
-            if (w <= 0 || h <= 0 || li.tex_off < 0 || li.tex_off + 3 * w * h > d->n_f ||
-                li.cond_func_off < 0 || li.cond_func_off + w * h > d->n_f || li.cond_cdf_off < 0 ||
-                li.cond_cdf_off + (w + 1) * h > d->n_f || li.cond_int_off < 0 || li.cond_int_off + h > d->n_f ||
-                li.marg_func_off < 0 || li.marg_func_off + h > d->n_f || li.marg_cdf_off < 0 ||
-                li.marg_cdf_off + h + 1 > d->n_f) {
+            if (w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || !in_pool(li.tex_off, 3 * w * h, d->n_f) ||
+                !in_pool(li.cond_func_off, w * h, d->n_f) || !in_pool(li.cond_cdf_off, (w + 1) * h, d->n_f) || !in_pool(li.cond_int_off, h, d->n_f) ||
+                !in_pool(li.marg_func_off, h, d->n_f) || !in_pool(li.marg_cdf_off, h + 1, d->n_f)) {
                 hpt_set_error("light %d: environment map tables out of range", l);
                 return HPT_E_INVALID;
             }

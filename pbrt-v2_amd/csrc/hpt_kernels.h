@@ -49,7 +49,7 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
-int path_kernel_cold_rows(int mats);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
+int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);

@@ -22,9 +22,9 @@
 
 namespace hpt {
 
-int path_kernel_cold_rows(int mats) {       // must mirror launch_path_kernel's choice of instantiation (below)
+int path_kernel_cold_rows(int mats, bool dl) {       // must mirror launch_path_kernel's choice of instantiation (below)
     const int set = (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
-    return HPT_PARK_MATS(set) ? HPT_COLD_ROWS : 0;
+    return (HPT_PARK_MATS(set) && !dl) ? HPT_COLD_ROWS : 0;
 }
 
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------

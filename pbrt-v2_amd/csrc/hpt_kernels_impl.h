@@ -307,7 +307,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // LDS rows of a lane's column: [walk stack][HPT_STEAL_ROWS, with stealing][HPT_COLD_ROWS] (hpt_api.hip, kernel_residency)
     // Cold lane state in LDS: for the material sets with a measured BRDF (same-box A/B, profiles/r02_ab.md: bunny +3.4 %; the
     // matte / plastic kernels gain < 1 % and a deep tree — the 1 M-triangle soup — would lose a resident workgroup to the ten rows)
-    constexpr bool PARK = HPT_PARK_MATS(MATS);
+    constexpr bool PARK = HPT_PARK_MATS(MATS) && !DL;   // (direct lighting keeps registers: its six stealing rows + a depth-24 tree + ten cold rows would not fit the 40 LDS rows)
     const int top = a.stack_entries - (PARK ? HPT_COLD_ROWS : 0);
     Lane<LdHashSrc, INST, MATS, DL, typename ColdSel<PARK>::type> lane;
     ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);

@@ -186,6 +186,15 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     return HPT_OK;
 }
 
+// film += other (float4 per pixel): the wide-filter sum of partial films on the peer-copy path, shard after shard in rank order
+__global__ __launch_bounds__(256) void hpt_film_add_kernel(float4 *__restrict__ film, const float4 *__restrict__ other, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 a = film[i], b = other[i];
+        film[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 // ---- one process, one host thread per GPU -----------------------------------------------------------------------------------------------------
 struct hpt_multi {
     int n = 0;
@@ -197,11 +206,13 @@ struct hpt_multi {
     std::vector<float4 *> recv;         // RCCL path: root's receive buffers
     std::vector<ncclComm_t> comms;      // RCCL path (distinct devices); empty: peer-copy path
     size_t film_bytes = 0, tiles_cap = 0;
+    void *stage = nullptr; size_t stage_bytes = 0;   // peer-copy path under a wide filter: one shard's film on the root's device while it is added
     bool wide = false;
 };
 
 extern "C" void hpt_multi_destroy(hpt_multi *m) {
     if (!m) return;
+    if (m->stage && m->n > 0) { (void)hipSetDevice(m->devices[0]); (void)hipFree(m->stage); }
     for (int i = 0; i < m->n; ++i) {
         (void)hipSetDevice(m->devices[(size_t)i]);
         if (i < (int)m->films.size() && m->films[(size_t)i]) (void)hipFree(m->films[(size_t)i]);
@@ -298,8 +309,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
             hpt_render_desc r = *rd;
             r.shard_rank = i; r.shard_count = n;
             int rc = hpt_render_device(m->scenes[(size_t)i], cam, &r, m->films[(size_t)i], m->streams[(size_t)i], &st[(size_t)i]);
-            if (rc == HPT_OK && i > 0 && !m->wide && m->packed[(size_t)i]) {
-                const int mine = local_tiles(n_tiles, i, n);
+            const int mine = local_tiles(n_tiles, i, n);   // (0 for a frame smaller than an earlier one of this handle: nothing to pack)
+            if (rc == HPT_OK && i > 0 && !m->wide && m->packed[(size_t)i] && mine > 0) {
                 hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, m->streams[(size_t)i], (const float4 *)m->films[(size_t)i], m->packed[(size_t)i],
                                    rd->x_count, rd->y_count, n_stx, n_tiles, i, n);
                 if (hipStreamSynchronize(m->streams[(size_t)i]) != hipSuccess) rc = HPT_E_HIP;
@@ -319,8 +330,25 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
                 for (int i = 0; i < n; ++i) NCCL_OK(r->Reduce(m->films[(size_t)i], m->films[(size_t)i], bytes / 4, ncclFloat32, ncclSum, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
                 NCCL_OK(r->GroupEnd());
             } else {
-                hpt_set_error("wide-filter film reduction across shards needs RCCL (distinct devices)");
-                return HPT_E_UNSUPPORTED;
+                // peer-copy path (shards that share a device, or HPT_GATHER=peer): the root adds the shards' films one after the other in rank
+                // order — a fixed order, so the film is bit-reproducible; a film of another device is staged on the root's device first
+                HIP_OK(hipSetDevice(m->devices[0]));
+                const size_t npx = bytes / sizeof(float4);
+                for (int i = 1; i < n; ++i) {
+                    const void *src = m->films[(size_t)i];
+                    if (m->devices[(size_t)i] != m->devices[0]) {
+                        if (m->stage_bytes < bytes) {
+                            if (m->stage) (void)hipFree(m->stage);
+                            m->stage = nullptr; m->stage_bytes = 0;
+                            HIP_OK(hipMalloc(&m->stage, bytes));
+                            m->stage_bytes = bytes;
+                        }
+                        HIP_OK(hipMemcpyPeerAsync(m->stage, m->devices[0], src, m->devices[(size_t)i], bytes, m->streams[0]));
+                        src = m->stage;
+                    }
+                    hipLaunchKernelGGL(hpt_film_add_kernel, dim3(2048), dim3(256), 0, m->streams[0], (float4 *)m->films[0], (const float4 *)src, npx);
+                }
+                HIP_OK(hipGetLastError());
             }
         } else {
             if (use_rccl) {

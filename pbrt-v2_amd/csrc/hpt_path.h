@@ -55,6 +55,8 @@ struct RenderParams {
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
     int64_t n_items;           // items_per_pass x (spp / chunk)
+    unsigned long long *bad_counter;   // camera samples whose radiance was NaN / negative / infinite and went to the film as black
+                                       // (samplerrenderer.cpp:214-228 reports them): one device atomic on that rare path; nullptr: not counted
 };
 
 struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
@@ -62,7 +64,14 @@ struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
 // ---- film -------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
 HPT_FN void film_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+HPT_FN void count_bad_sample(unsigned long long *p) { atomicAdd(p, 1ull); }
 #else
+HPT_FN void count_bad_sample(unsigned long long *p) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    *p += 1ull;
+}
 HPT_FN void film_atomic_add(float *p, float v) {   // tests/hostemu: OpenMP threads stand in for the lanes
 #ifdef _OPENMP
 #pragma omp atomic
@@ -285,7 +294,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         f3 Ls = cold.L();
         bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
-        if (bad) { Ls = S(0.f); if (wc) wc->bad++; }
+        if (bad) { Ls = S(0.f); if (wc) wc->bad++; else if (rp.bad_counter) count_bad_sample(rp.bad_counter); }
         float ia, ib;
         smp.image(rp, &ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
         float imgx = px + ia, imgy = py + ib;

@@ -23,6 +23,7 @@ EXPORTS = [
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
+    "hpt_calib_hbm_triad",
 ]
 
 
@@ -72,6 +73,7 @@ def lib():
         L.hpt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.hpt_comm_destroy.argtypes = [C.c_void_p]
         L.hpt_comm_exchange_film.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int]
+        L.hpt_calib_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.hpt_abi_sizes.argtypes = [C.c_void_p]
         sizes = (C.c_int32 * 10)()
         L.hpt_abi_sizes(sizes)
@@ -229,6 +231,13 @@ class Comm:
         if getattr(self, "h", None):
             lib().hpt_comm_destroy(self.h)
             self.h = None
+
+
+def hbm_triad(device=0, bytes_per_array=1 << 30, reps=5):
+    """Achieved-peak HBM bandwidth of `device` in GB/s (hpt_calib_hbm_triad: float4 triad over 3 x bytes_per_array)."""
+    v = C.c_double(0.0)
+    _check(lib().hpt_calib_hbm_triad(device, bytes_per_array, reps, C.byref(v)))
+    return float(v.value)
 
 
 def sampler(rd, x, y):

@@ -111,7 +111,9 @@ STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz
 
 # ---- round 2 cases (tests/golden/make_golden_r2.py): Oren-Nayar, specular, triangle emitters, regular half-angle BRDF, textures, alpha
 R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hpts.gz", "merl": "merl.hpts.gz", "tex": "tex.hpts.gz",
-            "alpha": "alpha.hpts.gz", "metal": "metal.hpts.gz", "mirtex": "mirtex.hpts.gz"}
+            "alpha": "alpha.hpts.gz", "metal": "metal.hpts.gz", "mirtex": "mirtex.hpts.gz",
+            # round 3 (tests/golden/make_golden_r3.py): metal.pbrt as shipped under the environment map SURVEY.md §8d names, textures/grace_latlong.exr (1000 x 500)
+            "metalg": "metalg.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
@@ -229,18 +231,36 @@ def crop_windows(xres, yres, n=CROP):
     return wins
 
 
-def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP):
-    """frame: the device's full film for `rd`.  Returns the worst per-crop RMSE."""
+def content_windows(frame, k=24, n=CROP):
+    """-> the k windows of n x n pixels of `frame` (the device's film, (H, W, 4) XYZ + weight) with the most going on: highest variance of
+    the pixel luminance Y / w inside the window — silhouettes, shadow edges, texture, noise of deep paths — on the grid of
+    non-overlapping windows.  The frame corners are mostly sky / floor in the shipped scenes; these are where the shading is."""
+    H, W = frame.shape[:2]
+    y = frame[..., 1].astype(np.float64) / np.maximum(frame[..., 3].astype(np.float64), 1e-30)
+    y = np.log1p(np.maximum(y, 0.0))                # emitters (L = 2000 in killeroo-simple) must not drown everything else
+    gy, gx = H // n, W // n
+    v = y[:gy * n, :gx * n].reshape(gy, n, gx, n).transpose(0, 2, 1, 3).reshape(gy, gx, n * n).var(axis=2)
+    order = np.argsort(v.ravel())[::-1][:k]
+    return [("content-%d-%d" % (i % gx, i // gx), int(i % gx) * n, int(i // gx) * n) for i in order]
+
+
+def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP, content=0, stats=None):
+    """frame: the device's full film for `rd`.  Crops: corners, centre, XCD-band border + the `content` highest-variance windows.
+    Returns the worst per-crop RMSE; stats (optional list of 6): the oracle's counters summed over the crops."""
     worst = 0.0
     import importlib
     film = importlib.import_module("pbrt-v2_amd.film")
-    for name, x0, y0 in crop_windows(rd.x_count, rd.y_count, n):
+    wins = crop_windows(rd.x_count, rd.y_count, n) + (content_windows(frame, content, n) if content else [])
+    for name, x0, y0 in wins:
         ax0, ay0 = max(x0 - 1, 0), max(y0 - 1, 0)
         ax1, ay1 = min(x0 + n + 1, rd.x_count), min(y0 + n + 1, rd.y_count)
         crd = abi.copy_struct(rd)
         crd.x_start, crd.y_start, crd.x_count, crd.y_count = ax0, ay0, ax1 - ax0, ay1 - ay0
         crd.count_work = 0
-        fo, _ = oracle.render(scene.camera, crd, flt=flt)
+        fo, so = oracle.render(scene.camera, crd, flt=flt)
+        if stats is not None:
+            for i in range(6):
+                stats[i] += int(so[i])
         fo = fo[y0 - ay0:y0 - ay0 + n, x0 - ax0:x0 - ax0 + n]
         fd = frame[y0:y0 + n, x0:x0 + n]
         assert np.array_equal(fo[..., 3], fd[..., 3]), "%s: film weights differ" % name
@@ -248,5 +268,3 @@ def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP):
         assert err < tol, (name, err)
         worst = max(worst, err)
     return worst
-
-
