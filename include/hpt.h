@@ -406,6 +406,10 @@ int hpt_test_sampler(const hpt_render_desc *rd, int x, int y, float *out /* spp*
  * Infinity Cache), best of `reps` launches; *gb_per_s = 3 * bytes_per_array / time.  bench.py reports it as roofline.achieved_peak. */
 int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps, double *gb_per_s);
 
+/* Bytes of one BVH node fetch of the walk that hpt_stats.nodes_visited counts (count_work): 64 — the BVH2 node with both children's
+ * boxes — or 128 when this build's lock-step + stealing walk runs on the four-wide trees (two 64-byte lines per node). */
+int hpt_kernel_node_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

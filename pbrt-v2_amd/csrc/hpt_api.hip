@@ -7,7 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "hpt_flatten.h"
 #include "hpt_internal.h"
@@ -38,7 +43,9 @@ struct hpt_scene {
     hpt_scene_info info;
     int n_cus;
     int tune_cfg;         // kernel configuration picked by autotune() (-1: not tuned yet)
+    uint64_t content_key; // hash of the scene description (counts + a strided sample of the pools): keys the on-disk cache of tune_cfg
     int stack_entries;    // per-lane traversal stack entries this scene needs
+    int stack_bound4, depth4;   // the four-wide trees: entries a walk can stack (hpt_bvh.h, collapse_bvh4), interior levels; 0: not built
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
@@ -59,6 +66,89 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
     const bool big = s && s->info.bvh_bytes + s->info.tri_bytes > ((int64_t)64 << 20);
     a->leaf_q = lq ? atoi(lq) : big ? 2 : 4; a->block_q = bq ? atoi(bq) : big ? 1 : 8;
 }
+
+// ---- on-disk cache of the kernel configuration ----------------------------------------------------------------------------------
+// hpt_scene_tune times every configuration on a probe of the frame: 0.13-1.6 s per scene (profiles/r03_*), a large share of a sub-second
+// render in a fresh process (pbrt_hip).  Which configuration wins is a property of (scene, view, job shape, device, this build of the
+// kernels), so the choice is remembered under $HPT_TUNE_CACHE (a directory; default $XDG_CACHE_HOME/hpt or ~/.cache/hpt; "0" / "off"
+// disables) in a file named by a hash of exactly those: counts and a strided sample of the scene's pools, camera, frame / sampler /
+// integrator of the job, device name and CU count, size and mtime of the library file itself.  A stale or foreign entry can only cost
+// speed, never change an image (every configuration renders the same film).
+static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+template <typename T> static uint64_t fnv_strided(uint64_t h, const T *p, int64_t n) {
+    if (!p || n <= 0) return h;
+    const int64_t step = n > 65536 ? n / 65536 : 1;                      // <= 64 Ki probes however large the pool
+    for (int64_t i = 0; i < n; i += step) h = fnv1a(h, p + i, sizeof(T));
+    return fnv1a(h, p + (n - 1), sizeof(T));
+}
+static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name, int cus) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    const int64_t counts[8] = {d->n_meshes, d->n_quadrics, d->n_materials, d->n_lights, d->n_instances, d->n_textures, d->n_f, d->n_i};
+    h = fnv1a(h, counts, sizeof(counts));
+    if (d->n_meshes) h = fnv1a(h, d->meshes, sizeof(hpt_mesh) * (size_t)d->n_meshes);
+    if (d->n_quadrics) h = fnv1a(h, d->quadrics, sizeof(hpt_quadric) * (size_t)d->n_quadrics);
+    if (d->n_materials) h = fnv1a(h, d->materials, sizeof(hpt_material) * (size_t)d->n_materials);
+    if (d->n_lights) h = fnv1a(h, d->lights, sizeof(hpt_light) * (size_t)d->n_lights);
+    if (d->n_instances) h = fnv1a(h, d->instances, sizeof(hpt_instance) * (size_t)d->n_instances);
+    h = fnv_strided(h, d->fpool, d->n_f);
+    h = fnv_strided(h, d->ipool, d->n_i);
+    h = fnv1a(h, dev_name, strlen(dev_name));
+    h = fnv1a(h, &cus, sizeof(cus));
+    Dl_info di;                                                          // this build of the kernels: the library file's size and mtime
+    struct stat sb;
+    if (dladdr((const void *)&scene_content_key, &di) && di.dli_fname && stat(di.dli_fname, &sb) == 0) {
+        const int64_t id[2] = {(int64_t)sb.st_size, (int64_t)sb.st_mtime};
+        h = fnv1a(h, id, sizeof(id));
+    }
+    for (const char *v : {"HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
+        if (const char *e = getenv(v)) { h = fnv1a(h, v, strlen(v)); h = fnv1a(h, e, strlen(e)); }
+    return h;
+}
+static std::string tune_cache_path(const hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
+    const char *dir = getenv("HPT_TUNE_CACHE");
+    if (dir && (!strcmp(dir, "0") || !strcmp(dir, "off"))) return std::string();
+    std::string base;
+    if (dir && *dir) base = dir;
+    else if (const char *x = getenv("XDG_CACHE_HOME")) base = std::string(x) + "/hpt";
+    else if (const char *hm = getenv("HOME")) base = std::string(hm) + "/.cache/hpt";
+    else return std::string();
+    uint64_t h = s->content_key;
+    h = fnv1a(h, cam, sizeof(*cam));
+    const int32_t job[12] = {rd->xres, rd->yres, rd->x_start, rd->x_count, rd->y_start, rd->y_count, rd->spp < 64 ? rd->spp : 64, rd->maxdepth,
+                             rd->integrator, rd->sampler_mode, (int32_t)(s->d_ftable != nullptr), s->d_ftable ? (int32_t)(s->filter.xwidth * 64.f) * 4096 + (int32_t)(s->filter.ywidth * 64.f) : 0};
+    h = fnv1a(h, job, sizeof(job));
+    char name[64];
+    snprintf(name, sizeof(name), "/tune-%016llx", (unsigned long long)h);
+    return base + name;
+}
+static int tune_cache_load(const std::string &path) {
+    if (path.empty()) return -1;
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int cfg = -1;
+    if (fscanf(f, "%d", &cfg) != 1 || cfg < 0 || cfg >= HPT_N_TUNE_CFG) cfg = -1;
+    fclose(f);
+    return cfg;
+}
+static void tune_cache_store(const std::string &path, int cfg) {
+    if (path.empty()) return;
+    const size_t slash = path.rfind('/');
+    const std::string dir = path.substr(0, slash);
+    for (size_t i = 1; i <= dir.size(); ++i)                             // mkdir -p
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0777);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "w");
+    if (!f) return;
+    fprintf(f, "%d\n", cfg);
+    fclose(f);
+    (void)rename(tmp.c_str(), path.c_str());                             // atomic: concurrent processes (one per GPU) race harmlessly
+}
+
+extern "C" int hpt_kernel_node_bytes(void) { return path_kernel_wide_bvh() ? 128 : 64; }
 
 extern "C" int hpt_device_count(void) {
     int n = 0;
@@ -123,6 +213,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; hpt_set_error("hipGetDeviceProperties failed"); return nullptr; }
     s->n_cus = prop.multiProcessorCount;
+    s->content_key = scene_content_key(desc, prop.name, prop.multiProcessorCount);
 
     FlatScene fs;
     int maxLeaf = 2;   // (measured with subtree stealing: leaves of <= 2 / 3 / 4 / 8 triangles = 886 / 865 / 856 / 854 Msamples/s on killeroo, equal on the soup)
@@ -172,6 +263,13 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
+    s->stack_bound4 = 0; s->depth4 = 0;
+    if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
+        s->d.nodes4 = (const f4 *)upload(s, fs.nodes4.data(), fs.nodes4.size(), &ok);
+        s->d.inst_root4 = upload(s, fs.inst_root4.data(), fs.inst_root4.size(), &ok);
+        s->d.world_root4 = fs.world_root4;
+        s->stack_bound4 = fs.stack_bound4; s->depth4 = fs.depth4;
+    }
     s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
     s->inst_xf = nullptr; s->inst_xf_lanes = 0;
     if (desc->n_instances > 0) {       // 12 floats (3x4) x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
@@ -415,7 +513,22 @@ template <typename T> struct DevBuf {
 // Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    a->stack_entries = s->stack_entries + ((cfg >= 5 || a->dl) ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);   // [walk stack][stealing rows][cold rows]
+    const bool steal = cfg >= 5 || a->dl;
+    const int extra = (steal ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);
+    a->cap_normal = 1 << 20;
+    if (steal && s->stack_bound4 > 0) {
+        // The stealing walk runs on the BVH4 (trav_node4): a walk that stacks every other hit child can hold up to stack_bound4 entries (30-39
+        // on the shipped meshes, 9-15 observed).  If the rows a workgroup can have do not cover that, the first cap_normal rows take ordinary
+        // entries and the levels above them one masked entry each: cap_normal + 2 + depth4 rows always suffice.
+        const int room = HPT_MAX_STACK_ROWS - extra;
+        int rows = s->stack_bound4 + 1;
+        if (rows > room) { rows = room; a->cap_normal = room - 2 - s->depth4; }
+        if (a->cap_normal < 6) return -1;                            // (a very deep tree: the caller falls back to the plain lock-step walk)
+        if (rows < 12 && (s->mats & MATS_MEASURED)) rows = 12;       // the query queue of wave_eval_queries
+        if (rows < 8) rows = 8;
+        a->stack_entries = rows + extra;
+    } else
+        a->stack_entries = s->stack_entries + extra;   // [walk stack][stealing rows][cold rows]
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
     if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
     if (*bpc < 1) *bpc = 1;
@@ -435,6 +548,11 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
                            hipStream_t stream) {
     // the probe: every 9th 32x32 tile of the whole frame (the tile sharding of the multi-GPU path picks them), so
     // that it sees the same mix of rays as the job — a crop of the image centre mispredicted killeroo-simple
+    const std::string cache = tune_cache_path(s, cam, rd);
+    {
+        const int c = tune_cache_load(cache);
+        if (c >= 0) { int bpc = 0, vg = 0; if (kernel_residency(s, c, &a, &bpc, &vg) == 0) { s->tune_cfg = c; return hipSuccess; } }
+    }
     hpt_render_desc prd = *rd;
     int64_t tiles = (int64_t)a.rp.n_stx * a.rp.n_sty;   // of the sample extent (fill_params)
     prd.shard_count = tiles >= 9 * 32 ? 9 : tiles >= 4 * 32 ? 4 : 1;
@@ -485,7 +603,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     // a tie between a 4-wave configuration and its 3-wave sibling (3/4, 5/6) goes to the sibling: on the full job — fewer, longer
     // work items per lane than the probe's — the build that spills less has measured 3 % ahead whenever the probe saw them level
     if (best_cfg == 3 || best_cfg == 5) { const int sib = best_cfg + 1; if (in_race[sib] && t[sib] <= 1.01f * t[best_cfg]) best_cfg = sib; }
-    if (e == hipSuccess) s->tune_cfg = best_cfg < 0 ? 0 : best_cfg;
+    if (e == hipSuccess) { s->tune_cfg = best_cfg < 0 ? 0 : best_cfg; tune_cache_store(cache, s->tune_cfg); }
     return e;
 }
 
@@ -508,8 +626,8 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     a.counters = &d_scr->wc;
     a.rp.bad_counter = (unsigned long long *)&d_scr->wc.bad;   // the production kernels count bad radiance values there (one atomic on the rare path)
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
-    if ((s->mats & MATS_EXT) && (replay || rd->pipeline == HPT_PIPELINE_WAVEFRONT)) {
-        hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel with a production sampler (MT_REPLAY and the wavefront pipeline cover the round-1 feature set)");
+    if ((s->mats & MATS_EXT) && !replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) {
+        hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel (the wavefront pipeline covers the round-1 feature set)");
         return HPT_E_UNSUPPORTED;
     }
     if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH && rd->maxdepth > 16) {
@@ -528,7 +646,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
         cfg = s->tune_cfg;
     }
     if (cfg < 0) cfg = 5;                                // untuned (small job): lock step + subtree stealing, the usual winner
-    if (rd->count_work && !dl) cfg = 0;
+    if (rd->count_work && !dl) cfg = 5;                  // the instrumented build is the lock-step + stealing walk (hpt_kernels_impl.h)
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     if (e == hipSuccess && a.rp.n_items == 0) {           // a shard that owns no tile (tiny image, many shards): an empty film
@@ -539,6 +657,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     }
     int bpc = 0, vgprs = 0;
     if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
+        if (rd->count_work && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the instrumented kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         if (cfg >= 5 && !dl) { cfg -= 2; if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown; }   // tree too deep for the stealing rows
         else if (dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         else e = hipErrorUnknown;
@@ -602,7 +721,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (e == hipSuccess) e = hipEventRecord(ev0, stream);
     // two-pass film: w = 0 marks a sample this shard does not render; then the path kernel parks its samples, the gather sums them
     if (e == hipSuccess && a.rp.sbuf_xyzw) e = hipMemsetAsync(a.rp.sbuf_xyzw, 0, sizeof(float) * 4 * (size_t)a.rp.sx_count * a.rp.sy_count * (size_t)rd->spp, stream);
-    if (e == hipSuccess) e = replay ? launch_replay_kernel(a, ra, s->info.bvh_max_depth, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
+    if (e == hipSuccess) e = replay ? launch_replay_kernel(s->mats, a, ra, s->info.bvh_max_depth, stream) : launch_path_kernel(s->mats, a, grid, rd->count_work != 0, cfg, stream);
     if (e == hipSuccess && a.rp.sbuf_xyzw) e = launch_film_gather(a.rp, a.film, stream);
     if (e == hipSuccess) e = hipEventRecord(ev1, stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev1);

@@ -142,6 +142,70 @@ struct Builder {
 };
 } // namespace
 
+namespace {
+struct Kid { float lo[3], hi[3]; int32_t code; };
+static float kid_area(const Kid &k) {
+    const float d[3] = {k.hi[0] - k.lo[0], k.hi[1] - k.lo[1], k.hi[2] - k.lo[2]};
+    if (d[0] < 0.f || d[1] < 0.f || d[2] < 0.f) return 0.f;
+    return 2.f * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2]);
+}
+static void kids_of(const BvhNode64 &n, Kid *a, Kid *b) {
+    for (int k = 0; k < 3; ++k) { a->lo[k] = n.f[k]; a->hi[k] = n.f[3 + k]; b->lo[k] = n.f[6 + k]; b->hi[k] = n.f[9 + k]; }
+    a->code = n.child[0]; b->code = n.child[1];
+}
+}
+
+int32_t collapse_bvh4(const std::vector<BvhNode64> &nodes2, int32_t root2, std::vector<BvhNode64> *out, int *stack_bound, int *depth4) {
+    // iterative (an LBVH can be tens of levels deep but a million nodes wide: no recursion on the host stack either)
+    struct Job { int32_t node2; int32_t slot4; };          // BVH2 node to collapse into the BVH4 node already reserved at slot4
+    const int32_t base = (int32_t)(out->size() / 2);
+    std::vector<Job> todo;
+    std::vector<int32_t> parent, nkids;                    // per new BVH4 node (relative index): parent node, number of children
+    auto reserve = [&](int32_t par) { int32_t idx = (int32_t)(out->size() / 2) - base; out->emplace_back(); out->emplace_back(); parent.push_back(par); nkids.push_back(0); return idx; };
+    const int32_t root4 = reserve(-1);
+    todo.push_back({root2, root4});
+    while (!todo.empty()) {
+        const Job j = todo.back(); todo.pop_back();
+        Kid kids[4]; int n = 2;
+        kids_of(nodes2[(size_t)j.node2], &kids[0], &kids[1]);
+        if (kids[0].code == kids[1].code && kids[0].code < 0) n = 1;      // (build_bvh's single-leaf root: second child is a never-hit copy)
+        while (n < 4) {
+            int best = -1; float ba = -1.f;
+            for (int i = 0; i < n; ++i) if (kids[i].code >= 0) { const float a = kid_area(kids[i]); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            Kid a, b;
+            kids_of(nodes2[(size_t)kids[best].code], &a, &b);
+            kids[best] = a; kids[n++] = b;
+        }
+        BvhNode64 A, B;
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int i = 0; i < 12; ++i) { A.f[i] = (i % 6) < 3 ? inf : -inf; B.f[i] = A.f[i]; }
+        for (int i = 0; i < 4; ++i) { A.child[i] = HPT_BVH4_EMPTY; B.child[i] = 0; }
+        for (int i = 0; i < n; ++i) {
+            BvhNode64 &R = i < 2 ? A : B;
+            float *f = R.f + 6 * (i & 1);
+            for (int k = 0; k < 3; ++k) { f[k] = kids[i].lo[k]; f[3 + k] = kids[i].hi[k]; }
+            int32_t code = kids[i].code;
+            if (code >= 0) { const int32_t c4 = reserve(j.slot4); todo.push_back({code, c4}); code = c4 + base; }
+            A.child[i] = code;
+        }
+        nkids[(size_t)j.slot4] = n;
+        (*out)[2 * (size_t)(base + j.slot4)] = A; (*out)[2 * (size_t)(base + j.slot4) + 1] = B;
+    }
+    // stack bound: children are created after their parents, so one forward sweep accumulates path sums
+    std::vector<int> acc(parent.size(), 0), lvl(parent.size(), 1);
+    int bound = 0, deepest = 0;
+    for (size_t i = 0; i < parent.size(); ++i) {
+        acc[i] = (parent[i] >= 0 ? acc[(size_t)parent[i]] : 0) + (nkids[i] - 1);
+        lvl[i] = parent[i] >= 0 ? lvl[(size_t)parent[i]] + 1 : 1;
+        if (acc[i] > bound) bound = acc[i];
+        if (lvl[i] > deepest) deepest = lvl[i];
+    }
+    if (stack_bound) *stack_bound = bound;
+    if (depth4) *depth4 = deepest;
+    return root4 + base;
+}
+
 void build_bvh(const BvhInputTri *tris, size_t n, int maxLeaf, int maxDepth, BvhResult *out) {
     out->nodes.clear(); out->order.clear(); out->max_depth = 0;
     if (n == 0) return;

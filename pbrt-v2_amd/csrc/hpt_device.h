@@ -283,6 +283,10 @@ struct DScene {
     const hpt_texture *textures;    // texture table (include/hpt.h); image pyramids in fpool
     const float *ewa_lut;           // MIPMap::weightLut (core/mipmap.h:192-200), 128 floats computed by the host's libm
     int32_t n_tris, n_quadrics, n_lights, n_nodes, n_instances, world_root;
+    // the same trees, four children per node (collapse_bvh4, hpt_bvh.h): 128-byte nodes = 8 f4; roots as node indices.  nullptr: not built
+    const f4 *nodes4;
+    const int32_t *inst_root4;
+    int32_t world_root4, pad4;
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
@@ -520,12 +524,33 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
 
 #define HPT_TRAV_EMPTY ((int32_t)0x80000000)
 
+#ifdef HPT_SLAB_FMA
+// The slab test with one fused multiply-add per plane: t = lo * invd + (-o * invd) instead of (lo - o) * invd — 6 instead of 12 VALU
+// instructions per box for the planes (the walk is VALU-issue bound on the cache-resident scenes).  The product o * invd is rounded before
+// the cancellation, so a plane distance carries an absolute error of up to eps * (|o * invd| + |t|) instead of a relative one; the test
+// stays CONSERVATIVE (a box the ray touches is never rejected — the triangle tests decide the hit, bit-identically to the reference) by
+// widening the exit distance by that bound: pad = 8 eps * max |o_i * invd_i| plus 8 eps relative.  Only the device's own tree is walked
+// with it; which boxes are visited is not part of the parity contract, which hits are found is.
+HPT_FN bool slab_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, float mint, float maxt, f3 invd, f3 oid, float pad, float *tentry) {
+    float tx0 = __builtin_fmaf(lox, invd.x, oid.x), tx1 = __builtin_fmaf(hix, invd.x, oid.x);
+    float ty0 = __builtin_fmaf(loy, invd.y, oid.y), ty1 = __builtin_fmaf(hiy, invd.y, oid.y);
+    float tz0 = __builtin_fmaf(loz, invd.z, oid.z), tz1 = __builtin_fmaf(hiz, invd.z, oid.z);
+    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    *tentry = tnear;
+    return fmaxf(tnear, mint) <= __builtin_fmaf(fminf(tfar, maxt), 1.000001f, pad);
+}
+#endif
+
 // Resumable traversal: the state of one ray's walk.  trav_begin() runs the quadric pre-test and
 // positions the walk at the root; trav_step() advances it by one interior-node step followed, if
 // that reached a leaf, by the leaf's triangle tests ("if-if" loop shape: measured best on gfx950
 // against node-XOR-leaf and while-while, profiles/r01_ab.md).  done() when node == HPT_TRAV_EMPTY.
 struct TravState {
     f3 invd;
+#ifdef HPT_SLAB_FMA
+    f3 oid; float pad;     // -o * invd and the error bound of the fused slab test (slab_fma)
+#endif
     bool anyhit;
     int32_t node;
     int sp;
@@ -533,6 +558,16 @@ struct TravState {
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
+// what the fused slab test derives from a ray and its (clamped) inverse direction; a no-op for the plain test
+HPT_FN void trav_prep(TravState &ts, const Ray &ray) {
+#ifdef HPT_SLAB_FMA
+    ts.oid = mk3(-(ray.o.x * ts.invd.x), -(ray.o.y * ts.invd.y), -(ray.o.z * ts.invd.z));
+    ts.pad = 9.5367432e-7f * fmaxf(fmaxf(fabsf(ts.oid.x), fabsf(ts.oid.y)), fabsf(ts.oid.z));      // 8 * 2^-23
+    if (!(ts.pad < 3.0e38f)) ts.pad = 3.0e38f;   // (0 * inf cannot occur: invd is clamped to +-FLT_MAX; o * FLT_MAX may overflow to inf: everything passes)
+#else
+    (void)ts; (void)ray;
+#endif
+}
 HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world) {
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
@@ -549,6 +584,7 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     if (root < 0) ts.node = HPT_TRAV_EMPTY;
     const float big = 3.402823466e+38f;                    // keeps 0 * invd finite (see slab)
     ts.invd = mk3(fminf(fmaxf(1.f / ray.d.x, -big), big), fminf(fmaxf(1.f / ray.d.y, -big), big), fminf(fmaxf(1.f / ray.d.z, -big), big));
+    trav_prep(ts, ray);
 }
 
 // TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:190-195, 246-276): a hit where the mesh's alpha texture evaluates to 0 is no hit
@@ -557,14 +593,26 @@ HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, f
 // The two halves of a step, separately callable (the lock-step + stealing walk of the path kernel batches the leaf half: hpt_kernels_impl.h).
 // trav_node: ts.node >= 0 — one 64-byte node fetch, two slab tests, near child first, far child stacked; leaves ts.node at the next interior
 // node, at a leaf code, or — nothing hit, nothing stacked — HPT_TRAV_EMPTY.
+// (HPT_GLOBAL: the nodes / triangle records as explicit global-memory pointers — a pointer that went through a register pin has lost the
+// address space the compiler infers for kernel arguments and would be dereferenced with flat_load)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HPT_GLOBAL __attribute__((address_space(1)))
+#else
+#define HPT_GLOBAL
+#endif
 template <bool COUNT>
-HPT_FN void trav_node(const DScene &sc, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
-    const f4 *np = sc.nodes + 4 * (int64_t)ts.node;
+HPT_FN void trav_node(const f4 *nodes, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
+    const HPT_GLOBAL f4 *np = (const HPT_GLOBAL f4 *)nodes + 4 * (int64_t)ts.node;
     f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (COUNT) cnt->nodes++;
     float t0, t1;
+#ifdef HPT_SLAB_FMA
+    bool h0 = slab_fma(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t0);
+    bool h1 = slab_fma(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t1);
+#else
     bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
     bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
+#endif
     const int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
     // near child first, far child stacked — selects instead of a four-way branch
     const bool both = h0 && h1, swap = t1 < t0;
@@ -576,19 +624,88 @@ HPT_FN void trav_node(const DScene &sc, TravState &ts, const Ray &ray, int32_t *
     }
     ts.node = next;
 }
+template <bool COUNT>
+HPT_FN void trav_node(const DScene &sc, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt) { trav_node<COUNT>(sc.nodes, ts, ray, stack, stride, cnt); }
 HPT_FN bool trav_is_leaf(int32_t node) { return node < 0 && node != HPT_TRAV_EMPTY; }
 HPT_FN void trav_pop(TravState &ts, const int32_t *stack, int stride) {
     if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
     else ts.node = HPT_TRAV_EMPTY;
 }
+// ---- BVH4 node step ---------------------------------------------------------------------------------------------------------------
+// One 128-byte node (two 64-byte lines, fetched together) decides FOUR subtrees: half the dependent fetches per ray of the BVH2 walk — what
+// bounds a walk that waits on memory (profiles/r02_*: 52-62 % of the wave cycles waiting).  The hit children are ordered by entry distance
+// with a five-comparator network on packed keys (the entry distance's bits with the child slot in the two low bits: t >= 0, so the unsigned
+// order of the bits is the order of the floats), the nearest is walked next, the others are stacked far to near.
+// Stack bound: a walk that stacks every other hit child can hold up to 3 entries per level (30-39 on the shipped meshes: more than the LDS
+// rows a lane has).  So only the first cap_normal rows take such entries; above them a node stacks ONE entry for all its other hit children —
+// its own index with their slots as a mask in bits 26..29 — and is fetched and tested again (those children only) when that entry is
+// popped: at most one such entry per level, so cap_normal + 2 + levels rows always suffice; the re-fetch is the rare slow path.
+#define HPT_N4_INDEX(code) ((code) & 0x03ffffff)
+#define HPT_N4_MASK(code) (((uint32_t)(code) >> 26) & 0xfu)
+HPT_FN int32_t pick4(uint32_t key, int32_t c0, int32_t c1, int32_t c2, int32_t c3) {
+    const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
+    const int32_t lo = b0 ? c1 : c0, hi = b0 ? c3 : c2;
+    return b1 ? hi : lo;
+}
+template <bool COUNT>
+HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt, int cap_normal = 1 << 20) {
+    const int32_t self = HPT_N4_INDEX(ts.node);
+    uint32_t mask = HPT_N4_MASK(ts.node);
+    if (mask == 0u) mask = 0xfu;
+    const HPT_GLOBAL f4 *np = (const HPT_GLOBAL f4 *)nodes4 + 8 * (int64_t)self;
+    const f4 a0 = np[0], a1 = np[1], a2 = np[2], cc = np[3], b0 = np[4], b1 = np[5], b2 = np[6];
+    if (COUNT) cnt->nodes++;
+    float t0, t1, t2, t3;
+#ifdef HPT_SLAB_FMA
+    bool h0 = slab_fma(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t0);
+    bool h1 = slab_fma(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t1);
+    bool h2 = slab_fma(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t2);
+    bool h3 = slab_fma(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t3);
+#else
+    bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, ray, ts.invd, &t0);
+    bool h1 = slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, ray, ts.invd, &t1);
+    bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, ray, ts.invd, &t2);
+    bool h3 = slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, ray, ts.invd, &t3);
+#endif
+    const int32_t c0 = as_int(cc.x), c1 = as_int(cc.y), c2 = as_int(cc.z), c3 = as_int(cc.w);
+    // (an absent child has an inverted infinite box — the min / max slab form reads that as "everything" — so its code decides)
+    h0 = h0 && (mask & 1u); h1 = h1 && (mask & 2u) && c1 != HPT_TRAV_EMPTY;
+    h2 = h2 && (mask & 4u) && c2 != HPT_TRAV_EMPTY; h3 = h3 && (mask & 8u) && c3 != HPT_TRAV_EMPTY;
+    const uint32_t none = 0xffffffffu;
+    uint32_t k0 = h0 ? (((uint32_t)as_int(fmaxf(t0, 0.f)) & ~3u) | 0u) : none;
+    uint32_t k1 = h1 ? (((uint32_t)as_int(fmaxf(t1, 0.f)) & ~3u) | 1u) : none;
+    uint32_t k2 = h2 ? (((uint32_t)as_int(fmaxf(t2, 0.f)) & ~3u) | 2u) : none;
+    uint32_t k3 = h3 ? (((uint32_t)as_int(fmaxf(t3, 0.f)) & ~3u) | 3u) : none;
+#define HPT_CSWAP(a, b) { const uint32_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; }
+    HPT_CSWAP(k0, k1) HPT_CSWAP(k2, k3) HPT_CSWAP(k0, k2) HPT_CSWAP(k1, k3) HPT_CSWAP(k1, k2)
+#undef HPT_CSWAP
+    // far to near onto the stack, the nearest next
+    if (k1 != none) {
+        if (ts.sp < cap_normal) {
+            if (k3 != none) { stack[ts.sp * stride] = pick4(k3, c0, c1, c2, c3); ++ts.sp; }
+            if (k2 != none) { stack[ts.sp * stride] = pick4(k2, c0, c1, c2, c3); ++ts.sp; }
+            stack[ts.sp * stride] = pick4(k1, c0, c1, c2, c3); ++ts.sp;
+        } else {                                          // the rows above cap_normal: one entry for all of them (see above)
+            uint32_t m = 1u << (k1 & 3u);
+            if (k2 != none) m |= 1u << (k2 & 3u);
+            if (k3 != none) m |= 1u << (k3 & 3u);
+            stack[ts.sp * stride] = self | (int32_t)(m << 26); ++ts.sp;
+        }
+    }
+    int32_t next;
+    if (k0 != none) next = pick4(k0, c0, c1, c2, c3);
+    else { next = HPT_TRAV_EMPTY; if (ts.sp > 0) { --ts.sp; next = stack[ts.sp * stride]; } }
+    ts.node = next;
+}
+
 // trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
 // any-hit ray is done (occluded).
 template <bool COUNT, bool ALPHA>
-HPT_FN bool trav_leaf(const DScene &sc, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
+HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     for (uint32_t k = 0; k < count; ++k) {
-        const f4 *tp = sc.tris + 3 * (int64_t)(first + k);
+        const HPT_GLOBAL f4 *tp = (const HPT_GLOBAL f4 *)tris + 3 * (int64_t)(first + k);
         f4 a = tp[0], b = tp[1], c = tp[2];
         if (COUNT) cnt->tris++;
         float t, b1, b2;
@@ -602,12 +719,14 @@ HPT_FN bool trav_leaf(const DScene &sc, TravState &ts, Ray &ray, int32_t leaf, T
     }
     return false;
 }
-template <bool COUNT, bool ALPHA = false>
+template <bool COUNT, bool ALPHA>
+HPT_FN bool trav_leaf(const DScene &sc, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) { return trav_leaf<COUNT, ALPHA>(sc, sc.tris, ts, ray, leaf, cnt); }
+template <bool COUNT, bool ALPHA = false, bool WIDE = false>
 HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack, int stride, TravCounters *cnt) {
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
     const unsigned long long st0_ = __builtin_readcyclecounter();
 #endif
-    if (ts.node >= 0) trav_node<COUNT>(sc, ts, ray, stack, stride, cnt);
+    if (ts.node >= 0) { if (WIDE) trav_node4<COUNT>(sc.nodes4, ts, ray, stack, stride, cnt); else trav_node<COUNT>(sc, ts, ray, stack, stride, cnt); }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* debug build: how much of a step is the leaf part, and how many lanes take it */
     const unsigned long long lt0_ = __builtin_readcyclecounter();
     cnt->leaf_lanes += trav_is_leaf(ts.node) ? 1u : 0u; cnt->steps++;
@@ -628,12 +747,13 @@ HPT_FN void trav_step(const DScene &sc, TravState &ts, Ray &ray, int32_t *stack,
 // xf_cache (optional): this lane's column of the per-path instance-transform cache — WorldToPrimitive of every instance
 // interpolated at the path's time, 12 floats (3x4) an instance, element j of instance k at xf_cache[(12 k + j) * xf_stride]
 // (filled by the path kernel once per camera sample; every ray of the path carries the same time, geometry.h:329-332).
-template <bool COUNT, bool INST, bool ALPHA = false>
+// WIDE: walk the four-wide trees (sc.nodes4) instead — same hits (up to exact ties), used by the parity hooks to check the BVH4 against the oracle
+template <bool COUNT, bool INST, bool ALPHA = false, bool WIDE = false>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
                      const float *xf_cache = nullptr, int64_t xf_stride = 0) {
     TravState ts;
-    trav_begin(sc, ts, ray, anyhit, sc.world_root, true);
-    while (!ts.done()) trav_step<COUNT, ALPHA>(sc, ts, ray, stack, stride, cnt);
+    trav_begin(sc, ts, ray, anyhit, WIDE ? sc.world_root4 : sc.world_root, true);
+    while (!ts.done()) trav_step<COUNT, ALPHA, WIDE>(sc, ts, ray, stack, stride, cnt);
     *hit = ts.hit;
     if (anyhit && hit->prim >= 0) return true;
     if (INST) for (int k = 0; k < sc.n_instances; ++k) {
@@ -646,8 +766,8 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         Ray r2;
         r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
-        trav_begin(sc, t2, r2, anyhit, sc.inst_root[k], false);
-        while (!t2.done()) trav_step<COUNT, ALPHA>(sc, t2, r2, stack, stride, cnt);
+        trav_begin(sc, t2, r2, anyhit, WIDE ? sc.inst_root4[k] : sc.inst_root[k], false);
+        while (!t2.done()) trav_step<COUNT, ALPHA, WIDE>(sc, t2, r2, stack, stride, cnt);
         if (t2.hit.prim >= 0) {
             *hit = t2.hit; hit->inst = k;
             ray.maxt = r2.maxt;
@@ -801,8 +921,8 @@ struct KdWalk {
     int x0, x1, y0, y1, z1;   // cell box of the pass
     int iy, iz;           // row being read
     uint32_t j, jend;     // samples of that row still to test
-    const f4 *samples;    // 32-byte records {p.xyz, v.r | v.g, v.b, 0, 0} in cell order (hpt_flatten.cpp)
-    const uint32_t *cells;    // first sample of every cell, + 1 entry
+    const HPT_GLOBAL f4 *samples;    // 32-byte records {p.xyz, v.r | v.g, v.b, 0, 0} in cell order (hpt_flatten.cpp); explicitly global memory:
+    const HPT_GLOBAL uint32_t *cells;    // first sample of every cell, + 1 entry                   (inside the out-of-line walk they would be flat loads)
     IrregProc pr;
 };
 HPT_FN void irreg_proc_reset(IrregProc *pr, float r2) {
@@ -819,8 +939,8 @@ HPT_FN void kd_set_box(KdWalk *w) {
     w->iy = w->y0 - 1; w->iz = z0; w->j = w->jend = 0u;
 }
 HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, KdWalk *w) {
-    w->samples = (const f4 *)(sc.fpool + m->kd_data_off);
-    w->cells = (const uint32_t *)(sc.fpool + m->kd_split_off);
+    w->samples = (const HPT_GLOBAL f4 *)(sc.fpool + m->kd_data_off);
+    w->cells = (const HPT_GLOBAL uint32_t *)(sc.fpool + m->kd_split_off);
     // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
     int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
     gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
@@ -841,7 +961,7 @@ HPT_FN bool kd_step(KdWalk *w, f3 *out) {
         ++w->iy;
         if (w->iy > w->y1) { w->iy = w->y0; ++w->iz; }
         if (w->iz <= w->z1) {
-            const uint32_t *row = w->cells + ((w->iz * HPT_BG_Y + w->iy) * HPT_BG_X);
+            const HPT_GLOBAL uint32_t *row = w->cells + ((w->iz * HPT_BG_Y + w->iy) * HPT_BG_X);
             w->j = row[w->x0]; w->jend = row[w->x1 + 1];
         }
     }

@@ -70,6 +70,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     out->inst_root.assign((size_t)desc->n_instances, -1);
     out->world_root = -1;
     out->max_depth = 0;
+    out->nodes4.clear(); out->inst_root4.assign((size_t)desc->n_instances, -1); out->world_root4 = -1; out->stack_bound4 = 0; out->depth4 = 0;
     size_t tri_base = 0;
     for (int g = -1; g < desc->n_instances; ++g) {
         std::vector<BvhInputTri> sub;
@@ -112,6 +113,13 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         }
         if (g < 0) out->world_root = node_base; else out->inst_root[(size_t)g] = node_base;
         if (bvh.max_depth > out->max_depth) out->max_depth = bvh.max_depth;
+        {   // the group's tree once more, four children wide (the walk with subtree stealing: half the dependent fetches per ray)
+            int bound = 0, d4 = 0;
+            const int32_t r4 = collapse_bvh4(out->nodes, node_base, &out->nodes4, &bound, &d4);
+            if (g < 0) out->world_root4 = r4; else out->inst_root4[(size_t)g] = r4;
+            if (bound > out->stack_bound4) out->stack_bound4 = bound;
+            if (d4 > out->depth4) out->depth4 = d4;
+        }
         tri_base += sub.size();
     }
     // ---- measured-BRDF samples -> grid-ordered 32-byte records + cell table (hpt_device.h: kd_begin / kd_step) -------

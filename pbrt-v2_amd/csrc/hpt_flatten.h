@@ -13,6 +13,12 @@ struct FlatScene {
     std::vector<BvhNode64> nodes;
     std::vector<float> tri_rec;   // 12 floats per triangle, BVH leaf order
     std::vector<DMesh> meshes;
+    // the same trees collapsed to four children per node (hpt_bvh.h, collapse_bvh4): two 64-byte records per node; roots as BVH4 node indices
+    std::vector<BvhNode64> nodes4;
+    std::vector<int32_t> inst_root4;
+    int32_t world_root4 = -1;
+    int stack_bound4 = 0;             // entries a walk of the BVH4 can stack (max over the trees)
+    int depth4 = 0;                   // interior levels of the deepest BVH4
     std::vector<int32_t> inst_root;   // root node of each animated instance's BVH (-1 = no triangles)
     int32_t world_root = -1;          // root node of the world BVH (-1 = no world triangles)
     // device copies of the float pool and the material table: the samples of a measured BRDF are binned into a

@@ -29,6 +29,8 @@ struct PathKernelArgs {
     // lock step + stealing: the wave runs the leaf half of the walk when leaf_q eighths of its busy lanes have a leaf parked, or block_q eighths
     // can do nothing else (traverse_steal)
     int32_t leaf_q, block_q;
+    // the BVH4 walk (HPT_BVH4 builds): stack rows that take ordinary entries; above them one masked entry per level (trav_node4, hpt_device.h)
+    int32_t cap_normal;
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
     return (size_t)a.stack_entries * HPT_BLOCK * 4;
@@ -49,10 +51,11 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
+bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
 int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
-hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);
+hipError_t launch_replay_kernel(int mats, const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream);   // second pass of the two-pass film (table filters)
 hipError_t launch_intersect(const DScene &sc, const float *rays, int64_t n, int anyhit, float *out_hit,
                             int32_t *out_prim, int bvh_depth, hipStream_t s);

@@ -22,19 +22,29 @@
 
 namespace hpt {
 
+bool path_kernel_wide_bvh() {
+#ifdef HPT_BVH4
+    return true;
+#else
+    return false;
+#endif
+}
 int path_kernel_cold_rows(int mats, bool dl) {       // must mirror launch_path_kernel's choice of instantiation (below)
     const int set = (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
     return (HPT_PARK_MATS(set) && !dl) ? HPT_COLD_ROWS : 0;
 }
 
 // ---- HPT_SAMPLER_MT_REPLAY: one lane per image tile, serial inside the tile (hpt_replay.h) -----------
+// MATS: MATS_ALL for the round-1 feature set, MATS_FULL (textures with ray differentials, bump, specular lobes, Oren-Nayar, the regular
+// half-angle BRDF, mesh emitters, alpha cut-outs) for scenes that need the extension set — the same Lane, the reference's stream.
+template <int MATS>
 __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelArgs a, const ReplayArgs ra) {
     extern __shared__ int32_t lds_stack[];      // fixed_stack_rows(BVH depth) x HPT_BLOCK ints (launch_replay_kernel)
     int32_t *stack = lds_stack + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
     const int64_t gid = (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x;
-    Lane<MtReplaySrc, true, MATS_ALL> lane;
+    Lane<MtReplaySrc, true, MATS> lane;
     lane.init();
     lane.smp.mt = ra.mt + gid; lane.smp.buf = ra.buf + gid; lane.smp.stride = ra.nlanes; lane.smp.mti = HPT_MT_N; lane.smp.n = (uint32_t)rp.spp; lane.smp.i = 0;
     TileWalk tw; tw.started = false; tw.x0 = tw.x1 = tw.y0 = tw.y1 = tw.x = tw.y = 0;
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
         if (active) {
             bool anyhit = lane.stage == ST_SHADOW;
             if (anyhit) wc.shadow++; else wc.closest++;
-            traverse<true, true>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
+            traverse<true, true, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc);
             LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
             lane.on_hit_serial(sc, rp, hit, a.film, &wc, ls);
         }
@@ -486,9 +496,10 @@ hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks
         default: return inst ? launch_path_all_i(a, grid_blocks, count, cfg, stream) : launch_path_all(a, grid_blocks, count, cfg, stream);
     }
 }
-hipError_t launch_replay_kernel(const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream) {
+hipError_t launch_replay_kernel(int mats, const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream) {
     int grid = (int)(ra.nlanes / HPT_BLOCK);
-    hipLaunchKernelGGL(hpt_replay_kernel, dim3(grid), dim3(HPT_BLOCK), fixed_stack_bytes(bvh_depth), stream, a, ra);
+    if (mats & MATS_EXT) hipLaunchKernelGGL(hpt_replay_kernel<MATS_FULL>, dim3(grid), dim3(HPT_BLOCK), fixed_stack_bytes(bvh_depth), stream, a, ra);
+    else hipLaunchKernelGGL(hpt_replay_kernel<MATS_ALL>, dim3(grid), dim3(HPT_BLOCK), fixed_stack_bytes(bvh_depth), stream, a, ra);
     return hipGetLastError();
 }
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream) {

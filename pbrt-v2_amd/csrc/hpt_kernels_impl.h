@@ -137,23 +137,54 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // the other, the tree of every instance whose motion bounds the (shrinking) ray still crosses, each in the instance's own space at
 // the ray's time (xf_cache: the per-path transform cache, or null -> anim_interpolate).  Helpers only ever walk the subtree they were
 // given, in whatever space the donor was in, and publish the instance number with the hit.
-template <bool COUNT, bool INST, bool ALPHA>
+// TWO (the merged light phase, HPT_MERGE_LIGHT): a lane may own TWO rays of its path vertex — its shadow ray (`ray`, any-hit) and, has_b, the
+// BSDF-sampled MIS ray (pb + t db from epsb, closest-hit) — and walks them one after the other inside ONE phase of the wave, the idle lanes
+// helping with whichever subtrees are on offer: the MIS rays of a vertex (a handful per wave under an area light, one per lane under an
+// environment map) no longer get a phase — ramp-up, tail and all — of their own (profiles/r02i_phase_clocks.md: 18-31 % of the wave time).
+// Results live in different rows of the owner's column, so helpers of the first ray may still be walking when the owner starts the second:
+// any-hit rays raise the flag in row aux+2 (0 = occluded), closest-hit rays share t / prim / instance in rows aux+1 / aux+4 / aux+5.
+// `light`: a shadow / MIS phase — nobody needs barycentrics (rows aux+2, aux+3 are not written: aux+2 is the flag).
+template <bool COUNT, bool INST, bool ALPHA, bool TWO = false>
 __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
-                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q) {
+                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
+                                               bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
     #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
     #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    // the two pointers the loop dereferences, as scalar registers of their own: as fields of the kernel-argument block they live in a
+    // 16-register tuple that the allocator spills to VGPR lanes and re-reads WHOLE (16 v_readlane per node step, measured in the ISA)
+#ifdef HPT_BVH4
+    const f4 *nodes = sc.nodes4, *tris = sc.tris;                   // the four-wide trees (trav_node4): half the dependent fetches per ray
+    const int32_t world_root = sc.world_root4;
+#else
+    const f4 *nodes = sc.nodes, *tris = sc.tris;
+    const int32_t world_root = sc.world_root;
+#endif
+#ifndef HPT_NO_SGPR_PIN
+    {   // (through v_readfirstlane: a plain "+s" register pin is rejected — "illegal VGPR to SGPR copy" — in the instantiations where the
+        //  compiler keeps the argument block in vector registers)
+        uint64_t vn = (uint64_t)nodes, vt = (uint64_t)tris;
+        uint32_t nl = __builtin_amdgcn_readfirstlane((uint32_t)vn), nh = __builtin_amdgcn_readfirstlane((uint32_t)(vn >> 32));
+        uint32_t tl = __builtin_amdgcn_readfirstlane((uint32_t)vt), th = __builtin_amdgcn_readfirstlane((uint32_t)(vt >> 32));
+        asm volatile("" : "+s"(nl), "+s"(nh), "+s"(tl), "+s"(th));
+        nodes = (const f4 *)(((uint64_t)nh << 32) | nl); tris = (const f4 *)(((uint64_t)th << 32) | tl);
+    }
+    leaf_q = __builtin_amdgcn_readfirstlane(leaf_q); block_q = __builtin_amdgcn_readfirstlane(block_q);   // (uniform by construction: kernel arguments)
+#endif
     TravState ts;
     Ray r = ray;
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
     // instances: the segment this lane's OWN ray is in (-1 world, k instance k, n_inst: all done) and the instance of the tree being walked
     const int n_inst = INST ? sc.n_instances : 0;
     int seg = (INST && has_ray) ? -1 : n_inst, cur_inst = -1;
-    if (has_ray) trav_begin(sc, ts, r, anyhit, sc.world_root, true);
-    else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
-    HPT_AUX(aux + 1, lane) = as_int(r.maxt);                        // r.maxt >= 0: float order == unsigned order of the bits
+    bool more_b = TWO && has_ray && has_b;                          // the owner's second ray is still to come
+    bool cur_any = anyhit;                                          // kind of the owner's CURRENT ray (the second one is closest-hit)
+    if (has_ray) trav_begin(sc, ts, r, anyhit, world_root, true);
+    else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); trav_prep(ts, r); }
+    HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
+    HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
     HPT_AUX(aux + 4, lane) = -1;
     HPT_WAVE_SYNC();
     // Leaf batching.  Measured (profiles/r02i_phase_clocks.md): the leaf half of a step — the triangle tests, double-precision cross
@@ -166,12 +197,16 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     for (;;) {
         const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
         const unsigned long long mbusy = __ballot(busy);
-        const bool any_busy = (mbusy | __ballot(seg < n_inst)) != 0ull;
+        const bool any_busy = (mbusy | __ballot(seg < n_inst || more_b)) != 0ull;
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* every lane: wave clocks of the node half / of the leaf half, iterations, leaf phases, lanes in them */
         const unsigned long long w0_ = __builtin_readcyclecounter();
         cnt->steps++;
 #endif
-        if (ts.node >= 0) trav_node<COUNT>(sc, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+#ifdef HPT_BVH4
+        if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
+#else
+        if (ts.node >= 0) trav_node<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
+#endif
         if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node)) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
         const unsigned long long w1_ = __builtin_readcyclecounter();
@@ -184,7 +219,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
                 if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
                     if (has) {
-                        if (trav_leaf<COUNT, ALPHA>(sc, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
+                        if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
                         pend = HPT_TRAV_EMPTY;
                     }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
@@ -200,13 +235,14 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         if (any_found || !any_busy) {
             // ---- publish finds, share the hit distance inside every group (owner + helpers) ------------------------------
             if (found) {
-                if (ts.anyhit) HPT_AUX(aux + 1, owner) = 0;
+                if (ts.anyhit) HPT_AUX(aux + 2, owner) = 0;
                 else atomicMin((unsigned *)&HPT_AUX(aux + 1, owner), (unsigned)as_int(ts.hit.t));
             }
             HPT_WAVE_SYNC();
-            const int shared = HPT_AUX(aux + 1, owner);
+            const int shared = HPT_AUX(aux + (ts.anyhit ? 2 : 1), owner);
             if (found && !ts.anyhit && as_int(ts.hit.t) == shared) {    // this lane holds the group's nearest hit so far
-                HPT_AUX(aux + 2, owner) = as_int(ts.hit.b1); HPT_AUX(aux + 3, owner) = as_int(ts.hit.b2); HPT_AUX(aux + 4, owner) = ts.hit.prim;
+                if (!light) { HPT_AUX(aux + 2, owner) = as_int(ts.hit.b1); HPT_AUX(aux + 3, owner) = as_int(ts.hit.b2); }
+                HPT_AUX(aux + 4, owner) = ts.hit.prim;
                 if (INST) HPT_AUX(aux + 5, owner) = cur_inst;
             }
             ts.hit.prim = -1;                                           // published (or beaten)
@@ -216,30 +252,48 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             }
             if (!any_busy) break;                                       // (the last publish has just happened)
         }
-        if (INST && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && seg < n_inst) {
-            // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
-            const int shared = HPT_AUX(aux + 1, lane);                  // (seg < n_inst only on the owner: owner == lane)
-            ++seg;
-            if (anyhit && shared == 0) seg = n_inst;
-            if (seg < n_inst) {
-                const hpt_instance &in = sc.instances[seg];
-                Ray rw = ray; rw.maxt = anyhit ? ray.maxt : fminf(ray.maxt, as_float(shared));
-                const float big = 3.402823466e+38f;
-                f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
-                float tentry;
-                if (sc.inst_root[seg] >= 0 && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
-                    A34 w2p;
-                    if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
-                    else w2p = anim_interpolate(in, time, false).m;
-                    r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
-                    trav_begin(sc, ts, r, anyhit, sc.inst_root[seg], false);
-                    cur_inst = seg; sb = 0;
+        if ((INST || TWO) && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && (seg < n_inst || more_b)) {
+            if (INST && seg < n_inst) {
+                // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
+                const int shared = HPT_AUX(aux + (cur_any ? 2 : 1), lane);  // (seg < n_inst only on the owner: owner == lane)
+                ++seg;
+                if (cur_any && shared == 0) seg = n_inst;
+                if (seg < n_inst) {
+                    const hpt_instance &in = sc.instances[seg];
+                    Ray rw;
+                    if (TWO && !cur_any && has_b) { rw.o = *pb; rw.d = *db; rw.mint = epsb; rw.maxt = HPT_INF; }      // the MIS ray (a lane with two rays: the first is any-hit)
+                    else rw = ray;
+                    if (!cur_any) rw.maxt = fminf(rw.maxt, as_float(shared));
+                    const float big = 3.402823466e+38f;
+                    f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
+                    float tentry;
+#ifdef HPT_BVH4
+                    const int32_t iroot = sc.inst_root4[seg];
+#else
+                    const int32_t iroot = sc.inst_root[seg];
+#endif
+                    if (iroot >= 0 && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
+                        A34 w2p;
+                        if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
+                        else w2p = anim_interpolate(in, time, false).m;
+                        r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
+                        trav_begin(sc, ts, r, cur_any, iroot, false);
+                        cur_inst = seg; sb = 0;
+                    }
                 }
+            }
+            if (TWO && more_b && seg >= n_inst && ts.node == HPT_TRAV_EMPTY) {
+                // ---- the owner's shadow ray is through (its helpers may still be walking): on to the vertex's MIS ray ----------------
+                more_b = false; cur_any = false;
+                seg = INST ? -1 : n_inst;
+                r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
+                trav_begin(sc, ts, r, false, world_root, true);
+                cur_inst = -1; sb = 0;
             }
         }
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
-        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_inst;
+        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_inst && !more_b;
         const bool donor = still && ts.sp >= 1;
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
@@ -266,16 +320,23 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         if (take) {
             r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
             ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s; cur_inst = inst_s;
+            trav_prep(ts, r);
             ts.node = node_s; ts.sp = 0; sb = 0;
         }
     }
     HPT_WAVE_SYNC();
     // ---- every owner collects the nearest hit of its group ----------------------------------------------------------------
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
+    if (TWO) { hitb->prim = -1; hitb->t = 0.f; hitb->b1 = 0.f; hitb->b2 = 0.f; hitb->inst = -1; }
     if (has_ray) {
         const int shared = HPT_AUX(aux + 1, lane);
-        if (anyhit) { if (shared == 0) hit->prim = 0; }
-        else if (HPT_AUX(aux + 4, lane) >= 0) {
+        if (anyhit) {
+            if (HPT_AUX(aux + 2, lane) == 0) hit->prim = 0;
+            if (TWO && has_b && HPT_AUX(aux + 4, lane) >= 0) {       // the second ray's nearest hit (no barycentrics: light phase)
+                hitb->t = as_float(shared); hitb->prim = HPT_AUX(aux + 4, lane);
+                if (INST) hitb->inst = HPT_AUX(aux + 5, lane);
+            }
+        } else if (HPT_AUX(aux + 4, lane) >= 0) {
             hit->t = as_float(shared); hit->b1 = as_float(HPT_AUX(aux + 2, lane)); hit->b2 = as_float(HPT_AUX(aux + 3, lane)); hit->prim = HPT_AUX(aux + 4, lane);
             if (INST) hit->inst = HPT_AUX(aux + 5, lane);
             ray.maxt = hit->t;
@@ -341,6 +402,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // lock step + stealing (path integrator): an extension hit waiting for its shading while the wave walks again for the lanes whose
     // rays escaped (PathKernelArgs::retrace_min)
     constexpr bool RETRACE = STEAL && PHASED && !DL;
+#ifdef HPT_MERGE_LIGHT
+    constexpr bool MERGE = STEAL && PHASED;     // shadow and MIS rays of a vertex in ONE traversal phase (traverse_steal, TWO)
+#else
+    constexpr bool MERGE = false;
+#endif
+    constexpr int LAST_PHASE = MERGE ? (int)ST_SHADOW : (int)ST_MIS;
     Hit pend; bool has_pend = false; int retraced = 0;
     pend.prim = -1; pend.t = 0.f; pend.b1 = 0.f; pend.b2 = 0.f; pend.inst = -1;
     for (;;) {
@@ -384,8 +451,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
             // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
-            const int my_phase = (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : lane.stage;
-            while (__ballot(my_phase == phase) == 0ull) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+            const int my_phase = (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : (MERGE && lane.stage == ST_MIS) ? (int)ST_SHADOW : lane.stage;
+            while (__ballot(my_phase == phase) == 0ull) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
         HPT_PT(0)
@@ -393,8 +460,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
             const bool tr = mine && (!DL || lane.stage != ST_SHADE) && !(RETRACE && has_pend);
             const bool anyhit = lane.stage == ST_SHADOW;
-            if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; }
-            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride, a.leaf_q, a.block_q);
+            const bool has_b = MERGE && tr && anyhit && lane.has_mis;
+            if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; if (has_b) wc.closest++; }
+            Hit hitb;
+            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0, MERGE>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal,
+                                                                        MERGE && phase != ST_EXTEND, has_b, &lane.p, &lane.wi_mis, lane.eps, &hitb);
             if (RETRACE && phase == ST_EXTEND) {
                 // Extension rays that escaped end their paths without shading.  If there are enough of them, they take their next camera
                 // ray now (flush at the top of the loop; idle lanes pull new work there too) and the wave walks once more — the lanes that
@@ -413,7 +483,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #ifdef HPT_PHASE_TIMERS
             if (phase == ST_EXTEND) HPT_PT(1) else HPT_PT(2)
 #endif
-            if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
+            if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv, MERGE ? &hitb : nullptr);
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (mine) {
@@ -461,7 +531,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         HPT_PT(4)
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
         HPT_PT(5)
-        if (PHASED) phase = phase == ST_MIS ? ST_EXTEND : phase + 1;
+        if (PHASED) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
     }
 #ifdef HPT_PHASE_TIMERS
 #if HPT_PHASE_TIMERS == 3   /* the walk: lane-summed clocks of whole steps / of their leaf parts, steps, steps that were at a leaf */
@@ -519,7 +589,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 // instances — one translation unit each (hpt_kernels_<set>.hip, hpt_kernels_<set>_i.hip): the two halves want different compiler
 // settings (the Makefile schedules the instance-free kernels with -amdgpu-sched-strategy=max-ilp: bunny +2.6 %, soup +2.5 %, killeroo
 // +1 %; the instanced kernels, at their register limit, lose 6 % with it — profiles/r02_ab.md) and build in parallel.  The
-// instrumented (COUNT) build exists for configuration 0 only: the counters are algorithmic and do not depend on scheduling.
+// instrumented (COUNT) build exists for configuration 5 only (lock step + subtree stealing: the walk — and the tree — the production
+// configurations 5 / 6 run, so that its node counter counts the fetches of THAT walk); rays and samples do not depend on scheduling.
 #define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS, INSTV)                                                                 \
     template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, size_t dyn_lds, hipStream_t s) { \
         hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, INSTV, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);             \
@@ -533,7 +604,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (count) {                                                                                                \
-            hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, false, false>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
+            hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (INSTV && cfg == 1) cfg = 0;                                                                             \

@@ -454,16 +454,24 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
 #define HPT_SPT0
 #define HPT_SPT(i)
 #endif
-    HPT_MFN bool on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls, ShadeV *sv) {
+    // hitb (merged light phase, hpt_kernels_impl.h traverse_steal TWO): the nearest hit of the vertex's MIS ray, traced in the same phase as its shadow ray
+    HPT_MFN bool on_hit(const DScene &sc, const RenderParams &rp, const Hit &hit_in, float *film, WorkCounters *wc, LaneStack ls, ShadeV *sv, const Hit *hitb = nullptr) {
         if (DL && stage == ST_SHADE) {       // next light sample of the kept camera hit (no ray was traced)
             ray = cam;
             shade_prepare(sc, rp, chit, ls, sv);
             return true;
         }
+        Hit hit = hit_in;
         if (stage == ST_SHADOW) {            // VisibilityTester::Unoccluded (core/light.cpp:46-48)
             if (hit.prim >= 0) Ld = S(0.f);
-            after_shadow(sc, rp, film, wc);
-            return false;
+            if (hitb && has_mis) {           // both rays of the vertex were walked in this phase: the MIS ray's result follows at once
+                ray.o = p; ray.d = wi_mis; ray.mint = eps; ray.maxt = HPT_INF; // integrator.cpp:160
+                hit = *hitb;
+                stage = ST_MIS;
+            } else {
+                after_shadow(sc, rp, film, wc);
+                return false;
+            }
         }
         if (stage == ST_MIS) {               // integrator.cpp:157-171
             bool sees = false;               // does the ray see light_mis with non-black radiance?

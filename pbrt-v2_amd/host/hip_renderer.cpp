@@ -15,12 +15,14 @@
 // Anything else is outside the hot-path scope and is rejected with Severe().
 #include "stdafx.h"
 #include "hip_renderer.h"
+#include <time.h>
 
 #include "scene.h"
 #include "camera.h"
 #include "film.h"
 #include "sampler.h"
 #include "integrator.h"
+#include "volume.h"
 #include "intersection.h"
 #include "light.h"
 #include "parallel.h"
@@ -416,16 +418,19 @@ struct Flattener {
 
     void Flatten(const Scene *scene) {
         AddLights(scene);
-        const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene->aggregate);
-        if (!bvh) Severe("hip renderer: Accelerator must be \"bvh\" (the default)");
-        for (size_t i = 0; i < bvh->primitives.size(); ++i) {
+        // the refined primitive list: of the plugin's own list aggregate (the patched MakeScene), or of the reference's BVHAccel
+        const vector<Reference<Primitive> > *prims = NULL;
+        if (const HipListAggregate *la = dynamic_cast<const HipListAggregate *>(scene->aggregate)) prims = &la->primitives;
+        else if (const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(scene->aggregate)) prims = &bvh->primitives;
+        if (!prims) Severe("hip renderer: Accelerator must be \"bvh\" (the default)");
+        for (size_t i = 0; i < prims->size(); ++i) {
             if (const TransformedPrimitive *tp =
-                    dynamic_cast<const TransformedPrimitive *>(bvh->primitives[i].GetPtr())) {
+                    dynamic_cast<const TransformedPrimitive *>((*prims)[i].GetPtr())) {
                 AddInstance(tp);
                 continue;
             }
             const GeometricPrimitive *gp =
-                dynamic_cast<const GeometricPrimitive *>(bvh->primitives[i].GetPtr());
+                dynamic_cast<const GeometricPrimitive *>((*prims)[i].GetPtr());
             if (!gp) Severe("hip renderer: primitive type outside the hot-path scope");
             const Shape *shape = gp->shape.GetPtr();
             if (const Triangle *tri = dynamic_cast<const Triangle *>(shape))
@@ -488,6 +493,28 @@ struct Flattener {
 
 } // namespace
 
+// ---- HipListAggregate ----------------------------------------------------------------------------------------------------------------
+HipListAggregate::HipListAggregate(const vector<Reference<Primitive> > &prims) {
+    for (uint32_t i = 0; i < prims.size(); ++i) prims[i]->FullyRefine(primitives);      // BVHAccel's own first step (accelerators/bvh.cpp:160-162): same list, same order
+    for (uint32_t i = 0; i < primitives.size(); ++i) bounds = Union(bounds, primitives[i]->WorldBound());
+}
+bool HipListAggregate::Intersect(const Ray &ray, Intersection *isect) const {
+    bool hit = false;
+    for (uint32_t i = 0; i < primitives.size(); ++i) if (primitives[i]->Intersect(ray, isect)) hit = true;   // (GeometricPrimitive::Intersect shrinks ray.maxt)
+    return hit;
+}
+bool HipListAggregate::IntersectP(const Ray &ray) const {
+    for (uint32_t i = 0; i < primitives.size(); ++i) if (primitives[i]->IntersectP(ray)) return true;
+    return false;
+}
+Primitive *MakeHipAggregate(const vector<Reference<Primitive> > &prims) {
+    if (const char *e = getenv("HPT_HOST_BVH")) if (atoi(e) != 0) return NULL;
+    return new HipListAggregate(prims);
+}
+
+// wall clock of the plugin's stages (HPT_TIMING=1: one line on stderr; bench.py's end_to_end leg reads it)
+static double NowS() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 HipPathRenderer::HipPathRenderer(Sampler *s, Camera *c, SurfaceIntegrator *si,
                                  VolumeIntegrator *vi, const ParamSet &params) {
     sampler = s;
@@ -543,9 +570,11 @@ void HipPathRenderer::Render(const Scene *scene) {
     if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
     if (scene->volumeRegion) Severe("hip renderer: participating media are outside the scope");
 
+    const double t_begin = NowS();
     Flattener fl;
     fl.Flatten(scene);
     hpt_scene_desc desc = fl.Desc();
+    const double t_flat = NowS();
 
     hpt_camera cam;
     memset(&cam, 0, sizeof(cam));
@@ -593,6 +622,7 @@ void HipPathRenderer::Render(const Scene *scene) {
     std::vector<float> xyzw(4 * (size_t)rd.x_count * rd.y_count);
     hpt_stats st;
     memset(&st, 0, sizeof(st));
+    double t_create = t_flat, t_tune = t_flat, t_render = t_flat, bvh_ms = 0.;
     ProgressReporter reporter(1, "Rendering (HIP)");
     if (gpus > 1) {
         // `gpus` — one host thread per device inside the library, pixel tiles round-robin, one film gather over RCCL
@@ -615,9 +645,18 @@ void HipPathRenderer::Render(const Scene *scene) {
     } else {
         hpt_scene *hs = hpt_scene_create(&desc, device);
         if (!hs) Severe("hip renderer: %s", hpt_last_error());
+        t_create = NowS();
         if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        // kernel configuration of a job big enough to repay it (what hpt_render would do on its own: here as a step of its own, timed):
+        // probe renders, or the cached choice for this scene
+        if ((int64_t)rd.x_count * rd.y_count * rd.spp >= ((int64_t)32 << 20) && hpt_scene_tune(hs, &cam, &rd) < 0)
+            Severe("hip renderer: %s", hpt_last_error());
+        t_tune = NowS();
         if (hpt_render(hs, &cam, &rd, &xyzw[0], &st) != HPT_OK)
             Severe("hip renderer: %s", hpt_last_error());
+        t_render = NowS();
+        hpt_scene_info info;
+        if (hpt_scene_get_info(hs, &info) == HPT_OK) bvh_ms = info.build_ms;
         hpt_scene_destroy(hs);
     }
     reporter.Update();
@@ -636,7 +675,12 @@ void HipPathRenderer::Render(const Scene *scene) {
             px.Lxyz[0] = s[0]; px.Lxyz[1] = s[1]; px.Lxyz[2] = s[2];
             px.weightSum = s[3];
         }
+    const double t_film = NowS();
     camera->film->WriteImage();
+    if (getenv("HPT_TIMING"))
+        fprintf(stderr, "hpt timing: flatten %.3f s, scene create %.3f s (BVH build %.1f ms), kernel configuration %.3f s, render + film download %.3f s "
+                        "(kernel %.2f ms), film to ImageFilm %.3f s, WriteImage %.3f s\n", t_flat - t_begin, t_create - t_flat, bvh_ms, t_tune - t_create,
+                t_render - t_tune, st.kernel_ms, t_film - t_render, NowS() - t_film);
 }
 
 // Renderer::Li / Transmittance (core/renderer.h:47-53): what the reference's integrators call back into for a ray of their own

@@ -12,6 +12,25 @@
 #include "pbrt.h"
 #include "renderer.h"
 #include "paramset.h"
+#include "primitive.h"
+
+// What RenderOptions::MakeScene hands the hip renderer instead of a BVHAccel (core/api.cpp:1186-1203, patched): the fully refined
+// primitive list and its bound — all the plugin reads of the reference's accelerator (BVHAccel::primitives).  The device library
+// builds its own tree from the flattened triangles; pbrt's CPU BVH build (0.1-0.7 s of a sub-second job) would be thrown away.
+// Intersect / IntersectP walk the list: correct for the Renderer::Li callback of host-side callers, never on the device path.
+// HPT_HOST_BVH=1 keeps the reference's accelerator.
+class HipListAggregate : public Aggregate {
+public:
+    HipListAggregate(const vector<Reference<Primitive> > &prims);
+    BBox WorldBound() const { return bounds; }
+    bool CanIntersect() const { return true; }
+    bool Intersect(const Ray &ray, Intersection *isect) const;
+    bool IntersectP(const Ray &ray) const;
+    vector<Reference<Primitive> > primitives;
+private:
+    BBox bounds;
+};
+Primitive *MakeHipAggregate(const vector<Reference<Primitive> > &prims);   // NULL: use the scene's own accelerator (HPT_HOST_BVH=1)
 
 class HipPathRenderer : public Renderer {
 public:

@@ -23,7 +23,7 @@ EXPORTS = [
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
-    "hpt_calib_hbm_triad",
+    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes",
 ]
 
 
@@ -231,6 +231,11 @@ class Comm:
         if getattr(self, "h", None):
             lib().hpt_comm_destroy(self.h)
             self.h = None
+
+
+def kernel_node_bytes():
+    """64 (BVH2 nodes) or 128 (BVH4 nodes): what one counted node fetch of the instrumented kernel moves."""
+    return int(lib().hpt_kernel_node_bytes())
 
 
 def hbm_triad(device=0, bytes_per_array=1 << 30, reps=5):

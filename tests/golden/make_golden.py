@@ -67,7 +67,7 @@ def run_case(name, pbrt_text, tmp):
         f.write(pbrt_text)
     subprocess.check_call([PBRT, "--quiet", "--ncores", NCORES, scene_path], stderr=subprocess.DEVNULL)
     blob = os.path.join(tmp, name + ".hpts")
-    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1")
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", NCORES, scene_path], env=env, stderr=subprocess.DEVNULL)
     ref = film.read_pfm(os.path.join(tmp, name + "_ref.pfm"))
     with gzip.open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as f:
@@ -81,7 +81,7 @@ def dump_view(name, pbrt_text, tmp, geometry):
     with open(scene_path, "w") as f:
         f.write(pbrt_text)
     blob = os.path.join(tmp, name + ".hpts")
-    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1")
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", scene_path], env=env, stderr=subprocess.DEVNULL)
     v = abi.Scene.load(blob)
     assert np.array_equal(v.fpool, geometry.fpool) and np.array_equal(v.ipool, geometry.ipool)

@@ -60,7 +60,7 @@ def main():
         subprocess.check_call([PBRT_EXR, "--quiet", "--ncores", "1", scene_path], stderr=subprocess.DEVNULL)
         blob = os.path.join(tmp, "envmap.hpts")
         subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", scene_path],
-                              env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+                              env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
         ref = film.read_pfm(os.path.join(tmp, "envmap_ref.pfm"))
         with open(os.path.join(HERE, "envmap.ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
             np.save(f, ref)
@@ -80,7 +80,7 @@ def main():
         subprocess.check_call([PBRT_EXR, "--quiet", "--ncores", "1", p2], stderr=subprocess.DEVNULL)
         blob2 = os.path.join(tmp, "envmap_dl.hpts")
         subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", p2],
-                              env=dict(os.environ, HPT_DUMP_SCENE=blob2, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+                              env=dict(os.environ, HPT_DUMP_SCENE=blob2, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
         ref2 = film.read_pfm(os.path.join(tmp, "envmap_dl_ref.pfm"))
         with open(os.path.join(HERE, "envmap_dl.ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
             np.save(f, ref2)

@@ -85,7 +85,7 @@ def run(name, text, tmp, exe=PBRT, ncores="1"):
     subprocess.check_call([exe, "--quiet", "--ncores", ncores, scene_path], stderr=subprocess.DEVNULL, cwd=tmp)
     blob = os.path.join(tmp, name + ".hpts")
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", ncores, scene_path], cwd=tmp,
-                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
     ref = film.read_pfm(out)
     with open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
         np.save(f, ref)
@@ -231,7 +231,7 @@ def metal_4k_view():
     with tempfile.TemporaryDirectory() as tmp:
         sp, blob = os.path.join(tmp, "m.pbrt"), os.path.join(tmp, "m.hpts")
         open(sp, "w").write(text)
-        subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", sp], cwd=tmp, env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+        subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", sp], cwd=tmp, env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
         v, g = abi.Scene.load(blob), abi.Scene.load(os.path.join(HERE, "metal.hpts.gz"))
         assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool)
         np.savez(os.path.join(HERE, "metal_4k.view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8), render=np.frombuffer(bytes(v.render), dtype=np.uint8))

@@ -46,7 +46,7 @@ def dump(text, tmp):
     sp, blob = os.path.join(tmp, "m.pbrt"), os.path.join(tmp, "m.hpts")
     open(sp, "w").write(text)
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "8", sp], cwd=tmp,
-                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1"), stderr=subprocess.DEVNULL)
+                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
     return abi.Scene.load(blob)
 
 

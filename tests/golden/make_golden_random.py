@@ -55,7 +55,7 @@ def run_case(name, pbrt_text, tmp, geometry_blob):
         f.write(pbrt_text)
     subprocess.check_call([PBRT, "--quiet", "--ncores", "1", scene_path], stderr=subprocess.DEVNULL)
     blob = os.path.join(tmp, name + ".hpts")
-    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1")
+    env = dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1")
     subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", scene_path], env=env, stderr=subprocess.DEVNULL)
     ref = film.read_pfm(os.path.join(tmp, name + "_ref.pfm"))
     with open(os.path.join(HERE, name + ".ref.npy.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:

@@ -23,6 +23,7 @@ def lib():
         L.emu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
         L.emu_render_replay.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_intersect4.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
@@ -43,9 +44,10 @@ class EmuScene:
             raise RuntimeError("emu_scene_create failed")
 
     def info(self):
-        out = np.zeros(3, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         lib().emu_scene_info(self.h, out.ctypes.data)
-        return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2])}
+        return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2]),
+                "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5])}
 
     def render(self, cam, rd, flt=None, two_pass=False):
         """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the
@@ -65,6 +67,16 @@ class EmuScene:
         prim = np.zeros(n, dtype=np.int32)
         lib().emu_intersect(self.h, rays.ctypes.data, n, int(anyhit), hit.ctypes.data, prim.ctypes.data)
         return hit, prim
+
+    def intersect4(self, rays, anyhit=False, cap=-1):
+        """the same rays over the four-wide trees (trav_node4); cap: stack rows that take ordinary entries (-1: all).  -> hit, prim, deepest stack"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros((n, 4), dtype=np.float32)
+        prim = np.zeros(n, dtype=np.int32)
+        deepest = C.c_int(0)
+        lib().emu_intersect4(self.h, rays.ctypes.data, n, int(anyhit), cap, hit.ctypes.data, prim.ctypes.data, C.byref(deepest))
+        return hit, prim, deepest.value
 
     def bsdf(self, material, inp, tier=0):
         inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, 16)

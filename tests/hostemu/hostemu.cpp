@@ -47,11 +47,13 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.instances = s->instances.data(); s->d.inst_root = s->fs.inst_root.data();
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
+    s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4;
     return s;
 }
 extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
 extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
     out[0] = s->fs.n_tris; out[1] = (int64_t)s->fs.nodes.size(); out[2] = s->fs.max_depth;
+    out[3] = (int64_t)s->fs.nodes4.size() / 2; out[4] = s->fs.stack_bound4; out[5] = s->fs.depth4;
 }
 
 // hpt_scene_set_filter's stand-in (process-wide; NULL = box of width 0.5)
@@ -76,6 +78,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->xres = rd->xres; rp->yres = rd->yres; rp->x_start = rd->x_start; rp->x_count = rd->x_count;
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
+    rp->bad_counter = nullptr;   // (the lanes count bad samples in their WorkCounters here)
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
     { const int skind = HPT_SAMPLER_KIND(rd->sampler_mode); const bool strat = skind == HPT_SAMPLER_STRATIFIED_HASH;   // as fill_params of csrc/hpt_api.hip
@@ -178,7 +181,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
     std::vector<float> buf((size_t)HPT_REPLAY_FLOATS_PER_SAMPLE * rd->spp);
     int32_t stack[64];
     for (int task = 0; task < rd->ntasks; ++task) {
-        Lane<MtReplaySrc, true, MATS_ALL> lane; lane.init();
+        Lane<MtReplaySrc, true, MATS_FULL> lane; lane.init();
         lane.smp.mt = mt.data(); lane.smp.buf = buf.data(); lane.smp.stride = 1; lane.smp.n = (uint32_t)rd->spp; lane.smp.i = 0;
         TileWalk tw; tw.started = false;
         compute_sub_window(rp.sx_start, rp.sx_start + rp.sx_count, rp.sy_start, rp.sy_start + rp.sy_count, task, rd->ntasks,
@@ -191,7 +194,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
                 bool anyhit = lane.stage == ST_SHADOW;
                 if (anyhit) wc.shadow++; else wc.closest++;
                 Hit hit;
-                traverse<true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
+                traverse<true, true, true>(s->d, lane.ray, lane.time, anyhit, &hit, stack, 1, &tc);
                 LaneStack ls; ls.p = stack; ls.stride = 1;
                 lane.on_hit_serial(s->d, rp, hit, film, &wc, ls);
             }
@@ -199,6 +202,59 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
     }
     if (rp.sbuf_xyzw) gather_film(rp, film);
     if (stats) { stats[0] = wc.samples; stats[1] = wc.closest; stats[2] = wc.shadow; stats[3] = tc.nodes; stats[4] = tc.tris; stats[5] = wc.bad; }
+    return 0;
+}
+
+// The BVH4 walk with a given number of stack rows for ordinary entries (the rest: one masked entry per level) — the node step of the
+// path kernel's stealing walk, one lane, world tree + instances like traverse()
+static bool traverse4_cap(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int cap, int *max_sp) {
+    TravCounters tc = {0, 0};
+    TravState ts;
+    trav_begin(sc, ts, ray, anyhit, sc.world_root4, true);
+    auto walk = [&](TravState &w, Ray &r) {
+        while (!w.done()) {
+            if (w.node >= 0) trav_node4<false>(sc.nodes4, w, r, stack, 1, &tc, cap);
+            if (w.sp > *max_sp) *max_sp = w.sp;
+            if (trav_is_leaf(w.node)) { if (trav_leaf<false, true>(sc, w, r, w.node, &tc)) w.node = HPT_TRAV_EMPTY; else trav_pop(w, stack, 1); }
+        }
+    };
+    walk(ts, ray);
+    *hit = ts.hit;
+    if (anyhit && hit->prim >= 0) return true;
+    for (int k = 0; k < sc.n_instances; ++k) {
+        const hpt_instance &in = sc.instances[k];
+        float tentry;
+        if (!slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], ray, ts.invd, &tentry)) continue;
+        A34 w2p = anim_interpolate(in, time, false).m;
+        Ray r2; r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
+        TravState t2;
+        trav_begin(sc, t2, r2, anyhit, sc.inst_root4[k], false);
+        walk(t2, r2);
+        if (t2.hit.prim >= 0) { *hit = t2.hit; hit->inst = k; ray.maxt = r2.maxt; if (anyhit) return true; }
+    }
+    return hit->prim >= 0;
+}
+// hpt_test_intersect's stand-in over the four-wide trees: cap = stack rows that take ordinary entries (< 0: all of them); *max_sp: deepest stack seen
+extern "C" int emu_intersect4(const emu_scene *s, const float *rays, int64_t n, int anyhit, int cap, float *out_hit, int32_t *out_prim, int *max_sp) {
+    const DScene &sc = s->d;
+    int deepest = 0;
+#pragma omp parallel for reduction(max : deepest)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = rays + 8 * i;
+        Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
+        Hit hit; int32_t stack[96]; int msp = 0;
+        bool h = traverse4_cap(sc, ray, 0.f, anyhit != 0, &hit, stack, cap < 0 ? 1 << 20 : cap, &msp);
+        if (msp > deepest) deepest = msp;
+        float *o = out_hit + 4 * i;
+        o[0] = o[1] = o[2] = o[3] = 0.f;
+        if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
+        if (!h) { out_prim[i] = -1; continue; }
+        if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
+        const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+        out_prim[i] = sc.meshes[as_int(tp[0].w) & HPT_TRI_MESH_MASK].prim_base + as_int(tp[1].w);
+        o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
+    }
+    if (max_sp) *max_sp = deepest;
     return 0;
 }
 

@@ -78,8 +78,8 @@ def test_anim_bench_frame_matches_oracle_on_content_crops():
     assert st.tune_cfg == cfg and st.bad_samples == 0 and st.camera_samples == 1920 * 1080 * 128
     wsum = float(f[..., 3].astype(np.float64).sum())
     assert 1920 * 1080 * 128 <= wsum <= 1920 * 1080 * 128 * (1 + 5e-4)
-    worst = compare_crops(s, orc.OracleScene(s), f, rd, content=24)
-    print("anim 128 spp, configuration %d: worst of 30 crops, RMSE vs oracle %.3g" % (st.tune_cfg, worst))
+    total, worst = compare_crops(s, orc.OracleScene(s), f, rd, content=24)
+    print("anim 128 spp, configuration %d: RMSE vs oracle over 30 crops %.3g, worst crop %.3g" % (st.tune_cfg, total, worst))
 
 
 def test_metal_4k_with_the_grace_environment_map_matches_oracle_on_content_crops():
@@ -91,13 +91,16 @@ def test_metal_4k_with_the_grace_environment_map_matches_oracle_on_content_crops
     rd = abi.copy_struct(s.render)
     assert (rd.xres, rd.yres, rd.spp, rd.maxdepth) == (3840, 2160, 128, 8)
     env = [l for l in s.lights if l.kind == abi.HPT_LIGHT_INFINITE][0]
-    assert (env.env_w, env.env_h) == (1000, 500)
+    assert (env.env_w, env.env_h) == (1024, 512)             # the 1000 x 500 map as InfiniteAreaLight's MIPMap resampled it (mipmap.h:113-160)
     dev = hpt.DeviceScene(s)
     dev.tune(s.camera, rd)
     f, st = dev.render(s.camera, rd)
     assert st.bad_samples == 0 and st.camera_samples == 3840 * 2160 * 128
-    worst = compare_crops(s, orc.OracleScene(s), f, rd, content=18)
-    print("metal 4K 128 spp, configuration %d: worst of 24 crops, RMSE vs oracle %.3g, %.1f ms" % (st.tune_cfg, worst, st.kernel_ms))
+    # HDR map (texels up to 18 against a frame mean of 0.017), Blinn exponent 1000 on the teapot: a camera sample whose discrete decision
+    # flips on an ulp of the device's libm moves its pixel by ~0.1 — one such sample in a 64x64 crop of 524 288 is an RMSE of 1e-3 for that
+    # crop.  The tolerance holds over all verified pixels; a single crop gets 5e-3.
+    total, worst = compare_crops(s, orc.OracleScene(s), f, rd, content=18, crop_tol=5e-3)
+    print("metal 4K 128 spp, configuration %d: RMSE vs oracle over 24 crops %.3g, worst crop %.3g, %.1f ms" % (st.tune_cfg, total, worst, st.kernel_ms))
 
 
 def test_bad_radiance_values_are_counted_by_the_production_kernel():
@@ -123,6 +126,32 @@ def test_bad_radiance_values_are_counted_by_the_production_kernel():
     rd.count_work = 1                                       # the instrumented build counts the same
     _, stc = hpt.DeviceScene(s).render(s.camera, rd)
     assert stc.bad_samples == st.bad_samples
+
+
+def test_kernel_configuration_is_remembered_on_disk(monkeypatch, tmp_path):
+    """hpt_scene_tune probes every configuration once per (scene, view, job, device, build) and remembers the winner under
+    $HPT_TUNE_CACHE: a second scene handle — a second process: pbrt_hip — takes the choice from the file instead of probing again."""
+    import time
+    monkeypatch.setenv("HPT_TUNE_CACHE", str(tmp_path))
+    monkeypatch.delenv("HPT_TUNE", raising=False)
+    s = bench_workload("killeroo", 64)
+    rd = abi.copy_struct(s.render)
+    t0 = time.time(); cfg = hpt.DeviceScene(s).tune(s.camera, rd); t_probe = time.time() - t0
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("tune-") and int(files[0].read_text()) == cfg
+    dev = hpt.DeviceScene(s)
+    t0 = time.time(); cfg2 = dev.tune(s.camera, rd); t_cached = time.time() - t0
+    assert cfg2 == cfg and t_cached < 0.5 * t_probe and t_cached < 0.05
+    _, st = dev.render(s.camera, rd)
+    assert st.tune_cfg == cfg
+    rd2 = abi.copy_struct(rd)
+    rd2.maxdepth = 5                                        # another job: another entry
+    hpt.DeviceScene(s).tune(s.camera, rd2)
+    assert len(list(tmp_path.iterdir())) == 2
+    files[0].write_text("99\n")                             # a damaged entry is ignored (and rewritten)
+    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(7) and int(files[0].read_text()) in range(7)
+    monkeypatch.setenv("HPT_TUNE_CACHE", "off")
+    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(7)
 
 
 def test_every_kernel_configuration_renders_the_same_bench_frame(monkeypatch):
@@ -177,8 +206,8 @@ def test_soup_1m_triangles_256_spp_matches_oracle_on_crops():
     dev.tune(s.camera, rd)
     f, st = dev.render(s.camera, rd)
     assert st.bad_samples == 0 and st.camera_samples == 1920 * 1080 * 256
-    worst = compare_crops(s, orc.OracleScene(s), f, rd, content=24)   # 6 fixed + 24 highest-variance windows: 31 M samples of the oracle
-    print("soup 256 spp, configuration %d, BVH depth %d: worst of 30 crops, RMSE vs oracle %.3g" % (st.tune_cfg, dev.info().bvh_max_depth, worst))
+    total, worst = compare_crops(s, orc.OracleScene(s), f, rd, content=24)   # 6 fixed + 24 highest-variance windows: 31 M samples of the oracle
+    print("soup 256 spp, configuration %d, BVH depth %d: RMSE vs oracle over 30 crops %.3g, worst crop %.3g" % (st.tune_cfg, dev.info().bvh_max_depth, total, worst))
 
 
 def test_filtered_bench_frame_matches_oracle_on_crops():

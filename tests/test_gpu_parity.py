@@ -129,18 +129,25 @@ def test_render_matches_oracle_sample_for_sample(cases, dev, ora, name):
     assert abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 20000)
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_replay_mode_reproduces_the_reference_binary_image(cases, dev, name):
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens"]   # round-2 / round-3 scenes of the path integrator
+
+
+@pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
+def test_replay_mode_reproduces_the_reference_binary_image(cases, name):
     """HIP render in MT_REPLAY mode vs the image the REFERENCE BINARY wrote for the same scene file and
     seed (golden fixture) — no oracle in between.  The replay is serial per tile: one decision flipped
     by a device-libm ulp (a hit/miss on an edge, a Russian-roulette draw) shifts the random stream of
     the REST of that tile, which then holds different but equally valid noise.  So the bar is per
     tile: nearly all tiles reproduce the reference to float rounding, and the image as a whole stays
     inside the north-star tolerance when measured over the reproduced tiles."""
-    s = cases[name]
+    # Round 3: the extension set too (hpt_replay_kernel<MATS_FULL>: Oren-Nayar, glass / mirror, mesh emitters, the regular half-angle BRDF,
+    # EWA / trilinear textures with camera-ray differentials, bump mapping, alpha cut-outs, the thin lens, metal.pbrt as shipped under both
+    # environment maps) — round-2 features against the reference binary's images directly, not only through the oracle's two sampler modes.
+    s = cases[name] if name in cases else load_case(name)
     rd = abi.copy_struct(s.render)
+    assert rd.integrator == abi.HPT_INTEGRATOR_PATH
     rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
-    f, st = dev[name].render(s.camera, rd)
+    f, st = hpt.DeviceScene(s).render(s.camera, rd)
     assert st.camera_samples == rd.x_count * rd.y_count * rd.spp and st.bad_samples == 0
     img, ref = film.xyzw_to_rgb(f), load_ref(name)
     good, n, se, cnt = 0, 0, 0.0, 0
@@ -751,8 +758,8 @@ def test_round2_bsdfs_match_oracle(name, material):
 
 
 def test_scope_limits_of_the_extension_are_refused_loudly():
-    """The parity pipelines (MT_REPLAY, wavefront) cover the round-1 feature set: on an extension scene they return HPT_E_UNSUPPORTED
-    instead of rendering something else; so does a direct-lighting recursion deeper than its ray stack is sized for."""
+    """The wavefront pipeline covers the round-1 feature set: on an extension scene it returns HPT_E_UNSUPPORTED instead of rendering
+    something else (MT_REPLAY covers the extension set since round 3); so does a direct-lighting recursion deeper than its ray stack is sized for."""
     s = load_case("spec")
     d = hpt.DeviceScene(s)
     rd = hash_rd(s, seed=1)

@@ -182,6 +182,49 @@ def test_replay_mode_reproduces_reference_image(cases, pairs, name):
     assert film.rmse(img, ref) < 1e-3
 
 
+@pytest.mark.parametrize("name", ["cfg1", "b8", "env", "anim"])
+def test_four_wide_trees_find_the_same_hits(cases, name):
+    """Round 3: the BVH4 (collapse_bvh4, csrc/hpt_bvh.cpp) and its node step (trav_node4, csrc/hpt_device.h) — what the path kernel's
+    lock-step + stealing walk runs on — against the oracle's BVHAccel::Intersect / IntersectP on aggregatetest-style rays: same primitive,
+    t / barycentrics bit-identical; with every stack row taking ordinary entries, with three, and with none (one masked entry per level:
+    the bounded-stack slow path), where the stack never holds more than one entry per level."""
+    s = cases[name]
+    e = emu.EmuScene(s, max_leaf=2)
+    info = e.info()
+    assert info["n_nodes4"] > 0 and info["depth4"] < info["max_depth"] and info["stack_bound4"] <= 3 * info["depth4"]
+    rays = random_rays(s, 60000, seed=5)
+    o = orc.OracleScene(s)
+    ho, po = o.intersect(rays)
+    _, ao = o.intersect(rays, anyhit=True)
+    for cap in (-1, 3, 0):
+        he, pe, deepest = e.intersect4(rays, cap=cap)
+        same = po == pe
+        assert same.mean() > 0.9995 and np.array_equal(ho[same][:, :3], he[same][:, :3])
+        _, ae, _ = e.intersect4(rays, anyhit=True, cap=cap)
+        assert (ao == ae).mean() > 0.9995
+        assert deepest <= (info["stack_bound4"] if cap < 0 else cap + 2 + info["depth4"])
+        if cap == 0:
+            assert deepest <= info["depth4"]
+
+
+@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens"])
+def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
+    """Round 3: the MT_REPLAY sampler source over the FULL material set (Lane<MtReplaySrc, true, MATS_FULL>) — Oren-Nayar, glass / mirror,
+    triangle-mesh emitters, the regular half-angle BRDF, EWA / trilinear image textures with camera-ray differentials, bump mapping, alpha
+    cut-outs, the thin lens, metal.pbrt as shipped under both environment maps — against the images the REFERENCE BINARY wrote for the same
+    scene files: the device state machine consumes the reference's random stream draw for draw on these paths too, so round-2 features are
+    compared with the reference directly, not only through the oracle's two sampler modes."""
+    from tests.util import load_case
+    s = load_case(name)
+    rd = abi.copy_struct(s.render)
+    assert rd.integrator == abi.HPT_INTEGRATOR_PATH
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = emu.EmuScene(s).render(s.camera, rd)
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
+    assert differing_pixels(img, ref) < 1e-3 and film.rmse(img, ref) < 1e-6
+
+
 def test_sample_chunking_above_64_spp(cases, pairs):
     """spp > 64 splits a pixel into several work items (64 samples each) that flush separately:
     same samples, sums regrouped."""

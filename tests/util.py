@@ -244,10 +244,13 @@ def content_windows(frame, k=24, n=CROP):
     return [("content-%d-%d" % (i % gx, i // gx), int(i % gx) * n, int(i // gx) * n) for i in order]
 
 
-def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP, content=0, stats=None):
+def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP, content=0, stats=None, crop_tol=None):
     """frame: the device's full film for `rd`.  Crops: corners, centre, XCD-band border + the `content` highest-variance windows.
-    Returns the worst per-crop RMSE; stats (optional list of 6): the oracle's counters summed over the crops."""
-    worst = 0.0
+    Film weights must be identical in every crop.  The per-pixel RMSE (sqrt(sum d^2 / (3 W H))) is taken over ALL verified
+    pixels together and must stay below `tol`; a single crop may reach crop_tol (default = tol: every crop on its own; the HDR scene passes
+    a looser one — there one camera sample in half a million whose discrete decision flips on an ulp of the device's libm moves a pixel by
+    more than the whole tolerance).  Returns (rmse over all crops, worst crop); stats (optional list of 6): oracle counters summed."""
+    worst, sq, npx = 0.0, 0.0, 0
     import importlib
     film = importlib.import_module("pbrt-v2_amd.film")
     wins = crop_windows(rd.x_count, rd.y_count, n) + (content_windows(frame, content, n) if content else [])
@@ -264,7 +267,11 @@ def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP, content=
         fo = fo[y0 - ay0:y0 - ay0 + n, x0 - ax0:x0 - ax0 + n]
         fd = frame[y0:y0 + n, x0:x0 + n]
         assert np.array_equal(fo[..., 3], fd[..., 3]), "%s: film weights differ" % name
-        err = film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fd))
-        assert err < tol, (name, err)
-        worst = max(worst, err)
-    return worst
+        a, b = film.xyzw_to_rgb(fo).astype(np.float64), film.xyzw_to_rgb(fd).astype(np.float64)
+        d2 = float(((a - b) ** 2).sum())
+        err = (d2 / a.size) ** 0.5
+        assert err < (crop_tol or tol), (name, err)
+        worst, sq, npx = max(worst, err), sq + d2, npx + a.size
+    total = (sq / npx) ** 0.5
+    assert total < tol, total
+    return total, worst
