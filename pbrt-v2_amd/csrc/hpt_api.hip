@@ -513,7 +513,9 @@ template <typename T> struct DevBuf {
 // Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
     const bool inst = s->d.n_instances > 0;
-    const bool steal = cfg >= 5 || a->dl;
+    // (the extension set runs configurations 3 / 4 as 5 / 6: the rows must be those of the kernel that runs — round 2 sized them for the
+    //  plain lock-step walk and the stealing rows overlapped the top of the traversal stacks)
+    const bool steal = path_kernel_effective_cfg(s->mats, cfg) >= 5 || a->dl;
     const int extra = (steal ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);
     a->cap_normal = 1 << 20;
     if (steal && s->stack_bound4 > 0) {
@@ -575,7 +577,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
         for (int cfg = 0; cfg < HPT_N_TUNE_CFG && e == hipSuccess; ++cfg) {
             if (!in_race[cfg]) continue;
             int bpc = 0, vg = 0;
-            if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { if (cfg >= 5) { in_race[cfg] = false; continue; } e = hipErrorUnknown; break; }
+            if (kernel_residency(s, cfg, &a, &bpc, &vg) != 0) { if (path_kernel_effective_cfg(s->mats, cfg) >= 5) { in_race[cfg] = false; continue; } e = hipErrorUnknown; break; }
             int grid = s->n_cus * bpc;
             int64_t max_useful = (a.rp.n_items + HPT_BLOCK - 1) / HPT_BLOCK;
             if ((int64_t)grid > max_useful) grid = (int)(max_useful > 0 ? max_useful : 1);
@@ -658,7 +660,10 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int bpc = 0, vgprs = 0;
     if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
         if (rd->count_work && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the instrumented kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
-        if (cfg >= 5 && !dl) { cfg -= 2; if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown; }   // tree too deep for the stealing rows
+        if (path_kernel_effective_cfg(s->mats, cfg) >= 5 && !dl) {      // tree too deep for the stealing rows: the plain lock-step walk (extension set: free-running)
+            cfg = (s->mats & MATS_EXT) ? 0 : cfg - 2;
+            if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+        }
         else if (dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         else e = hipErrorUnknown;
     }

@@ -524,23 +524,6 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
 
 #define HPT_TRAV_EMPTY ((int32_t)0x80000000)
 
-#ifdef HPT_SLAB_FMA
-// The slab test with one fused multiply-add per plane: t = lo * invd + (-o * invd) instead of (lo - o) * invd — 6 instead of 12 VALU
-// instructions per box for the planes (the walk is VALU-issue bound on the cache-resident scenes).  The product o * invd is rounded before
-// the cancellation, so a plane distance carries an absolute error of up to eps * (|o * invd| + |t|) instead of a relative one; the test
-// stays CONSERVATIVE (a box the ray touches is never rejected — the triangle tests decide the hit, bit-identically to the reference) by
-// widening the exit distance by that bound: pad = 8 eps * max |o_i * invd_i| plus 8 eps relative.  Only the device's own tree is walked
-// with it; which boxes are visited is not part of the parity contract, which hits are found is.
-HPT_FN bool slab_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, float mint, float maxt, f3 invd, f3 oid, float pad, float *tentry) {
-    float tx0 = __builtin_fmaf(lox, invd.x, oid.x), tx1 = __builtin_fmaf(hix, invd.x, oid.x);
-    float ty0 = __builtin_fmaf(loy, invd.y, oid.y), ty1 = __builtin_fmaf(hiy, invd.y, oid.y);
-    float tz0 = __builtin_fmaf(loz, invd.z, oid.z), tz1 = __builtin_fmaf(hiz, invd.z, oid.z);
-    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-    *tentry = tnear;
-    return fmaxf(tnear, mint) <= __builtin_fmaf(fminf(tfar, maxt), 1.000001f, pad);
-}
-#endif
 
 // Resumable traversal: the state of one ray's walk.  trav_begin() runs the quadric pre-test and
 // positions the walk at the root; trav_step() advances it by one interior-node step followed, if
@@ -548,9 +531,6 @@ HPT_FN bool slab_fma(float lox, float loy, float loz, float hix, float hiy, floa
 // against node-XOR-leaf and while-while, profiles/r01_ab.md).  done() when node == HPT_TRAV_EMPTY.
 struct TravState {
     f3 invd;
-#ifdef HPT_SLAB_FMA
-    f3 oid; float pad;     // -o * invd and the error bound of the fused slab test (slab_fma)
-#endif
     bool anyhit;
     int32_t node;
     int sp;
@@ -558,16 +538,6 @@ struct TravState {
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
-// what the fused slab test derives from a ray and its (clamped) inverse direction; a no-op for the plain test
-HPT_FN void trav_prep(TravState &ts, const Ray &ray) {
-#ifdef HPT_SLAB_FMA
-    ts.oid = mk3(-(ray.o.x * ts.invd.x), -(ray.o.y * ts.invd.y), -(ray.o.z * ts.invd.z));
-    ts.pad = 9.5367432e-7f * fmaxf(fmaxf(fabsf(ts.oid.x), fabsf(ts.oid.y)), fabsf(ts.oid.z));      // 8 * 2^-23
-    if (!(ts.pad < 3.0e38f)) ts.pad = 3.0e38f;   // (0 * inf cannot occur: invd is clamped to +-FLT_MAX; o * FLT_MAX may overflow to inf: everything passes)
-#else
-    (void)ts; (void)ray;
-#endif
-}
 HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world) {
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
@@ -584,7 +554,6 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     if (root < 0) ts.node = HPT_TRAV_EMPTY;
     const float big = 3.402823466e+38f;                    // keeps 0 * invd finite (see slab)
     ts.invd = mk3(fminf(fmaxf(1.f / ray.d.x, -big), big), fminf(fmaxf(1.f / ray.d.y, -big), big), fminf(fmaxf(1.f / ray.d.z, -big), big));
-    trav_prep(ts, ray);
 }
 
 // TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:190-195, 246-276): a hit where the mesh's alpha texture evaluates to 0 is no hit
@@ -606,13 +575,8 @@ HPT_FN void trav_node(const f4 *nodes, TravState &ts, const Ray &ray, int32_t *s
     f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (COUNT) cnt->nodes++;
     float t0, t1;
-#ifdef HPT_SLAB_FMA
-    bool h0 = slab_fma(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t0);
-    bool h1 = slab_fma(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t1);
-#else
     bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ray, ts.invd, &t0);
     bool h1 = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ray, ts.invd, &t1);
-#endif
     const int32_t c0 = as_int(n3.x), c1 = as_int(n3.y);
     // near child first, far child stacked — selects instead of a four-way branch
     const bool both = h0 && h1, swap = t1 < t0;
@@ -656,17 +620,10 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
     const f4 a0 = np[0], a1 = np[1], a2 = np[2], cc = np[3], b0 = np[4], b1 = np[5], b2 = np[6];
     if (COUNT) cnt->nodes++;
     float t0, t1, t2, t3;
-#ifdef HPT_SLAB_FMA
-    bool h0 = slab_fma(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t0);
-    bool h1 = slab_fma(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t1);
-    bool h2 = slab_fma(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t2);
-    bool h3 = slab_fma(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, ray.mint, ray.maxt, ts.invd, ts.oid, ts.pad, &t3);
-#else
     bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, ray, ts.invd, &t0);
     bool h1 = slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, ray, ts.invd, &t1);
     bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, ray, ts.invd, &t2);
     bool h3 = slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, ray, ts.invd, &t3);
-#endif
     const int32_t c0 = as_int(cc.x), c1 = as_int(cc.y), c2 = as_int(cc.z), c3 = as_int(cc.w);
     // (an absent child has an inverted infinite box — the min / max slab form reads that as "everything" — so its code decides)
     h0 = h0 && (mask & 1u); h1 = h1 && (mask & 2u) && c1 != HPT_TRAV_EMPTY;

@@ -29,6 +29,10 @@ bool path_kernel_wide_bvh() {
     return false;
 #endif
 }
+int path_kernel_effective_cfg(int mats, int cfg) {
+    if (!(mats & MATS_EXT)) return cfg;
+    return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // HPT_CFG_ALIAS under HPT_LEAN_SET (hpt_kernels_impl.h)
+}
 int path_kernel_cold_rows(int mats, bool dl) {       // must mirror launch_path_kernel's choice of instantiation (below)
     const int set = (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
     return (HPT_PARK_MATS(set) && !dl) ? HPT_COLD_ROWS : 0;

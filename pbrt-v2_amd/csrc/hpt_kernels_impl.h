@@ -182,7 +182,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     bool more_b = TWO && has_ray && has_b;                          // the owner's second ray is still to come
     bool cur_any = anyhit;                                          // kind of the owner's CURRENT ray (the second one is closest-hit)
     if (has_ray) trav_begin(sc, ts, r, anyhit, world_root, true);
-    else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); trav_prep(ts, r); }
+    else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
     HPT_AUX(aux + 4, lane) = -1;
@@ -320,7 +320,6 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         if (take) {
             r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
             ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s; cur_inst = inst_s;
-            trav_prep(ts, r);
             ts.node = node_s; ts.sp = 0; sb = 0;
         }
     }
@@ -402,10 +401,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // lock step + stealing (path integrator): an extension hit waiting for its shading while the wave walks again for the lanes whose
     // rays escaped (PathKernelArgs::retrace_min)
     constexpr bool RETRACE = STEAL && PHASED && !DL;
-#ifdef HPT_MERGE_LIGHT
-    constexpr bool MERGE = STEAL && PHASED;     // shadow and MIS rays of a vertex in ONE traversal phase (traverse_steal, TWO)
-#else
+    // shadow and MIS rays of a vertex in ONE traversal phase (traverse_steal, TWO): same-box A/B (profiles/r03_ab.md) bunny +16 %, metal.pbrt
+    // at 4K +20 %, killeroo +3 %, soup +1 %; HPT_NO_MERGE_LIGHT builds the three-phase cycle of round 2
+#ifdef HPT_NO_MERGE_LIGHT
     constexpr bool MERGE = false;
+#else
+    constexpr bool MERGE = STEAL && PHASED;
 #endif
     constexpr int LAST_PHASE = MERGE ? (int)ST_SHADOW : (int)ST_MIS;
     Hit pend; bool has_pend = false; int retraced = 0;
