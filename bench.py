@@ -562,6 +562,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed film")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only (no killeroo / anim / soup lines, no pbrt_hip end-to-end run)")
     ap.add_argument("--count-work", action="store_true", help="instrumented kernel for the TIMED frames too: report rays / nodes / tris of the timed frame")
+    ap.add_argument("--shard-balance", type=int, default=0, metavar="N",
+                    help="render the N tile shards of the frame one after the other on this one GPU and report their kernel times: the load balance an N-GPU run of the static round-robin sharding would see")
     ap.add_argument("--no-work", action="store_true", help="skip the work counters (device count_work frame, oracle node / triangle counters) and with them the roofline")
     ap.add_argument("--pmc", dest="pmc", action="store_true", default=None, help="collect FETCH_SIZE / WRITE_SIZE / VALU counters of this workload now (rocprofv3 --pmc child runs); default: on for the headline workload of the default run")
     ap.add_argument("--no-pmc", dest="pmc", action="store_false")
@@ -606,6 +608,25 @@ def main():
             comm = None
             _EXCHANGE["fallback"] = err or "hpt_comm_create failed on another rank"
 
+    if args.shard_balance > 1:
+        scene, desc = load_workload(workload, args.spp)
+        dev = hpt.DeviceScene(scene, local)
+        rd = abi.copy_struct(scene.render)
+        dev.tune(scene.camera, rd)
+        film = torch.zeros((rd.y_count, rd.x_count, 4), dtype=torch.float32, device="cuda")
+        ms = []
+        for r in range(args.shard_balance):
+            rd.shard_rank, rd.shard_count = r, args.shard_balance
+            best = min(dev.render_device(scene.camera, rd, film.data_ptr(), torch.cuda.current_stream().cuda_stream).kernel_ms for _ in range(max(1, args.steps)))
+            ms.append(best)
+        rd.shard_rank, rd.shard_count = 0, 1
+        whole = min(dev.render_device(scene.camera, rd, film.data_ptr(), torch.cuda.current_stream().cuda_stream).kernel_ms for _ in range(max(1, args.steps)))
+        print(json.dumps({"workload": desc, "shards": args.shard_balance, "kernel_ms_per_shard": [round(x, 3) for x in ms], "kernel_ms_whole_frame": round(whole, 3),
+                          "balance_mean_over_max": round(float(np.mean(ms)) / max(ms), 4),
+                          "predicted_kernel_speedup": round(whole / max(ms), 3),
+                          "what": "the %d round-robin tile shards of the frame rendered one after the other on ONE GPU (best of %d): what each GPU of an N-GPU run would have to do; "
+                                  "speed-up = whole-frame kernel time / slowest shard (film exchange not included)" % (args.shard_balance, max(1, args.steps))}))
+        return
     args.pmc = want_pmc
     out, scene, flt = measure(args, workload, args.spp, args.steps, args.warmup, world, rank, local, dist, torch, comm)
     args.pmc = False                                     # the counters are collected for the headline workload only
@@ -622,11 +643,13 @@ def main():
                     ref = cpu_baseline_reference(w, sc_w)
                     extras[-1]["cpu_baseline"] = ref or cpu_baseline_port(sc_w)
         else:
-            # strong scaling of the north-star frame: the fixed 256-spp 1M-triangle frame split N ways (BASELINE configs[2])
-            o, _, _ = measure(args, "soup", 0, min(2, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm, strong=True)
-            if rank == 0:
-                extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle") if k in o})
-                extras[-1]["workload"] = "soup (strong scaling: fixed 256-spp frame)"
+            # strong scaling (north_star's ">= 6x at 8 GPUs" is a statement about a FIXED frame): the 256-spp 1M-triangle frame of configs[2],
+            # the north-star target scene (killeroo 64 spp) and configs[3] (anim 128 spp), each split N ways
+            for w, st in (("soup", 2), ("killeroo", 5), ("anim", 3)):
+                o, _, _ = measure(args, w, 0, min(st, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm, strong=True)
+                if rank == 0:
+                    extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle", "roofline") if k in o})
+                    extras[-1]["workload"] = "%s (strong scaling: the fixed %d-spp frame split over %d GPUs)" % (w, DEFAULT_SPP[w], world)
     if rank == 0:
         if extras:
             out["workloads"] = extras

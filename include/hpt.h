@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 6   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights) still load */
+#define HPT_VERSION 7   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights) and 6 (no mesh tangents) still load */
 
 enum {
     HPT_OK = 0,
@@ -99,6 +99,8 @@ enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3 }
  *   P   : nverts*3 floats, WORLD space (the reference transforms at construction, :70-71)
  *   N   : nverts*3 floats, OBJECT space (transformed per hit, trianglemesh.cpp:323-325)
  *   uv  : nverts*2 floats
+ *   S   : nverts*3 floats, OBJECT space: TriangleMesh::s, the explicit tangents "vector S" (version 7; Triangle::GetShadingGeometry takes
+ *         the shading tangent from them instead of dpdu, shapes/trianglemesh.cpp:326-329)
  *   idx : ntris*3 ints
  * All triangles of a mesh share material and area light (GeometricPrimitive::Refine,
  * core/primitive.cpp:147-157). */
@@ -113,6 +115,7 @@ typedef struct hpt_mesh {
     int32_t alpha_tex;           /* 1 + index of the float texture TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:191-195), 0 = none */
     float o2w[16];               /* ObjectToWorld->m    */
     float o2w_inv[16];           /* ObjectToWorld->mInv */
+    int64_t s_off;               /* version 7: TriangleMesh::s in fpool, or -1 */
 } hpt_mesh;
 
 /* One animated instance: TransformedPrimitive(BVHAccel(refined shape), AnimatedTransform)
@@ -348,6 +351,14 @@ typedef struct hpt_filter {
 } hpt_filter;
 int hpt_scene_set_filter(hpt_scene *scene, const hpt_filter *filter);
 
+/* A moving camera: PerspectiveCamera::CameraToWorld as an AnimatedTransform (core/camera.h:49; GenerateRay[Differential] ends with
+ * CameraToWorld(*ray, ray), cameras/perspective.cpp:110,135 -> AnimatedTransform::operator()(Ray), core/transform.cpp:416-442).  The record
+ * type of an animated instance, read as camera-to-world: actually_animated, start_time / end_time (RenderOptions::transformStartTime /
+ * EndTime), T / R / S of the two decomposed end transforms, w2p_m[e] / w2p_minv[e] = the end transforms' m / mInv; bounds unused.  State of
+ * the scene handle for the following renders; NULL = static camera (hpt_camera.camera_to_world, the default).  The camera samples a time
+ * in [shutter_open, shutter_close] whether or not the scene has animated instances. */
+int hpt_scene_set_camera_motion(hpt_scene *scene, const hpt_instance *camera_to_world);
+
 /* ---- multi-GPU (SURVEY.md §8b "gpus", §8e) ------------------------------------------------------------------------------------
  * The path shards with no data-path collective: the scene is replicated per GPU, shard r renders the 32x32 pixel tiles t with
  * t % n == r (shard_rank / shard_count above), and ONE exchange of film data per frame brings the frame to shard 0 — a gather of the
@@ -361,6 +372,7 @@ typedef struct hpt_multi hpt_multi;
 hpt_multi *hpt_multi_create(const hpt_scene_desc *desc, const int *devices, int n_devices);
 void hpt_multi_destroy(hpt_multi *m);
 int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *filter);
+int hpt_multi_set_camera_motion(hpt_multi *m, const hpt_instance *camera_to_world);   /* hpt_scene_set_camera_motion on every shard */
 int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out);     /* the shard's scene handle (hpt_scene_tune, hpt_scene_get_info) */
 int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc *rd, float *film_xyzw_host, hpt_stats *stats);
 

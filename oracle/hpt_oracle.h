@@ -35,6 +35,10 @@ int orc_render(const orc_scene *s, const hpt_camera *cam, const hpt_render_desc 
  * ImageFilm's filter + filterTable, film/image.cpp:41-75. */
 void orc_set_filter(const hpt_filter *f);
 
+/* A moving camera for the following orc_render calls (process-wide; NULL = static): CameraToWorld as an AnimatedTransform in the record
+ * type of an animated instance (include/hpt.h, hpt_scene_set_camera_motion). */
+void orc_set_camera_motion(const hpt_instance *camera_to_world);
+
 /* Function-level entry points with the same array conventions as hpt_test_* (include/hpt.h). */
 int orc_intersect(const orc_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit,
                   int32_t *out_prim);

@@ -36,6 +36,8 @@ def lib():
         L.orc_mt_fill.argtypes = [C.c_uint32, C.c_void_p, C.c_int]
         L.orc_set_filter.argtypes = [C.POINTER(abi.Filter)]
         L.orc_set_filter.restype = None
+        L.orc_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
+        L.orc_set_camera_motion.restype = None
         _lib = L
     return _lib
 
@@ -56,9 +58,11 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, cam, rd, nthreads=0, flt=None):
-        """flt: abi.Filter (ImageFilm's reconstruction filter) or None = box of width 0.5"""
+    def render(self, cam, rd, nthreads=0, flt=None, cam_motion=None):
+        """flt: abi.Filter (ImageFilm's reconstruction filter) or None = box of width 0.5; cam_motion: abi.Instance (the camera's
+        AnimatedTransform, camera to world) or None = static camera"""
         lib().orc_set_filter(C.byref(flt) if flt is not None else None)
+        lib().orc_set_camera_motion(C.byref(cam_motion) if cam_motion is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         rc = lib().orc_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, nthreads,

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 6
+HPT_VERSION = 7
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
@@ -38,12 +38,24 @@ f32, i32, i64, u32, u64 = C.c_float, C.c_int32, C.c_int64, C.c_uint32, C.c_uint6
 M16 = f32 * 16
 
 
+_MESH_V6 = [("p_off", i64), ("n_off", i64), ("uv_off", i64), ("idx_off", i64),
+            ("ntris", i32), ("nverts", i32), ("material", i32), ("arealight", i32),
+            ("reverse_orientation", i32), ("swaps_handedness", i32),
+            ("instance", i32), ("alpha_tex", i32),
+            ("o2w", M16), ("o2w_inv", M16)]
+
+
+class MeshV6(C.Structure):
+    _fields_ = _MESH_V6
+
+
 class Mesh(C.Structure):
-    _fields_ = [("p_off", i64), ("n_off", i64), ("uv_off", i64), ("idx_off", i64),
-                ("ntris", i32), ("nverts", i32), ("material", i32), ("arealight", i32),
-                ("reverse_orientation", i32), ("swaps_handedness", i32),
-                ("instance", i32), ("alpha_tex", i32),
-                ("o2w", M16), ("o2w_inv", M16)]
+    _fields_ = _MESH_V6 + [("s_off", i64)]     # version 7: TriangleMesh::s (explicit tangents), -1 = absent
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        if "s_off" not in kw:
+            self.s_off = -1
 
 
 class Instance(C.Structure):
@@ -108,6 +120,8 @@ def _upgrade(old, new_type):
     if new_type is Light:
         n.set_off = n.set_area_off = -1
         n.set_n = 0
+    if new_type is Mesh:
+        n.s_off = -1
     return n
 
 
@@ -325,12 +339,13 @@ class Scene:
         with _open(path, "rb") as f:
             raw = f.read()
         h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
-        if h.magic != HPT_MAGIC or h.version not in (5, HPT_VERSION):
-            raise ValueError(f"{path}: not an HPTS v5 / v{HPT_VERSION} blob")
+        if h.magic != HPT_MAGIC or h.version not in (5, 6, HPT_VERSION):
+            raise ValueError(f"{path}: not an HPTS v5 / v6 / v{HPT_VERSION} blob")
         v5 = h.version == 5          # round-1 fixtures: smaller material / light records, no texture table
         mat_t, light_t = (MaterialV5, LightV5) if v5 else (Material, Light)
+        mesh_t = MeshV6 if h.version < 7 else Mesh       # versions 5 / 6: mesh records without s_off
         if (h.sizeof_mesh, h.sizeof_quadric, h.sizeof_material, h.sizeof_light, h.sizeof_instance) != \
-                (C.sizeof(Mesh), C.sizeof(Quadric), C.sizeof(mat_t), C.sizeof(light_t), C.sizeof(Instance)):
+                (C.sizeof(mesh_t), C.sizeof(Quadric), C.sizeof(mat_t), C.sizeof(light_t), C.sizeof(Instance)):
             raise ValueError(f"{path}: record sizes differ from this build of the ABI")
         off = C.sizeof(BlobHeader)
 
@@ -341,7 +356,12 @@ class Scene:
             off += nbytes
             return a
         s = Scene()
-        s.meshes = take(Mesh, h.n_meshes)
+        s.meshes = take(mesh_t, h.n_meshes)
+        if mesh_t is MeshV6:
+            up = _arr(Mesh, h.n_meshes)
+            for i in range(h.n_meshes):
+                up[i] = _upgrade(s.meshes[i], Mesh)
+            s.meshes = up
         s.quadrics = take(Quadric, h.n_quadrics)
         s.materials = take(mat_t, h.n_materials)
         s.lights = take(light_t, h.n_lights)

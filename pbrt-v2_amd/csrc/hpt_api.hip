@@ -49,6 +49,7 @@ struct hpt_scene {
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
+    bool cam_animated; hpt_instance cam_xf;        // hpt_scene_set_camera_motion: the camera's AnimatedTransform (camera to world)
     float *dl_stack; size_t dl_stack_floats;       // direct lighting over specular surfaces: the recursion's per-lane ray stacks (grown on demand)
     void *d_film; size_t film_bytes;               // device film of hpt_render (host-film entry point), grown on demand
     void *d_scr; hipEvent_t ev0, ev1;              // per-frame scratch (work-queue heads + counters) and timing events, created once
@@ -118,6 +119,7 @@ static std::string tune_cache_path(const hpt_scene *s, const hpt_camera *cam, co
     else return std::string();
     uint64_t h = s->content_key;
     h = fnv1a(h, cam, sizeof(*cam));
+    if (s->cam_animated) h = fnv1a(h, &s->cam_xf, sizeof(s->cam_xf));
     const int32_t job[12] = {rd->xres, rd->yres, rd->x_start, rd->x_count, rd->y_start, rd->y_count, rd->spp < 64 ? rd->spp : 64, rd->maxdepth,
                              rd->integrator, rd->sampler_mode, (int32_t)(s->d_ftable != nullptr), s->d_ftable ? (int32_t)(s->filter.xwidth * 64.f) * 4096 + (int32_t)(s->filter.ywidth * 64.f) : 0};
     h = fnv1a(h, job, sizeof(job));
@@ -208,6 +210,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->sbuf = nullptr; s->sbuf_floats = 0;
     s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0; s->dl_stack = nullptr; s->dl_stack_floats = 0;
     s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
+    s->cam_animated = false; memset(&s->cam_xf, 0, sizeof(s->cam_xf));
     memset(&s->d, 0, sizeof(s->d));
     memset(&s->info, 0, sizeof(s->info));
     hipDeviceProp_t prop;
@@ -256,7 +259,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.meshes = upload(s, fs.meshes.data(), fs.meshes.size(), &ok);
     s->d.quadrics = upload(s, desc->quadrics, (size_t)desc->n_quadrics, &ok);
     s->d.materials = upload(s, fs.materials.data(), fs.materials.size(), &ok);
-    s->d.lights = upload(s, desc->lights, (size_t)desc->n_lights, &ok);
+    s->d.lights = upload(s, fs.lights.data(), fs.lights.size(), &ok);       // (device copy: guide-table offsets of the infinite lights)
     s->d.fpool = upload(s, fs.fpool.data(), fs.fpool.size(), &ok);
     s->d.ipool = upload(s, fs.ipool.data(), fs.ipool.size(), &ok);
     s->d.textures = upload(s, desc->textures, (size_t)desc->n_textures, &ok);
@@ -290,7 +293,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         if (k == HPT_MAT_MEASURED_REGULAR || (k == HPT_MAT_MATTE && ma.sigma != 0.f)) ext = true;
         for (int t = 0; t < HPT_N_TEXSLOTS; ++t) if (ma.tex[t] >= 0) ext = true;
     }
-    for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0) ext = true;
+    for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0 || desc->meshes[m].s_off >= 0) ext = true;   // (explicit tangents: the extension set's shading geometry)
     for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
     if (ext) s->mats = MATS_FULL;
@@ -327,6 +330,20 @@ extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
     }
     HIP_CHECK_RET(hipMemcpy(d, f->table, sizeof(f->table), hipMemcpyHostToDevice), HPT_E_HIP);
     s->filter = *f; s->d_ftable = d;
+    return HPT_OK;
+}
+
+// PerspectiveCamera::CameraToWorld as an AnimatedTransform (include/hpt.h); state of the scene handle like the filter
+extern "C" int hpt_scene_set_camera_motion(hpt_scene *s, const hpt_instance *c2w) {
+    if (!s) { hpt_set_error("null scene"); return HPT_E_INVALID; }
+    if (!c2w) { s->cam_animated = false; return HPT_OK; }
+    for (int e = 0; e < 2; ++e) {
+        const float *m = c2w->w2p_m[e];
+        for (int i = 0; i < 16; ++i) if (!(m[i] == m[i]) || m[i] > 3.0e38f || m[i] < -3.0e38f) { hpt_set_error("camera motion: transform %d is not finite", e); return HPT_E_INVALID; }
+        if (m[12] != 0.f || m[13] != 0.f || m[14] != 0.f || m[15] != 1.f) { hpt_set_error("camera motion: CameraToWorld is not affine (last row must be 0 0 0 1)"); return HPT_E_UNSUPPORTED; }
+    }
+    if (!(c2w->end_time > c2w->start_time) && c2w->actually_animated) { hpt_set_error("camera motion: end time must follow start time"); return HPT_E_INVALID; }
+    s->cam_xf = *c2w; s->cam_animated = true;
     return HPT_OK;
 }
 
@@ -369,6 +386,8 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->seed = rd->seed;
     rp->bad_counter = nullptr;
     rp->has_motion = 0;
+    rp->cam_animated = 0; memset(&rp->cam_xf, 0, sizeof(rp->cam_xf));
+    if (s && s->cam_animated) { rp->cam_animated = 1; rp->cam_xf = s->cam_xf; }
     rp->integrator = rd->integrator;
     rp->random_sampler = random_sampler ? 1 : 0;
     rp->sampler_kind = stratified ? 2 : random_sampler ? 1 : 0;
@@ -464,7 +483,7 @@ static int render_wavefront(hpt_scene *s, PathKernelArgs &pa, const hpt_render_d
     if (e == hipSuccess) e = hipMemsetAsync(a.state, 0, sizeof(float4) * 10 * (size_t)P, stream);
     if (e == hipSuccess) e = hipMemsetAsync(a.qcount, 0, sizeof(int) * 4, stream);
     int bpc = 1, vgprs = 0;
-    if (e == hipSuccess && wf_trace_occupancy(s->d.n_instances > 0, s->info.bvh_max_depth, &bpc, &vgprs) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess && wf_trace_occupancy(s->d.n_instances > 0 || s->cam_animated, s->info.bvh_max_depth, &bpc, &vgprs) != 0) e = hipErrorUnknown;
     if (bpc < 1) bpc = 1;
     int grid = s->n_cus * bpc;
     int *h_q = nullptr;
@@ -512,7 +531,7 @@ template <typename T> struct DevBuf {
 
 // Resident blocks per CU of configuration `cfg` with this scene's traversal stacks in LDS.
 static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int *bpc, int *vgprs) {
-    const bool inst = s->d.n_instances > 0;
+    const bool inst = s->d.n_instances > 0 || s->cam_animated;     // (a moving camera runs the kernels that carry a time sample)
     // (the extension set runs configurations 3 / 4 as 5 / 6: the rows must be those of the kernel that runs — round 2 sized them for the
     //  plain lock-step walk and the stealing rows overlapped the top of the traversal stacks)
     const bool steal = path_kernel_effective_cfg(s->mats, cfg) >= 5 || a->dl;
@@ -525,7 +544,8 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
         const int room = HPT_MAX_STACK_ROWS - extra;
         int rows = s->stack_bound4 + 1;
         if (rows > room) { rows = room; a->cap_normal = room - 2 - s->depth4; }
-        if (a->cap_normal < 6) return -1;                            // (a very deep tree: the caller falls back to the plain lock-step walk)
+        if (const char *e = getenv("HPT_BVH4_CAP")) { const int c = atoi(e); if (c >= 0 && c + 2 + s->depth4 <= rows) a->cap_normal = c; }   // (tests: exercise the masked entries)
+        else if (a->cap_normal < 6) return -1;                       // (a very deep tree: the caller falls back to the plain lock-step walk)
         if (rows < 12 && (s->mats & MATS_MEASURED)) rows = 12;       // the query queue of wave_eval_queries
         if (rows < 8) rows = 8;
         a->stack_entries = rows + extra;
@@ -562,7 +582,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipError_t e = hipEventCreate(&ev0);
     if (e == hipSuccess) e = hipEventCreate(&ev1);
-    const bool inst = s->d.n_instances > 0;
+    const bool inst = s->d.n_instances > 0 || s->cam_animated;     // (a moving camera runs the kernels that carry a time sample)
     float t[HPT_N_TUNE_CFG];
     bool in_race[HPT_N_TUNE_CFG];
     for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1); }  // early exit is not compiled for instanced scenes
@@ -620,7 +640,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (rc != HPT_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
     a.sc = s->d;
-    a.rp.has_motion = s->d.n_instances > 0 ? 1 : 0;
+    a.rp.has_motion = (s->d.n_instances > 0 || s->cam_animated) ? 1 : 0;
     a.film = (float *)d_film;
     typedef RenderScratch Scratch;
     Scratch *d_scr = (Scratch *)s->d_scr;                // (one render at a time per scene handle)

@@ -47,6 +47,11 @@ struct hpt_light_v5 {
     float marg_int; int32_t nsamples; float l2w[16]; float l2w_inv[16];
 };
 
+struct hpt_mesh_v6 {   // versions 5 and 6: hpt_mesh without s_off
+    int64_t p_off, n_off, uv_off, idx_off; int32_t ntris, nverts, material, arealight, reverse_orientation, swaps_handedness, instance, alpha_tex;
+    float o2w[16]; float o2w_inv[16];
+};
+
 struct hpt_blob {
     hpt_blob_header h;
     hpt_scene_desc desc;
@@ -113,6 +118,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
             me.p_off > d->n_f || 3ll * me.nverts > d->n_f - me.p_off || me.idx_off > d->n_i || 3ll * me.ntris > d->n_i - me.idx_off ||
             (me.n_off >= 0 && (me.n_off > d->n_f || 3ll * me.nverts > d->n_f - me.n_off)) ||
             (me.uv_off >= 0 && (me.uv_off > d->n_f || 2ll * me.nverts > d->n_f - me.uv_off)) ||
+            me.s_off < -1 || (me.s_off >= 0 && (me.s_off > d->n_f || 3ll * me.nverts > d->n_f - me.s_off)) ||
             me.material < 0 || me.material >= d->n_materials || me.arealight < -1 || me.arealight >= d->n_lights ||
             me.instance < -1 || me.instance >= d->n_instances) {
             hpt_set_error("mesh %d: offsets/indices out of range", m);
@@ -295,15 +301,17 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     const long fsize = ftell(f);
     rewind(f);
     hpt_blob *b = (hpt_blob *)calloc(1, sizeof(hpt_blob));
-    if (fsize < (long)sizeof(b->h) || fread(&b->h, sizeof(b->h), 1, f) != 1 || b->h.magic != HPT_MAGIC || (b->h.version != 5 && b->h.version != HPT_VERSION)) {
-        hpt_set_error("%s: not an HPTS v5 / v%d blob", path, HPT_VERSION);
+    if (fsize < (long)sizeof(b->h) || fread(&b->h, sizeof(b->h), 1, f) != 1 || b->h.magic != HPT_MAGIC || (b->h.version != 5 && b->h.version != 6 && b->h.version != HPT_VERSION)) {
+        hpt_set_error("%s: not an HPTS v5 / v6 / v%d blob", path, HPT_VERSION);
         fclose(f); free(b); return NULL;
     }
     const hpt_blob_header &h = b->h;
     const bool v5 = h.version == 5;
     const size_t sz_mat = v5 ? sizeof(hpt_material_v5) : sizeof(hpt_material), sz_light = v5 ? sizeof(hpt_light_v5) : sizeof(hpt_light);
     const int64_t n_tex = v5 ? 0 : (int64_t)h.n_textures;
-    if (h.sizeof_mesh != sizeof(hpt_mesh) || h.sizeof_quadric != sizeof(hpt_quadric) || h.sizeof_material != sz_mat ||
+    const bool mesh6 = h.version < 7;                                    // meshes without tangents: records grow by s_off = -1
+    const size_t sz_mesh = mesh6 ? sizeof(hpt_mesh_v6) : sizeof(hpt_mesh);
+    if (h.sizeof_mesh != sz_mesh || h.sizeof_quadric != sizeof(hpt_quadric) || h.sizeof_material != sz_mat ||
         h.sizeof_light != sz_light || h.sizeof_instance != sizeof(hpt_instance)) {
         hpt_set_error("%s: record sizes differ from this build of the ABI", path);
         fclose(f); free(b); return NULL;
@@ -311,7 +319,7 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     // payload size with overflow checks; it must be exactly what is left of the file
     uint64_t bytes = 0;
     const uint64_t limit = (uint64_t)fsize - sizeof(b->h);
-    bool ok = add_bytes(&bytes, sizeof(hpt_mesh), h.n_meshes, limit) && add_bytes(&bytes, sizeof(hpt_quadric), h.n_quadrics, limit) &&
+    bool ok = add_bytes(&bytes, sz_mesh, h.n_meshes, limit) && add_bytes(&bytes, sizeof(hpt_quadric), h.n_quadrics, limit) &&
               add_bytes(&bytes, sz_mat, h.n_materials, limit) && add_bytes(&bytes, sz_light, h.n_lights, limit) &&
               add_bytes(&bytes, sizeof(hpt_instance), h.n_instances, limit) && add_bytes(&bytes, sizeof(hpt_texture), n_tex, limit) &&
               add_bytes(&bytes, sizeof(float), h.n_f, limit) && add_bytes(&bytes, sizeof(int32_t), h.n_i, limit);
@@ -320,7 +328,8 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
         fclose(f); free(b); return NULL;
     }
     // version 5: the material / light records grow to today's layout (new fields at their "absent" values)
-    const size_t extra = v5 ? (sizeof(hpt_material) - sz_mat) * (size_t)h.n_materials + (sizeof(hpt_light) - sz_light) * (size_t)h.n_lights : 0;
+    const size_t extra = (v5 ? (sizeof(hpt_material) - sz_mat) * (size_t)h.n_materials + (sizeof(hpt_light) - sz_light) * (size_t)h.n_lights : 0) +
+                         (sizeof(hpt_mesh) - sz_mesh) * (size_t)h.n_meshes;
     b->storage = malloc((size_t)bytes + extra + 1);
     std::vector<char> raw((size_t)bytes + 1);
     if (!b->storage || fread(raw.data(), 1, (size_t)bytes, f) != (size_t)bytes) {
@@ -331,7 +340,12 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     const char *src = raw.data();
     char *p = (char *)b->storage;
     #define TAKE(field, T, n) do { b->desc.field = (const T *)p; memcpy(p, src, sizeof(T) * (size_t)(n)); p += sizeof(T) * (size_t)(n); src += sizeof(T) * (size_t)(n); } while (0)
-    TAKE(meshes, hpt_mesh, h.n_meshes);
+    if (!mesh6) TAKE(meshes, hpt_mesh, h.n_meshes);
+    else {
+        hpt_mesh *mo = (hpt_mesh *)p; b->desc.meshes = mo;
+        for (int i = 0; i < h.n_meshes; ++i) { memcpy(&mo[i], src + sizeof(hpt_mesh_v6) * (size_t)i, sizeof(hpt_mesh_v6)); mo[i].s_off = -1; }
+        p += sizeof(hpt_mesh) * (size_t)h.n_meshes; src += sizeof(hpt_mesh_v6) * (size_t)h.n_meshes;
+    }
     TAKE(quadrics, hpt_quadric, h.n_quadrics);
     if (!v5) { TAKE(materials, hpt_material, h.n_materials); TAKE(lights, hpt_light, h.n_lights); }
     else {

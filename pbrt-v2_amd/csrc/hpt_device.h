@@ -266,6 +266,8 @@ struct DMesh {
     float o2w_inv[12];              // rows 0..2 of ObjectToWorld->mInv (for normals)
     int64_t p_off;                  // vertex positions in fpool (area-light sampling addresses triangles by (mesh, triangle))
     int32_t flip_ro, pad3;          // Shape::ReverseOrientation alone (Triangle::Sample flips its normal by it, trianglemesh.cpp:455)
+    int64_t s_off;                  // TriangleMesh::s (explicit tangents, object space) in fpool, -1 = absent
+    float o2w[12];                  // rows 0..2 of ObjectToWorld->m (carries the tangents to world space)
 };
 #define HPT_TRI_ALPHA_BIT 0x40000000   /* set in a triangle record's mesh word when its mesh has an alpha texture */
 #define HPT_TRI_MESH_MASK 0x3fffffff
@@ -1722,25 +1724,37 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
         *arealight = me.arealight;
         mat = &sc.materials[me.material];
         dgs = dg;
-        if (me.n_off >= 0) {
+        if (me.n_off >= 0 || me.s_off >= 0) {               // Triangle::GetShadingGeometry (trianglemesh.cpp:290-364): per-vertex normals and / or tangents
             float A00 = uv[1][0] - uv[0][0], A01 = uv[2][0] - uv[0][0], A10 = uv[1][1] - uv[0][1], A11 = uv[2][1] - uv[0][1];
             float bb0, bb1 = 0.f, bb2 = 0.f;
             if (!solve2x2(A00, A01, A10, A11, dg.u - uv[0][0], dg.v - uv[0][1], &bb1, &bb2)) bb0 = bb1 = bb2 = 1.f / 3.f;
             else bb0 = 1.f - bb1 - bb2;
-            const float *N = sc.fpool + me.n_off;
-            const f3 n0 = mk3(N[3 * v0], N[3 * v0 + 1], N[3 * v0 + 2]);
-            const f3 n1 = mk3(N[3 * v1], N[3 * v1 + 1], N[3 * v1 + 2]);
-            const f3 n2 = mk3(N[3 * v2], N[3 * v2 + 1], N[3 * v2 + 2]);
-            const f3 nsum = (n0 * bb0 + n1 * bb1) + n2 * bb2;
             float minv[12];
             for (int k = 0; k < 12; ++k) minv[k] = inInstance ? w2p.m.m[k] : me.o2w_inv[k];
-            const f3 ns = normalize(xf_normal(minv, nsum));
-            f3 ss = normalize(dg.dpdu);
+            f3 n0 = S(0.f), n1 = S(0.f), n2 = S(0.f);
+            f3 ns = dg.nn;
+            if (me.n_off >= 0) {
+                const float *N = sc.fpool + me.n_off;
+                n0 = mk3(N[3 * v0], N[3 * v0 + 1], N[3 * v0 + 2]);
+                n1 = mk3(N[3 * v1], N[3 * v1 + 1], N[3 * v1 + 2]);
+                n2 = mk3(N[3 * v2], N[3 * v2 + 1], N[3 * v2 + 2]);
+                const f3 nsum = (n0 * bb0 + n1 * bb1) + n2 * bb2;
+                ns = normalize(xf_normal(minv, nsum));
+            }
+            f3 ss;
+            if (me.s_off >= 0) {                            // explicit tangents "S": ss = Normalize(obj2world(b0 s0 + b1 s1 + b2 s2)), :326-329
+                const float *Sv = sc.fpool + me.s_off;
+                const f3 ssum = (mk3(Sv[3 * v0], Sv[3 * v0 + 1], Sv[3 * v0 + 2]) * bb0 + mk3(Sv[3 * v1], Sv[3 * v1 + 1], Sv[3 * v1 + 2]) * bb1)
+                                + mk3(Sv[3 * v2], Sv[3 * v2 + 1], Sv[3 * v2 + 2]) * bb2;
+                float mfw[12];
+                for (int k = 0; k < 12; ++k) mfw[k] = inInstance ? w2p.minv.m[k] : me.o2w[k];
+                ss = normalize(xf_vec(mfw, ssum));
+            } else ss = normalize(dg.dpdu);
             f3 ts = cross(ss, ns);
             if (len2(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
             else coordinate_system(ns, &ss, &ts);
             f3 dndu = S(0.f), dndv = S(0.f);
-            if (determinant != 0.f) {
+            if (determinant != 0.f && me.n_off >= 0) {
                 const float invdet = 1.f / determinant;
                 const f3 dn1 = n0 - n2, dn2 = n1 - n2;
                 dndu = (dn1 * dv2 - dn2 * dv1) * invdet;
@@ -1820,8 +1834,17 @@ HPT_FN f3 all_lights_Le(const DScene &sc, f3 d) {
     for (int i = 0; i < sc.n_lights; ++i) L = L + light_Le(sc, sc.lights[i], d);
     return L;
 }
-HPT_FN float dist1d_sample(const float *func, const float *cdf, float funcInt, int count, float u, float *pdf, int *off) {
+// guide (optional, hpt_flatten.cpp): count + 1 ints, guide[k] = upper_bound(cdf, k / count) - 1.  With b = floor(u count): (b - 1) / count <= u <
+// (b + 2) / count whatever the rounding of u * count, so cdf[guide[b - 1]] <= u and the first entry above u is at most guide[b + 2] + 1: the
+// search runs over that handful of entries and returns the index std::upper_bound returns over the whole array (the cdf is non-decreasing).
+HPT_FN float dist1d_sample(const float *func, const float *cdf, float funcInt, int count, float u, float *pdf, int *off, const int32_t *guide = nullptr) {
     int lo = 0, hi = count + 1; // std::upper_bound(cdf, cdf+count+1, u) (montecarlo.h:82)
+    if (guide) {
+        int b = (int)(u * (float)count);
+        b = b < 0 ? 0 : b > count ? count : b;
+        lo = guide[b > 0 ? b - 1 : 0];
+        hi = guide[b + 2 < count ? b + 2 : count] + 1;
+    }
     while (lo < hi) { int mid = (lo + hi) / 2; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
     int offset = lo - 1; if (offset < 0) offset = 0;
     if (off) *off = offset;
@@ -2000,8 +2023,10 @@ HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float
     const float *cf = sc.fpool + l.cond_func_off, *cc = sc.fpool + l.cond_cdf_off, *ci = sc.fpool + l.cond_int_off;
     const float *mf = sc.fpool + l.marg_func_off, *mc = sc.fpool + l.marg_cdf_off;
     float uv[2], pdfs[2]; int v;
-    uv[1] = dist1d_sample(mf, mc, l.marg_int, l.env_h, u1, &pdfs[1], &v);
-    uv[0] = dist1d_sample(cf + (int64_t)v * l.env_w, cc + (int64_t)v * (l.env_w + 1), ci[v], l.env_w, u0, &pdfs[0], nullptr);
+    const int32_t *gm = l.pad > 0 ? sc.ipool + (l.pad - 1) : nullptr;          // guide tables: marginal, then one per row (hpt_flatten.cpp)
+    uv[1] = dist1d_sample(mf, mc, l.marg_int, l.env_h, u1, &pdfs[1], &v, gm);
+    uv[0] = dist1d_sample(cf + (int64_t)v * l.env_w, cc + (int64_t)v * (l.env_w + 1), ci[v], l.env_w, u0, &pdfs[0], nullptr,
+                          gm ? gm + (l.env_h + 1) + (int64_t)v * (l.env_w + 1) : nullptr);
     float mapPdf = pdfs[0] * pdfs[1];
     if (mapPdf == 0.f) { *pdf = 0.f; *wi = mk3(0, 0, 1); return S(0.f); }
     float theta = uv[1] * HPT_PI, phi = uv[0] * 2.f * HPT_PI;
@@ -2019,7 +2044,10 @@ HPT_FN float power_heuristic(int nf, float fPdf, int ng, float gPdf) { // montec
 }
 
 // ---- camera (cameras/perspective.cpp:81-138) --------------------------------------------------------
-HPT_FN void camera_ray(const hpt_camera &cam, float imageX, float imageY, float lensU, float lensV, Ray *ray) {
+// motion (a moving camera, hpt_scene_set_camera_motion): CameraToWorld is an AnimatedTransform — AnimatedTransform::operator()(Ray)
+// (core/transform.cpp:416-427): the start transform up to startTime, the end transform from endTime on, the interpolated
+// Translate * Rotate * Scale in between (anim_interpolate: the reference's matrix products term for term)
+HPT_FN void camera_ray(const hpt_camera &cam, float imageX, float imageY, float lensU, float lensV, Ray *ray, const hpt_instance *motion = nullptr, float time = 0.f) {
     f3 Pcamera = xf_point(cam.raster_to_camera, mk3(imageX, imageY, 0));
     f3 dir = normalize(Pcamera);
     ray->o = mk3(0, 0, 0); ray->d = dir; ray->mint = 0.f; ray->maxt = HPT_INF;
@@ -2032,15 +2060,16 @@ HPT_FN void camera_ray(const hpt_camera &cam, float imageX, float imageY, float 
         ray->o = mk3(lu, lv, 0.f);
         ray->d = normalize(Pfocus - ray->o);
     }
+    if (motion) {
+        const A34 m = anim_interpolate(*motion, time, false).m;
+        ray->o = xf_point_affine(m.m, ray->o); ray->d = xf_vec(m.m, ray->d);
+        return;
+    }
     ray->o = xf_point(cam.camera_to_world, ray->o);
     ray->d = xf_vec(cam.camera_to_world, ray->d);
 }
-
-// Ray differentials of a camera ray (cameras/perspective.cpp:105-131) after ray.ScaleDifferentials(1 / sqrt(spp))
-// (renderers/samplerrenderer.cpp:190, core/geometry.h:370-375).  dxc / dyc: PerspectiveCamera::dxCamera, dyCamera (ctor, :46-48);
-// `ray` is the world-space camera ray camera_ray() made from the same sample.
 HPT_FN void camera_ray_differentials(const hpt_camera &cam, f3 dxc, f3 dyc, float scale, float imageX, float imageY, float lensU, float lensV,
-                                     const Ray &ray, RayDiff *rd) {
+                                     const Ray &ray, RayDiff *rd, const hpt_instance *motion = nullptr, float time = 0.f) {
     const f3 Pcamera = xf_point(cam.raster_to_camera, mk3(imageX, imageY, 0));
     f3 rxo = S(0.f), ryo = S(0.f), rxd, ryd;
     if (cam.lens_radius > 0.f) {
@@ -2061,8 +2090,13 @@ HPT_FN void camera_ray_differentials(const hpt_camera &cam, f3 dxc, f3 dyc, floa
         rxd = normalize(Pcamera + dxc);
         ryd = normalize(Pcamera + dyc);
     }
-    rxo = xf_point(cam.camera_to_world, rxo); ryo = xf_point(cam.camera_to_world, ryo);
-    rxd = xf_vec(cam.camera_to_world, rxd); ryd = xf_vec(cam.camera_to_world, ryd);
+    if (motion) {            // AnimatedTransform::operator()(RayDifferential), core/transform.cpp:430-442
+        const A34 m = anim_interpolate(*motion, time, false).m;
+        rxo = xf_point_affine(m.m, rxo); ryo = xf_point_affine(m.m, ryo); rxd = xf_vec(m.m, rxd); ryd = xf_vec(m.m, ryd);
+    } else {
+        rxo = xf_point(cam.camera_to_world, rxo); ryo = xf_point(cam.camera_to_world, ryo);
+        rxd = xf_vec(cam.camera_to_world, rxd); ryd = xf_vec(cam.camera_to_world, ryd);
+    }
     rd->has = true;
     rd->rxo = ray.o + (rxo - ray.o) * scale;
     rd->ryo = ray.o + (ryo - ray.o) * scale;

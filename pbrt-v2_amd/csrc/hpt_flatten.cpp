@@ -50,7 +50,8 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         dm.flip = me.reverse_orientation ^ me.swaps_handedness;
         dm.instance = me.instance; dm.alpha_tex = me.alpha_tex;
         dm.p_off = me.p_off; dm.flip_ro = me.reverse_orientation; dm.pad3 = 0;
-        for (int k = 0; k < 12; ++k) dm.o2w_inv[k] = me.o2w_inv[k];
+        for (int k = 0; k < 12; ++k) { dm.o2w_inv[k] = me.o2w_inv[k]; dm.o2w[k] = me.o2w[k]; }
+        dm.s_off = me.s_off;
         const float *P = desc->fpool + me.p_off;
         const int32_t *idx = desc->ipool + me.idx_off;
         for (int t = 0; t < me.ntris; ++t) {
@@ -189,6 +190,25 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
                 mb += desc->meshes[m].ntris;
             }
         }
+    }
+    // ---- Distribution2D guide tables of the infinite lights (a 1024 x 512 map: ten + nine dependent loads per light sample without them) ----
+    out->lights.assign(desc->lights, desc->lights + desc->n_lights);
+    for (int l = 0; l < desc->n_lights; ++l) {
+        hpt_light &li = out->lights[(size_t)l];
+        li.pad = 0;
+        if (li.kind != HPT_LIGHT_INFINITE || (int64_t)li.env_w * li.env_h < 64) continue;
+        const int w = li.env_w, h = li.env_h;
+        auto guide = [&](const float *cdf, int n) {            // n + 1 ints
+            int i = 0;                                         // first index with cdf[i] > k / n, non-decreasing in k
+            for (int k = 0; k <= n; ++k) {
+                const float x = (float)k / (float)n;
+                while (i <= n && !(cdf[i] > x)) ++i;
+                out->ipool.push_back(k == n ? n : (i > 0 ? i - 1 : 0));
+            }
+        };
+        li.pad = 1 + (int32_t)out->ipool.size();
+        guide(desc->fpool + li.marg_cdf_off, h);
+        for (int v = 0; v < h; ++v) guide(desc->fpool + li.cond_cdf_off + (int64_t)v * (w + 1), w);
     }
     // ---- MIPMap::weightLut (core/mipmap.h:192-200) with the HOST's expf: the table the reference's lookups use -----------------------
     while (out->fpool.size() % 4) out->fpool.push_back(0.f);

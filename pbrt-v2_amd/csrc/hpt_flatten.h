@@ -30,6 +30,10 @@ struct FlatScene {
     std::vector<int32_t> ipool;       // device copy of the int pool: shape sets of area lights rewritten to (mesh, triangle in mesh)
     int64_t ewa_lut_off = 0;          // MIPMap::weightLut in fpool
     std::vector<hpt_material> materials;
+    // device copy of the light table: an infinite light's `pad` = 1 + offset in ipool of its Distribution2D guide tables (0: none) — per
+    // CDF of n + 1 entries, n + 1 ints g[k] = upper_bound(cdf, k / n) - 1 (g[n] = n): the inversion of a sample value starts its binary
+    // search between g[b - 1] and g[b + 2] + 1, b = floor(u n), instead of over the whole array (hpt_device.h, dist1d_sample)
+    std::vector<hpt_light> lights;
     int64_t n_tris = 0;
     int max_depth = 0;
     bool has_measured = false;        // some material is a measured (IrregIsotropic) BRDF

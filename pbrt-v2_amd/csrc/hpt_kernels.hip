@@ -492,7 +492,7 @@ int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds,
     }
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {
-    const bool inst = a.sc.n_instances > 0;
+    const bool inst = a.sc.n_instances > 0 || a.rp.cam_animated != 0;   // (a moving camera: the kernels that carry a time sample)
     switch (pick_variant(mats)) {
         case 0: return inst ? launch_path_basic_i(a, grid_blocks, count, cfg, stream) : launch_path_basic(a, grid_blocks, count, cfg, stream);
         case 1: return inst ? launch_path_measured_i(a, grid_blocks, count, cfg, stream) : launch_path_measured(a, grid_blocks, count, cfg, stream);

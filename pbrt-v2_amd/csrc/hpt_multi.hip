@@ -271,6 +271,12 @@ extern "C" int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *f) {
     return HPT_OK;
 }
 
+extern "C" int hpt_multi_set_camera_motion(hpt_multi *m, const hpt_instance *c2w) {
+    if (!m) { hpt_set_error("null handle"); return HPT_E_INVALID; }
+    for (int i = 0; i < m->n; ++i) { int rc = hpt_scene_set_camera_motion(m->scenes[(size_t)i], c2w); if (rc != HPT_OK) return rc; }
+    return HPT_OK;
+}
+
 extern "C" int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out) {
     if (!m || !out || shard < 0 || shard >= m->n) { hpt_set_error("bad shard"); return HPT_E_INVALID; }
     *out = m->scenes[(size_t)shard];

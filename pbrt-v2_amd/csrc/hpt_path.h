@@ -42,7 +42,9 @@ struct RenderParams {
     uint32_t seed;
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
-    int32_t has_motion;        // scene has animated instances: rays carry a time sample
+    int32_t has_motion;        // scene has animated instances or a moving camera: rays carry a time sample
+    int32_t cam_animated;      // cam_xf holds the camera's AnimatedTransform (hpt_scene_set_camera_motion); 0: static, cam.camera_to_world
+    hpt_instance cam_xf;       // CameraToWorld at both ends, decomposed (the record type of an animated instance)
     int32_t integrator;        // HPT_INTEGRATOR_*
     int32_t random_sampler;    // HPT_SAMPLER_RANDOM_HASH / STRATIFIED_HASH: any spp, light sample counts not rounded
     uint32_t sampler_w;        // LdHash::w of this job: spp - 1 (low discrepancy), HPT_RANDOM_W, HPT_STRAT_W
@@ -275,9 +277,9 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         float imgx = px + a, imgy = py + b; // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
         float lu = 0.f, lv = 0.f;
         if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
-        camera_ray(rp.cam, imgx, imgy, lu, lv, &ray);
         time = 0.f;
         if (INST && rp.has_motion) { float t = smp.time01(rp); time = (1.f - t) * rp.cam.shutter_open + t * rp.cam.shutter_close; } // montecarlo.cpp:235
+        camera_ray(rp.cam, imgx, imgy, lu, lv, &ray, (INST && rp.cam_animated) ? &rp.cam_xf : nullptr, time);   // (a moving camera: perspective.cpp:135)
         cold.setL(S(0.f)); cold.setBeta(S(1.f)); bounce = 0; specular = false; depth = 0; nsp = 0;
         stage = ST_EXTEND;
     }
@@ -388,7 +390,8 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             float ia, ib, lu = 0.f, lv = 0.f;
             smp.image(rp, &ia, &ib);
             if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
-            camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, r, rd);
+            camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, r, rd,
+                                     (INST && rp.cam_animated) ? &rp.cam_xf : nullptr, time);
         }
     }
     // A node of the direct-lighting recursion is finished (all its light samples taken, or its ray escaped): spawn its specular rays,

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(HPT_BLOCK, HPT_WF_TRACE_WAVES) void wf_trace_kernel
 template <int MATS>
 static hipError_t launch_advance_m(const WfArgs &a, bool count, hipStream_t s) {
     int grid = (int)(a.P / HPT_BLOCK);
-    const bool inst = a.sc.n_instances > 0;
+    const bool inst = a.sc.n_instances > 0 || a.rp.cam_animated != 0;   // (a moving camera: the kernels that carry a time sample)
     if (count && inst) hipLaunchKernelGGL((wf_advance_kernel<true, true, MATS>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
     else if (count) hipLaunchKernelGGL((wf_advance_kernel<true, false, MATS>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
     else if (inst) hipLaunchKernelGGL((wf_advance_kernel<false, true, MATS>), dim3(grid), dim3(HPT_BLOCK), 0, s, a);
@@ -202,7 +202,7 @@ hipError_t wf_launch_advance(int mats, const WfArgs &a, bool count, hipStream_t 
     return launch_advance_m<MATS_ALL>(a, count, s);
 }
 hipError_t wf_launch_trace(const WfArgs &a, int grid, bool count, int bvh_depth, hipStream_t s) {
-    const bool inst = a.sc.n_instances > 0;
+    const bool inst = a.sc.n_instances > 0 || a.rp.cam_animated != 0;   // (a moving camera: the kernels that carry a time sample)
     const size_t lds = fixed_stack_bytes(bvh_depth);
     if (count && inst) hipLaunchKernelGGL((wf_trace_kernel<true, true>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);
     else if (count) hipLaunchKernelGGL((wf_trace_kernel<true, false>), dim3(grid), dim3(HPT_BLOCK), lds, s, a);

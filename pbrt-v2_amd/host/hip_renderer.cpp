@@ -274,8 +274,6 @@ struct Flattener {
     void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp, int instance = -1) {
         const TriangleMesh *mesh = tri->mesh.GetPtr();
         if (meshIndex.find(mesh) != meshIndex.end()) return;
-        if (mesh->s)
-            Severe("hip renderer: meshes with explicit tangents \"S\" are outside the hot-path scope");
         if (gp->areaLight && instance >= 0)
             Severe("hip renderer: emitting meshes inside animated instances are outside the hot-path scope");
         hpt_mesh r;
@@ -285,6 +283,7 @@ struct Flattener {
         r.p_off = PushF(&mesh->p[0].x, 3 * (size_t)mesh->nverts);
         r.n_off = mesh->n ? PushF(&mesh->n[0].x, 3 * (size_t)mesh->nverts) : -1;
         r.uv_off = mesh->uvs ? PushF(mesh->uvs, 2 * (size_t)mesh->nverts) : -1;
+        r.s_off = mesh->s ? PushF(&mesh->s[0].x, 3 * (size_t)mesh->nverts) : -1;     // "vector S": explicit tangents (trianglemesh.cpp:326-329)
         r.idx_off = PushI(mesh->vertexIndex, 3 * (size_t)mesh->ntris);
         r.material = AddMaterial(gp->material.GetPtr());
         r.arealight = LightOf(gp->areaLight);
@@ -327,22 +326,26 @@ struct Flattener {
     }
 
     // TransformedPrimitive over BVHAccel(refined shape) (core/api.cpp:1012-1044)
+    // An AnimatedTransform as the library's record: both end transforms and their decomposition (core/transform.cpp:345-369), read in place
+    static void FillAnimated(const AnimatedTransform &at, hpt_instance *r) {
+        memset(r, 0, sizeof(*r));
+        r->actually_animated = at.actuallyAnimated;
+        r->start_time = at.startTime; r->end_time = at.endTime;
+        for (int k = 0; k < 2; ++k) {
+            r->T[k][0] = at.T[k].x; r->T[k][1] = at.T[k].y; r->T[k][2] = at.T[k].z;
+            r->R[k][0] = at.R[k].v.x; r->R[k][1] = at.R[k].v.y; r->R[k][2] = at.R[k].v.z; r->R[k][3] = at.R[k].w;
+            CopyM(at.S[k], r->S[k]);
+            const Transform *t = k == 0 ? at.startTransform : at.endTransform;
+            CopyM(t->m, r->w2p_m[k]); CopyM(t->mInv, r->w2p_minv[k]);
+        }
+    }
     void AddInstance(const TransformedPrimitive *tp) {
         const AnimatedTransform &at = tp->WorldToPrimitive;
         hpt_instance r;
-        memset(&r, 0, sizeof(r));
-        r.actually_animated = at.actuallyAnimated;
-        r.start_time = at.startTime; r.end_time = at.endTime;
+        FillAnimated(at, &r);
         BBox wb = tp->WorldBound();
         r.bounds[0] = wb.pMin.x; r.bounds[1] = wb.pMin.y; r.bounds[2] = wb.pMin.z;
         r.bounds[3] = wb.pMax.x; r.bounds[4] = wb.pMax.y; r.bounds[5] = wb.pMax.z;
-        for (int k = 0; k < 2; ++k) {
-            r.T[k][0] = at.T[k].x; r.T[k][1] = at.T[k].y; r.T[k][2] = at.T[k].z;
-            r.R[k][0] = at.R[k].v.x; r.R[k][1] = at.R[k].v.y; r.R[k][2] = at.R[k].v.z; r.R[k][3] = at.R[k].w;
-            CopyM(at.S[k], r.S[k]);
-            const Transform *t = k == 0 ? at.startTransform : at.endTransform;
-            CopyM(t->m, r.w2p_m[k]); CopyM(t->mInv, r.w2p_minv[k]);
-        }
         int idx = (int)instances.size();
         instances.push_back(r);
         std::vector<const Primitive *> todo;
@@ -548,8 +551,6 @@ void HipPathRenderer::Render(const Scene *scene) {
     // --- what the device path replaces must be exactly what pbrt was asked to run ---------
     const PerspectiveCamera *pc = dynamic_cast<const PerspectiveCamera *>(camera);
     if (!pc) Severe("hip renderer: Camera must be \"perspective\"");
-    if (pc->CameraToWorld.actuallyAnimated)
-        Severe("hip renderer: animated cameras are outside the hot-path scope");
     ImageFilm *film = dynamic_cast<ImageFilm *>(camera->film);
     if (!film) Severe("hip renderer: Film must be \"image\"");
     // PixelFilter: any Filter plugin.  The device looks weights up in ImageFilm's own 16x16 table (film/image.cpp:56-68),
@@ -584,6 +585,10 @@ void HipPathRenderer::Render(const Scene *scene) {
     cam.focal_distance = pc->focalDistance;
     cam.shutter_open = pc->shutterOpen;
     cam.shutter_close = pc->shutterClose;
+    // a moving camera (ActiveTransform StartTime / EndTime around the camera's CTM): CameraToWorld as the AnimatedTransform it is
+    const bool movingCamera = pc->CameraToWorld.actuallyAnimated;
+    hpt_instance camMotion;
+    Flattener::FillAnimated(pc->CameraToWorld, &camMotion);
 
     hpt_render_desc rd;
     memset(&rd, 0, sizeof(rd));
@@ -609,6 +614,12 @@ void HipPathRenderer::Render(const Scene *scene) {
     if (dumpPath != "") {
         if (hpt_blob_save(dumpPath.c_str(), &desc, &cam, &rd) != HPT_OK)
             Severe("hip renderer: %s", hpt_last_error());
+        if (movingCamera) {   // sidecar: the hpt_instance record of CameraToWorld
+            string mpath = dumpPath + ".camera_motion";
+            FILE *mf = fopen(mpath.c_str(), "wb");
+            if (!mf || fwrite(&camMotion, sizeof(camMotion), 1, mf) != 1) Severe("hip renderer: cannot write %s", mpath.c_str());
+            fclose(mf);
+        }
         if (!defaultBox) {   // sidecar: 258 floats {xwidth, ywidth, table[256]} = hpt_filter
             string fpath = dumpPath + ".filter";
             FILE *ff = fopen(fpath.c_str(), "wb");
@@ -635,6 +646,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         hpt_multi *hm = hpt_multi_create(&desc, &devs[0], (int)devs.size());
         if (!hm) Severe("hip renderer: %s", hpt_last_error());
         if (!defaultBox && hpt_multi_set_filter(hm, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        if (movingCamera && hpt_multi_set_camera_motion(hm, &camMotion) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         std::vector<hpt_stats> sts(devs.size());
         if (hpt_multi_render(hm, &cam, &rd, &xyzw[0], &sts[0]) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         hpt_multi_destroy(hm);
@@ -647,6 +659,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         if (!hs) Severe("hip renderer: %s", hpt_last_error());
         t_create = NowS();
         if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        if (movingCamera && hpt_scene_set_camera_motion(hs, &camMotion) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         // kernel configuration of a job big enough to repay it (what hpt_render would do on its own: here as a step of its own, timed):
         // probe renders, or the cached choice for this scene
         if ((int64_t)rd.x_count * rd.y_count * rd.spp >= ((int64_t)32 << 20) && hpt_scene_tune(hs, &cam, &rd) < 0)

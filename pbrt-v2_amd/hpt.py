@@ -23,7 +23,7 @@ EXPORTS = [
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
-    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes",
+    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion",
 ]
 
 
@@ -57,6 +57,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.hpt_scene_tune.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc)]
         L.hpt_scene_set_filter.argtypes = [C.c_void_p, C.POINTER(abi.Filter)]
+        L.hpt_scene_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
+        L.hpt_multi_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
         L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.hpt_test_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -105,6 +107,8 @@ class DeviceScene:
         self.h = lib().hpt_scene_create(C.byref(d), device)
         if not self.h:
             raise HptError(f"hpt_scene_create failed: {last_error()}")
+        if getattr(scene, "camera_motion", None) is not None:      # a moving camera travels with the scene (abi.Scene.camera_motion)
+            self.set_camera_motion(scene.camera_motion)
 
     def info(self):
         i = abi.SceneInfo()
@@ -117,6 +121,10 @@ class DeviceScene:
         if rc < 0:
             _check(rc)
         return rc
+
+    def set_camera_motion(self, c2w):
+        """A moving camera: CameraToWorld as an AnimatedTransform (abi.Instance record; None = static camera)."""
+        _check(lib().hpt_scene_set_camera_motion(self.h, C.byref(c2w) if c2w is not None else None))
 
     def set_filter(self, flt):
         """ImageFilm's reconstruction filter for the following renders (abi.Filter; None = box of width 0.5)."""

@@ -6,6 +6,11 @@
             (oracle/_ref/pbrt_exr); metropolis Renderer line replaced by sampler + path.  160 x 90, 4 spp, maxdepth 5:
             metalg.ref.npy.gz = the reference binary's image, metalg.hpts.gz = the blob pbrt_hip extracted from the same file
             (the 1000 x 500 map, its MIPMap-filtered luminance and the Distribution2D tables the reference built).
+  tang      TriangleMesh "vector S" — explicit per-vertex tangents (shapes/trianglemesh.cpp:326-329): the shading frame
+            of a brushed (anisotropic substrate, uroughness 0.02 / vroughness 0.35) floor quad follows S instead of dpdu; an octahedron with
+            normals AND tangents under a rotated, non-uniformly scaled CTM (obj2world of a Vector); a wall with tangents but no normals.
+  acam      a moving camera (AnimatedTransform CameraToWorld) + a moving octahedron; acam.view.npz holds the camera's
+            hpt_instance record (the plugin's .camera_motion sidecar)
   metalg_4k.view.npz  camera + render descriptor of BASELINE.json configs[4] as written (3840 x 2160, 128 spp per GPU,
             path maxdepth 8) over the same blob — bench.py's `metal` workload and tests/test_gpu_fullsize.py.
 """
@@ -50,8 +55,124 @@ def dump(text, tmp):
     return abi.Scene.load(blob)
 
 
+TANG = """LookAt 0 2.2 6.5  0 0.9 0  0 1 0
+Camera "perspective" "float fov" [38]
+Film "image" "integer xresolution" [160] "integer yresolution" [90] "string filename" "%OUT%"
+Sampler "lowdiscrepancy" "integer pixelsamples" [8]
+SurfaceIntegrator "path" "integer maxdepth" [4]
+WorldBegin
+AttributeBegin
+LightSource "point" "color I" [30 30 30] "point from" [1 4 4]
+AttributeEnd
+AttributeBegin
+AreaLightSource "area" "color L" [10 10 10] "integer nsamples" [1]
+Translate -2 3 1.5
+Shape "sphere" "float radius" [0.4]
+AttributeEnd
+AttributeBegin
+Material "substrate" "color Kd" [.5 .45 .4] "color Ks" [.4 .4 .4] "float uroughness" [.02] "float vroughness" [.35]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4] "float uv" [0 0 1 0 1 1 0 1]
+  "vector S" [1 0 1  1 0 -1  -1 0 -1  -1 0 1]
+AttributeEnd
+AttributeBegin
+Material "substrate" "color Kd" [.3 .35 .5] "color Ks" [.5 .5 .5] "float uroughness" [.3] "float vroughness" [.03]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -3  4 0 -3  4 4 -3  -4 4 -3] "float uv" [0 0 2 0 2 1 0 1]
+  "vector S" [0 1 0  0.3 1 0  0 1 0.2  -0.3 1 0]
+AttributeEnd
+AttributeBegin
+Material "metal" "float roughness" [.08]
+Translate 0.3 0.9 0.6
+Rotate 25 0 1 0
+Scale 1 1.3 0.8
+Shape "trianglemesh" "integer indices" [0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5]
+  "point P" [0.7 0 0  -0.7 0 0  0 0.7 0  0 -0.7 0  0 0 0.7  0 0 -0.7] "normal N" [1 0 0  -1 0 0  0 1 0  0 -1 0  0 0 1  0 0 -1]
+  "float uv" [0 0  1 0  0.5 1  0.5 0  0 0.5  1 0.5]
+  "vector S" [0 1 1  0 1 -1  1 0 1  -1 0 1  1 1 0  1 -1 0]
+AttributeEnd
+WorldEnd
+"""
+
+
+ACAM = """ActiveTransform StartTime
+LookAt 0 2.2 6.5  0 0.9 0  0 1 0
+ActiveTransform EndTime
+LookAt 0.7 2.5 6.1  0.1 0.8 0  0.05 1 0
+ActiveTransform All
+Camera "perspective" "float fov" [38] "float shutteropen" [0.1] "float shutterclose" [0.9]
+Film "image" "integer xresolution" [160] "integer yresolution" [90] "string filename" "%OUT%"
+Sampler "lowdiscrepancy" "integer pixelsamples" [8]
+SurfaceIntegrator "path" "integer maxdepth" [4]
+WorldBegin
+AttributeBegin
+LightSource "point" "color I" [30 30 30] "point from" [1 4 4]
+AttributeEnd
+AttributeBegin
+AreaLightSource "area" "color L" [10 10 10] "integer nsamples" [1]
+Translate -2 3 1.5
+Shape "sphere" "float radius" [0.4]
+AttributeEnd
+AttributeBegin
+Material "plastic" "color Kd" [.5 .45 .4] "color Ks" [.3 .3 .3] "float roughness" [.1]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+Material "matte" "color Kd" [.3 .35 .5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -3  4 0 -3  4 4 -3  -4 4 -3]
+AttributeEnd
+AttributeBegin
+Material "matte" "color Kd" [.7 .6 .2]
+Translate 0.3 0.9 0.6
+ActiveTransform EndTime
+Translate 0.5 0.2 0
+ActiveTransform All
+Shape "trianglemesh" "integer indices" [0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5]
+  "point P" [0.7 0 0  -0.7 0 0  0 0.7 0  0 -0.7 0  0 0 0.7  0 0 -0.7] "normal N" [1 0 0  -1 0 0  0 1 0  0 -1 0  0 0 1  0 0 -1]
+AttributeEnd
+WorldEnd
+"""
+
+
+def acam(tmp):
+    """acam: a MOVING camera (ActiveTransform StartTime / EndTime LookAt: translation + rotation between the ends, shutter 0.1 .. 0.9) over a
+    static floor / wall and a moving octahedron — CameraToWorld(*ray, ray) with an AnimatedTransform (cameras/perspective.cpp:135, row a6)."""
+    PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+    sp, out, blob = os.path.join(tmp, "acam.pbrt"), os.path.join(tmp, "acam.pfm"), os.path.join(tmp, "acam.hpts")
+    open(sp, "w").write(ACAM.replace("%OUT%", out))
+    subprocess.check_call([PBRT, "--quiet", "--ncores", "1", sp], cwd=tmp, stderr=subprocess.DEVNULL)
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", sp], cwd=tmp,
+                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
+    with gzip.open(os.path.join(HERE, "acam.ref.npy.gz"), "wb", compresslevel=9) as f:
+        np.save(f, film.read_pfm(out))
+    s = abi.Scene.load(blob)
+    assert len(s.instances) == 1
+    s.save(os.path.join(HERE, "acam.hpts.gz"))
+    motion = np.fromfile(blob + ".camera_motion", dtype=np.uint8)
+    assert motion.size == __import__("ctypes").sizeof(abi.Instance)
+    np.savez(os.path.join(HERE, "acam.view.npz"), camera_motion=motion)
+
+
+def tang(tmp):
+    PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+    sp, out, blob = os.path.join(tmp, "tang.pbrt"), os.path.join(tmp, "tang.pfm"), os.path.join(tmp, "tang.hpts")
+    open(sp, "w").write(TANG.replace("%OUT%", out))
+    subprocess.check_call([PBRT, "--quiet", "--ncores", "1", sp], cwd=tmp, stderr=subprocess.DEVNULL)
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", sp], cwd=tmp,
+                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
+    with gzip.open(os.path.join(HERE, "tang.ref.npy.gz"), "wb", compresslevel=9) as f:
+        np.save(f, film.read_pfm(out))
+    s = abi.Scene.load(blob)
+    assert sum(1 for m in s.meshes if m.s_off >= 0) == 3
+    s.save(os.path.join(HERE, "tang.hpts.gz"))
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
+        if "tang" in sys.argv[1:] or len(sys.argv) == 1:
+            tang(tmp)
+        if "acam" in sys.argv[1:] or len(sys.argv) == 1:
+            acam(tmp)
+        if len(sys.argv) > 1 and "metalg" not in sys.argv[1:]:
+            return
         out = os.path.join(tmp, "o.pfm")
         text = metal_text(160, 90, 4, 5, out)
         sp = os.path.join(tmp, "s.pbrt")

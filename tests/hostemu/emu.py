@@ -28,6 +28,8 @@ def lib():
         L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
         L.emu_set_filter.restype = None
+        L.emu_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
+        L.emu_set_camera_motion.restype = None
         L.emu_set_two_pass.argtypes = [C.c_int]
         L.emu_set_two_pass.restype = None
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -49,11 +51,12 @@ class EmuScene:
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2]),
                 "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5])}
 
-    def render(self, cam, rd, flt=None, two_pass=False):
+    def render(self, cam, rd, flt=None, two_pass=False, cam_motion=None):
         """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the
         one-pass atomic splat"""
         lib().emu_set_filter(C.byref(flt) if flt is not None else None)
         lib().emu_set_two_pass(1 if two_pass else 0)
+        lib().emu_set_camera_motion(C.byref(cam_motion) if cam_motion is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         fn = lib().emu_render_replay if rd.sampler_mode == abi.HPT_SAMPLER_MT_REPLAY else lib().emu_render

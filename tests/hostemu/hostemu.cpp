@@ -31,7 +31,7 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     if (flatten_scene(desc, max_leaf, 24, &s->fs) != HPT_OK) { delete s; return nullptr; }
     s->quadrics.assign(desc->quadrics, desc->quadrics + desc->n_quadrics);
     s->materials = s->fs.materials;
-    s->lights.assign(desc->lights, desc->lights + desc->n_lights);
+    s->lights = s->fs.lights;        // (device copy: guide tables of the infinite lights)
     s->fpool = s->fs.fpool;
     s->ipool = s->fs.ipool;          // (shape sets rewritten by flatten_scene)
     s->textures.assign(desc->textures, desc->textures + desc->n_textures);
@@ -61,6 +61,8 @@ static hpt_filter g_filter; static bool g_filter_set = false;
 static bool g_two_pass = false;   // the device's two-pass film (sample records + film_gather_pixel) instead of the atomic splat
 extern "C" void emu_set_filter(const hpt_filter *f) { g_filter_set = f != nullptr; if (f) g_filter = *f; }
 extern "C" void emu_set_two_pass(int on) { g_two_pass = on != 0; }
+static hpt_instance g_cam_motion; static bool g_cam_motion_set = false;      // hpt_scene_set_camera_motion's stand-in (process-wide; NULL = static camera)
+extern "C" void emu_set_camera_motion(const hpt_instance *c) { g_cam_motion_set = c != nullptr; if (c) g_cam_motion = *c; }
 static void gather_film(const RenderParams &rp, float *film) {
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = rp.y_start; y < rp.y_start + rp.y_count; ++y)
@@ -79,6 +81,8 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     rp->y_start = rd->y_start; rp->y_count = rd->y_count; rp->spp = rd->spp; rp->maxdepth = rd->maxdepth;
     rp->seed = rd->seed;
     rp->bad_counter = nullptr;   // (the lanes count bad samples in their WorkCounters here)
+    rp->cam_animated = g_cam_motion_set ? 1 : 0; memset(&rp->cam_xf, 0, sizeof(rp->cam_xf));
+    if (g_cam_motion_set) rp->cam_xf = g_cam_motion;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
     { const int skind = HPT_SAMPLER_KIND(rd->sampler_mode); const bool strat = skind == HPT_SAMPLER_STRATIFIED_HASH;   // as fill_params of csrc/hpt_api.hip
@@ -117,7 +121,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
 template <bool DL>
 static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
-    rp.has_motion = s->d.n_instances > 0;
+    rp.has_motion = s->d.n_instances > 0 || rp.cam_animated;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
     std::vector<float> sbuf;
     if (g_two_pass && rp.ftable) {
@@ -167,7 +171,7 @@ extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_r
 // the order `pbrt --ncores 1` (and the golden images) use.
 extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
-    rp.has_motion = s->d.n_instances > 0;
+    rp.has_motion = s->d.n_instances > 0 || rp.cam_animated;
     memset(film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count);
     std::vector<float> sbuf;
     if (g_two_pass && rp.ftable) {

@@ -10,6 +10,7 @@ Bars
     in practice ~1e-6 with a few pixels where an ulp flips a discrete decision.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -129,7 +130,7 @@ def test_render_matches_oracle_sample_for_sample(cases, dev, ora, name):
     assert abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 20000)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -704,7 +705,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)
@@ -758,6 +759,35 @@ def test_round2_bsdfs_match_oracle(name, material):
         assert close.mean() > 0.99, close.mean()
     else:
         assert close.all(), np.abs(a - b).max()
+
+
+def test_moving_camera_matches_oracle_and_reference_image():
+    """Round 3, row a6: hpt_scene_set_camera_motion — CameraToWorld as an AnimatedTransform (a camera that translates and rotates while the
+    shutter is open, over a scene with a moving instance).  Production sampler against the oracle sample for sample on every kernel
+    configuration; MT_REPLAY against the image the reference binary wrote; and the static camera renders something else."""
+    s = load_case("acam")
+    ref = load_ref("acam")
+    dev = hpt.DeviceScene(s)                         # (the scene's camera_motion travels with it: hpt.DeviceScene applies it)
+    o = orc.OracleScene(s)
+    rd = hash_rd(s, seed=3)
+    fo, so = o.render(s.camera, rd, cam_motion=s.camera_motion)
+    for cfg in ("0", "3", "5", "6"):
+        os.environ["HPT_TUNE"] = cfg
+        try:
+            f, st = dev.render(s.camera, rd)
+        finally:
+            del os.environ["HPT_TUNE"]
+        assert st.camera_samples == so[0] and st.bad_samples == 0
+        assert np.array_equal(f[..., 3], fo[..., 3])
+        assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = dev.render(s.camera, rd)
+    img = film.xyzw_to_rgb(f)
+    assert np.isclose(img, ref, rtol=1e-3, atol=1e-4).all(axis=2).mean() > 0.97 and abs(float(img.mean()) / float(ref.mean()) - 1) < 0.02
+    dev.set_camera_motion(None)
+    f0, _ = dev.render(s.camera, hash_rd(s, seed=3))
+    assert film.rmse(film.xyzw_to_rgb(f0), film.xyzw_to_rgb(fo)) > 0.1
 
 
 def test_scope_limits_of_the_extension_are_refused_loudly():

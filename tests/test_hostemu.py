@@ -99,7 +99,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,
@@ -207,7 +207,7 @@ def test_four_wide_trees_find_the_same_hits(cases, name):
             assert deepest <= info["depth4"]
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens"])
+@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang"])
 def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     """Round 3: the MT_REPLAY sampler source over the FULL material set (Lane<MtReplaySrc, true, MATS_FULL>) — Oren-Nayar, glass / mirror,
     triangle-mesh emitters, the regular half-angle BRDF, EWA / trilinear image textures with camera-ray differentials, bump mapping, alpha
@@ -223,6 +223,23 @@ def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     img, ref = film.xyzw_to_rgb(f), load_ref(name)
     assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
     assert differing_pixels(img, ref) < 1e-3 and film.rmse(img, ref) < 1e-6
+
+
+def test_moving_camera_matches_the_reference_and_the_oracle():
+    """The device's camera_ray / camera_ray_differentials with an AnimatedTransform CameraToWorld: in MT_REPLAY mode against the image the
+    reference binary wrote, with the production sampler against the oracle."""
+    from tests.util import load_case
+    s = load_case("acam")
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    e = emu.EmuScene(s)
+    f, st = e.render(s.camera, rd, cam_motion=s.camera_motion)
+    img, ref = film.xyzw_to_rgb(f), load_ref("acam")
+    assert differing_pixels(img, ref) < 1e-3 and film.rmse(img, ref) < 1e-6
+    rd = hash_rd(s, seed=3)
+    fo, _ = orc.OracleScene(s).render(s.camera, rd, cam_motion=s.camera_motion)
+    fe, _ = e.render(s.camera, rd, cam_motion=s.camera_motion)
+    assert np.array_equal(fo[..., 3], fe[..., 3]) and film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)) < 1e-6
 
 
 def test_sample_chunking_above_64_spp(cases, pairs):

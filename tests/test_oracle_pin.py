@@ -132,6 +132,22 @@ def test_oracle_replays_exr_environment_map_under_direct_lighting_bit_exact():
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
 
 
+def test_oracle_replays_a_moving_camera_bit_exact():
+    """Round 3, SURVEY §8 row a6: PerspectiveCamera::CameraToWorld as an AnimatedTransform (ActiveTransform StartTime / EndTime around the
+    camera's LookAt: translation and rotation between the ends, shutter 0.1 .. 0.9) — GenerateRayDifferential's CameraToWorld(*ray, ray)
+    (cameras/perspective.cpp:135) through AnimatedTransform::operator() (core/transform.cpp:416-442) — over a scene with a moving instance."""
+    s = load_case("acam")
+    assert s.camera_motion.actually_animated and len(s.instances) == 1
+    rd = abi.copy_struct(s.render)
+    rd.sampler_mode = abi.HPT_SAMPLER_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1, cam_motion=s.camera_motion)
+    assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
+    img, ref = film.xyzw_to_rgb(f), load_ref("acam")
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    f0, _ = orc.OracleScene(s).render(s.camera, rd, nthreads=1)          # the static camera renders another image
+    assert film.rmse(film.xyzw_to_rgb(f0), ref) > 0.1
+
+
 def test_oracle_replays_everything_at_once_bit_exact():
     """killeroo-simple as shipped (direct lighting, the light with 3 samples) under Sampler "stratified" 3 x 2, PixelFilter
     "mitchell" 2.5 x 1.5 and a crop window: the stratified sub-samplers' tiles are cut from a sample extent wider than the

@@ -64,6 +64,10 @@ def load_case(name):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
+    if name == "acam":     # round 3: a moving camera — the blob + the camera's AnimatedTransform record (tests/golden/make_golden_r3.py)
+        s = abi.Scene.load(os.path.join(GOLDEN, "acam.hpts.gz"))
+        s.camera_motion = abi.Instance.from_buffer_copy(np.load(os.path.join(GOLDEN, "acam.view.npz"))["camera_motion"].tobytes())
+        return s
     if name in R2_CASES:
         s = abi.Scene.load(os.path.join(GOLDEN, R2_CASES[name]))
         if name == "merl":       # the 17.5 MB half-angle table is rebuilt from its formula instead of being committed
@@ -113,7 +117,9 @@ STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz
 R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hpts.gz", "merl": "merl.hpts.gz", "tex": "tex.hpts.gz",
             "alpha": "alpha.hpts.gz", "metal": "metal.hpts.gz", "mirtex": "mirtex.hpts.gz",
             # round 3 (tests/golden/make_golden_r3.py): metal.pbrt as shipped under the environment map SURVEY.md §8d names, textures/grace_latlong.exr (1000 x 500)
-            "metalg": "metalg.hpts.gz"}
+            "metalg": "metalg.hpts.gz",
+            # round 3: TriangleMesh "vector S" — explicit tangents under anisotropic substrates and a metal octahedron (row a13)
+            "tang": "tang.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
