@@ -183,7 +183,7 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
 
 extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     if (hpt_validate_desc(desc) != HPT_OK) return nullptr;
-    {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_DEPTH, no textured quadrics
+    {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_DEPTH
         std::vector<int> depth((size_t)desc->n_textures, 0);
         for (int t = 0; t < desc->n_textures; ++t) {
             const hpt_texture &tx = desc->textures[t];
@@ -193,11 +193,6 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
                 depth[(size_t)t] = d + 1;
                 if (d + 1 > HPT_TEX_DEPTH) { hpt_set_error("texture %d: scale / mix textures nested deeper than %d", t, HPT_TEX_DEPTH); return nullptr; }
             }
-        }
-        for (int q = 0; q < desc->n_quadrics; ++q) {
-            const hpt_material &ma = desc->materials[desc->quadrics[q].material];
-            for (int t = 0; t < HPT_N_TEXSLOTS; ++t)
-                if (ma.tex[t] >= 0) { hpt_set_error("quadric %d: textured materials on spheres / disks are outside the hot-path scope (triangle meshes only)", q); return nullptr; }
         }
     }
     int ndev = hpt_device_count();
@@ -452,7 +447,9 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     // rays), so the float sums of a pixel are no longer formed in sample order: the film is reproducible to rounding (~1e-7 relative), the
     // weights exactly.  Small jobs (the parity tests) keep one item per pixel up to 64 spp, summed in order.  HPT_CHUNK=<power of two> overrides.
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
-    if (local * 1024 * (int64_t)rd->spp >= ((int64_t)32 << 20)) rp->chunk = 1;
+    // (the size of the FRAME decides, not of this shard: the eighth of a 1080p / 64 spp frame a GPU of eight renders must not fall back to
+    //  64-sample items — measured on one GPU, run E: a bunny shard took 40-47 ms against 71 ms for the whole frame)
+    if (nst * 1024 * (int64_t)rd->spp >= ((int64_t)32 << 20)) rp->chunk = 1;
     if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
     if (rp->chunk == 1) rp->n_heads = 8;
     if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;

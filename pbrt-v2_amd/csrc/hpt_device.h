@@ -295,6 +295,7 @@ struct Ray { f3 o, d; float mint, maxt; };
 HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
 struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or n_tris + quadric; -1 miss; inst: animated instance or -1
 struct DGeom { f3 p, nn, dpdu; };
+struct DGeomX { f3 p, nn, dpdu, dpdv, dndu, dndv, dpdx, dpdy; float u, v, dudx, dvdx, dudy, dvdy; };   // the full DifferentialGeometry (extension set)
 
 HPT_FN int32_t as_int(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
 HPT_FN float as_float(int32_t i) { union { float f; int32_t i; } u; u.i = i; return u.f; }
@@ -338,7 +339,9 @@ HPT_FN void dg_init(DGeom *dg, f3 P, f3 dpdu, f3 dpdv, int flip) { // core/diffg
 }
 // Sphere::Intersect (shapes/sphere.cpp:58-157) / Disk::Intersect (shapes/disk.cpp:56-102);
 // world-space ray in, transformed by WorldToObject (= ObjectToWorld->mInv) as the reference does
-HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, DGeom *dg) {
+// dgx (optional, with dg): the rest of the DifferentialGeometry — u, v, dpdv, dndu, dndv (sphere.cpp:108-146, disk.cpp:80-92) — for textured /
+// bump-mapped quadrics
+HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, DGeom *dg, DGeomX *dgx = nullptr) {
     Ray ray;
     ray.o = xf_point(q.o2w_inv, r.o);
     ray.d = xf_vec(q.o2w_inv, r.d);
@@ -376,6 +379,23 @@ HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, D
             f3 dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0);
             f3 dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (q.theta_max - q.theta_min);
             dg_init(dg, xf_point(q.o2w, phit), xf_vec(q.o2w, dpdu), xf_vec(q.o2w, dpdv), flip);
+            if (dgx) {
+                dgx->u = phi / phiMax;
+                dgx->v = (theta - q.theta_min) / (q.theta_max - q.theta_min);
+                // dndu, dndv from the fundamental forms (sphere.cpp:121-140)
+                const float dth = q.theta_max - q.theta_min;
+                const f3 d2Pduu = mk3(phit.x, phit.y, 0.f) * (-phiMax * phiMax);
+                const f3 d2Pduv = mk3(-sinphi, cosphi, 0.f) * (dth * phit.z * phiMax);
+                const f3 d2Pdvv = mk3(phit.x, phit.y, phit.z) * (-dth * dth);
+                const float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+                const f3 N = normalize(cross(dpdu, dpdv));
+                const float e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+                const float invEGF2 = 1.f / (E * G - F * F);
+                const f3 dndu = dpdu * ((f * F - e * G) * invEGF2) + dpdv * ((e * F - f * E) * invEGF2);
+                const f3 dndv = dpdu * ((g * F - f * G) * invEGF2) + dpdv * ((f * F - g * E) * invEGF2);
+                dgx->dpdv = xf_vec(q.o2w, dpdv);
+                dgx->dndu = xf_normal(q.o2w_inv, dndu); dgx->dndv = xf_normal(q.o2w_inv, dndv);
+            }
         }
         *tHit = thit;
         return true;
@@ -395,6 +415,13 @@ HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, D
         f3 dpdu = mk3(-q.phi_max * phit.y, q.phi_max * phit.x, 0.f);
         f3 dpdv = mk3(phit.x, phit.y, 0.f) * ((q.radius - q.inner_radius) / R);
         dg_init(dg, xf_point(q.o2w, phit), xf_vec(q.o2w, dpdu), xf_vec(q.o2w, dpdv), flip);
+        if (dgx) {
+            dgx->u = phi / q.phi_max;
+            const float oneMinusV = (R - q.inner_radius) / (q.radius - q.inner_radius);
+            dgx->v = 1.f - oneMinusV;
+            dgx->dpdv = xf_vec(q.o2w, dpdv);
+            dgx->dndu = dgx->dndv = S(0.f);
+        }
     }
     *tHit = thit;
     return true;
@@ -1298,7 +1325,6 @@ HPT_FN bool bsdf_query_point(const Bsdf &b, f3 wo, f3 wi, f3 woW, f3 wiW, int fl
 // ---- textures (MATS_EXT kernels only) ------------------------------------------------------------------------------
 // The full DifferentialGeometry of core/diffgeom.h: what texture lookups (u, v and their screen-space derivatives) and bump mapping
 // (dpdv, dndu, dndv) need on top of the {p, nn, dpdu} the untextured kernels carry.
-struct DGeomX { f3 p, nn, dpdu, dpdv, dndu, dndv, dpdx, dpdy; float u, v, dudx, dvdx, dudy, dvdy; };
 HPT_FN int mod_i(int a, int b);
 struct TexV { float c[3]; };
 // MIPMap<T>::Texel (core/mipmap.h:204-223).  Level l of a pyramid starts right after level l - 1 (include/hpt.h).
@@ -1666,8 +1692,8 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
     if (hit.prim >= sc.n_tris) {
         const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
         float t; DGeom d3;
-        quadric_intersect(q, ray, &t, &d3);           // (textures on quadrics are refused at scene creation: u, v, dpdv are not needed)
-        dg.p = d3.p; dg.nn = d3.nn; dg.dpdu = d3.dpdu; dg.dpdv = cross(d3.nn, d3.dpdu); dg.u = dg.v = 0.f;
+        quadric_intersect(q, ray, &t, &d3, &dg);      // Shape::GetShadingGeometry's default: dgShading = dg (core/shape.h:59) with the quadric's own u, v, dpdv, dndu, dndv
+        dg.p = d3.p; dg.nn = d3.nn; dg.dpdu = d3.dpdu;
         compute_differentials(&dg, rdiff);
         *rayEps = 5e-4f * hit.t;
         *arealight = q.arealight;

@@ -23,7 +23,7 @@
 namespace hpt {
 
 bool path_kernel_wide_bvh() {
-#ifdef HPT_BVH4
+#ifndef HPT_NO_BVH4
     return true;
 #else
     return false;

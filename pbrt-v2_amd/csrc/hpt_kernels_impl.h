@@ -155,7 +155,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
     // the two pointers the loop dereferences, as scalar registers of their own: as fields of the kernel-argument block they live in a
     // 16-register tuple that the allocator spills to VGPR lanes and re-reads WHOLE (16 v_readlane per node step, measured in the ISA)
-#ifdef HPT_BVH4
+#ifndef HPT_NO_BVH4
     const f4 *nodes = sc.nodes4, *tris = sc.tris;                   // the four-wide trees (trav_node4): half the dependent fetches per ray
     const int32_t world_root = sc.world_root4;
 #else
@@ -202,7 +202,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         const unsigned long long w0_ = __builtin_readcyclecounter();
         cnt->steps++;
 #endif
-#ifdef HPT_BVH4
+#ifndef HPT_NO_BVH4
         if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
 #else
         if (ts.node >= 0) trav_node<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                     const float big = 3.402823466e+38f;
                     f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
                     float tentry;
-#ifdef HPT_BVH4
+#ifndef HPT_NO_BVH4
                     const int32_t iroot = sc.inst_root4[seg];
 #else
                     const int32_t iroot = sc.inst_root[seg];

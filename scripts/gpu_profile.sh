@@ -10,7 +10,7 @@ O=$ROOT/gpurun_out/prof_${W}_$(date +%H%M%S)
 mkdir -p $O
 cd /tmp
 rocprofv3 -L > $O/counters_list.txt 2>&1
-B="python $ROOT/bench.py --workload $W --no-cpu-baseline --no-verify --no-extra ${BENCH_EXTRA:-}"
+B="python $ROOT/bench.py --workload $W --no-cpu-baseline --no-verify --no-extra --no-pmc --no-work ${BENCH_EXTRA:-}"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B --steps 3 --warmup 1 > $O/trace.log 2>&1
 pass() { # name counters...
   n=$1; shift

@@ -107,8 +107,9 @@ with open(os.path.join(out_dir, tag + ".md"), "w") as f:
         f.write("| %s | %.6g |\n" % (kk, v))
 if len(sys.argv) > 3:
     # what bench.py reports beside its live numbers: profiles/pmc_<workload>.json
-    spp = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "killeroo-dl": 64}.get(sys.argv[3], 64)
-    doc2 = {"source": "profiles/%s.json" % tag, "samples_per_launch": 1920 * 1080 * int(os.environ.get("PROF_SPP", spp)),
+    spp = {"bunny": 64, "killeroo": 64, "anim": 128, "soup": 256, "soup4m": 64, "killeroo-dl": 64, "metal": 128}.get(sys.argv[3], 64)
+    pixels = 3840 * 2160 if sys.argv[3] == "metal" else 1920 * 1080
+    doc2 = {"source": "profiles/%s.json" % tag, "samples_per_launch": pixels * int(os.environ.get("PROF_SPP", spp)),
             "bytes_per_launch": derived.get("hbm_bytes_per_launch"), "read_bytes": derived.get("hbm_read_bytes_per_launch"),
             "write_bytes": derived.get("hbm_write_bytes_per_launch"),
             "valu_wave_instructions_per_launch": derived.get("valu_wave_instructions_per_launch"),

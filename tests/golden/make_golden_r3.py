@@ -9,6 +9,7 @@
   tang      TriangleMesh "vector S" — explicit per-vertex tangents (shapes/trianglemesh.cpp:326-329): the shading frame
             of a brushed (anisotropic substrate, uroughness 0.02 / vroughness 0.35) floor quad follows S instead of dpdu; an octahedron with
             normals AND tangents under a rotated, non-uniformly scaled CTM (obj2world of a Vector); a wall with tangents but no normals.
+  qtex      textures, a float roughness texture and bump mapping on spheres (partial, transformed) and a disk (row a14's tail)
   acam      a moving camera (AnimatedTransform CameraToWorld) + a moving octahedron; acam.view.npz holds the camera's
             hpt_instance record (the plugin's .camera_motion sidecar)
   metalg_4k.view.npz  camera + render descriptor of BASELINE.json configs[4] as written (3840 x 2160, 128 spp per GPU,
@@ -151,6 +152,67 @@ def acam(tmp):
     np.savez(os.path.join(HERE, "acam.view.npz"), camera_motion=motion)
 
 
+QTEX = """LookAt 0 2.2 6.5  0 0.9 0  0 1 0
+Camera "perspective" "float fov" [38]
+Film "image" "integer xresolution" [160] "integer yresolution" [90] "string filename" "%OUT%"
+Sampler "lowdiscrepancy" "integer pixelsamples" [8]
+SurfaceIntegrator "path" "integer maxdepth" [4]
+WorldBegin
+AttributeBegin
+LightSource "point" "color I" [30 30 30] "point from" [1 4 4]
+AttributeEnd
+AttributeBegin
+AreaLightSource "area" "color L" [10 10 10] "integer nsamples" [1]
+Translate -2 3 1.5
+Shape "sphere" "float radius" [0.4]
+AttributeEnd
+Texture "pat" "color" "imagemap" "string filename" "%TEX%" "float uscale" [4] "float vscale" [2]
+Texture "patf" "float" "imagemap" "string filename" "%TEX%" "float uscale" [6] "float vscale" [6] "float udelta" [0.25]
+Texture "bumpy" "float" "scale" "texture tex1" "patf" "float tex2" [-0.06]
+Texture "rough" "float" "scale" "texture tex1" "patf" "float tex2" [0.2]
+AttributeBegin
+Material "matte" "color Kd" [.5 .5 .5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4  4 0 -4  4 0 4  -4 0 4] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+Material "plastic" "texture Kd" "pat" "color Ks" [.3 .3 .3] "texture roughness" "rough" "texture bumpmap" "bumpy"
+Translate -0.9 1.0 0.4
+Rotate 30 0 1 0
+Scale 1 1.2 1
+Shape "sphere" "float radius" [0.9] "float zmin" [-0.7] "float zmax" [0.8] "float phimax" [300]
+AttributeEnd
+AttributeBegin
+Material "matte" "texture Kd" "pat" "texture bumpmap" "bumpy"
+Translate 1.6 0.02 1.0
+Rotate -90 1 0 0
+Shape "disk" "float radius" [1.1] "float innerradius" [0.3]
+AttributeEnd
+AttributeBegin
+Material "substrate" "texture Kd" "pat" "color Ks" [.4 .4 .4] "float uroughness" [.05] "float vroughness" [.2]
+Translate 1.2 1.4 -1.0
+Shape "sphere" "float radius" [0.6]
+AttributeEnd
+WorldEnd
+"""
+
+
+def qtex(tmp):
+    """qtex: image textures (EWA at the camera hit, trilinear behind it), a float roughness texture and Material::Bump on SPHERES (partial: zmin /
+    zmax / phimax, under a rotated, non-uniformly scaled CTM) and a DISK (annulus): Shape::GetShadingGeometry's default (core/shape.h:59) over the
+    quadrics' own u, v, dpdu, dpdv, dndu, dndv (shapes/sphere.cpp:108-146, disk.cpp:80-92) — SURVEY §8 row a14's tail."""
+    PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+    sp, out, blob = os.path.join(tmp, "qtex.pbrt"), os.path.join(tmp, "qtex.pfm"), os.path.join(tmp, "qtex.hpts")
+    open(sp, "w").write(QTEX.replace("%OUT%", out).replace("%TEX%", os.path.join(HERE, "tex16x12.pfm")))
+    subprocess.check_call([PBRT, "--quiet", "--ncores", "1", sp], cwd=tmp, stderr=subprocess.DEVNULL)
+    subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", sp], cwd=tmp,
+                          env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
+    with gzip.open(os.path.join(HERE, "qtex.ref.npy.gz"), "wb", compresslevel=9) as f:
+        np.save(f, film.read_pfm(out))
+    s = abi.Scene.load(blob)
+    assert len(s.quadrics) == 4 and len(s.textures) >= 4
+    s.save(os.path.join(HERE, "qtex.hpts.gz"))
+
+
 def tang(tmp):
     PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
     sp, out, blob = os.path.join(tmp, "tang.pbrt"), os.path.join(tmp, "tang.pfm"), os.path.join(tmp, "tang.hpts")
@@ -171,6 +233,8 @@ def main():
             tang(tmp)
         if "acam" in sys.argv[1:] or len(sys.argv) == 1:
             acam(tmp)
+        if "qtex" in sys.argv[1:] or len(sys.argv) == 1:
+            qtex(tmp)
         if len(sys.argv) > 1 and "metalg" not in sys.argv[1:]:
             return
         out = os.path.join(tmp, "o.pfm")

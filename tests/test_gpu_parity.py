@@ -130,7 +130,7 @@ def test_render_matches_oracle_sample_for_sample(cases, dev, ora, name):
     assert abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 20000)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -705,7 +705,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)

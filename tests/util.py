@@ -119,7 +119,9 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             # round 3 (tests/golden/make_golden_r3.py): metal.pbrt as shipped under the environment map SURVEY.md §8d names, textures/grace_latlong.exr (1000 x 500)
             "metalg": "metalg.hpts.gz",
             # round 3: TriangleMesh "vector S" — explicit tangents under anisotropic substrates and a metal octahedron (row a13)
-            "tang": "tang.hpts.gz"}
+            "tang": "tang.hpts.gz",
+            # round 3: image textures, a roughness texture and bump mapping on spheres and a disk (row a14)
+            "qtex": "qtex.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
