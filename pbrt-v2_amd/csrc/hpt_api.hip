@@ -2,6 +2,7 @@
 // call that replaces SamplerRenderer::Render (renderers/samplerrenderer.cpp:283-317) and the
 // function-level parity hooks.  HIP runtime only; there is deliberately NO CPU path: without a
 // device every compute entry point fails with HPT_E_NODEVICE.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -182,6 +183,7 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
 }
 
 extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
+    const auto t_create0 = std::chrono::steady_clock::now();
     if (hpt_validate_desc(desc) != HPT_OK) return nullptr;
     {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_DEPTH
         std::vector<int> depth((size_t)desc->n_textures, 0);
@@ -233,7 +235,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     const char *bb = getenv("HPT_BVH_BUILD");
     if (bb && !strcmp(bb, "lbvh")) dev_build = build_bvh_lbvh_gpu;
     else if (!(bb && !strcmp(bb, "sah")) && total_tris >= dev_min) { dev_build = build_bvh_lbvh_gpu; dev_depth = 30; }
-    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs, dev_build, dev_depth) != HPT_OK) { delete s; return nullptr; }
+    const auto t_flat0 = std::chrono::steady_clock::now();
+    if (flatten_scene(desc, maxLeaf, HPT_STACK_DEPTH - 2, &fs, dev_build, dev_depth, /*defer_levels=*/true) != HPT_OK) { delete s; return nullptr; }
+    const auto t_flat1 = std::chrono::steady_clock::now();
     if (fs.max_depth + 2 > HPT_MAX_STACK_ROWS) { delete s; hpt_set_error("BVH depth %d exceeds the traversal stack", fs.max_depth); return nullptr; }
     s->device_build_ms = fs.device_build_ms; s->device_built = fs.device_built;
     const int64_t ntris = fs.n_tris;
@@ -269,6 +273,13 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         s->stack_bound4 = fs.stack_bound4; s->depth4 = fs.depth4;
     }
     s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
+    double levels_ms = 0.0;
+    if (ok && !fill_kd_levels_gpu(fs, const_cast<float *>(s->d.fpool), s->d.ipool, &levels_ms)) { hpt_scene_destroy(s); return nullptr; }
+    if (getenv("HPT_TIMING"))
+        fprintf(stderr, "hpt scene_create: validation + HIP runtime start + device query %.1f ms, flatten %.1f ms, device allocations + uploads (%.1f MB) %.1f ms (of which measured-BRDF level kernels %.2f ms)\n",
+                std::chrono::duration<double, std::milli>(t_flat0 - t_create0).count(),
+                std::chrono::duration<double, std::milli>(t_flat1 - t_flat0).count(), s->info.total_device_bytes / 1e6,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flat1).count(), levels_ms);
     s->inst_xf = nullptr; s->inst_xf_lanes = 0;
     if (desc->n_instances > 0) {       // 12 floats (3x4) x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
         s->inst_xf_lanes = (size_t)s->n_cus * 4 * HPT_BLOCK;

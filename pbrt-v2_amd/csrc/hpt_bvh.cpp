@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace hpt {
 
@@ -36,11 +37,13 @@ struct Box {
 
 struct Builder {
     const BvhInputTri *tris;
-    std::vector<Box> boxes;
-    std::vector<float> cent; // 3 per tri
-    std::vector<uint32_t> idx;
+    // shared by the builders of one tree (a subtree built on another thread works on its own range of idx)
+    const Box *boxes;
+    const float *cent;  // 3 per tri
+    uint32_t *idx;
+    // this builder's output: the nodes in depth-first order, children coded relative to THIS array; leaf order -> input triangle
     std::vector<BvhNode64> nodes;
-    std::vector<uint32_t> order; // leaf order -> input triangle
+    std::vector<uint32_t> order;
     int maxLeaf, maxDepth, deepest;
     int nbins = 16;     // SAH bins per axis (HPT_BVH_BINS, 4..64)
 
@@ -52,9 +55,25 @@ struct Builder {
         uint32_t count = end - start;
         return (int32_t)~(first | ((count - 1u) << 28));
     }
+    // appends a finished subtree (built by another Builder over a range of the same idx) and returns its root's code in this array:
+    // depth-first order is concatenation, so the result is the array a serial build would have produced
+    int32_t splice(const Builder &sub, int32_t code) {
+        const int32_t nb = (int32_t)nodes.size();
+        const uint32_t ob = (uint32_t)order.size();
+        auto fix = [&](int32_t c) {
+            if (c >= 0) return c + nb;
+            const uint32_t u = (uint32_t)~c;
+            return (int32_t)~(((u & 0x0fffffffu) + ob) | (u & 0xf0000000u));
+        };
+        for (BvhNode64 nd : sub.nodes) { nd.child[0] = fix(nd.child[0]); nd.child[1] = fix(nd.child[1]); nodes.push_back(nd); }
+        order.insert(order.end(), sub.order.begin(), sub.order.end());
+        if (sub.deepest > deepest) deepest = sub.deepest;
+        return fix(code);
+    }
 
     // returns the child code (>=0 interior node index, <0 leaf) and the subtree's box
-    int32_t build(uint32_t start, uint32_t end, int depth, Box *outBox) {
+    // par: levels below this one whose two subtrees may still be built on separate threads
+    int32_t build(uint32_t start, uint32_t end, int depth, Box *outBox, int par = 0) {
         Box bb; bb.reset();
         Box cb; cb.reset();
         for (uint32_t i = start; i < end; ++i) { bb.grow(boxes[idx[i]]); cb.grow(&cent[3 * (size_t)idx[i]]); }
@@ -74,7 +93,7 @@ struct Builder {
         } else if (forceMedian) {
             if ((int)n <= maxLeaf) return make_leaf(start, end);
             mid = (start + end) / 2;
-            std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
+            std::nth_element(idx + start, idx + mid, idx + end,
                              [&](uint32_t a, uint32_t b) { return cent[3 * (size_t)a + dim] < cent[3 * (size_t)b + dim]; });
         } else {
             enum { NBMAX = 64 };
@@ -109,20 +128,20 @@ struct Builder {
             if ((int)n <= maxLeaf && leafCost <= splitCost) return make_leaf(start, end);
             if (bestDim < 0) {
                 mid = (start + end) / 2;
-                std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
+                std::nth_element(idx + start, idx + mid, idx + end,
                                  [&](uint32_t a, uint32_t b) { return cent[3 * (size_t)a + dim] < cent[3 * (size_t)b + dim]; });
             } else {
                 float scale = NB / ext[bestDim];
-                auto it = std::partition(idx.begin() + start, idx.begin() + end, [&](uint32_t a) {
+                auto it = std::partition(idx + start, idx + end, [&](uint32_t a) {
                     int b = (int)((cent[3 * (size_t)a + bestDim] - cb.lo[bestDim]) * scale);
                     if (b >= NB) b = NB - 1;
                     if (b < 0) b = 0;
                     return b <= bestSplit;
                 });
-                mid = (uint32_t)(it - idx.begin());
+                mid = (uint32_t)(it - idx);
                 if (mid == start || mid == end) {
                     mid = (start + end) / 2;
-                    std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
+                    std::nth_element(idx + start, idx + mid, idx + end,
                                      [&](uint32_t a, uint32_t b) { return cent[3 * (size_t)a + dim] < cent[3 * (size_t)b + dim]; });
                 }
             }
@@ -130,8 +149,20 @@ struct Builder {
         int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         Box b0, b1;
-        int32_t c0 = build(start, mid, depth + 1, &b0);
-        int32_t c1 = build(mid, end, depth + 1, &b1);
+        int32_t c0, c1;
+        if (par > 0 && n >= 4096) {
+            Builder L, R;
+            for (Builder *b : {&L, &R}) { b->tris = tris; b->boxes = boxes; b->cent = cent; b->idx = idx; b->maxLeaf = maxLeaf; b->maxDepth = maxDepth; b->deepest = 0; b->nbins = nbins; }
+            L.nodes.reserve(mid - start); L.order.reserve(mid - start); R.nodes.reserve(end - mid); R.order.reserve(end - mid);
+            std::thread left([&] { c0 = L.build(start, mid, depth + 1, &b0, par - 1); });
+            c1 = R.build(mid, end, depth + 1, &b1, par - 1);
+            left.join();
+            c0 = splice(L, c0);
+            c1 = splice(R, c1);
+        } else {
+            c0 = build(start, mid, depth + 1, &b0);
+            c1 = build(mid, end, depth + 1, &b1);
+        }
         BvhNode64 &nd = nodes[(size_t)me];
         nd.f[0] = b0.lo[0]; nd.f[1] = b0.lo[1]; nd.f[2] = b0.lo[2]; nd.f[3] = b0.hi[0];
         nd.f[4] = b0.hi[1]; nd.f[5] = b0.hi[2]; nd.f[6] = b1.lo[0]; nd.f[7] = b1.lo[1];
@@ -212,18 +243,27 @@ void build_bvh(const BvhInputTri *tris, size_t n, int maxLeaf, int maxDepth, Bvh
     Builder b;
     b.tris = tris; b.maxLeaf = std::min(std::max(maxLeaf, 1), 8); b.maxDepth = maxDepth; b.deepest = 0;
     if (const char *e = getenv("HPT_BVH_BINS")) { int v = atoi(e); if (v >= 4 && v <= 64) b.nbins = v; }
-    b.boxes.resize(n); b.cent.resize(3 * n); b.idx.resize(n);
+    std::vector<Box> boxes(n); std::vector<float> cent(3 * n); std::vector<uint32_t> idx(n);
     for (size_t i = 0; i < n; ++i) {
         Box bx; bx.reset();
         bx.grow(tris[i].v[0]); bx.grow(tris[i].v[1]); bx.grow(tris[i].v[2]);
-        b.boxes[i] = bx;
-        for (int k = 0; k < 3; ++k) b.cent[3 * i + k] = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
-        b.idx[i] = (uint32_t)i;
+        boxes[i] = bx;
+        for (int k = 0; k < 3; ++k) cent[3 * i + k] = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
+        idx[i] = (uint32_t)i;
     }
+    b.boxes = boxes.data(); b.cent = cent.data(); b.idx = idx.data();
     b.nodes.reserve(n);
     b.order.reserve(n);
+    // the top levels fork: subtrees of disjoint triangle ranges are independent, and spliced back in depth-first order they give the
+    // array of the serial build bit for bit (HPT_BVH_THREADS=1: serial).  Four levels = up to sixteen subtrees in flight.
+    int par = 4;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char *e = getenv("HPT_BVH_THREADS")) hw = (unsigned)atoi(e);
+        par = hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : hw >= 2 ? 1 : 0;
+    }
     Box rootBox;
-    int32_t root = b.build(0, (uint32_t)n, 0, &rootBox);
+    int32_t root = b.build(0, (uint32_t)n, 0, &rootBox, par);
     if (root < 0) {
         // a single leaf: wrap it in a root node whose second child is an empty box (never hit)
         BvhNode64 nd;

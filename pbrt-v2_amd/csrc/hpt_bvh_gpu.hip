@@ -25,6 +25,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hpt_bvh.h"
+#include "hpt_flatten.h"
 #include "hpt_internal.h"
 
 namespace hpt {
@@ -201,6 +202,68 @@ bool build_bvh_lbvh_gpu(const BvhInputTri *tris, size_t n_, int maxLeaf, BvhResu
     for (int i = 0; i < n; ++i) out->order[(size_t)i] = (uint32_t)(keys[(size_t)i] & 0xffffffffull);
     out->max_depth = rootHeight;
     if (ms_out) *ms_out = ms;
+    return true;
+}
+
+// ---- starting-level tables of the measured BRDFs (hpt_flatten.h: FlatScene::level_jobs) ----------------------------------------------
+// One thread per cell of the 64^3 grid over (sin*sin, dphi/pi, cos*cos): the level k at which the reference's growing-radius query
+// (reflection.cpp:262-271: double the squared radius until more than two samples are inside) would stop at the cell's centre.  The count
+// walks the reference's kd-tree (KdTree::privateLookup's pruning rule, core/kdtree.h:159-183) with an explicit stack and stops at
+// three; the tree is balanced (median splits), so 48 entries cover any sample count an int can hold.  The table only seeds the walk
+// of kd_begin (a wrong entry costs passes, not correctness: kd_step corrects in both directions).
+namespace {
+#define HPT_KDL_GRID 64
+__global__ __launch_bounds__(256) void kd_level_table(const float *split, const int32_t *bits, const float *data, uint32_t n_nodes, uint8_t *table) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = HPT_KDL_GRID;
+    if (cell >= G * G * G) return;
+    const int x = cell % G, y = (cell / G) % G, z = cell / (G * G);
+    const float q[3] = {(x + .5f) / G, (y + .5f) / G, -1.f + 2.f * (z + .5f) / G};
+    float r = .001f; int k = 0;
+    for (;;) {
+        int found = 0, sp = 0;
+        uint32_t stack[48];
+        stack[sp++] = 0u;
+        while (sp > 0 && found < 3) {
+            const uint32_t node = stack[--sp];
+            const uint32_t b = (uint32_t)bits[node];
+            const int axis = (int)(b & 3u);
+            const float *p = data + 6 * (size_t)node;
+            const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            if (dx * dx + dy * dy + dz * dz < r) ++found;
+            if (axis != 3) {
+                const uint32_t left = ((b >> 2) & 1u) ? node + 1 : n_nodes, right = b >> 3;
+                const float d = q[axis] - split[node];
+                const uint32_t near_c = d <= 0.f ? left : right, far_c = d <= 0.f ? right : left;
+                if (d * d < r && far_c < n_nodes && sp < 48) stack[sp++] = far_c;
+                if (near_c < n_nodes && sp < 48) stack[sp++] = near_c;
+            }
+        }
+        if (found > 2 || r > 1.5f) break;
+        r *= 2.f; ++k;
+    }
+    table[cell] = (uint8_t)k;
+}
+} // namespace
+
+bool fill_kd_levels_gpu(const FlatScene &fs, float *d_fpool, const int32_t *d_ipool, double *kernel_ms) {
+    if (fs.level_jobs.empty()) return true;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, nullptr) == hipSuccess;
+    const int cells = HPT_KDL_GRID * HPT_KDL_GRID * HPT_KDL_GRID;
+    for (const FlatScene::KdLevelJob &j : fs.level_jobs) {
+        if (!ok) break;
+        hipLaunchKernelGGL(kd_level_table, dim3(cells / 256), dim3(256), 0, nullptr, d_fpool + j.split_off, d_ipool + j.bits_off, d_fpool + j.data_off,
+                           (uint32_t)j.n_nodes, (uint8_t *)(d_fpool + j.table_off));
+        ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+    float ms = 0.f;
+    if (ok) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (!ok) { hpt_set_error("measured-BRDF level table: kernel failed (%s)", hipGetErrorString(hipGetLastError())); return false; }
+    if (kernel_ms) *kernel_ms = ms;
     return true;
 }
 

@@ -924,16 +924,16 @@ HPT_FN void kd_set_box(KdWalk *w) {
     const int z0 = bg_cell_z(fmaxf(w->q.z - R, -1.f)); w->z1 = bg_cell_z(w->q.z + R);
     w->iy = w->y0 - 1; w->iz = z0; w->j = w->jend = 0u;
 }
-HPT_FN void kd_begin(const DScene &sc, const hpt_material *m, f3 mpt, KdWalk *w) {
-    w->samples = (const HPT_GLOBAL f4 *)(sc.fpool + m->kd_data_off);
-    w->cells = (const HPT_GLOBAL uint32_t *)(sc.fpool + m->kd_split_off);
+HPT_FN void kd_begin(const float *fpool, const hpt_material *m, f3 mpt, KdWalk *w) {
+    w->samples = (const HPT_GLOBAL f4 *)(fpool + m->kd_data_off);
+    w->cells = (const HPT_GLOBAL uint32_t *)(fpool + m->kd_split_off);
     // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
     int gx = (int)(mpt.x * HPT_KD_GRID), gy = (int)(mpt.y * HPT_KD_GRID), gz = (int)((mpt.z + 1.f) * (.5f * HPT_KD_GRID));
     gx = gx < 0 ? 0 : gx > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gx;
     gy = gy < 0 ? 0 : gy > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gy;
     gz = gz < 0 ? 0 : gz > HPT_KD_GRID - 1 ? HPT_KD_GRID - 1 : gz;
     int cell = (gz * HPT_KD_GRID + gy) * HPT_KD_GRID + gx;
-    w->level = (as_int(sc.fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
+    w->level = (as_int(fpool[m->kd_bits_off + (cell >> 2)]) >> (8 * (cell & 3))) & 0xff;
     w->q = mpt;
     float r = .001f;
     for (int i = 0; i < w->level; ++i) r *= 2.f;         // the reference's lastMaxDist2 after `level` doublings
@@ -1000,16 +1000,18 @@ HPT_FN f3 irreg_point(f3 wo, f3 wi) {
     if (dphi > HPT_PI) dphi = 2.f * HPT_PI - dphi;
     return mk3(sini * sino, dphi / HPT_PI, cosi * coso);
 }
-// ... and the weighted average of the samples around it (reflection.cpp:261-271), one lane for itself.  Out of line.
-HPT_FN_NOINLINE f3 irreg_eval(const DScene &sc, const hpt_material *m, f3 mpt) {
+// ... and the weighted average of the samples around it (reflection.cpp:261-271), one lane for itself.  Out of line; an out-of-line
+// function takes the pools it reads BY VALUE: a reference to the scene record would force the whole kernel-argument block (where
+// the record lives) into private memory, and every later field read of the caller would become a scratch load.
+HPT_FN_NOINLINE f3 irreg_eval(const float *fpool, const hpt_material *m, f3 mpt) {
     KdWalk w;
-    kd_begin(sc, m, mpt, &w);
+    kd_begin(fpool, m, mpt, &w);
     f3 out = S(0.f);
     while (!kd_step(&w, &out)) {}
     return out;
 }
 HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {
-    return irreg_eval(sc, m, irreg_point(wo, wi));
+    return irreg_eval(sc.fpool, m, irreg_point(wo, wi));
 }
 
 // FrCond (reflection.cpp:70-79) through FresnelConductor::Evaluate (:110-112), per RGB channel
@@ -1327,13 +1329,16 @@ HPT_FN bool bsdf_query_point(const Bsdf &b, f3 wo, f3 wi, f3 woW, f3 wiW, int fl
 // (dpdv, dndu, dndv) need on top of the {p, nn, dpdu} the untextured kernels carry.
 HPT_FN int mod_i(int a, int b);
 struct TexV { float c[3]; };
+// What a texture lookup reads of the scene and of the hit, by value (see irreg_eval on why not a reference to the scene record)
+struct TexPools { const hpt_texture *textures; const float *fpool; const float *ewa_lut; };
+struct TexUV { float u, v, dudx, dvdx, dudy, dvdy; };
 // MIPMap<T>::Texel (core/mipmap.h:204-223).  Level l of a pyramid starts right after level l - 1 (include/hpt.h).
 HPT_FN void mip_level(const hpt_texture &t, int level, int64_t *off, int *w, int *h) {
     int64_t o = t.pyr_off; int ww = t.width, hh = t.height;
     for (int l = 0; l < level; ++l) { o += (int64_t)ww * hh * t.channels; ww = ww > 1 ? ww / 2 : 1; hh = hh > 1 ? hh / 2 : 1; }
     *off = o; *w = ww; *h = hh;
 }
-HPT_FN TexV mip_texel(const DScene &sc, const hpt_texture &t, int64_t off, int w, int h, int si, int ti) {
+HPT_FN TexV mip_texel(const TexPools &sc, const hpt_texture &t, int64_t off, int w, int h, int si, int ti) {
     TexV r; r.c[0] = r.c[1] = r.c[2] = 0.f;
     if (t.wrap == HPT_WRAP_REPEAT) { si = mod_i(si, w); ti = mod_i(ti, h); }
     else if (t.wrap == HPT_WRAP_CLAMP) { si = si < 0 ? 0 : si > w - 1 ? w - 1 : si; ti = ti < 0 ? 0 : ti > h - 1 ? h - 1 : ti; }
@@ -1343,7 +1348,7 @@ HPT_FN TexV mip_texel(const DScene &sc, const hpt_texture &t, int64_t off, int w
     if (t.channels == 3) { r.c[1] = px[1]; r.c[2] = px[2]; }
     return r;
 }
-HPT_FN TexV mip_triangle(const DScene &sc, const hpt_texture &t, int level, float s, float tt) {     // :258-269
+HPT_FN TexV mip_triangle(const TexPools &sc, const hpt_texture &t, int level, float s, float tt) {     // :258-269
     level = level < 0 ? 0 : level > t.levels - 1 ? t.levels - 1 : level;
     int64_t off; int w, h;
     mip_level(t, level, &off, &w, &h);
@@ -1358,7 +1363,7 @@ HPT_FN TexV mip_triangle(const DScene &sc, const hpt_texture &t, int level, floa
     return r;
 }
 HPT_FN float log2_pbrt(float x) { const float invLog2 = 1.f / logf(2.f); return logf(x) * invLog2; }    // pbrt.h:255-258
-HPT_FN TexV mip_ewa(const DScene &sc, const hpt_texture &t, int level, float s, float tt, float ds0, float dt0, float ds1, float dt1) {   // :317-366
+HPT_FN TexV mip_ewa(const TexPools &sc, const hpt_texture &t, int level, float s, float tt, float ds0, float dt0, float ds1, float dt1) {   // :317-366
     int64_t off; int w, h;
     if (level >= t.levels) { mip_level(t, t.levels - 1, &off, &w, &h); return mip_texel(sc, t, off, w, h, 0, 0); }
     mip_level(t, level, &off, &w, &h);
@@ -1395,7 +1400,7 @@ HPT_FN TexV mip_ewa(const DScene &sc, const hpt_texture &t, int level, float s, 
     return sum;
 }
 // MIPMap::Lookup(s, t, ds0, dt0, ds1, dt1) (core/mipmap.h:272-314) and the trilinear Lookup(s, t, width) (:238-255)
-HPT_FN_NOINLINE TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s, float tt, float ds0, float dt0, float ds1, float dt1) {
+HPT_FN_NOINLINE TexV mip_lookup(const TexPools sc, const hpt_texture &t, float s, float tt, float ds0, float dt0, float ds1, float dt1) {
     if (t.do_trilinear) {
         const float width = 2.f * maxf(maxf(fabsf(ds0), fabsf(dt0)), maxf(fabsf(ds1), fabsf(dt1)));
         const float level = t.levels - 1 + log2_pbrt(maxf(width, 1e-8f));
@@ -1428,7 +1433,7 @@ HPT_FN_NOINLINE TexV mip_lookup(const DScene &sc, const hpt_texture &t, float s,
 // per level: inlined, the filtering code would be copied into every operand of every call site).
 #define HPT_TEX_DEPTH 3
 template <int DEPTH>
-HPT_FN_NOINLINE TexV tex_eval(const DScene &sc, int id, const DGeomX &dg) {
+HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg) {
     const hpt_texture &t = sc.textures[id];
     TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
     if (t.kind == HPT_TEX_CONSTANT) return r;
@@ -1444,8 +1449,10 @@ HPT_FN_NOINLINE TexV tex_eval(const DScene &sc, int id, const DGeomX &dg) {
     }
     return r;
 }
-HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_eval<HPT_TEX_DEPTH>(sc, id, dg).c[0]; }
-HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_eval<HPT_TEX_DEPTH>(sc, id, dg); return mk3(v.c[0], v.c[1], v.c[2]); }
+HPT_FN TexPools tex_pools(const DScene &sc) { TexPools p; p.textures = sc.textures; p.fpool = sc.fpool; p.ewa_lut = sc.ewa_lut; return p; }
+HPT_FN TexUV tex_uv(const DGeomX &dg) { TexUV t; t.u = dg.u; t.v = dg.v; t.dudx = dg.dudx; t.dvdx = dg.dvdx; t.dudy = dg.dudy; t.dvdy = dg.dvdy; return t; }
+HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_eval<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)).c[0]; }
+HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_eval<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)); return mk3(v.c[0], v.c[1], v.c[2]); }
 
 HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2) {
     const DMesh &me = sc.meshes[mesh_word & HPT_TRI_MESH_MASK];

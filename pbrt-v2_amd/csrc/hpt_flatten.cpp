@@ -2,6 +2,7 @@
 #include "hpt_flatten.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <thread>
 #include <utility>
@@ -31,7 +32,7 @@ static int kd_count_within(const float *split, const int32_t *bits, const float 
     return found;
 }
 
-int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out, BvhDeviceBuildFn device_build, int device_max_depth) {
+int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out, BvhDeviceBuildFn device_build, int device_max_depth, bool defer_levels) {
     auto t0 = std::chrono::steady_clock::now();
     int64_t ntris = 0;
     for (int m = 0; m < desc->n_meshes; ++m) ntris += desc->meshes[m].ntris;
@@ -123,8 +124,10 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         }
         tri_base += sub.size();
     }
+    const auto t_trees = std::chrono::steady_clock::now();
     // ---- measured-BRDF samples -> grid-ordered 32-byte records + cell table (hpt_device.h: kd_begin / kd_step) -------
     out->fpool.assign(desc->fpool, desc->fpool + desc->n_f);
+    out->level_jobs.clear();
     out->materials.assign(desc->materials, desc->materials + desc->n_materials);
     for (int m = 0; m < desc->n_materials; ++m) {
         hpt_material &ma = out->materials[(size_t)m];
@@ -155,7 +158,11 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         // (sin*sin, dphi/pi, cos*cos) in [0,1] x [0,1] x [-1,1]; one byte per cell, four to a pool word
         const int G = HPT_KD_GRID;
         std::vector<uint8_t> lev((size_t)G * G * G);
-        {   // z-slices over the host's threads (the table is G^3 independent little queries)
+        if (defer_levels) {
+            FlatScene::KdLevelJob j; j.split_off = ma.kd_split_off; j.data_off = ma.kd_data_off; j.bits_off = ma.kd_bits_off;
+            j.table_off = (int64_t)out->fpool.size(); j.n_nodes = ma.kd_nnodes;
+            out->level_jobs.push_back(j);
+        } else {   // z-slices over the host's threads (the table is G^3 independent little queries)
             unsigned nth = std::thread::hardware_concurrency();
             if (nth < 1) nth = 1;
             if (nth > 16) nth = 16;
@@ -176,6 +183,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         for (size_t i = 0; i < lev.size(); i += 4) { float w; memcpy(&w, &lev[i], 4); out->fpool.push_back(w); }
         ma.kd_data_off = base; ma.kd_split_off = cbase; ma.kd_bits_off = gbase;
     }
+    const auto t_measured = std::chrono::steady_clock::now();
     // ---- area lights over shape sets: (kind, global triangle number | quadric) -> (mesh | -1, triangle in mesh | quadric) ----------
     out->ipool.assign(desc->ipool, desc->ipool + desc->n_i);
     for (int l = 0; l < desc->n_lights; ++l) {
@@ -219,7 +227,12 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         out->fpool.push_back(expf(-alpha * r2) - expf(-alpha));
     }
     out->n_tris = ntris;
-    out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const auto t1 = std::chrono::steady_clock::now();
+    out->build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (getenv("HPT_TIMING"))
+        fprintf(stderr, "hpt flatten: trees (BVH2 + BVH4 + triangle records) %.1f ms, measured-BRDF tables %.1f ms, light tables %.1f ms\n",
+                std::chrono::duration<double, std::milli>(t_trees - t0).count(), std::chrono::duration<double, std::milli>(t_measured - t_trees).count(),
+                std::chrono::duration<double, std::milli>(t1 - t_measured).count());
     return HPT_OK;
 }
 

@@ -37,6 +37,11 @@ struct FlatScene {
     int64_t n_tris = 0;
     int max_depth = 0;
     bool has_measured = false;        // some material is a measured (IrregIsotropic) BRDF
+    // the starting-level tables of the measured BRDFs left for the device to fill (flatten_scene(..., defer_levels = true)): the table
+    // is 64^3 independent kd-tree queries — 100 ms on sixteen host threads, under a millisecond as a kernel over the uploaded pools
+    // (hpt_bvh_gpu.hip, fill_kd_levels_gpu).  Offsets into THIS scene's fpool / ipool (the descriptor's pools are their prefixes).
+    struct KdLevelJob { int64_t split_off, data_off, bits_off, table_off; int32_t n_nodes; };
+    std::vector<KdLevelJob> level_jobs;
     double build_ms = 0.0;
     double device_build_ms = 0.0;     // kernel time of the device BVH builder, if it ran
     int device_built = 0;             // groups (world / instances) whose BVH the device builder made
@@ -46,7 +51,9 @@ struct FlatScene {
 // device_build: optional device BVH builder (hpt_bvh_gpu.hip); a group falls back to the host binned-SAH builder if it
 // declines or its tree is deeper than device_max_depth.
 int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out,
-                  BvhDeviceBuildFn device_build = nullptr, int device_max_depth = 0);
+                  BvhDeviceBuildFn device_build = nullptr, int device_max_depth = 0, bool defer_levels = false);
+// fills the tables of fs.level_jobs in the device copies of the pools; false (hpt_last_error() set) if a launch failed
+bool fill_kd_levels_gpu(const FlatScene &fs, float *d_fpool, const int32_t *d_ipool, double *kernel_ms);
 
 } // namespace hpt
 #endif

@@ -417,7 +417,7 @@ __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, 
                 if (k == 1) wi = normalize(mk3(q[6] - .5f, q[7] - .5f, q[8]));
                 if (k == 2) wo = normalize(mk3(q[7] - .5f, q[6] - .5f, q[8] + .1f));
                 sv.fq[k] = irreg_point(wo, wi);
-                ser[k] = irreg_eval(sc, &sc.materials[material], sv.fq[k]);
+                ser[k] = irreg_eval(sc.fpool, &sc.materials[material], sv.fq[k]);
             }
         }
         wave_eval_queries(sc, ls, sv, live);

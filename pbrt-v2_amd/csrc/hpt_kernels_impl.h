@@ -57,7 +57,7 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
 #define HPT_QSLOT(idx, j) col0[((idx) & 63) + (ls.qrow + 4 * ((idx) >> 6) + (j)) * ls.stride]
 // The walks: out of line so that the loop has a register budget of its own (the caller's live lane state is saved
 // around ONE call per vertex instead of being spilled inside the loop).
-__device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int total) {
+__device__ __noinline__ void wave_kd_run(const float *fpool, const hpt_material *materials, LaneStack ls, int total) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     HPT_LDS int32_t *col0 = ls.p - lane;
@@ -66,7 +66,7 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
     KdWalk w;
     w.j = w.jend = 0u; w.iy = w.iz = 0; w.y0 = w.y1 = w.z1 = -1; w.x0 = w.x1 = 0; w.samples = nullptr; w.cells = nullptr;
     if (slot >= 0)
-        kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
+        kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
     for (;;) {
         if (__ballot(slot >= 0) == 0ull) break;
         if (slot >= 0) {                                 // a burst of steps between two looks at the queue
@@ -85,7 +85,7 @@ __device__ __noinline__ void wave_kd_run(const DScene &sc, LaneStack ls, int tot
                 next += __popcll(mneed);
                 if (slot < 0 && idx < total) {
                     slot = idx;
-                    kd_begin(sc, &sc.materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
+                    kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
                 }
             }
         }
@@ -97,7 +97,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), total = n0 + n1 + n2;
     if (total == 0) return;
 #if defined(HPT_KD_DBG) && HPT_KD_DBG == 5
-    if (shaded) for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
+    if (shaded) for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
     return;
 #endif
     const int lane = lane_id();
@@ -110,7 +110,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    wave_kd_run(sc, ls, total);
+    wave_kd_run(sc.fpool, sc.materials, ls, total);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         if (MATS & MATS_MEASURED) {
             if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
-                for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
+                for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
         }
         HPT_PT(4)
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);

@@ -686,7 +686,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     HPT_MFN void on_hit_serial(const DScene &sc, const RenderParams &rp, const Hit &hit, float *film, WorkCounters *wc, LaneStack ls) {
         ShadeV sv;
         if (on_hit(sc, rp, hit, film, wc, ls, &sv)) {
-            for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc, &sc.materials[sv.mat], sv.fq[k]);
+            for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
             shade_finish(sc, rp, film, wc, sv);
         }
         flush(rp, film, wc);
