@@ -310,6 +310,11 @@ typedef struct hpt_scene hpt_scene; /* opaque: device-resident flattened scene +
 
 int hpt_device_count(void);
 const char *hpt_last_error(void);
+/* Starts the HIP runtime and `device`'s context on a thread of the library's own and returns at once; the first call that needs the
+ * runtime (hpt_device_count, hpt_scene_create, ...) waits for that thread.  For hosts that know they will render before they have a
+ * scene: the reference's pbrtWorldBegin (core/api.cpp:855) — its parser then reads the world while the runtime starts (50-190 ms on
+ * an MI355X box).  Optional; HPT_OK, or HPT_E_INVALID for a negative device. */
+int hpt_warmup(int device);
 
 /* Build the device BVH (binned SAH, host) and upload everything to HBM of `device`. */
 hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device);

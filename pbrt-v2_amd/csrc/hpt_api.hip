@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -153,20 +155,67 @@ static void tune_cache_store(const std::string &path, int cfg) {
 
 extern "C" int hpt_kernel_node_bytes(void) { return path_kernel_wide_bvh() ? 128 : 64; }
 
+// hpt_warmup: the runtime start (hipInit, device context) on a thread of its own; warmup_wait() before the library's first HIP call
+static std::mutex g_warm_mu;
+static std::thread *g_warm = nullptr;
+static void warmup_wait() {
+    std::lock_guard<std::mutex> lk(g_warm_mu);
+    if (g_warm) { g_warm->join(); delete g_warm; g_warm = nullptr; }
+}
+extern "C" int hpt_warmup(int device) {
+    if (device < 0) { hpt_set_error("hpt_warmup: device %d", device); return HPT_E_INVALID; }
+    std::lock_guard<std::mutex> lk(g_warm_mu);
+    if (g_warm) return HPT_OK;
+    g_warm = new std::thread([device] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n || hipSetDevice(device) != hipSuccess) return;
+        (void)hipFree(nullptr);                        // (creates the context)
+        // ... and the first host-to-device copy of a process (staging buffers, the copy kernels' code object: 20-25 ms on the MI355X box)
+        void *d = nullptr;
+        std::vector<char> h((size_t)1 << 20, 0);
+        if (hipMalloc(&d, h.size()) == hipSuccess) { (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice); (void)hipFree(d); }
+    });
+    return HPT_OK;
+}
+
 extern "C" int hpt_device_count(void) {
+    warmup_wait();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
 
-template <typename T> static T *upload(hpt_scene *s, const T *host, size_t n, bool *ok) {
+// The scene's arrays live in ONE device allocation (each array 256-byte aligned): a dozen hipMalloc / hipFree pairs cost more than the
+// copies of a 10 MB scene.  upload() falls back to an allocation of its own if the arena was sized too small.
+// A small scene (<= 64 MB) is first gathered in a host mirror of the arena and goes over in ONE copy: a dozen separate hipMemcpy calls of a
+// pageable 10 MB scene took 22-28 ms on the MI355X box, almost all of it per-call cost.
+struct UploadArena { char *base = nullptr; size_t cap = 0, used = 0; std::vector<char> stage; };
+static size_t arena_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+template <typename T> static T *upload(hpt_scene *s, UploadArena *ar, const T *host, size_t n, bool *ok) {
     if (n == 0) return nullptr;
     void *p = nullptr;
-    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { *ok = false; return nullptr; }
-    s->allocs.push_back(p);
-    if (hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { *ok = false; return nullptr; }
-    s->info.total_device_bytes += (int64_t)(n * sizeof(T));
+    const size_t bytes = n * sizeof(T);
+    if (ar->base && ar->used + arena_round(bytes) <= ar->cap) {
+        p = ar->base + ar->used;
+        if (!ar->stage.empty()) {                      // (flushed by arena_flush)
+            memcpy(ar->stage.data() + ar->used, host, bytes);
+            ar->used += arena_round(bytes);
+            s->info.total_device_bytes += (int64_t)bytes;
+            return (T *)p;
+        }
+        ar->used += arena_round(bytes);
+    } else {
+        if (hipMalloc(&p, bytes) != hipSuccess) { *ok = false; return nullptr; }
+        s->allocs.push_back(p);
+    }
+    if (hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) { *ok = false; return nullptr; }
+    s->info.total_device_bytes += (int64_t)bytes;
     return (T *)p;
+}
+
+static bool arena_flush(UploadArena *ar) {
+    if (ar->stage.empty() || ar->used == 0) return true;
+    return hipMemcpy(ar->base, ar->stage.data(), ar->used, hipMemcpyHostToDevice) == hipSuccess;
 }
 
 extern "C" void hpt_scene_destroy(hpt_scene *s) {
@@ -215,6 +264,31 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->n_cus = prop.multiProcessorCount;
     s->content_key = scene_content_key(desc, prop.name, prop.multiProcessorCount);
 
+    s->mats = 0; s->n_materials = desc->n_materials;
+    s->has_specular = false;
+    bool ext = desc->n_textures > 0;
+    for (int m = 0; m < desc->n_materials; ++m) {
+        const hpt_material &ma = desc->materials[m];
+        const int k = ma.kind;
+        s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
+                 : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
+        if (k == HPT_MAT_GLASS || k == HPT_MAT_MIRROR) { ext = true; s->has_specular = true; }
+        if (k == HPT_MAT_MEASURED_REGULAR || (k == HPT_MAT_MATTE && ma.sigma != 0.f)) ext = true;
+        for (int t = 0; t < HPT_N_TEXSLOTS; ++t) if (ma.tex[t] >= 0) ext = true;
+    }
+    for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0 || desc->meshes[m].s_off >= 0) ext = true;   // (explicit tangents: the extension set's shading geometry)
+    for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
+    // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
+    if (ext) s->mats = MATS_FULL;
+    // The code object of the scene's kernel set (one fat binary per set, 2-9 MB) loads on first use — 20 ms that the first render would
+    // wait for: load it now, on a thread of its own, while the host builds the trees (an occupancy query is a first use).
+    const int pre_mats = s->mats; const bool pre_inst = desc->n_instances > 0;
+    std::thread preload([pre_mats, pre_inst, device] {
+        if (getenv("HPT_NO_PRELOAD") || hipSetDevice(device) != hipSuccess) return;
+        int b = 0, v = 0;
+        (void)path_kernel_occupancy(pre_mats, pre_inst, 5, false, 0, &b, &v);
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } preload_joiner{preload};
     FlatScene fs;
     int maxLeaf = 2;   // (measured with subtree stealing: leaves of <= 2 / 3 / 4 / 8 triangles = 886 / 865 / 856 / 854 Msamples/s on killeroo, equal on the soup)
     if (const char *e = getenv("HPT_BVH_MAXLEAF")) maxLeaf = atoi(e);   // tuning knob (default 2, range 1..8)
@@ -253,33 +327,51 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     if (s->stack_entries > HPT_MAX_STACK_ROWS) s->stack_entries = HPT_MAX_STACK_ROWS;
 
     bool ok = true;
-    s->d.nodes = (const f4 *)upload(s, fs.nodes.data(), fs.nodes.size(), &ok);
-    s->d.tris = (const f4 *)upload(s, fs.tri_rec.data(), fs.tri_rec.size(), &ok);
-    s->d.meshes = upload(s, fs.meshes.data(), fs.meshes.size(), &ok);
-    s->d.quadrics = upload(s, desc->quadrics, (size_t)desc->n_quadrics, &ok);
-    s->d.materials = upload(s, fs.materials.data(), fs.materials.size(), &ok);
-    s->d.lights = upload(s, fs.lights.data(), fs.lights.size(), &ok);       // (device copy: guide-table offsets of the infinite lights)
-    s->d.fpool = upload(s, fs.fpool.data(), fs.fpool.size(), &ok);
-    s->d.ipool = upload(s, fs.ipool.data(), fs.ipool.size(), &ok);
-    s->d.textures = upload(s, desc->textures, (size_t)desc->n_textures, &ok);
-    s->d.instances = upload(s, desc->instances, (size_t)desc->n_instances, &ok);
-    s->d.inst_root = upload(s, fs.inst_root.data(), fs.inst_root.size(), &ok);
+    UploadArena arena;
+    {
+        const bool wide = path_kernel_wide_bvh() && !fs.nodes4.empty();
+        size_t cap = arena_round(fs.nodes.size() * sizeof(BvhNode64)) + arena_round(fs.tri_rec.size() * sizeof(float)) + arena_round(fs.meshes.size() * sizeof(DMesh))
+                   + arena_round((size_t)desc->n_quadrics * sizeof(hpt_quadric)) + arena_round(fs.materials.size() * sizeof(hpt_material))
+                   + arena_round(fs.lights.size() * sizeof(hpt_light)) + arena_round(fs.fpool.size() * sizeof(float)) + arena_round(fs.ipool.size() * sizeof(int32_t))
+                   + arena_round((size_t)desc->n_textures * sizeof(hpt_texture)) + arena_round((size_t)desc->n_instances * sizeof(hpt_instance))
+                   + arena_round(fs.inst_root.size() * sizeof(int32_t))
+                   + (wide ? arena_round(fs.nodes4.size() * sizeof(BvhNode64)) + arena_round(fs.inst_root4.size() * sizeof(int32_t)) : 0);
+        void *p = nullptr;
+        if (cap > 0 && hipMalloc(&p, cap) == hipSuccess) {
+            arena.base = (char *)p; arena.cap = cap; s->allocs.push_back(p);
+            if (cap <= ((size_t)64 << 20) && !getenv("HPT_NO_UPLOAD_STAGE")) arena.stage.resize(cap);
+        }
+    }
+    const auto t_arena = std::chrono::steady_clock::now();
+    s->d.nodes = (const f4 *)upload(s, &arena, fs.nodes.data(), fs.nodes.size(), &ok);
+    s->d.tris = (const f4 *)upload(s, &arena, fs.tri_rec.data(), fs.tri_rec.size(), &ok);
+    s->d.meshes = upload(s, &arena, fs.meshes.data(), fs.meshes.size(), &ok);
+    s->d.quadrics = upload(s, &arena, desc->quadrics, (size_t)desc->n_quadrics, &ok);
+    s->d.materials = upload(s, &arena, fs.materials.data(), fs.materials.size(), &ok);
+    s->d.lights = upload(s, &arena, fs.lights.data(), fs.lights.size(), &ok);       // (device copy: guide-table offsets of the infinite lights)
+    s->d.fpool = upload(s, &arena, fs.fpool.data(), fs.fpool.size(), &ok);
+    s->d.ipool = upload(s, &arena, fs.ipool.data(), fs.ipool.size(), &ok);
+    s->d.textures = upload(s, &arena, desc->textures, (size_t)desc->n_textures, &ok);
+    s->d.instances = upload(s, &arena, desc->instances, (size_t)desc->n_instances, &ok);
+    s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->stack_bound4 = 0; s->depth4 = 0;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
-        s->d.nodes4 = (const f4 *)upload(s, fs.nodes4.data(), fs.nodes4.size(), &ok);
-        s->d.inst_root4 = upload(s, fs.inst_root4.data(), fs.inst_root4.size(), &ok);
+        s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);
+        s->d.inst_root4 = upload(s, &arena, fs.inst_root4.data(), fs.inst_root4.size(), &ok);
         s->d.world_root4 = fs.world_root4;
         s->stack_bound4 = fs.stack_bound4; s->depth4 = fs.depth4;
     }
     s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
+    if (ok && !arena_flush(&arena)) ok = false;
     double levels_ms = 0.0;
     if (ok && !fill_kd_levels_gpu(fs, const_cast<float *>(s->d.fpool), s->d.ipool, &levels_ms)) { hpt_scene_destroy(s); return nullptr; }
     if (getenv("HPT_TIMING"))
-        fprintf(stderr, "hpt scene_create: validation + HIP runtime start + device query %.1f ms, flatten %.1f ms, device allocations + uploads (%.1f MB) %.1f ms (of which measured-BRDF level kernels %.2f ms)\n",
+        fprintf(stderr, "hpt scene_create: validation + HIP runtime start + device query %.1f ms, flatten %.1f ms, device allocations + uploads (%.1f MB) %.1f ms (of which the allocation %.1f ms, measured-BRDF level kernels %.2f ms)\n",
                 std::chrono::duration<double, std::milli>(t_flat0 - t_create0).count(),
                 std::chrono::duration<double, std::milli>(t_flat1 - t_flat0).count(), s->info.total_device_bytes / 1e6,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flat1).count(), levels_ms);
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flat1).count(),
+                std::chrono::duration<double, std::milli>(t_arena - t_flat1).count(), levels_ms);
     s->inst_xf = nullptr; s->inst_xf_lanes = 0;
     if (desc->n_instances > 0) {       // 12 floats (3x4) x instances x the most lanes a launch can have (4 workgroups of 256 per CU)
         s->inst_xf_lanes = (size_t)s->n_cus * 4 * HPT_BLOCK;
@@ -287,22 +379,6 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         if (hipMalloc(&p, sizeof(float) * 12 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
         else ok = false;
     }
-    s->mats = 0; s->n_materials = desc->n_materials;
-    s->has_specular = false;
-    bool ext = desc->n_textures > 0;
-    for (int m = 0; m < desc->n_materials; ++m) {
-        const hpt_material &ma = desc->materials[m];
-        const int k = ma.kind;
-        s->mats |= k == HPT_MAT_PLASTIC ? MATS_PLASTIC : k == HPT_MAT_MEASURED_IRREG ? MATS_MEASURED
-                 : k == HPT_MAT_METAL ? MATS_METAL : k == HPT_MAT_SUBSTRATE ? MATS_SUBSTRATE : 0;
-        if (k == HPT_MAT_GLASS || k == HPT_MAT_MIRROR) { ext = true; s->has_specular = true; }
-        if (k == HPT_MAT_MEASURED_REGULAR || (k == HPT_MAT_MATTE && ma.sigma != 0.f)) ext = true;
-        for (int t = 0; t < HPT_N_TEXSLOTS; ++t) if (ma.tex[t] >= 0) ext = true;
-    }
-    for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0 || desc->meshes[m].s_off >= 0) ext = true;   // (explicit tangents: the extension set's shading geometry)
-    for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
-    // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
-    if (ext) s->mats = MATS_FULL;
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
     // what every frame needs besides the film: allocated once, so that a render call neither allocates nor frees (hipFree synchronises the device)
@@ -807,6 +883,12 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
     a.sc = s->d;
+    {   // a cached answer needs no probe film (a 33 MB allocation and its release: 20 ms of a 0.4 s job)
+        const int c = tune_cache_load(tune_cache_path(s, cam, rd));
+        PathKernelArgs a2 = a;
+        int bpc = 0, vg = 0;
+        if (c >= 0 && kernel_residency(s, c, &a2, &bpc, &vg) == 0) { s->tune_cfg = c; return c; }
+    }
     struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
     DevBuf<Scratch> scr;
     DevBuf<float> filmbuf;

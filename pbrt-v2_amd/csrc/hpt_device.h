@@ -1338,15 +1338,30 @@ HPT_FN void mip_level(const hpt_texture &t, int level, int64_t *off, int *w, int
     for (int l = 0; l < level; ++l) { o += (int64_t)ww * hh * t.channels; ww = ww > 1 ? ww / 2 : 1; hh = hh > 1 ? hh / 2 : 1; }
     *off = o; *w = ww; *h = hh;
 }
-HPT_FN TexV mip_texel(const TexPools &sc, const hpt_texture &t, int64_t off, int w, int h, int si, int ti) {
+// One coordinate under the texture's wrap mode: the texel index, or -1 for a texel outside a "black" texture.  The integer remainder of
+// "repeat" costs some forty instructions on a machine without an integer divider, which is why the filters below wrap a row / a first
+// column once and step from there instead of wrapping every texel they touch.
+HPT_FN int mip_wrap(int wrap, int i, int n) {
+    if (wrap == HPT_WRAP_REPEAT) return mod_i(i, n);
+    if (wrap == HPT_WRAP_CLAMP) return i < 0 ? 0 : i > n - 1 ? n - 1 : i;
+    return i < 0 || i >= n ? -1 : i;
+}
+// the next column after wrapped column c (of unwrapped index i)
+HPT_FN int mip_wrap_next(int wrap, int c, int i, int n) {
+    if (wrap == HPT_WRAP_REPEAT) return c + 1 == n ? 0 : c + 1;
+    return mip_wrap(wrap, i + 1, n);
+}
+// texel (si, ti) of a level, both already wrapped (-1: outside)
+HPT_FN TexV mip_fetch(const float *level, int channels, int w, int si, int ti) {
     TexV r; r.c[0] = r.c[1] = r.c[2] = 0.f;
-    if (t.wrap == HPT_WRAP_REPEAT) { si = mod_i(si, w); ti = mod_i(ti, h); }
-    else if (t.wrap == HPT_WRAP_CLAMP) { si = si < 0 ? 0 : si > w - 1 ? w - 1 : si; ti = ti < 0 ? 0 : ti > h - 1 ? h - 1 : ti; }
-    else if (si < 0 || si >= w || ti < 0 || ti >= h) return r;
-    const float *px = sc.fpool + off + ((int64_t)ti * w + si) * t.channels;
+    if (si < 0 || ti < 0) return r;
+    const float *px = level + ((int64_t)ti * w + si) * channels;
     r.c[0] = px[0];
-    if (t.channels == 3) { r.c[1] = px[1]; r.c[2] = px[2]; }
+    if (channels == 3) { r.c[1] = px[1]; r.c[2] = px[2]; }
     return r;
+}
+HPT_FN TexV mip_texel(const TexPools &sc, const hpt_texture &t, int64_t off, int w, int h, int si, int ti) {
+    return mip_fetch(sc.fpool + off, t.channels, w, mip_wrap(t.wrap, si, w), mip_wrap(t.wrap, ti, h));
 }
 HPT_FN TexV mip_triangle(const TexPools &sc, const hpt_texture &t, int level, float s, float tt) {     // :258-269
     level = level < 0 ? 0 : level > t.levels - 1 ? t.levels - 1 : level;
@@ -1356,8 +1371,11 @@ HPT_FN TexV mip_triangle(const TexPools &sc, const hpt_texture &t, int level, fl
     tt = tt * h - 0.5f;
     const int s0 = (int)floorf(s), t0 = (int)floorf(tt);
     const float ds = s - s0, dt = tt - t0;
-    const TexV a = mip_texel(sc, t, off, w, h, s0, t0), b = mip_texel(sc, t, off, w, h, s0, t0 + 1);
-    const TexV c = mip_texel(sc, t, off, w, h, s0 + 1, t0), d = mip_texel(sc, t, off, w, h, s0 + 1, t0 + 1);
+    const int wrap = t.wrap, ch = t.channels;
+    const float *lv = sc.fpool + off;
+    const int sa = mip_wrap(wrap, s0, w), sb = mip_wrap_next(wrap, sa, s0, w), ta = mip_wrap(wrap, t0, h), tb = mip_wrap_next(wrap, ta, t0, h);
+    const TexV a = mip_fetch(lv, ch, w, sa, ta), b = mip_fetch(lv, ch, w, sa, tb);
+    const TexV c = mip_fetch(lv, ch, w, sb, ta), d = mip_fetch(lv, ch, w, sb, tb);
     TexV r;
     for (int k = 0; k < 3; ++k) r.c[k] = (((1.f - ds) * (1.f - dt)) * a.c[k] + ((1.f - ds) * dt) * b.c[k]) + (ds * (1.f - dt)) * c.c[k] + (ds * dt) * d.c[k];
     return r;
@@ -1382,18 +1400,24 @@ HPT_FN TexV mip_ewa(const TexPools &sc, const hpt_texture &t, int level, float s
     const int t0 = (int)ceilf(tt - 2.f * invDet * vSqrt), t1 = (int)floorf(tt + 2.f * invDet * vSqrt);
     TexV sum; sum.c[0] = sum.c[1] = sum.c[2] = 0.f;
     float sumWts = 0.f;
+    const int wrap = t.wrap, ch = t.channels;
+    const float *lv = sc.fpool + off;
+    const int col0 = mip_wrap(wrap, s0, w);              // column of s0; every row restarts from it
     for (int it = t0; it <= t1; ++it) {
         const float tc = it - tt;
+        const int ti = mip_wrap(wrap, it, h);
+        int si = col0;
         for (int is = s0; is <= s1; ++is) {
             const float ss = is - s;
             const float r2 = A * ss * ss + B * ss * tc + C * tc * tc;
             if (r2 < 1.f) {
                 int li = (int)(r2 * 128); if (li > 127) li = 127;
                 const float weight = sc.ewa_lut[li];
-                const TexV tx = mip_texel(sc, t, off, w, h, is, it);
+                const TexV tx = mip_fetch(lv, ch, w, si, ti);
                 for (int k = 0; k < 3; ++k) sum.c[k] += tx.c[k] * weight;
                 sumWts += weight;
             }
+            si = mip_wrap_next(wrap, si, is, w);
         }
     }
     for (int k = 0; k < 3; ++k) sum.c[k] = sum.c[k] / sumWts;
@@ -1432,27 +1456,39 @@ HPT_FN_NOINLINE TexV mip_lookup(const TexPools sc, const hpt_texture &t, float s
 // refused above HPT_TEX_DEPTH levels of nesting (hpt_api.hip), so the recursion is a template of bounded depth (out-of-line functions, one
 // per level: inlined, the filtering code would be copied into every operand of every call site).
 #define HPT_TEX_DEPTH 3
+// ... and a call costs its callee's saved registers (50 scratch stores + loads for a level of tex_eval), so the two leaf kinds never pay for a
+// level of their own: a constant is read in place and an image map goes straight to mip_lookup — scale(imagemap, constant), the bump map of
+// scenes/metal.pbrt, is two calls instead of four.
+HPT_FN TexV tex_image(const TexPools sc, const hpt_texture &t, const TexUV dg) {
+    return mip_lookup(sc, t, t.su * dg.u + t.du, t.sv * dg.v + t.dv, t.su * dg.dudx, t.sv * dg.dvdx, t.su * dg.dudy, t.sv * dg.dvdy);
+}
+template <int DEPTH> HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg);
+template <int DEPTH> HPT_FN TexV tex_node(const TexPools sc, int id, const TexUV dg) {
+    const hpt_texture &t = sc.textures[id];
+    if (t.kind == HPT_TEX_CONSTANT) { TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2]; return r; }
+    if (t.kind == HPT_TEX_IMAGEMAP) return tex_image(sc, t, dg);
+    return tex_eval<DEPTH>(sc, id, dg);
+}
 template <int DEPTH>
 HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg) {
     const hpt_texture &t = sc.textures[id];
     TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
     if (t.kind == HPT_TEX_CONSTANT) return r;
-    if (t.kind == HPT_TEX_IMAGEMAP)
-        return mip_lookup(sc, t, t.su * dg.u + t.du, t.sv * dg.v + t.dv, t.su * dg.dudx, t.sv * dg.dvdx, t.su * dg.dudy, t.sv * dg.dvdy);
+    if (t.kind == HPT_TEX_IMAGEMAP) return tex_image(sc, t, dg);
     if (DEPTH > 0) {
-        TexV a = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex1, dg), b = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex2, dg);
+        TexV a = tex_node<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex1, dg), b = tex_node<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex2, dg);
         if (sc.textures[t.tex1].channels < t.channels) a.c[1] = a.c[2] = a.c[0];   // a float operand of a spectrum texture acts on every channel
         if (sc.textures[t.tex2].channels < t.channels) b.c[1] = b.c[2] = b.c[0];
         if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k]; return r; }
-        const float amt = tex_eval<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
+        const float amt = tex_node<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
         for (int k = 0; k < 3; ++k) r.c[k] = (1.f - amt) * a.c[k] + amt * b.c[k];
     }
     return r;
 }
 HPT_FN TexPools tex_pools(const DScene &sc) { TexPools p; p.textures = sc.textures; p.fpool = sc.fpool; p.ewa_lut = sc.ewa_lut; return p; }
 HPT_FN TexUV tex_uv(const DGeomX &dg) { TexUV t; t.u = dg.u; t.v = dg.v; t.dudx = dg.dudx; t.dvdx = dg.dvdx; t.dudy = dg.dudy; t.dvdy = dg.dvdy; return t; }
-HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_eval<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)).c[0]; }
-HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_eval<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)); return mk3(v.c[0], v.c[1], v.c[2]); }
+HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)).c[0]; }
+HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)); return mk3(v.c[0], v.c[1], v.c[2]); }
 
 HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2) {
     const DMesh &me = sc.meshes[mesh_word & HPT_TRI_MESH_MASK];
@@ -1852,8 +1888,14 @@ HPT_FN f3 env_lookup(const DScene &sc, const hpt_light &l, float s, float t) { /
     t = t * l.env_h - 0.5f;
     int s0 = (int)floorf(s), t0 = (int)floorf(t);
     float ds = s - s0, dt = t - t0;
-    return ((env_texel(sc, l, s0, t0) * ((1.f - ds) * (1.f - dt)) + env_texel(sc, l, s0, t0 + 1) * ((1.f - ds) * dt)) +
-            env_texel(sc, l, s0 + 1, t0) * (ds * (1.f - dt))) + env_texel(sc, l, s0 + 1, t0 + 1) * (ds * dt);
+    // (the map repeats: two integer remainders instead of eight — the second column / row is the first one stepped, as in mip_triangle)
+    const int w = l.env_w, h = l.env_h;
+    const int sa = mod_i(s0, w), ta = mod_i(t0, h), sb = sa + 1 == w ? 0 : sa + 1, tb = ta + 1 == h ? 0 : ta + 1;
+    const float *base = sc.fpool + l.tex_off;
+    const float *p00 = base + 3 * ((int64_t)ta * w + sa), *p01 = base + 3 * ((int64_t)tb * w + sa);
+    const float *p10 = base + 3 * ((int64_t)ta * w + sb), *p11 = base + 3 * ((int64_t)tb * w + sb);
+    return ((mk3(p00[0], p00[1], p00[2]) * ((1.f - ds) * (1.f - dt)) + mk3(p01[0], p01[1], p01[2]) * ((1.f - ds) * dt)) +
+            mk3(p10[0], p10[1], p10[2]) * (ds * (1.f - dt))) + mk3(p11[0], p11[1], p11[2]) * (ds * dt);
 }
 HPT_FN f3 light_Le(const DScene &sc, const hpt_light &l, f3 d) { // Light::Le / InfiniteAreaLight::Le (infinite.cpp:117-122)
     if (l.kind != HPT_LIGHT_INFINITE) return S(0.f);

@@ -30,6 +30,8 @@ public:
 private:
     BBox bounds;
 };
+// called from pbrtWorldBegin (api_hip_renderer.patch): starts the HIP runtime on the device the renderer will use while the world is parsed
+void HipRendererWarmup(const ParamSet &rendererParams);
 Primitive *MakeHipAggregate(const vector<Reference<Primitive> > &prims);   // NULL: use the scene's own accelerator (HPT_HOST_BVH=1)
 
 class HipPathRenderer : public Renderer {

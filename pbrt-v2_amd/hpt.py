@@ -23,7 +23,7 @@ EXPORTS = [
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
-    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion",
+    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
 ]
 
 
@@ -91,6 +91,11 @@ def last_error():
 
 def device_count():
     return int(lib().hpt_device_count())
+
+
+def warmup(device=0):
+    """hpt_warmup: start the HIP runtime on a library thread; returns at once (the next call that needs the runtime waits for it)."""
+    _check(lib().hpt_warmup(int(device)))
 
 
 def _check(rc):
