@@ -1444,6 +1444,9 @@ HPT_FN_NOINLINE TexV mip_lookup(const TexPools sc, const hpt_texture &t, float s
         ds1 *= scale; dt1 *= scale; minorLength *= scale;
     }
     if (minorLength == 0.f) return mip_triangle(sc, t, 0, s, tt);
+#ifdef HPT_DBG_NO_EWA     /* timing experiment only (wrong images) */
+    return mip_triangle(sc, t, 0, s, tt);
+#endif
     const float lod = maxf(0.f, t.levels - 1.f + log2_pbrt(minorLength));
     const int ilod = (int)floorf(lod);
     const float d = lod - ilod;
@@ -1465,8 +1468,23 @@ HPT_FN TexV tex_image(const TexPools sc, const hpt_texture &t, const TexUV dg) {
 template <int DEPTH> HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg);
 template <int DEPTH> HPT_FN TexV tex_node(const TexPools sc, int id, const TexUV dg) {
     const hpt_texture &t = sc.textures[id];
+#ifdef HPT_DBG_NO_TEX     /* timing experiment only (wrong images): every texture is its constant */
+    { TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2]; return r; }
+#endif
     if (t.kind == HPT_TEX_CONSTANT) { TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2]; return r; }
     if (t.kind == HPT_TEX_IMAGEMAP) return tex_image(sc, t, dg);
+    if (DEPTH == HPT_TEX_DEPTH && t.kind == HPT_TEX_SCALE) {        // a product of two leaves (a scaled map: the usual bump texture), at the call site only
+        const hpt_texture &o1 = sc.textures[t.tex1], &o2 = sc.textures[t.tex2];
+        if (o1.kind <= HPT_TEX_IMAGEMAP && o2.kind <= HPT_TEX_IMAGEMAP) {
+            TexV a, b, r;
+            if (o1.kind == HPT_TEX_CONSTANT) { a.c[0] = o1.value[0]; a.c[1] = o1.value[1]; a.c[2] = o1.value[2]; } else a = tex_image(sc, o1, dg);
+            if (o2.kind == HPT_TEX_CONSTANT) { b.c[0] = o2.value[0]; b.c[1] = o2.value[1]; b.c[2] = o2.value[2]; } else b = tex_image(sc, o2, dg);
+            if (o1.channels < t.channels) a.c[1] = a.c[2] = a.c[0];
+            if (o2.channels < t.channels) b.c[1] = b.c[2] = b.c[0];
+            for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k];
+            return r;
+        }
+    }
     return tex_eval<DEPTH>(sc, id, dg);
 }
 template <int DEPTH>
@@ -1835,7 +1853,9 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
             dgs.dndu = xf_normal(minv, dndu); dgs.dndv = xf_normal(minv, dndv);
         }
     }
+#ifndef HPT_DBG_NO_BUMP   /* timing experiment only (wrong images) */
     if (mat->tex[HPT_TEXSLOT_BUMP] >= 0) { DGeomX db; bump_geometry(sc, mat->tex[HPT_TEXSLOT_BUMP], dg.nn, dgs, flip, &db); dgs = db; }
+#endif
     dgo->p = dgs.p; dgo->nn = dg.nn; dgo->dpdu = dgs.dpdu;
     if (dgs_out) *dgs_out = dgs;
     bsdf_frame(b, dgs.nn, dgs.dpdu, dg.nn);
@@ -1877,7 +1897,21 @@ HPT_FN void specular_differentials(const RayDiff &rd, f3 rayd_unused, const DGeo
 HPT_FN f3 area_L(const hpt_light &l, f3 n, f3 w) { // DiffuseAreaLight::L (lights/diffuse.h:51-53)
     return dot(n, w) > 0.f ? mk3(l.intensity[0], l.intensity[1], l.intensity[2]) : S(0.f);
 }
-HPT_FN int mod_i(int a, int b) { int n = (int)(a / b); a -= n * b; if (a < 0) a += b; return a; }
+// a mod b in [0, b) for b > 0 (Mod, core/pbrt.h:216-221).  The device has no integer divider (a / b is some forty instructions): the quotient is
+// estimated in float, and the remainder corrected in integers — exact whatever the estimate, which only decides how often the loops turn
+// (never more than once for |a| < 2^22; larger values take the division).
+HPT_FN int mod_i(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((unsigned)(a + (1 << 22)) < (1u << 23)) {
+        const int q = (int)floorf((float)a * __builtin_amdgcn_rcpf((float)b));
+        int r = a - q * b;
+        while (r < 0) r += b;
+        while (r >= b) r -= b;
+        return r;
+    }
+#endif
+    int n = (int)(a / b); a -= n * b; if (a < 0) a += b; return a;
+}
 HPT_FN f3 env_texel(const DScene &sc, const hpt_light &l, int si, int ti) {
     si = mod_i(si, l.env_w); ti = mod_i(ti, l.env_h);
     const float *t = sc.fpool + l.tex_off + 3 * ((int64_t)ti * l.env_w + si);
