@@ -49,7 +49,7 @@ class EmuScene:
         out = np.zeros(8, dtype=np.int64)
         lib().emu_scene_info(self.h, out.ctypes.data)
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2]),
-                "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5])}
+                "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5]), "tree_hash": int(out[6])}
 
     def render(self, cam, rd, flt=None, two_pass=False, cam_motion=None):
         """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the

@@ -54,6 +54,13 @@ extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
 extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
     out[0] = s->fs.n_tris; out[1] = (int64_t)s->fs.nodes.size(); out[2] = s->fs.max_depth;
     out[3] = (int64_t)s->fs.nodes4.size() / 2; out[4] = s->fs.stack_bound4; out[5] = s->fs.depth4;
+    // FNV-1a over the node arrays and the leaf-ordered triangle records: the builder's output, byte for byte
+    auto fnv = [](uint64_t h, const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; };
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, s->fs.nodes.data(), s->fs.nodes.size() * sizeof(BvhNode64));
+    h = fnv(h, s->fs.nodes4.data(), s->fs.nodes4.size() * sizeof(BvhNode64));
+    h = fnv(h, s->fs.tri_rec.data(), s->fs.tri_rec.size() * sizeof(float));
+    out[6] = (int64_t)h;
 }
 
 // hpt_scene_set_filter's stand-in (process-wide; NULL = box of width 0.5)

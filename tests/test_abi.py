@@ -66,6 +66,12 @@ def test_invalid_descriptors_are_rejected(cases, tmp_path):
     assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -3
 
 
+def test_warmup_validates_its_argument_before_any_runtime_work():
+    """hpt_warmup (include/hpt.h): a negative device is refused on the calling thread — no thread is started, no HIP call made."""
+    assert hpt.lib().hpt_warmup(-1) == -2
+    assert "hpt_warmup" in hpt.last_error()
+
+
 def test_no_cpu_fallback_without_device(cases):
     if hpt.device_count() > 0:
         pytest.skip("a HIP device is present")

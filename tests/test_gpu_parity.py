@@ -130,6 +130,30 @@ def test_render_matches_oracle_sample_for_sample(cases, dev, ora, name):
     assert abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 20000)
 
 
+def test_warmup_thread_starts_the_runtime_for_a_fresh_process(cases, dev, tmp_path):
+    """hpt_warmup (what pbrtWorldBegin calls through the plugin): in a FRESH process the library starts the HIP runtime, the device context
+    and the first host-to-device copy on a thread of its own; the first call that needs the runtime waits for it.  The film of that process
+    is the film of this one (which never warmed up), a second hpt_warmup is a no-op, and the measured-BRDF scene exercises the device-filled
+    level table (fill_kd_levels_gpu) behind it."""
+    import subprocess, sys
+    from tests.util import ROOT
+    s = cases["b8"]
+    rd = hash_rd(s, seed=9)
+    fd, _ = dev["b8"].render(s.camera, rd)
+    out = tmp_path / "film.npy"
+    code = (
+        "import sys, importlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.util import load_case, hash_rd\n"
+        "hpt = importlib.import_module('pbrt-v2_amd.hpt')\n"
+        "hpt.warmup(0); hpt.warmup(0)\n"
+        "s = load_case('b8'); rd = hash_rd(s, seed=9)\n"
+        "f, st = hpt.DeviceScene(s).render(s.camera, rd)\n"
+        "np.save(%r, f)\n" % (ROOT, str(out)))
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT, timeout=600)
+    assert np.array_equal(np.load(out), fd)
+
+
 R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex"]   # round-2 / round-3 scenes of the path integrator
 
 

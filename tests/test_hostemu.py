@@ -207,6 +207,21 @@ def test_four_wide_trees_find_the_same_hits(cases, name):
             assert deepest <= info["depth4"]
 
 
+@pytest.mark.parametrize("name", ["b8", "anim"])
+def test_forked_tree_build_equals_the_serial_build(cases, name, monkeypatch):
+    """Round 3: the host SAH builder (csrc/hpt_bvh.cpp) builds the subtrees of its top four levels on threads of their own and splices them
+    back in depth-first order.  The result must be the array the serial build produces, byte for byte (BVH2 nodes, the collapsed BVH4, the
+    leaf-ordered triangle records) — HPT_BVH_THREADS pins the thread count the fork depth is derived from."""
+    hashes = {}
+    for threads in ("1", "2", "16"):
+        monkeypatch.setenv("HPT_BVH_THREADS", threads)
+        e = emu.EmuScene(cases[name], max_leaf=2)
+        info = e.info()
+        hashes[threads] = (info["tree_hash"], info["n_nodes"], info["max_depth"])
+        e.close()
+    assert hashes["1"] == hashes["2"] == hashes["16"], hashes
+
+
 @pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex"])
 def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     """Round 3: the MT_REPLAY sampler source over the FULL material set (Lane<MtReplaySrc, true, MATS_FULL>) — Oren-Nayar, glass / mirror,
