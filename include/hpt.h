@@ -4,9 +4,9 @@
  * behind pbrt's own Renderer plugin surface, the reference's
  *
  *     Renderer::Render(const Scene *)                 core/renderer.h:43-54
- *       = SamplerRenderer::Render                     renderers/samplerrenderer.cpp:283-317
- *       + SamplerRendererTask::Run                    renderers/samplerrenderer.cpp:155-259
- *       + SamplerRenderer::Li / PathIntegrator::Li    samplerrenderer.cpp:320-342, integrators/path.cpp:52-123
+ *       = SamplerRenderer::Render                     renderers/samplerrenderer.cpp:188-222
+ *       + SamplerRendererTask::Run                    renderers/samplerrenderer.cpp:60-164
+ *       + SamplerRenderer::Li / PathIntegrator::Li    samplerrenderer.cpp:225-247, integrators/path.cpp:52-123
  *
  * The reference has no FFI of its own (plugins are statically linked C++ classes,
  * README.txt:55-61); the binding a maintainer adds is one Renderer subclass
@@ -230,7 +230,7 @@ typedef struct hpt_camera {
  *                          sample is O(1) computable on any lane (no sample buffer in HBM).
  *  HPT_SAMPLER_MT_REPLAY : parity tool.  Replays the reference's own random stream: one
  *                          MT19937 per image tile seeded with the task number
- *                          (samplerrenderer.cpp:168), LDPixelSample (montecarlo.cpp:200-252),
+ *                          (samplerrenderer.cpp:73), LDPixelSample (montecarlo.cpp:200-252),
  *                          rng draws for bounces >= 3 and Russian roulette in reference order.
  *                          One lane per tile, serial inside the tile: slow, bit-for-bit sequence. */
 enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
@@ -274,7 +274,7 @@ typedef struct hpt_render_desc {
     int32_t maxdepth;                 /* PathIntegrator::maxDepth                         */
     int32_t sampler_mode;
     uint32_t seed;                    /* LD_HASH seed                                     */
-    int32_t ntasks;                   /* MT_REPLAY: nTasks of samplerrenderer.cpp:298-300 */
+    int32_t ntasks;                   /* MT_REPLAY: nTasks of samplerrenderer.cpp:203-205 */
     int32_t shard_rank, shard_count;  /* pixel-tile shard of this device (0,1 = all)      */
     int32_t count_work;               /* 1: fill the traversal counters of hpt_stats      */
     int32_t pipeline;                 /* HPT_PIPELINE_*                                   */
@@ -287,7 +287,7 @@ typedef struct hpt_stats {
     uint64_t closest_rays, shadow_rays;
     uint64_t nodes_visited;    /* 64-byte BVH2 nodes fetched                                */
     uint64_t tris_tested;      /* 48-byte triangle records fetched                          */
-    uint64_t bad_samples;      /* NaN / negative / inf radiance zeroed (samplerrenderer.cpp:214-228) */
+    uint64_t bad_samples;      /* NaN / negative / inf radiance zeroed (samplerrenderer.cpp:118-131) */
     uint32_t resident_waves, grid_blocks, block_threads, vgprs;
     uint32_t tune_cfg;         /* kernel configuration that ran: 0 = 4 waves/SIMD, 1 = 4 waves + early-exit
                                 * traversal, 2 = 3 waves/SIMD, 3 / 4 = 4 / 3 waves with the wave's lanes in lock
@@ -367,7 +367,7 @@ int hpt_scene_set_camera_motion(hpt_scene *scene, const hpt_instance *camera_to_
 /* ---- multi-GPU (SURVEY.md §8b "gpus", §8e) ------------------------------------------------------------------------------------
  * The path shards with no data-path collective: the scene is replicated per GPU, shard r renders the 32x32 pixel tiles t with
  * t % n == r (shard_rank / shard_count above), and ONE exchange of film data per frame brings the frame to shard 0 — a gather of the
- * owned tiles over RCCL send / recv (the reference's disjoint image tiles, renderers/samplerrenderer.cpp:298-307, core/sampler.cpp:55-74),
+ * owned tiles over RCCL send / recv (the reference's disjoint image tiles, renderers/samplerrenderer.cpp:203-212, core/sampler.cpp:55-74),
  * or a sum-reduce of the full-frame films under a reconstruction filter wider than the box (film/image.cpp:96-136).
  *
  * hpt_multi: one process, one host thread per GPU — what `Renderer "hip" "integer gpus" [N]` of the pbrt plugin drives.  `devices` may

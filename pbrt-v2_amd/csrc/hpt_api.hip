@@ -1,5 +1,5 @@
 // hpt_api.hip — implementation of the C ABI in include/hpt.h: scene upload to HBM, the render
-// call that replaces SamplerRenderer::Render (renderers/samplerrenderer.cpp:283-317) and the
+// call that replaces SamplerRenderer::Render (renderers/samplerrenderer.cpp:188-222) and the
 // function-level parity hooks.  HIP runtime only; there is deliberately NO CPU path: without a
 // device every compute entry point fails with HPT_E_NODEVICE.
 #include <chrono>
@@ -444,7 +444,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
     if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY && !random_sampler) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
     if (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY) {
-        if (rd->ntasks <= 0 || (rd->ntasks & (rd->ntasks - 1))) { hpt_set_error("MT_REPLAY needs ntasks = the reference's nTasks (a power of two, samplerrenderer.cpp:298-300)"); return HPT_E_INVALID; }
+        if (rd->ntasks <= 0 || (rd->ntasks & (rd->ntasks - 1))) { hpt_set_error("MT_REPLAY needs ntasks = the reference's nTasks (a power of two, samplerrenderer.cpp:203-205)"); return HPT_E_INVALID; }
         if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
     }
     rp->cam = *cam;
@@ -864,7 +864,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
             stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
             stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris;
         }
-        if (!getenv("HPT_PHASE_TIMERS")) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:214-228: the host plugin reports them)
+        if (!getenv("HPT_PHASE_TIMERS")) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:118-131: the host plugin reports them)
         stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
         stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs;
         stats->tune_cfg = replay ? 0u : (uint32_t)cfg;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_replay_kernel(const PathKernelA
     if (!exhausted) {
         compute_sub_window(rp.sx_start, rp.sx_start + rp.sx_count, rp.sy_start, rp.sy_start + rp.sy_count, (int)gid, ra.ntasks,
                            &tw.x0, &tw.x1, &tw.y0, &tw.y1);
-        lane.smp.seed((uint32_t)gid);                       // RNG rng(taskNum), samplerrenderer.cpp:168
+        lane.smp.seed((uint32_t)gid);                       // RNG rng(taskNum), samplerrenderer.cpp:73
     }
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
     TravCounters tc = {0, 0};
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void hpt_film_gather_kernel(const RenderParams
 // with E = 0x7f7f7f7f, which no pixel passes.  A pixel's records sit (spp + 1) slots apart, so the lanes of a pixel row — which walk BW different
 // source pixels in step — hit different banks with both the b128 and the b64 read (MI355X_MICROARCH.md, LDS lane groups).
 //   Per record the lane's work is straight-line: the table index is computed and the weight LOADED for every record and then selected to +0
-// when the record is out of reach, which leaves the sums unchanged bit for bit (radiance values are finite: samplerrenderer.cpp:214-228 zeroes
+// when the record is out of reach, which leaves the sums unchanged bit for bit (radiance values are finite: samplerrenderer.cpp:118-131 zeroes
 // the others).  (x - dimageX) * invWidth * 16 is computed as (x - dimageX) * (invWidth * 16): scaling by 16 commutes with rounding.  Records go
 // eight at a time, loads first, so their LDS latency overlaps.
 //   Summation order: rows, source pixels, sample index — the order of film_gather_pixel (hpt_path.h), so the film is bit-identical to it, to the

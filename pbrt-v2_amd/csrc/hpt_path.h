@@ -1,8 +1,8 @@
 // hpt_path.h — per-lane path state machine of the persistent-threads wavefront kernel.
 //
 // What it replaces in the reference (one lane == one SamplerRendererTask "thread of control"):
-//   SamplerRendererTask::Run sample loop     renderers/samplerrenderer.cpp:155-259
-//   SamplerRenderer::Li                      renderers/samplerrenderer.cpp:320-342
+//   SamplerRendererTask::Run sample loop     renderers/samplerrenderer.cpp:60-164
+//   SamplerRenderer::Li                      renderers/samplerrenderer.cpp:225-247
 //   PathIntegrator::Li                       integrators/path.cpp:52-123
 //   UniformSampleOneLight / EstimateDirect   core/integrator.cpp:82-174
 //   ImageFilm::AddSample (box filter)        film/image.cpp:77-137
@@ -52,13 +52,13 @@ struct RenderParams {
     int32_t strat_n, strat_jitter;                 // stratified: spp, jitter
     float strat_fxs, strat_dx, strat_dy, strat_dt; // (float)xsamples, 1.f / xsamples, 1.f / ysamples, 1.f / spp
     f3 dx_camera, dy_camera;   // PerspectiveCamera::dxCamera / dyCamera (cameras/perspective.cpp:46-48): camera-ray differentials (MATS_EXT kernels)
-    float diff_scale;          // 1 / sqrt(samplesPerPixel): ray.ScaleDifferentials (renderers/samplerrenderer.cpp:190)
+    float diff_scale;          // 1 / sqrt(samplesPerPixel): ray.ScaleDifferentials (renderers/samplerrenderer.cpp:91)
     int32_t n_heads;           // work-queue heads: 8 (one per XCD, each over a band of the frame's tiles) or 1
     int32_t chunk;             // camera samples per work item (a pixel's spp are split into spp/chunk items)
     int64_t items_per_pass;    // this shard's pixels incl. padding (local super-tiles x 1024)
     int64_t n_items;           // items_per_pass x (spp / chunk)
     unsigned long long *bad_counter;   // camera samples whose radiance was NaN / negative / infinite and went to the film as black
-                                       // (samplerrenderer.cpp:214-228 reports them): one device atomic on that rare path; nullptr: not counted
+                                       // (samplerrenderer.cpp:118-131 reports them): one device atomic on that rare path; nullptr: not counted
 };
 
 struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
@@ -269,7 +269,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; fin = false; }
     HPT_MFN void flush(const RenderParams &rp, float *film, WorkCounters *wc) { if (fin) { fin = false; finish_path(rp, film, wc); } }
 
-    // samplerrenderer.cpp:185-206 for one camera sample
+    // samplerrenderer.cpp:90-111 for one camera sample
     HPT_MFN void begin_sample(const RenderParams &rp) {
         smp.begin_sample(si);
         float a, b;
@@ -291,7 +291,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     }
 
     // ImageFilm::AddSample with the box filter (film/image.cpp:77-137) + the radiance sanity
-    // checks of samplerrenderer.cpp:214-228; then advance to the next sample / flush the pixel.
+    // checks of samplerrenderer.cpp:118-131; then advance to the next sample / flush the pixel.
     HPT_MFN void finish_path(const RenderParams &rp, float *film, WorkCounters *wc) {
         f3 Ls = cold.L();
         bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
@@ -436,10 +436,10 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         fin = true;
     }
 
-    // The extension ray escaped: the radiance it sees (samplerrenderer.cpp:335-338, path.cpp:114-116); the path is complete.
+    // The extension ray escaped: the radiance it sees (samplerrenderer.cpp:240-243, path.cpp:114-116); the path is complete.
     HPT_MFN void extend_miss(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
         if (DL_REC && depth > 0) { cold.setL(cold.L() + smul(cold.beta(), all_lights_Le(sc, ray.d))); node_done(sc, rp, film, wc, false); return; }
-        if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:335-338
+        if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:240-243
         else if (specular)                                             // path.cpp:114-116
             for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
         fin = true;

@@ -3,7 +3,7 @@
 // for the same scene file at the same seed.
 //
 // The reference couples every sample of an image tile through one serial generator:
-//   RNG rng(taskNum)                         renderers/samplerrenderer.cpp:168   (MT19937, core/rng.cpp)
+//   RNG rng(taskNum)                         renderers/samplerrenderer.cpp:73   (MT19937, core/rng.cpp)
 //   LDPixelSample(x, y, ..., rng)            core/montecarlo.cpp:200-252  — scrambles + shuffles per pixel
 //   rng.RandomFloat() for bounces >= 3, RR   integrators/path.cpp:77-105, core/integrator.cpp:95-108
 // and the number of draws a path consumes depends on the path.  Replaying it is therefore serial per

@@ -634,7 +634,7 @@ void HipPathRenderer::Render(const Scene *scene) {
                                                  strat->xPixelSamples, strat->jitterSamples);
     }
     rd.seed = seed;
-    // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:298-300)
+    // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:203-205)
     int nPixels = film->xResolution * film->yResolution;
     rd.ntasks = (int)RoundUpPow2((uint32_t)max(32 * NumSystemCores(), nPixels / (16 * 16)));
     rd.shard_rank = 0; rd.shard_count = 1;
@@ -737,7 +737,7 @@ void HipPathRenderer::Render(const Scene *scene) {
 // Renderer::Li / Transmittance (core/renderer.h:47-53): what the reference's integrators call back into for a ray of their own
 // (SpecularReflect / SpecularTransmit, core/integrator.cpp:177-258; irradiance caching, photon mapping ...).  Nothing on the device path
 // calls them — the kernel owns the whole per-sample loop — but the interface is honoured for host-side callers: the same evaluation
-// SamplerRenderer::Li performs (renderers/samplerrenderer.cpp:320-342), with the plugins this renderer owns, on the CPU.
+// SamplerRenderer::Li performs (renderers/samplerrenderer.cpp:225-247), with the plugins this renderer owns, on the CPU.
 Spectrum HipPathRenderer::Li(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng,
                              MemoryArena &arena, Intersection *isect, Spectrum *T) const {
     Spectrum localT;

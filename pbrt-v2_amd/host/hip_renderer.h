@@ -5,7 +5,7 @@
 //
 // Mirrors SamplerRenderer's interface (renderers/samplerrenderer.h:44-62): same constructor
 // arguments, same ownership (the renderer owns and deletes sampler, camera, both integrators —
-// samplerrenderer.cpp:275-280), same error convention (Error()/Severe(), core/error.h:49-52).
+// samplerrenderer.cpp:180-185), same error convention (Error()/Severe(), core/error.h:49-52).
 #ifndef PBRT_RENDERERS_HIPRENDERER_H
 #define PBRT_RENDERERS_HIPRENDERER_H
 

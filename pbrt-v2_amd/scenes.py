@@ -85,7 +85,7 @@ def render_desc(xres, yres, spp, maxdepth, seed=0, ncores_for_ntasks=8):
     rd.x_start, rd.x_count, rd.y_start, rd.y_count = 0, xres, 0, yres
     rd.spp, rd.maxdepth = spp, maxdepth
     rd.sampler_mode, rd.seed = abi.HPT_SAMPLER_LD_HASH, seed
-    n = max(32 * ncores_for_ntasks, (xres * yres) // 256)   # samplerrenderer.cpp:298-300
+    n = max(32 * ncores_for_ntasks, (xres * yres) // 256)   # samplerrenderer.cpp:203-205
     rd.ntasks = 1 << (n - 1).bit_length()
     rd.shard_rank, rd.shard_count, rd.count_work = 0, 1, 0
     return rd

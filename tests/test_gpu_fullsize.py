@@ -13,7 +13,7 @@ bunny and killeroo (64 spp) are compared over the WHOLE frame; anim (128 spp), t
 30 / 30 / 24 windows of 64x64 pixels: the four frame corners, the centre, one window that straddles the border between two per-XCD
 bands of the work queue (hpt_kernels_impl.h: head k hands out the k-th eighth of the frame's 32x32 tiles) and the windows of the
 rendered frame with the highest luminance variance (tests/util.py content_windows) — where the shading is, not the sky.
-Reference for what is being replaced: SamplerRendererTask::Run, renderers/samplerrenderer.cpp:155-259.
+Reference for what is being replaced: SamplerRendererTask::Run, renderers/samplerrenderer.cpp:60-164.
 """
 import importlib
 
@@ -104,7 +104,7 @@ def test_metal_4k_with_the_grace_environment_map_matches_oracle_on_content_crops
 
 
 def test_bad_radiance_values_are_counted_by_the_production_kernel():
-    """samplerrenderer.cpp:214-228: NaN / negative-luminance / infinite radiance values are reported and go to the film as black.  The
+    """renderers/samplerrenderer.cpp:118-131: NaN / negative-luminance / infinite radiance values are reported and go to the film as black.  The
     production kernel counts them (one device atomic on that rare path) so that hpt_stats.bad_samples — and with it the plugin's
     Error() — is real without the instrumented build.  A light with negative radiance makes every lit sample bad."""
     from tests.util import load_case
