@@ -210,11 +210,14 @@ def end_to_end_pbrt_hip(workload, scene):
         # The first process that loads ROCm's own HIP runtime on a fresh box pages it in from the image (measured: 156 s once, against
         # 0.7-1.2 s — this bench process runs on torch's bundled runtime and does not warm it).  So the first run's
         # wall time is only reported as cold_wall_s; a first run beyond 240 s is given up on.
-        # After that the wall time still moves by 0.1-0.2 s from run to run: the start of the HIP runtime took 60-270 ms on the same box in
-        # back-to-back runs (profiles/r03_ab.md, run H).  Four warm runs: the MEDIAN is the figure, the best is reported beside it; two more
-        # runs with HPT_FAST_EXIT=1 (no runtime teardown after main() returns) give wall_fast_exit_s.
+        # After that the wall time still depends on what the GPU did a moment ago: while the driver tears down the context of the PREVIOUS
+        # process, the next one's hipInit takes 150-280 ms instead of 50 (scripts/calib/hip_init_time.cpp, profiles/r03_ab.md run P: back to
+        # back 175-240 ms in all, after a 1 s pause 74-88 ms — which the parser hides, hpt_warmup).  So every warm run starts after a 1 s
+        # pause (a renderer is not normally started in the millisecond another one exits); four warm runs, the MEDIAN is the figure, the
+        # best beside it; two runs back to back (back_to_back_s) and two with HPT_FAST_EXIT=1 (no runtime teardown after main() returns).
         runs, errs = [], []
-        def once(extra_env):
+        def once(extra_env, pause=1.0):
+            time.sleep(pause)
             t = time.time()
             p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, env=dict(os.environ, HPT_TIMING="1", **extra_env))
             dt_ = time.time() - t
@@ -227,6 +230,7 @@ def end_to_end_pbrt_hip(workload, scene):
                 if not ok:
                     return {"error": e_[-300:]}
                 runs.append(dt_); errs.append(e_)
+            b2b = [once({}, pause=0.0)[0] for _ in range(2)]
             fast = [once({"HPT_FAST_EXIT": "1"})[0] for _ in range(2)]
         except subprocess.TimeoutExpired:
             return {"error": "pbrt_hip did not finish within 240 s (cold start of the HIP runtime on a fresh box?)", "runs_s": runs}
@@ -258,10 +262,10 @@ def end_to_end_pbrt_hip(workload, scene):
         stages["pbrt_cleanup_s"] = float(m.group(1)); stages["process_until_exit_handlers_s"] = float(m.group(2))
         stages["runtime_teardown_and_wait_s"] = round(dt - float(m.group(2)), 3)
     return {"wall_s": round(dt, 3), "wall_best_s": round(min(runs[1:]), 3), "warm_runs_s": [round(r, 3) for r in runs[1:]], "cold_wall_s": round(runs[0], 3),
-            "wall_fast_exit_s": round(min(fast), 3), "msamples_per_s_inclusive": round(n / dt / 1e6, 2), "stages": stages,
+            "wall_fast_exit_s": round(min(fast), 3), "back_to_back_s": [round(x, 3) for x in b2b], "msamples_per_s_inclusive": round(n / dt / 1e6, 2), "stages": stages,
             "what": "pbrt_hip --quiet %s (%dx%d, %d spp): process start, parse (the HIP runtime starts on a thread of its own from WorldBegin on), pbrt scene "
                     "construction, flatten, tree build + upload, kernel configuration (cached on disk after the first run), render, film D2H, WriteImage (.pfm), "
-                    "process exit; median of four warm runs" % (REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.spp)}
+                    "process exit; median of four warm runs, each started 1 s after the previous process exited" % (REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.spp)}
 
 
 # ---- verification of the timed film ----------------------------------------------------------------------------------
