@@ -245,7 +245,15 @@ enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
         * counts not rounded.  The sampler's parameters ride in the upper bits of sampler_mode (the descriptor's layout is
         * frozen by the scene blobs): HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter).  STRATIFIED_HASH: production,
         * stateless; STRATIFIED_MT_REPLAY: the reference's stream — oracle only. */
-       HPT_SAMPLER_STRATIFIED_HASH = 4, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 5 };
+       HPT_SAMPLER_STRATIFIED_HASH = 4, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 5,
+       /* Sampler "halton" (samplers/halton.cpp:54-80; SURVEY.md §8f-4 tail): the image positions of a sampler window are the Halton points
+        * (radical inverses in bases 3 and 2) of sample numbers 0 .. spp * delta^2 - 1 scaled over the window's delta x delta square, points
+        * outside the window rejected; lens (bases 5, 7) and time (base 11) from the sample number + 1; the integrators' arrays one Latin
+        * hypercube per camera sample (counts not rounded).  Samples belong to a WINDOW, not to a pixel.  HALTON_MT_REPLAY: the reference's
+        * windows (Sampler::ComputeSubWindow over ntasks) and the tile generator's stream — oracle only.  HALTON_HASH: production — the
+        * windows are the 32 x 32 pixel super-tiles of the sample extent (the unit the work queue and the multi-GPU shards already use), the
+        * array values the stateless hash of (tile, seed, sample number, array, index) of the stratified mode's Latin hypercubes; any spp. */
+       HPT_SAMPLER_HALTON_HASH = 6, HPT_SAMPLER_HALTON_MT_REPLAY = 7 };
 #define HPT_SAMPLER_KIND(mode) ((mode) & 0x7f)
 #define HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter) ((kind) | ((jitter) ? 0x80 : 0) | ((xsamples) << 8))
 #define HPT_SAMPLER_STRAT_XS(mode) (((mode) >> 8) & 0xfff)

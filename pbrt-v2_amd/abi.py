@@ -21,6 +21,7 @@ HPT_N_TEXSLOTS = 8
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER_RANDOM_MT_REPLAY = 0, 1, 2, 3
 HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
+HPT_SAMPLER_HALTON_HASH, HPT_SAMPLER_HALTON_MT_REPLAY = 6, 7
 
 
 def sampler_kind(mode):

@@ -52,6 +52,7 @@
 #include "samplers/lowdiscrepancy.h"
 #include "samplers/random.h"
 #include "samplers/stratified.h"
+#include "samplers/halton.h"
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
@@ -593,7 +594,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     const LDSampler *lds = dynamic_cast<const LDSampler *>(sampler);
     const RandomSampler *rnds = dynamic_cast<const RandomSampler *>(sampler);
     const StratifiedSampler *strat = dynamic_cast<const StratifiedSampler *>(sampler);
-    if (!lds && !rnds && !strat) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\" or \"stratified\"");
+    const HaltonSampler *halt = dynamic_cast<const HaltonSampler *>(sampler);
+    if (!lds && !rnds && !strat && !halt) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\", \"stratified\" or \"halton\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
     const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
     if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
@@ -623,7 +625,7 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.xres = film->xResolution; rd.yres = film->yResolution;
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
-    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : strat->xPixelSamples * strat->yPixelSamples;
+    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : halt ? halt->samplesPerPixel : strat->xPixelSamples * strat->yPixelSamples;
     rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
     rd.integrator = path ? HPT_INTEGRATOR_PATH
                          : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
@@ -633,6 +635,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         rd.sampler_mode = HPT_SAMPLER_STRATIFIED(samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_STRATIFIED_MT_REPLAY : HPT_SAMPLER_STRATIFIED_HASH,
                                                  strat->xPixelSamples, strat->jitterSamples);
     }
+    if (halt) rd.sampler_mode = samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_HALTON_MT_REPLAY : HPT_SAMPLER_HALTON_HASH;   // samplers/halton.cpp:54-80
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:203-205)
     int nPixels = film->xResolution * film->yResolution;

@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
+from tests.util import CASES, DL_CASES, FILTER_CASES, HALTON_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -102,6 +102,26 @@ def test_oracle_replays_stratified_sampler_reference_image_bit_exact(name):
     img, ref = film.xyzw_to_rgb(f), load_ref(name)
     assert img.shape == ref.shape
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+
+
+@pytest.mark.parametrize("name", list(HALTON_CASES))
+def test_oracle_replays_halton_sampler_reference_image_bit_exact(name):
+    """SURVEY.md §8f-4's tail: `Sampler "halton"` (samplers/halton.cpp:54-80) — the windows' Halton points (RadicalInverse in double with
+    its truncating `n *= invBase`, core/montecarlo.h:185-196) with the points outside a window rejected, lens / time from the incremented
+    sample number, a Latin hypercube per array and camera sample on the tile's generator (over 5 unrounded light samples in `hdl`), the
+    sample count of a window = spp * max(width, height)^2 minus the rejections (`hanim`: windows that are not square), and the windows cut
+    from the wider sample extent of a 2 x 2 gaussian filter (`hgauss`)."""
+    s = load_case(name)
+    rd = abi.copy_struct(s.render)
+    assert rd.sampler_mode == abi.HPT_SAMPLER_HALTON_HASH
+    rd.sampler_mode = abi.HPT_SAMPLER_HALTON_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1, flt=getattr(s, "filter", None))
+    assert st[5] == 0 and st[0] > 0
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert img.shape == ref.shape
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    if name == "hk":     # square windows (96 x 96 over 1024 tasks: 3 x 3 pixels): nothing rejected, every window holds spp * 9 samples
+        assert st[0] == rd.x_count * rd.y_count * rd.spp
 
 
 def test_oracle_replays_exr_environment_map_reference_image_bit_exact():

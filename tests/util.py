@@ -81,6 +81,15 @@ def load_case(name):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
+    if name in HALTON_CASES:   # Sampler "halton" cases (tests/golden/make_golden_halton.py): as the random / stratified ones; `hgauss` with the film's filter
+        s = abi.Scene.load(os.path.join(GOLDEN, HALTON_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
+        if "filter" in v.files:
+            s.filter = abi.filter_from_array(v["filter"])
+        return s
     if name in FILTER_CASES or name in COMBO_CASES:   # reconstruction-filter cases: as above + the film's filter (scene.filter)
         s = abi.Scene.load(os.path.join(GOLDEN, (FILTER_CASES.get(name) or COMBO_CASES[name])))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
@@ -111,6 +120,9 @@ RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "
 # Sampler "stratified" (same generator): 3 x 2 jittered, path; 2 x 2 jittered, direct lighting with 5 light samples; 2 x 3 unjittered,
 # path on the animated scene
 STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz", "sanim": "anim_killeroos.hpts.gz"}
+# Sampler "halton" (tests/golden/make_golden_halton.py): 3 spp, path; 2 spp, direct lighting with 5 light samples; 4 spp on the animated scene (time
+# sample, windows that are not square); 2 spp under PixelFilter "gaussian" (windows cut from the sample extent)
+HALTON_CASES = {"hk": "killeroo_cfg1.hpts.gz", "hdl": "killeroo_cfg1.hpts.gz", "hanim": "anim_killeroos.hpts.gz", "hgauss": "killeroo_cfg1.hpts.gz"}
 
 
 # ---- round 2 cases (tests/golden/make_golden_r2.py): Oren-Nayar, specular, triangle emitters, regular half-angle BRDF, textures, alpha
