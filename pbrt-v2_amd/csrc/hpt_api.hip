@@ -434,8 +434,14 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (rd->sampler_mode == HPT_SAMPLER_RANDOM_MT_REPLAY) { hpt_set_error("RANDOM_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"random\" as HPT_SAMPLER_RANDOM_HASH"); return HPT_E_UNSUPPORTED; }
     const int skind = HPT_SAMPLER_KIND(rd->sampler_mode);
     if (skind == HPT_SAMPLER_STRATIFIED_MT_REPLAY) { hpt_set_error("STRATIFIED_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"stratified\" as HPT_SAMPLER_STRATIFIED_HASH"); return HPT_E_UNSUPPORTED; }
+    if (skind == HPT_SAMPLER_HALTON_MT_REPLAY) { hpt_set_error("HALTON_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"halton\" as HPT_SAMPLER_HALTON_HASH"); return HPT_E_UNSUPPORTED; }
+    // Sampler "halton" (samplers/halton.cpp): the arrays are the stratified mode's Latin hypercubes, the camera values Halton points of the
+    // 32x32 super-tile the work item names (item_to_halton); any spp up to 65536 (the sample numbers of a window are ints)
+    const bool halton = rd->sampler_mode == HPT_SAMPLER_HALTON_HASH;
+    if (halton && (rd->spp <= 0 || rd->spp > 65536)) { hpt_set_error("halton sampler: spp must be 1 .. 65536 (got %d)", rd->spp); return HPT_E_INVALID; }
+    if (halton && rd->pipeline != HPT_PIPELINE_PERSISTENT) { hpt_set_error("Sampler \"halton\" runs on the persistent kernel (its work items are sample numbers of a window, not pixels)"); return HPT_E_UNSUPPORTED; }
     const bool stratified = skind == HPT_SAMPLER_STRATIFIED_HASH;
-    const bool random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH || stratified;
+    const bool random_sampler = rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH || stratified || halton;
     if (stratified) {
         const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode);
         if (xs <= 0 || rd->spp <= 0 || rd->spp % xs || rd->spp > 0xfff) { hpt_set_error("stratified sampler: spp = xsamples * ysamples, at most 4095 (got spp %d, xsamples %d)", rd->spp, xs); return HPT_E_INVALID; }
@@ -472,8 +478,8 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (s && s->cam_animated) { rp->cam_animated = 1; rp->cam_xf = s->cam_xf; }
     rp->integrator = rd->integrator;
     rp->random_sampler = random_sampler ? 1 : 0;
-    rp->sampler_kind = stratified ? 2 : random_sampler ? 1 : 0;
-    rp->sampler_w = stratified ? HPT_STRAT_W : random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
+    rp->sampler_kind = halton ? 3 : stratified ? 2 : random_sampler ? 1 : 0;
+    rp->sampler_w = (stratified || halton) ? HPT_STRAT_W : random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
     rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
     if (stratified) {
         const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
@@ -512,7 +518,8 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         double cap_gb = 48.0;
         if (const char *e = getenv("HPT_SBUF_MAX_GB")) cap_gb = atof(e);
         const size_t need = (size_t)rp->sx_count * rp->sy_count * (size_t)rd->spp * 6;
-        if (!(fm && !strcmp(fm, "atomic")) && (double)need * 4.0 <= cap_gb * 1e9) {
+        // (Sampler "halton": a window's samples are not a fixed count per pixel, so there is no slot for them in the record buffer: they splat)
+        if (!halton && !(fm && !strcmp(fm, "atomic")) && (double)need * 4.0 <= cap_gb * 1e9) {
             if (s->sbuf_floats < need) {
                 if (s->sbuf) (void)hipFree(s->sbuf);
                 s->sbuf = nullptr; s->sbuf_floats = 0;
@@ -524,6 +531,11 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         }
     }
     rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
+    rp->hx0 = rp->sx_start; rp->hy0 = rp->sy_start;
+    if (halton) {   // the windows of Sampler "halton" are cells of the GLOBAL 32x32 raster grid (a crop renders the full frame's samples)
+        rp->hx0 = rp->sx_start & ~31; rp->hy0 = rp->sy_start & ~31;
+        rp->n_stx = (rp->sx_start + rp->sx_count - rp->hx0 + 31) / 32; rp->n_sty = (rp->sy_start + rp->sy_count - rp->hy0 + 31) / 32;
+    }
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
     // A pixel's samples are split into work items of `chunk` samples.  A LARGE job (>= 32 M camera samples in this shard) takes ONE sample per
@@ -538,6 +550,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     //  64-sample items — measured on one GPU, run E: a bunny shard took 40-47 ms against 71 ms for the whole frame)
     if (nst * 1024 * (int64_t)rd->spp >= ((int64_t)32 << 20)) rp->chunk = 1;
     if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
+    if (halton) rp->chunk = 1;     // the items of Sampler "halton" are single sample numbers of a window (item_to_halton)
     if (rp->chunk == 1) rp->n_heads = 8;
     if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;
     rp->items_per_pass = local * 1024;

@@ -251,6 +251,22 @@ struct LdHash {
     HPT_MFN uint32_t draw_key() const { return hash3(pk, i, 3u); }
 };
 HPT_FN uint32_t pixel_key(uint32_t pixelIndex, uint32_t seed) { return hash3(pixelIndex, seed, 0x50495845u); }
+// Sampler "halton" (samplers/halton.cpp:54-80; HPT_SAMPLER_HALTON_HASH, definition: oracle/hpt_oracle.c halton_camera / halton_hash_arrays).
+// RadicalInverse (core/montecarlo.h:185-196) in double as written there: `n *= invBase` is the DOUBLE product truncated to int.
+HPT_FN double radical_inverse(int n, int base) {
+    double val = 0.;
+    const double invBase = 1. / (double)base;
+    double invBi = invBase;
+    while (n > 0) {
+        const int d_i = n % base;
+        val += (double)d_i * invBi;
+        n = (int)((double)n * invBase);
+        invBi *= invBase;
+    }
+    return val;
+}
+// key of the window = cell of the global 32x32 raster grid with origin (x0, y0) (multiples of 32, negative under a filter's margin)
+HPT_FN uint32_t halton_tile_key(int x0, int y0, uint32_t seed) { return hash3(((uint32_t)(x0 >> 5) & 0xffffu) | (((uint32_t)(y0 >> 5) & 0xffffu) << 16), seed, 0x48414c54u); }
 
 // ---- device scene ---------------------------------------------------------------------------
 // BVH2 node, 64 bytes = one coalesced 64-B line per visit (both children's boxes inline):

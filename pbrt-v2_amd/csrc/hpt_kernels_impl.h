@@ -431,7 +431,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (need && !over) {
                 const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
                 int x, y; uint32_t s0;
-                if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
+                if (rp.sampler_kind == 3) {          // Sampler "halton" (scalar branch): the item is a sample number of a super-tile's window
+                    if (item_to_halton(rp, item, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
+                } else if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
             if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }

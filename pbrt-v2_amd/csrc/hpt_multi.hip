@@ -148,6 +148,8 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_OK(hipSetDevice(c->device));
     const size_t n_floats = (size_t)rd->x_count * rd->y_count * 4;
+    // Sampler "halton" on a pixel extent that does not start on the global 32x32 grid: a shard's windows are not its film tiles — sum as well
+    if (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31)) wide_filter = 1;
     if (wide_filter) {                                   // partial sums over the whole frame: one sum-reduce to rank 0
         NCCL_OK(r->Reduce(d_film, d_film, n_floats, ncclFloat32, ncclSum, 0, c->comm, stream));
         return HPT_OK;
@@ -291,6 +293,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
     const size_t bytes = sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count;
     const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
     const bool use_rccl = !m->comms.empty();
+    // (Sampler "halton" on a pixel extent off the global 32x32 grid: a shard's windows are not its film tiles — partial films are summed)
+    const bool wide = m->wide || (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31));
     // buffers (grown on demand, kept with the handle)
     if (m->film_bytes < bytes || m->tiles_cap < (size_t)n_tiles) {
         for (int i = 0; i < n; ++i) {
@@ -316,7 +320,7 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
             r.shard_rank = i; r.shard_count = n;
             int rc = hpt_render_device(m->scenes[(size_t)i], cam, &r, m->films[(size_t)i], m->streams[(size_t)i], &st[(size_t)i]);
             const int mine = local_tiles(n_tiles, i, n);   // (0 for a frame smaller than an earlier one of this handle: nothing to pack)
-            if (rc == HPT_OK && i > 0 && !m->wide && m->packed[(size_t)i] && mine > 0) {
+            if (rc == HPT_OK && i > 0 && !wide && m->packed[(size_t)i] && mine > 0) {
                 hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, m->streams[(size_t)i], (const float4 *)m->films[(size_t)i], m->packed[(size_t)i],
                                    rd->x_count, rd->y_count, n_stx, n_tiles, i, n);
                 if (hipStreamSynchronize(m->streams[(size_t)i]) != hipSuccess) rc = HPT_E_HIP;
@@ -329,7 +333,7 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
     if (stats) for (int i = 0; i < n; ++i) stats[i] = st[(size_t)i];
     // ---- film exchange to shard 0 ---------------------------------------------------------------------------------------------------
     if (n > 1) {
-        if (m->wide) {                 // sum of partial films
+        if (wide) {                    // sum of partial films
             if (use_rccl) {
                 Rccl *r = rccl();
                 NCCL_OK(r->GroupStart());

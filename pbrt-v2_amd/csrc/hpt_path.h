@@ -42,13 +42,15 @@ struct RenderParams {
     uint32_t seed;
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
+    int32_t hx0, hy0;          // Sampler "halton": origin of the super-tile grid = the sample extent's corner floored to the GLOBAL 32x32 raster grid
+                               // (its windows are cells of that grid, so that a crop renders the full frame's samples); otherwise sx_start, sy_start
     int32_t has_motion;        // scene has animated instances or a moving camera: rays carry a time sample
     int32_t cam_animated;      // cam_xf holds the camera's AnimatedTransform (hpt_scene_set_camera_motion); 0: static, cam.camera_to_world
     hpt_instance cam_xf;       // CameraToWorld at both ends, decomposed (the record type of an animated instance)
     int32_t integrator;        // HPT_INTEGRATOR_*
     int32_t random_sampler;    // HPT_SAMPLER_RANDOM_HASH / STRATIFIED_HASH: any spp, light sample counts not rounded
     uint32_t sampler_w;        // LdHash::w of this job: spp - 1 (low discrepancy), HPT_RANDOM_W, HPT_STRAT_W
-    int32_t sampler_kind;      // 0 low discrepancy, 1 random, 2 stratified
+    int32_t sampler_kind;      // 0 low discrepancy, 1 random, 2 stratified, 3 halton (work items are (super-tile, sample number) pairs: item_to_halton)
     int32_t strat_n, strat_jitter;                 // stratified: spp, jitter
     float strat_fxs, strat_dx, strat_dy, strat_dt; // (float)xsamples, 1.f / xsamples, 1.f / ysamples, 1.f / spp
     f3 dx_camera, dy_camera;   // PerspectiveCamera::dxCamera / dyCamera (cameras/perspective.cpp:46-48): camera-ray differentials (MATS_EXT kernels)
@@ -158,6 +160,24 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
     if (x >= rp.sx_count || y >= rp.sy_count) return false;
     *px = rp.sx_start + x; *py = rp.sy_start + y;
     return true;
+}
+
+// Sampler "halton" (HPT_SAMPLER_HALTON_HASH): samples belong to a WINDOW — here a cell of the global 32x32 raster grid —, not to a pixel.
+// Item -> (window, sample number k): the 1024 items of a super-tile in pass p are its sample numbers 1024 p .. 1024 p + 1023 (spp passes
+// of one-sample items: 1024 spp numbers per window = samplesPerPixel * delta^2, halton.cpp:50).  *x0, *y0: the window's origin.
+HPT_FN bool item_to_halton(const RenderParams &rp, int64_t item, int *x0, int *y0, uint32_t *k) {
+    const int64_t pass = item / rp.items_per_pass;
+    item -= pass * rp.items_per_pass;
+    const int64_t st = (item >> 10) * rp.shard_count + rp.shard_rank;
+    if (st >= (int64_t)rp.n_stx * rp.n_sty) return false;
+    *k = (uint32_t)pass * 1024u + (uint32_t)(item & 1023);
+    *x0 = rp.hx0 + (int)(st % rp.n_stx) * 32; *y0 = rp.hy0 + (int)(st / rp.n_stx) * 32;
+    return true;
+}
+// image position of sample number k of the window at (x0, y0): origin + 32 * (radical inverse base 3, base 2) (halton.cpp:57-62)
+HPT_FN void halton_image(uint32_t k, int x0, int y0, float *ix, float *iy) {
+    const float u = (float)radical_inverse((int)k, 3), v = (float)radical_inverse((int)k, 2);
+    *ix = (float)x0 + 32.f * u; *iy = (float)y0 + 32.f * v;
 }
 
 // Light samples per camera sample of the direct-lighting integrator: LDSampler::RoundSize(Light::nSamples)
@@ -273,7 +293,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     HPT_MFN void begin_sample(const RenderParams &rp) {
         smp.begin_sample(si);
         float a, b;
-        smp.image(rp, &a, &b);
+        smp.image(rp, px, py, &a, &b);
         float imgx = px + a, imgy = py + b; // LDPixelSample: xPos + imageSamples[2i] (montecarlo.cpp:233-234)
         float lu = 0.f, lv = 0.f;
         if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
@@ -290,6 +310,21 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         begin_sample(rp);
     }
 
+    // Sampler "halton": sample number k of the window at (x0, y0).  false: the point lies outside the sample extent (which cuts the windows
+    // at its edges) and is rejected (halton.cpp:64-65) — the item is spent, the lane stays idle.  The lane's "pixel" is the one the sample
+    // falls into; its one-sample item adds itself to the film like every one-sample item does.
+    HPT_MFN bool begin_halton(const RenderParams &rp, int x0, int y0, uint32_t k) {
+        float ix, iy;
+        halton_image(k, x0, y0, &ix, &iy);
+        const int xe = rp.sx_start + rp.sx_count, ye = rp.sy_start + rp.sy_count;
+        const int x1 = x0 + 32 < xe ? x0 + 32 : xe, y1 = y0 + 32 < ye ? y0 + 32 : ye;
+        if (ix >= (float)x1 || iy >= (float)y1 || ix < (float)rp.sx_start || iy < (float)rp.sy_start) return false;
+        px = (int)floorf(ix); py = (int)floorf(iy); si = k; s_end = k + 1u; cold.film_zero();
+        smp.begin_tile(rp, x0, y0);
+        begin_sample(rp);
+        return true;
+    }
+
     // ImageFilm::AddSample with the box filter (film/image.cpp:77-137) + the radiance sanity
     // checks of samplerrenderer.cpp:118-131; then advance to the next sample / flush the pixel.
     HPT_MFN void finish_path(const RenderParams &rp, float *film, WorkCounters *wc) {
@@ -298,7 +333,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
         if (bad) { Ls = S(0.f); if (wc) wc->bad++; else if (rp.bad_counter) count_bad_sample(rp.bad_counter); }
         float ia, ib;
-        smp.image(rp, &ia, &ib);                 // CameraSample::imageX/Y again (cheaper than 2 live registers)
+        smp.image(rp, px, py, &ia, &ib);         // CameraSample::imageX/Y again (cheaper than 2 live registers)
         float imgx = px + ia, imgy = py + ib;
         float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
         float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
@@ -388,7 +423,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         }
         if (DL ? true : bounce == 0) {
             float ia, ib, lu = 0.f, lv = 0.f;
-            smp.image(rp, &ia, &ib);
+            smp.image(rp, px, py, &ia, &ib);
             if (rp.cam.lens_radius > 0.f) smp.lens(rp, &lu, &lv);
             camera_ray_differentials(rp.cam, rp.dx_camera, rp.dy_camera, rp.diff_scale, px + ia, py + ib, lu, lv, r, rd,
                                      (INST && rp.cam_animated) ? &rp.cam_xf : nullptr, time);
@@ -702,11 +737,23 @@ struct LdHashSrc {
         h.pk = pixel_key(pixelIndex, rp.seed);
         h.w = rp.sampler_w;
     }
+    HPT_MFN void begin_tile(const RenderParams &rp, int x0, int y0) { h.pk = halton_tile_key(x0, y0, rp.seed); h.w = rp.sampler_w; }   // Sampler "halton": the window's key
     HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; }
     HPT_MFN void end_pixel(const RenderParams &) {}
     HPT_MFN float one(int j) const { return h.one(j); }
     HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
     // camera samples and the direct-lighting arrays: the sampler kind is a scalar (kernel argument) branch
+    // (px, py): the lane's pixel — under Sampler "halton" it names the window (its cell of the global 32x32 grid), and the offsets returned are those of
+    // the window's Halton point h.i inside the pixel: (origin + 32 u) - px is exact, and so is px + that
+    HPT_MFN void image(const RenderParams &rp, int px, int py, float *a, float *b) const {
+        if (rp.sampler_kind == 3) {
+            float ix, iy;
+            halton_image(h.i, px & ~31, py & ~31, &ix, &iy);
+            *a = ix - (float)px; *b = iy - (float)py;
+            return;
+        }
+        image(rp, a, b);
+    }
     HPT_MFN void image(const RenderParams &rp, float *a, float *b) const {
         if (rp.sampler_kind == 0) { h.image(a, b); return; }
         if (rp.sampler_kind == 1) { *a = h.rnd(0u, 0u); *b = h.rnd(1u, 0u); return; }
@@ -715,11 +762,13 @@ struct LdHashSrc {
     HPT_MFN void lens(const RenderParams &rp, float *a, float *b) const {
         if (rp.sampler_kind == 0) { h.lens(a, b); return; }
         if (rp.sampler_kind == 1) { *a = h.rnd(2u, 0u); *b = h.rnd(3u, 0u); return; }
+        if (rp.sampler_kind == 3) { *a = (float)radical_inverse((int)h.i + 1, 5); *b = (float)radical_inverse((int)h.i + 1, 7); return; }   // halton.cpp:68-69 (the incremented number)
         h.strat2(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 1u, 2u)), 2u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
     }
     HPT_MFN float time01(const RenderParams &rp) const {
         if (rp.sampler_kind == 0) return h.time01();
         if (rp.sampler_kind == 1) return h.rnd(4u, 0u);
+        if (rp.sampler_kind == 3) return (float)radical_inverse((int)h.i + 1, 11);   // halton.cpp:70
         return h.strat1(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 2u, 2u)), 4u, rp.strat_jitter != 0, rp.strat_dt);
     }
     HPT_MFN float one_c(const RenderParams &rp, int j, uint32_t c, uint32_t k) const {

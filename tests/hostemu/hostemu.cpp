@@ -92,12 +92,12 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
     if (g_cam_motion_set) rp->cam_xf = g_cam_motion;
     rp->has_motion = 0;
     rp->integrator = rd->integrator;
-    { const int skind = HPT_SAMPLER_KIND(rd->sampler_mode); const bool strat = skind == HPT_SAMPLER_STRATIFIED_HASH;   // as fill_params of csrc/hpt_api.hip
+    { const int skind = HPT_SAMPLER_KIND(rd->sampler_mode); const bool halton = skind == HPT_SAMPLER_HALTON_HASH, strat = skind == HPT_SAMPLER_STRATIFIED_HASH || halton;   // as fill_params of csrc/hpt_api.hip
       rp->random_sampler = (rd->sampler_mode == HPT_SAMPLER_RANDOM_HASH || strat) ? 1 : 0;
-      rp->sampler_kind = strat ? 2 : rp->random_sampler ? 1 : 0;
+      rp->sampler_kind = halton ? 3 : strat ? 2 : rp->random_sampler ? 1 : 0;
       rp->sampler_w = strat ? HPT_STRAT_W : rp->random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
       rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
-      if (strat) {
+      if (strat && !halton) {
           const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
           rp->strat_jitter = HPT_SAMPLER_STRAT_JITTER(rd->sampler_mode);
           rp->strat_fxs = (float)xs; rp->strat_dx = 1.f / (float)xs; rp->strat_dy = 1.f / (float)ys; rp->strat_dt = 1.f / (float)rd->spp;
@@ -117,8 +117,14 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
         rp->sy_count = (int)ceilf((float)rd->y_start - 0.5f + (float)rd->y_count + rp->fyw) - rp->sy_start;
     }
     rp->n_stx = (rp->sx_count + 31) / 32; rp->n_sty = (rp->sy_count + 31) / 32;
+    rp->hx0 = rp->sx_start; rp->hy0 = rp->sy_start;
+    if (rp->sampler_kind == 3) {   // Sampler "halton": the windows are cells of the global 32x32 grid
+        rp->hx0 = rp->sx_start & ~31; rp->hy0 = rp->sy_start & ~31;
+        rp->n_stx = (rp->sx_start + rp->sx_count - rp->hx0 + 31) / 32; rp->n_sty = (rp->sy_start + rp->sy_count - rp->hy0 + 31) / 32;
+    }
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
+    if (rp->sampler_kind == 3) rp->chunk = 1;     // Sampler "halton": one-sample items (a window's sample numbers)
     rp->items_per_pass = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
     rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);
 }
@@ -147,11 +153,13 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
 #pragma omp for schedule(dynamic, 64)
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
-            if (!item_to_pixel(rp, item, &x, &y, &s0)) continue;
+            const bool halton = rp.sampler_kind == 3;
+            if (halton ? !item_to_halton(rp, item, &x, &y, &s0) : !item_to_pixel(rp, item, &x, &y, &s0)) continue;
             Lane<LdHashSrc, true, MATS_FULL, DL> lane; lane.init();
             std::vector<float> dls((size_t)(rd->maxdepth + 2) * HPT_DLS_FLOATS, 0.f);
             if (DL) { lane.dls = dls.data(); lane.dls_stride = 1; lane.dls_cap = rd->maxdepth + 1; }
-            lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
+            if (halton) { if (!lane.begin_halton(rp, x, y, s0)) continue; }
+            else lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 Hit hit;
                 hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;

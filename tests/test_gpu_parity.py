@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sub_windows
+from tests.util import CASES, DL_CASES, FILTER_CASES, HALTON_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sub_windows
 
 film = importlib.import_module("pbrt-v2_amd.film")
 hpt = importlib.import_module("pbrt-v2_amd.hpt")
@@ -663,6 +663,73 @@ def test_stratified_sampler_matches_oracle_sample_for_sample(name):
     if rd.spp % 4:
         with pytest.raises(hpt.HptError):
             d.render(s.camera, rd)
+
+
+@pytest.mark.parametrize("name", list(HALTON_CASES))
+def test_halton_sampler_matches_oracle_sample_for_sample(name):
+    """SURVEY.md §8f-4's tail, `Sampler "halton"` (HPT_SAMPLER_HALTON_HASH; samplers/halton.cpp:54-80): the production kernel pulls sample
+    numbers of 32 x 32 windows instead of pixels, computes the Halton points with the reference's double-precision RadicalInverse, rejects
+    what falls outside the sample extent, and every sample adds itself to the pixel it lands in — path 3 spp, direct lighting with a Latin
+    hypercube over 5 (unrounded) light samples at 2 spp, the animated scene at 4 spp (time sample), and 2 spp under a 2 x 2 gaussian filter
+    (atomic splat: a window's samples have no slot in the two-pass record buffer).  The oracle is pinned bit-identical to the reference
+    binary on these scenes in HALTON_MT_REPLAY mode; here both sides use the stateless definition."""
+    s = load_case(name)
+    flt = getattr(s, "filter", None)
+    d, o = hpt.DeviceScene(s), orc.OracleScene(s)
+    if flt is not None:
+        d.set_filter(flt)
+    rd = abi.copy_struct(s.render)
+    assert rd.sampler_mode == abi.HPT_SAMPLER_HALTON_HASH
+    rd.seed = 5
+    f, _ = d.render(s.camera, rd)
+    rd.count_work = 1
+    _, st = d.render(s.camera, rd)
+    fo, so = o.render(s.camera, rd, flt=flt)
+    assert st.camera_samples == so[0] > 0 and st.bad_samples == 0
+    assert abs(int(st.closest_rays) - int(so[1])) <= 8 and abs(int(st.shadow_rays) - int(so[2])) <= 8
+    if flt is None:
+        assert np.array_equal(f[..., 3], fo[..., 3])          # the per-pixel sample counts (they vary under this sampler)
+        assert f[..., 3].std() > 0
+    else:
+        assert np.allclose(f[..., 3], fo[..., 3], rtol=1e-5, atol=1e-5)
+    assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3
+    # shards partition the windows: the films add up
+    rd.count_work = 0
+    acc = np.zeros_like(f)
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        fr, _ = d.render(s.camera, rd)
+        acc += fr
+    assert np.allclose(acc, f, rtol=1e-4, atol=1e-4)
+    rd.shard_rank, rd.shard_count = 0, 1
+    rd.sampler_mode = abi.HPT_SAMPLER_HALTON_MT_REPLAY
+    with pytest.raises(hpt.HptError):
+        d.render(s.camera, rd)
+    rd.sampler_mode, rd.pipeline = abi.HPT_SAMPLER_HALTON_HASH, abi.HPT_PIPELINE_WAVEFRONT
+    with pytest.raises(hpt.HptError):
+        d.render(s.camera, rd)
+
+
+def test_halton_sampler_at_a_bench_sized_job(dev):
+    """1080p-class job under Sampler "halton" (killeroo, 512 x 512, 16 spp: 4 M sample numbers over 256 windows, eight queue heads) against
+    the oracle on the whole frame: identical sample counts per pixel, RMSE under the stated 1e-3."""
+    s = load_case("hk")
+    rd = abi.copy_struct(s.render)
+    rd.xres = rd.yres = rd.x_count = rd.y_count = 512
+    rd.spp, rd.seed = 16, 3
+    cam = abi.copy_struct(s.camera)
+    sc = 96.0 / 512.0        # raster -> camera of the 96 x 96 fixture rescaled to 512 x 512 (a pure scale of the raster x, y columns)
+    m = list(cam.raster_to_camera)
+    for r in range(4):
+        m[4 * r + 0] *= sc; m[4 * r + 1] *= sc
+    for i in range(16):
+        cam.raster_to_camera[i] = m[i]
+    d = dev["cfg1"]
+    f, st = d.render(cam, rd)
+    fo, so = orc.OracleScene(s).render(cam, rd)
+    assert st.bad_samples == 0 and so[0] == 512 * 512 * 16
+    assert np.array_equal(f[..., 3], fo[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3
 
 
 def test_random_sampler_values_bit_identical_and_any_spp(cases, dev):

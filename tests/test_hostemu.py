@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
+from tests.util import CASES, DL_CASES, FILTER_CASES, HALTON_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc
@@ -416,6 +416,76 @@ def test_stratified_sampler_render_matches_oracle(name):
     assert np.array_equal(fo[..., 3], fe[..., 3])
     io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
     assert differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-4
+
+
+@pytest.mark.parametrize("name", list(HALTON_CASES))
+def test_halton_sampler_render_matches_oracle(name):
+    """SURVEY.md §8f-4's tail, `Sampler "halton"` as HPT_SAMPLER_HALTON_HASH: work items that are sample numbers of a 32 x 32 window
+    (item_to_halton), the double-precision radical inverses of the device headers, rejection at the sample extent's edge (96 = 3 x 32:
+    none; 64 + the gaussian filter's margin and 100 x 60: partial windows), the time sample, the Latin hypercube over 5 light samples —
+    the device lane against the oracle, which is pinned to the reference binary on these scenes in its replay mode."""
+    s = load_case(name)
+    flt = getattr(s, "filter", None)
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    rd = abi.copy_struct(s.render)
+    assert rd.sampler_mode == abi.HPT_SAMPLER_HALTON_HASH
+    rd.seed = 5
+    fo, so = o.render(s.camera, rd, flt=flt)
+    fe, se = e.render(s.camera, rd, flt=flt)
+    xs, xe, ys, ye = abi.sample_extent(rd, flt) if flt is not None else (rd.x_start, rd.x_start + rd.x_count, rd.y_start, rd.y_start + rd.y_count)
+    assert so[0] == se[0] and 0.9 * (xe - xs) * (ye - ys) * rd.spp <= so[0] <= 1.1 * (xe - xs) * (ye - ys) * rd.spp
+    if (xe - xs) % 32 == 0 and (ye - ys) % 32 == 0:
+        assert so[0] == (xe - xs) * (ye - ys) * rd.spp           # whole windows: every sample number lands inside
+    assert abs(int(so[1]) - int(se[1])) <= 4 and abs(int(so[2]) - int(se[2])) <= 4
+    if flt is None:
+        assert np.array_equal(fo[..., 3], fe[..., 3])            # box filter: the weights are the per-pixel sample counts
+        assert fo[..., 3].min() >= 0 and abs(float(fo[..., 3].mean()) - rd.spp) < 0.1 * rd.spp and fo[..., 3].std() > 0   # ... which vary from pixel to pixel
+    io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
+    assert differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-4
+
+
+def test_halton_sampler_shards_partition_the_windows():
+    """Round-robin super-tile shards under Sampler "halton": a window's samples stay in its own 32 x 32 pixels, so the shard films add up
+    to the unsharded film exactly (weights) / to rounding (sums in another order)."""
+    s = load_case("hk")
+    rd = abi.copy_struct(s.render)
+    rd.seed = 9
+    e = emu.EmuScene(s)
+    full, st = e.render(s.camera, rd)
+    acc, n = np.zeros_like(full), 0
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        f, sr = e.render(s.camera, rd)
+        acc += f; n += int(sr[0])
+    assert n == int(st[0]) and np.array_equal(acc[..., 3], full[..., 3]) and np.allclose(acc, full, rtol=1e-5, atol=1e-5)
+
+
+def test_halton_crop_window_renders_the_full_frames_samples():
+    """The windows of HPT_SAMPLER_HALTON_HASH are cells of the GLOBAL 32 x 32 raster grid: a crop window off that grid (and one reaching into
+    negative raster coordinates under a filter's margin) renders exactly the samples of the full frame that fall inside it — oracle and device
+    lane alike (what lets bench.py verify a timed frame on crops)."""
+    s = load_case("hk")
+    rd = abi.copy_struct(s.render)
+    rd.seed = 2
+    o, e = orc.OracleScene(s), emu.EmuScene(s)
+    full, _ = o.render(s.camera, rd)
+    crd = abi.copy_struct(rd)
+    crd.x_start, crd.y_start, crd.x_count, crd.y_count = 21, 38, 50, 37
+    for r in (o, e):
+        f, st = r.render(s.camera, crd)
+        ref = full[38:38 + 37, 21:21 + 50]
+        assert st[0] <= ref[..., 3].sum() <= 1.03 * st[0]     # (a Halton point on an integer raster coordinate counts in two pixels, film/image.cpp:82-89)
+        # (the last column / row aside: a point exactly on the crop's upper edge is outside the crop's extent, yet reaches the edge pixel in the full frame)
+        assert np.array_equal(f[:-1, :-1, 3], ref[:-1, :-1, 3]) and np.allclose(f[:-1, :-1], ref[:-1, :-1], rtol=1e-5, atol=1e-6)
+        assert (f[..., 3] <= ref[..., 3]).all()
+    # a wide filter: the sample extent starts at -2 — cells with negative grid coordinates
+    flt = abi.make_filter("gaussian")
+    fo, so = o.render(s.camera, rd, flt=flt)
+    fe, se = e.render(s.camera, rd, flt=flt)
+    assert so[0] == se[0] and np.allclose(fo, fe, rtol=1e-4, atol=1e-5)
+    crd.x_start, crd.y_start, crd.x_count, crd.y_count = 40, 40, 16, 16
+    fc, _ = o.render(s.camera, crd, flt=flt)
+    assert np.allclose(fc, fo[40:56, 40:56], rtol=1e-4, atol=1e-5)
 
 
 def test_stratified_sampler_values_stratify():
