@@ -759,6 +759,8 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     a.dl = dl ? 1 : 0;
     if (dl) cfg = 6;                                     // direct lighting is compiled for lock step + subtree stealing at HPT_DL_WAVES = 3 waves/SIMD only
+    const bool windowed = a.rp.sampler_kind == 3;        // Sampler "halton": the window samplers' kernels exist for configuration 5 (and direct lighting) only
+    if (windowed && !dl) cfg = 5;
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)a.rp.sx_count * a.rp.sy_count * rd->spp >= ((int64_t)32 << 20))
             e = autotune(s, cam, rd, a, d_scr, sizeof(Scratch), stream);
@@ -777,6 +779,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     int bpc = 0, vgprs = 0;
     if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
         if (rd->count_work && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the instrumented kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
+        if (windowed && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the window samplers' kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         if (path_kernel_effective_cfg(s->mats, cfg) >= 5 && !dl) {      // tree too deep for the stealing rows: the plain lock-step walk (extension set: free-running)
             cfg = (s->mats & MATS_EXT) ? 0 : cfg - 2;
             if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown;

@@ -357,7 +357,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
 // block behind an extension hit (BSDF set-up, light sampling, three BSDF evaluations — kd-tree queries for a
 // measured BRDF) runs with about a third of the lanes (measured VALU lane utilisation 7-12 %).  In lock step
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
-template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false>
+// WIN: the kernels of the window samplers (Sampler "halton": a work item is a sample number of a 32x32 window, item_to_halton) — instantiations
+// of their own so that the default sampler's kernels stay instruction for instruction what they were (LdHashSrcT, hpt_path.h)
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false, bool WIN = false>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     extern __shared__ uint64_t dyn_lds[];      // traversal stacks — sized per scene (path_kernel_dyn_lds)
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // matte / plastic kernels gain < 1 % and a deep tree — the 1 M-triangle soup — would lose a resident workgroup to the ten rows)
     constexpr bool PARK = HPT_PARK_MATS(MATS) && !DL;   // (direct lighting keeps registers: its six stealing rows + a depth-24 tree + ten cold rows would not fit the 40 LDS rows)
     const int top = a.stack_entries - (PARK ? HPT_COLD_ROWS : 0);
-    Lane<LdHashSrc, INST, MATS, DL, typename ColdSel<PARK>::type> lane;
+    Lane<LdHashSrcT<WIN>, INST, MATS, DL, typename ColdSel<PARK>::type> lane;
     ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);
     ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (need && !over) {
                 const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
                 int x, y; uint32_t s0;
-                if (rp.sampler_kind == 3) {          // Sampler "halton" (scalar branch): the item is a sample number of a super-tile's window
+                if (WIN) {                           // Sampler "halton": the item is a sample number of a super-tile's window
                     if (item_to_halton(rp, item, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
                 } else if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_DL_WAVES 3   /* measured on killeroo-simple.pbrt as shipped: 4 / 3 / 2 waves per SIMD = 374 / 461 / 384 M camera samples/s (lane utilisation is 69 % there: the spills cost more than the fourth wave hides) */
 #endif
 #define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true>
+#define HPT_DL_KERNEL_W(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true, true>
 
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS and for scenes with (INSTV = true) or without animated
 // instances — one translation unit each (hpt_kernels_<set>.hip, hpt_kernels_<set>_i.hip): the two halves want different compiler
@@ -601,6 +604,14 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     }                                                                                                               \
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
         const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
+        if (a.rp.sampler_kind == 3) {   /* window samplers: configuration 5 / the direct-lighting kernel, WIN = true */ \
+            if (a.dl) {                                                                                             \
+                if (count) hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);    \
+                else hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);         \
+            } else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, true, false, true, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); \
+            else hipLaunchKernelGGL((hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);             \
+            return hipGetLastError();                                                                               \
+        }                                                                                                           \
         if (a.dl) {                                                                                                 \
             if (count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
             else hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, INSTV, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);               \

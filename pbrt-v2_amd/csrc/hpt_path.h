@@ -729,7 +729,11 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
 };
 
 // ---- production sampler adaptor ---------------------------------------------------------------------
-struct LdHashSrc {
+// WINDOWED: the instantiation that also knows the window samplers (Sampler "halton": rp.sampler_kind 3).  Their code — f64 radical
+// inverses in the refill path — moved the register allocation of every kernel it was compiled into (same-box A/B, profiles/r03_ab.md run Q:
+// killeroo -1.9 %), so it lives in kernel instantiations of its own (hpt_path_kernel<..., WIN = true>) and the default sampler's kernels are,
+// instruction for instruction, what they were without it.
+template <bool WINDOWED> struct LdHashSrcT {
     LdHash h;
     uint32_t dcount;
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
@@ -746,7 +750,7 @@ struct LdHashSrc {
     // (px, py): the lane's pixel — under Sampler "halton" it names the window (its cell of the global 32x32 grid), and the offsets returned are those of
     // the window's Halton point h.i inside the pixel: (origin + 32 u) - px is exact, and so is px + that
     HPT_MFN void image(const RenderParams &rp, int px, int py, float *a, float *b) const {
-        if (rp.sampler_kind == 3) {
+        if (WINDOWED && rp.sampler_kind == 3) {
             float ix, iy;
             halton_image(h.i, px & ~31, py & ~31, &ix, &iy);
             *a = ix - (float)px; *b = iy - (float)py;
@@ -762,13 +766,13 @@ struct LdHashSrc {
     HPT_MFN void lens(const RenderParams &rp, float *a, float *b) const {
         if (rp.sampler_kind == 0) { h.lens(a, b); return; }
         if (rp.sampler_kind == 1) { *a = h.rnd(2u, 0u); *b = h.rnd(3u, 0u); return; }
-        if (rp.sampler_kind == 3) { *a = (float)radical_inverse((int)h.i + 1, 5); *b = (float)radical_inverse((int)h.i + 1, 7); return; }   // halton.cpp:68-69 (the incremented number)
+        if (WINDOWED && rp.sampler_kind == 3) { *a = (float)radical_inverse((int)h.i + 1, 5); *b = (float)radical_inverse((int)h.i + 1, 7); return; }   // halton.cpp:68-69 (the incremented number)
         h.strat2(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 1u, 2u)), 2u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
     }
     HPT_MFN float time01(const RenderParams &rp) const {
         if (rp.sampler_kind == 0) return h.time01();
         if (rp.sampler_kind == 1) return h.rnd(4u, 0u);
-        if (rp.sampler_kind == 3) return (float)radical_inverse((int)h.i + 1, 11);   // halton.cpp:70
+        if (WINDOWED && rp.sampler_kind == 3) return (float)radical_inverse((int)h.i + 1, 11);   // halton.cpp:70
         return h.strat1(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 2u, 2u)), 4u, rp.strat_jitter != 0, rp.strat_dt);
     }
     HPT_MFN float one_c(const RenderParams &rp, int j, uint32_t c, uint32_t k) const {
@@ -782,6 +786,8 @@ struct LdHashSrc {
     }
     HPT_MFN float draw() { return h.draw(h.draw_key(), dcount++); }
 };
+typedef LdHashSrcT<false> LdHashSrc;
+typedef LdHashSrcT<true> LdHashWinSrc;
 
 } // namespace hpt
 #endif

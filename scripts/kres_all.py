@@ -39,7 +39,7 @@ with concurrent.futures.ThreadPoolExecutor(8) as ex:
 out = os.path.join(ROOT, "profiles", "%s_kernel_resources.md" % tag)
 with open(out, "w") as f:
     f.write("# %s — kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950; the build's own flags per translation unit)\n\n" % tag)
-    f.write("hpt_path_kernel<COUNT, INST, MATS, WAVES, EE, PHASED, DL, STEAL>; MATS 1 = matte + plastic, 3 = + measured, 15 = + metal + substrate, 31 = + extension set;\n"
+    f.write("hpt_path_kernel<COUNT, INST, MATS, WAVES, EE, PHASED, DL, STEAL, WIN>; WIN = the window samplers' kernels (Sampler \"halton\"); MATS 1 = matte + plastic, 3 = + measured, 15 = + metal + substrate, 31 = + extension set;\n"
             "the instance-free kernels of MATS 1, 3 and 31 are scheduled with -amdgpu-sched-strategy=max-ilp.  Demangled with c++filt.\n\n")
     f.write("| kernel | VGPRs | spilled VGPRs | spilled SGPRs | scratch B/lane | occupancy (waves/SIMD) |\n|---|---:|---:|---:|---:|---:|\n")
     names = [r["name"] for r in rows]

@@ -155,7 +155,7 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
             int x, y; uint32_t s0;
             const bool halton = rp.sampler_kind == 3;
             if (halton ? !item_to_halton(rp, item, &x, &y, &s0) : !item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashSrc, true, MATS_FULL, DL> lane; lane.init();
+            Lane<LdHashWinSrc, true, MATS_FULL, DL> lane; lane.init();
             std::vector<float> dls((size_t)(rd->maxdepth + 2) * HPT_DLS_FLOATS, 0.f);
             if (DL) { lane.dls = dls.data(); lane.dls_stride = 1; lane.dls_cap = rd->maxdepth + 1; }
             if (halton) { if (!lane.begin_halton(rp, x, y, s0)) continue; }
