@@ -253,7 +253,17 @@ enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
         * windows (Sampler::ComputeSubWindow over ntasks) and the tile generator's stream — oracle only.  HALTON_HASH: production — the
         * windows are the 32 x 32 pixel super-tiles of the sample extent (the unit the work queue and the multi-GPU shards already use), the
         * array values the stateless hash of (tile, seed, sample number, array, index) of the stratified mode's Latin hypercubes; any spp. */
-       HPT_SAMPLER_HALTON_HASH = 6, HPT_SAMPLER_HALTON_MT_REPLAY = 7 };
+       HPT_SAMPLER_HALTON_HASH = 6, HPT_SAMPLER_HALTON_MT_REPLAY = 7,
+       /* Sampler "adaptive" (samplers/adaptive.cpp; SURVEY.md §8f-4 tail), method "contrast": a pixel is rendered with minsamples LDPixelSample
+        * samples; if any sample's luminance differs from the batch's mean by more than half of it (needsSupersampling, adaptive.cpp:149-160)
+        * the batch is DISCARDED and the pixel rendered again with maxsamples samples (ReportResults, adaptive.cpp:111-137).  hpt_render_desc.spp
+        * = maxsamples (a power of two, the sampler's samplesPerPixel: it scales the ray differentials), minsamples (a power of two, >= 2,
+        * < spp) rides in the upper bits of sampler_mode: HPT_SAMPLER_ADAPTIVE(kind, minsamples).  ADAPTIVE_HASH: production — both batches
+        * are the LD_HASH sampler's patterns of the pixel for minsamples / maxsamples; ADAPTIVE_MT_REPLAY: the reference's stream — oracle
+        * only.  Method "shapeid" (a comparison of Intersection ids the device does not carry) is refused. */
+       HPT_SAMPLER_ADAPTIVE_HASH = 8, HPT_SAMPLER_ADAPTIVE_MT_REPLAY = 9 };
+#define HPT_SAMPLER_ADAPTIVE(kind, minsamples) ((kind) | ((minsamples) << 8))
+#define HPT_SAMPLER_ADAPT_MIN(mode) (((mode) >> 8) & 0xfff)
 #define HPT_SAMPLER_KIND(mode) ((mode) & 0x7f)
 #define HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter) ((kind) | ((jitter) ? 0x80 : 0) | ((xsamples) << 8))
 #define HPT_SAMPLER_STRAT_XS(mode) (((mode) >> 8) & 0xfff)

@@ -22,6 +22,7 @@ HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER_RANDOM_MT_REPLAY = 0, 1, 2, 3
 HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
 HPT_SAMPLER_HALTON_HASH, HPT_SAMPLER_HALTON_MT_REPLAY = 6, 7
+HPT_SAMPLER_ADAPTIVE_HASH, HPT_SAMPLER_ADAPTIVE_MT_REPLAY = 8, 9
 
 
 def sampler_kind(mode):
@@ -31,6 +32,13 @@ def sampler_kind(mode):
 def stratified_mode(kind, xsamples, jitter=True):
     """HPT_SAMPLER_STRATIFIED(kind, xsamples, jitter): the sampler's parameters ride in sampler_mode's upper bits"""
     return kind | (0x80 if jitter else 0) | (xsamples << 8)
+
+
+def adaptive_mode(kind, minsamples):
+    """HPT_SAMPLER_ADAPTIVE(kind, minsamples): spp of the render descriptor = maxsamples"""
+    return kind | (minsamples << 8)
+
+
 HPT_PIPELINE_PERSISTENT, HPT_PIPELINE_WAVEFRONT = 0, 1
 HPT_INTEGRATOR_PATH, HPT_INTEGRATOR_DIRECT_ALL, HPT_INTEGRATOR_DIRECT_ONE = 0, 1, 2
 SAMPLE_FLOATS = 35  # 5 camera + 12 one-D + 9 two-D pairs

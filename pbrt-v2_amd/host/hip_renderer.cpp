@@ -53,6 +53,7 @@
 #include "samplers/random.h"
 #include "samplers/stratified.h"
 #include "samplers/halton.h"
+#include "samplers/adaptive.h"
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
@@ -595,7 +596,9 @@ void HipPathRenderer::Render(const Scene *scene) {
     const RandomSampler *rnds = dynamic_cast<const RandomSampler *>(sampler);
     const StratifiedSampler *strat = dynamic_cast<const StratifiedSampler *>(sampler);
     const HaltonSampler *halt = dynamic_cast<const HaltonSampler *>(sampler);
-    if (!lds && !rnds && !strat && !halt) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\", \"stratified\" or \"halton\"");
+    const AdaptiveSampler *adapt = dynamic_cast<const AdaptiveSampler *>(sampler);
+    if (!lds && !rnds && !strat && !halt && !adapt) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\", \"stratified\", \"halton\" or \"adaptive\"");
+    if (adapt && adapt->method != AdaptiveSampler::ADAPTIVE_CONTRAST_THRESHOLD) Severe("hip renderer: Sampler \"adaptive\" with method \"shapeid\" is outside the scope (the device carries no Intersection ids); use \"contrast\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
     const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
     if (!path && !direct) Severe("hip renderer: SurfaceIntegrator must be \"path\" or \"directlighting\"");
@@ -625,7 +628,7 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.xres = film->xResolution; rd.yres = film->yResolution;
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
-    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : halt ? halt->samplesPerPixel : strat->xPixelSamples * strat->yPixelSamples;
+    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : halt ? halt->samplesPerPixel : adapt ? adapt->maxSamples : strat->xPixelSamples * strat->yPixelSamples;
     rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
     rd.integrator = path ? HPT_INTEGRATOR_PATH
                          : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
@@ -635,6 +638,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         rd.sampler_mode = HPT_SAMPLER_STRATIFIED(samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_STRATIFIED_MT_REPLAY : HPT_SAMPLER_STRATIFIED_HASH,
                                                  strat->xPixelSamples, strat->jitterSamples);
     }
+    if (adapt) rd.sampler_mode = HPT_SAMPLER_ADAPTIVE(samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_ADAPTIVE_MT_REPLAY : HPT_SAMPLER_ADAPTIVE_HASH, adapt->minSamples);   // samplers/adaptive.cpp:44-83 (both counts already powers of two)
     if (halt) rd.sampler_mode = samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_HALTON_MT_REPLAY : HPT_SAMPLER_HALTON_HASH;   // samplers/halton.cpp:54-80
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:203-205)

@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, HALTON_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
+from tests.util import ADAPTIVE_CASES, CASES, DL_CASES, FILTER_CASES, HALTON_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -122,6 +122,27 @@ def test_oracle_replays_halton_sampler_reference_image_bit_exact(name):
     assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
     if name == "hk":     # square windows (96 x 96 over 1024 tasks: 3 x 3 pixels): nothing rejected, every window holds spp * 9 samples
         assert st[0] == rd.x_count * rd.y_count * rd.spp
+
+
+@pytest.mark.parametrize("name", list(ADAPTIVE_CASES))
+def test_oracle_replays_adaptive_sampler_reference_image_bit_exact(name):
+    """SURVEY.md §8f-4's tail: `Sampler "adaptive"`, method "contrast" (samplers/adaptive.cpp:100-160) — minSamples LDPixelSample samples per pixel,
+    all evaluated before ReportResults looks at their luminances; a batch that needs supersampling is dropped (its draws stay consumed) and the
+    pixel rendered again with maxSamples; ray differentials scaled by 1 / sqrt(maxSamples) in both batches."""
+    s = load_case(name)
+    rd = abi.copy_struct(s.render)
+    assert abi.sampler_kind(rd.sampler_mode) == abi.HPT_SAMPLER_ADAPTIVE_HASH
+    lo = (rd.sampler_mode >> 8) & 0xfff
+    rd.sampler_mode = (rd.sampler_mode & ~0x7f) | abi.HPT_SAMPLER_ADAPTIVE_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1)
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert img.shape == ref.shape and st[5] == 0
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    # both kinds of pixel exist: the film weight of a pixel is the size of the batch that reached the film
+    w = f[..., 3]
+    n_lo, n_hi = int((w == lo).sum()), int((w == rd.spp).sum())
+    assert n_lo > 0 and n_hi > 0 and n_lo + n_hi >= 0.99 * w.size
+    assert abs(int(st[0]) - (lo * w.size + rd.spp * n_hi)) <= 0.01 * st[0]        # evaluated: every pixel's first batch + the second of the supersampled ones
 
 
 def test_oracle_replays_exr_environment_map_reference_image_bit_exact():

@@ -81,6 +81,13 @@ def load_case(name):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
+    if name in ADAPTIVE_CASES:   # Sampler "adaptive" cases (tests/golden/make_golden_adaptive.py)
+        s = abi.Scene.load(os.path.join(GOLDEN, ADAPTIVE_CASES[name]))
+        v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
+        s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
+        s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
+        s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
+        return s
     if name in HALTON_CASES:   # Sampler "halton" cases (tests/golden/make_golden_halton.py): as the random / stratified ones; `hgauss` with the film's filter
         s = abi.Scene.load(os.path.join(GOLDEN, HALTON_CASES[name]))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
@@ -122,6 +129,8 @@ RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "
 STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz", "sanim": "anim_killeroos.hpts.gz"}
 # Sampler "halton" (tests/golden/make_golden_halton.py): 3 spp, path; 2 spp, direct lighting with 5 light samples; 4 spp on the animated scene (time
 # sample, windows that are not square); 2 spp under PixelFilter "gaussian" (windows cut from the sample extent)
+# Sampler "adaptive", method "contrast" (tests/golden/make_golden_adaptive.py): 2 .. 8 samples, path; 4 .. 16, direct lighting; 2 .. 4 on the animated scene
+ADAPTIVE_CASES = {"ak": "killeroo_cfg1.hpts.gz", "adl": "killeroo_cfg1.hpts.gz", "aanim": "anim_killeroos.hpts.gz"}
 HALTON_CASES = {"hk": "killeroo_cfg1.hpts.gz", "hdl": "killeroo_cfg1.hpts.gz", "hanim": "anim_killeroos.hpts.gz", "hgauss": "killeroo_cfg1.hpts.gz"}
 
 
