@@ -261,7 +261,17 @@ enum { HPT_SAMPLER_LD_HASH = 0, HPT_SAMPLER_MT_REPLAY = 1,
         * < spp) rides in the upper bits of sampler_mode: HPT_SAMPLER_ADAPTIVE(kind, minsamples).  ADAPTIVE_HASH: production — both batches
         * are the LD_HASH sampler's patterns of the pixel for minsamples / maxsamples; ADAPTIVE_MT_REPLAY: the reference's stream — oracle
         * only.  Method "shapeid" (a comparison of Intersection ids the device does not carry) is refused. */
-       HPT_SAMPLER_ADAPTIVE_HASH = 8, HPT_SAMPLER_ADAPTIVE_MT_REPLAY = 9 };
+       HPT_SAMPLER_ADAPTIVE_HASH = 8, HPT_SAMPLER_ADAPTIVE_MT_REPLAY = 9,
+       /* Sampler "bestcandidate" (samplers/bestcandidate.cpp:50-91; SURVEY.md §8f-4 tail): the reference's precomputed 64 x 64 table of (image x,
+        * y, time, lens u, v) points, tiled over the image in squares of 64 / sqrt(pixelsamples) pixels; per tile three shifts of time / lens
+        * from a generator seeded with the tile's coordinates, points outside the sampler's window rejected; the integrators' arrays are
+        * scrambled (0,2)-sequences drawn per camera sample (counts rounded up to powers of two).  The table is DATA of the reference
+        * (BestCandidateSampler::sampleTable): the caller hands it over with hpt_scene_set_sample_table.  The camera samples do not depend on
+        * the generator of a task — the production mode (BESTCANDIDATE_HASH) reproduces the reference's set of camera samples exactly (table
+        * tiles are its work items) and replaces only the arrays' scrambles by the stateless hash of (tile, table entry, seed);
+        * BESTCANDIDATE_MT_REPLAY: the reference's windows and stream — oracle only. */
+       HPT_SAMPLER_BESTCANDIDATE_HASH = 10, HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY = 11 };
+#define HPT_SAMPLE_TABLE_SIZE 4096     /* SAMPLE_TABLE_SIZE, samplers/bestcandidate.h:43-45; entries of 5 floats */
 #define HPT_SAMPLER_ADAPTIVE(kind, minsamples) ((kind) | ((minsamples) << 8))
 #define HPT_SAMPLER_ADAPT_MIN(mode) (((mode) >> 8) & 0xfff)
 #define HPT_SAMPLER_KIND(mode) ((mode) & 0x7f)
@@ -381,6 +391,10 @@ int hpt_scene_set_filter(hpt_scene *scene, const hpt_filter *filter);
  * the scene handle for the following renders; NULL = static camera (hpt_camera.camera_to_world, the default).  The camera samples a time
  * in [shutter_open, shutter_close] whether or not the scene has animated instances. */
 int hpt_scene_set_camera_motion(hpt_scene *scene, const hpt_instance *camera_to_world);
+/* Sampler "bestcandidate" (HPT_SAMPLER_BESTCANDIDATE_HASH): the reference's precomputed sample table — BestCandidateSampler::sampleTable,
+ * samplers/bestcandidate.h:86 / bestcandidate.out: HPT_SAMPLE_TABLE_SIZE entries of 5 floats (image x, y, time, lens u, v, all in [0, 1)) —
+ * copied to the device.  A render under that sampler without a table fails with HPT_E_INVALID.  NULL removes it. */
+int hpt_scene_set_sample_table(hpt_scene *scene, const float *table, int n_entries);
 
 /* ---- multi-GPU (SURVEY.md §8b "gpus", §8e) ------------------------------------------------------------------------------------
  * The path shards with no data-path collective: the scene is replicated per GPU, shard r renders the 32x32 pixel tiles t with
@@ -396,6 +410,7 @@ hpt_multi *hpt_multi_create(const hpt_scene_desc *desc, const int *devices, int 
 void hpt_multi_destroy(hpt_multi *m);
 int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *filter);
 int hpt_multi_set_camera_motion(hpt_multi *m, const hpt_instance *camera_to_world);   /* hpt_scene_set_camera_motion on every shard */
+int hpt_multi_set_sample_table(hpt_multi *m, const float *table, int n_entries);         /* hpt_scene_set_sample_table on every shard */
 int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out);     /* the shard's scene handle (hpt_scene_tune, hpt_scene_get_info) */
 int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc *rd, float *film_xyzw_host, hpt_stats *stats);
 

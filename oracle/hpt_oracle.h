@@ -38,6 +38,8 @@ void orc_set_filter(const hpt_filter *f);
 /* A moving camera for the following orc_render calls (process-wide; NULL = static): CameraToWorld as an AnimatedTransform in the record
  * type of an animated instance (include/hpt.h, hpt_scene_set_camera_motion). */
 void orc_set_camera_motion(const hpt_instance *camera_to_world);
+/* Sampler "bestcandidate": the reference's 4096 x 5 sample table (BestCandidateSampler::sampleTable), or NULL */
+void orc_set_sample_table(const float *table);
 
 /* Function-level entry points with the same array conventions as hpt_test_* (include/hpt.h). */
 int orc_intersect(const orc_scene *s, const float *rays, int64_t n, int anyhit, float *out_hit,

@@ -38,6 +38,8 @@ def lib():
         L.orc_set_filter.restype = None
         L.orc_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
         L.orc_set_camera_motion.restype = None
+        L.orc_set_sample_table.argtypes = [C.c_void_p]
+        L.orc_set_sample_table.restype = None
         _lib = L
     return _lib
 
@@ -58,11 +60,13 @@ class OracleScene:
     def __del__(self):
         self.close()
 
-    def render(self, cam, rd, nthreads=0, flt=None, cam_motion=None):
+    def render(self, cam, rd, nthreads=0, flt=None, cam_motion=None, sample_table=None):
         """flt: abi.Filter (ImageFilm's reconstruction filter) or None = box of width 0.5; cam_motion: abi.Instance (the camera's
         AnimatedTransform, camera to world) or None = static camera"""
         lib().orc_set_filter(C.byref(flt) if flt is not None else None)
         lib().orc_set_camera_motion(C.byref(cam_motion) if cam_motion is not None else None)
+        tbl = np.ascontiguousarray(sample_table, dtype=np.float32) if sample_table is not None else None   # Sampler "bestcandidate": the reference's 4096 x 5 table
+        lib().orc_set_sample_table(tbl.ctypes.data if tbl is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)
         rc = lib().orc_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, nthreads,

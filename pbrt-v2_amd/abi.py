@@ -23,6 +23,7 @@ HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER
 HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
 HPT_SAMPLER_HALTON_HASH, HPT_SAMPLER_HALTON_MT_REPLAY = 6, 7
 HPT_SAMPLER_ADAPTIVE_HASH, HPT_SAMPLER_ADAPTIVE_MT_REPLAY = 8, 9
+HPT_SAMPLER_BESTCANDIDATE_HASH, HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY = 10, 11
 
 
 def sampler_kind(mode):

@@ -20,6 +20,7 @@
 #include "hpt_flatten.h"
 #include "hpt_internal.h"
 #include "hpt_kernels.h"
+#include "hpt_bc.h"
 #include "hpt_replay.h"
 #include "hpt_wavefront.h"
 
@@ -54,6 +55,10 @@ struct hpt_scene {
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
     bool cam_animated; hpt_instance cam_xf;        // hpt_scene_set_camera_motion: the camera's AnimatedTransform (camera to world)
     float *dl_stack; size_t dl_stack_floats;       // direct lighting over specular surfaces: the recursion's per-lane ray stacks (grown on demand)
+    float *adapt_buf; size_t adapt_buf_floats;     // Sampler "adaptive": the parked radiances of the pixels' first batches (grown on demand)
+    float *d_bc_table, *d_bc_table_alloc;          // Sampler "bestcandidate": the reference's sample table (hpt_scene_set_sample_table; 4096 x 5 floats)
+    float *d_bc_shifts; size_t bc_shifts_floats;   // ... and the shifts of the table tiles of the last render's grid (grown on demand)
+    BcGrid bc_grid_cached;                         // the grid those shifts were tabulated for (nx = 0: none)
     void *d_film; size_t film_bytes;               // device film of hpt_render (host-film entry point), grown on demand
     void *d_scr; hipEvent_t ev0, ev1;              // per-frame scratch (work-queue heads + counters) and timing events, created once
     float *sbuf; size_t sbuf_floats;             // two-pass film: per-sample records of the last filtered render (grown on demand)         // hpt_scene_set_filter: 16x16 weights in HBM (nullptr: box 0.5) + widths
@@ -226,6 +231,8 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
     if (s->d_scr) (void)hipFree(s->d_scr);
     if (s->d_film) (void)hipFree(s->d_film);
     if (s->dl_stack) (void)hipFree(s->dl_stack);
+    if (s->adapt_buf) (void)hipFree(s->adapt_buf);
+    if (s->d_bc_shifts) (void)hipFree(s->d_bc_shifts);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -254,7 +261,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->device = device;
     s->tune_cfg = -1;
     s->sbuf = nullptr; s->sbuf_floats = 0;
-    s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0; s->dl_stack = nullptr; s->dl_stack_floats = 0;
+    s->d_scr = nullptr; s->ev0 = s->ev1 = nullptr; s->d_film = nullptr; s->film_bytes = 0; s->dl_stack = nullptr; s->dl_stack_floats = 0; s->adapt_buf = nullptr; s->adapt_buf_floats = 0; s->d_bc_table = s->d_bc_table_alloc = nullptr; s->d_bc_shifts = nullptr; s->bc_shifts_floats = 0; memset(&s->bc_grid_cached, 0, sizeof(s->bc_grid_cached));
     s->d_ftable = s->d_ftable_alloc = nullptr; memset(&s->filter, 0, sizeof(s->filter));
     s->cam_animated = false; memset(&s->cam_xf, 0, sizeof(s->cam_xf));
     memset(&s->d, 0, sizeof(s->d));
@@ -415,6 +422,21 @@ extern "C" int hpt_scene_set_filter(hpt_scene *s, const hpt_filter *f) {
     return HPT_OK;
 }
 
+// BestCandidateSampler::sampleTable (samplers/bestcandidate.h:86) as state of the scene handle; see include/hpt.h
+extern "C" int hpt_scene_set_sample_table(hpt_scene *s, const float *table, int n_entries) {
+    if (!s) { hpt_set_error("null scene"); return HPT_E_INVALID; }
+    if (!table) { s->d_bc_table = nullptr; return HPT_OK; }      // (the 80 KB allocation stays with the scene)
+    if (n_entries != HPT_SAMPLE_TABLE_SIZE) { hpt_set_error("sample table: %d entries, expected %d (64 x 64, samplers/bestcandidate.h:43-45)", n_entries, HPT_SAMPLE_TABLE_SIZE); return HPT_E_INVALID; }
+    for (int i = 0; i < 5 * HPT_SAMPLE_TABLE_SIZE; ++i)
+        if (!(table[i] >= 0.f && table[i] <= 1.f)) { hpt_set_error("sample table: value %d is outside [0, 1]", i); return HPT_E_INVALID; }
+    HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
+    float *d = s->d_bc_table_alloc;
+    if (!d) { HIP_CHECK_RET(hipMalloc((void **)&d, sizeof(float) * 5 * HPT_SAMPLE_TABLE_SIZE), HPT_E_HIP); s->allocs.push_back(d); s->d_bc_table_alloc = d; }
+    HIP_CHECK_RET(hipMemcpy(d, table, sizeof(float) * 5 * HPT_SAMPLE_TABLE_SIZE, hipMemcpyHostToDevice), HPT_E_HIP);
+    s->d_bc_table = d;
+    return HPT_OK;
+}
+
 // PerspectiveCamera::CameraToWorld as an AnimatedTransform (include/hpt.h); state of the scene handle like the filter
 extern "C" int hpt_scene_set_camera_motion(hpt_scene *s, const hpt_instance *c2w) {
     if (!s) { hpt_set_error("null scene"); return HPT_E_INVALID; }
@@ -434,6 +456,21 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (rd->sampler_mode == HPT_SAMPLER_RANDOM_MT_REPLAY) { hpt_set_error("RANDOM_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"random\" as HPT_SAMPLER_RANDOM_HASH"); return HPT_E_UNSUPPORTED; }
     const int skind = HPT_SAMPLER_KIND(rd->sampler_mode);
     if (skind == HPT_SAMPLER_STRATIFIED_MT_REPLAY) { hpt_set_error("STRATIFIED_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"stratified\" as HPT_SAMPLER_STRATIFIED_HASH"); return HPT_E_UNSUPPORTED; }
+    if (skind == HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY) { hpt_set_error("BESTCANDIDATE_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"bestcandidate\" as HPT_SAMPLER_BESTCANDIDATE_HASH"); return HPT_E_UNSUPPORTED; }
+    // Sampler "bestcandidate" (samplers/bestcandidate.cpp): the work items are the entries of the reference's sample table in the table tiles that
+    // meet the sample extent; any spp (it only sets the tiles' width); the arrays are LD_HASH's for one pixel sample, counts rounded to powers of two
+    const bool bestcand = rd->sampler_mode == HPT_SAMPLER_BESTCANDIDATE_HASH;
+    if (bestcand && (!s || !s->d_bc_table)) { hpt_set_error("Sampler \"bestcandidate\" needs the reference's sample table (hpt_scene_set_sample_table)"); return HPT_E_INVALID; }
+    if (bestcand && (rd->spp <= 0 || rd->spp > 4096)) { hpt_set_error("bestcandidate sampler: pixelsamples must be 1 .. 4096 (got %d)", rd->spp); return HPT_E_INVALID; }
+    if (bestcand && rd->pipeline != HPT_PIPELINE_PERSISTENT) { hpt_set_error("Sampler \"bestcandidate\" runs on the persistent kernel"); return HPT_E_UNSUPPORTED; }
+    if (skind == HPT_SAMPLER_ADAPTIVE_MT_REPLAY) { hpt_set_error("ADAPTIVE_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"adaptive\" as HPT_SAMPLER_ADAPTIVE_HASH"); return HPT_E_UNSUPPORTED; }
+    // Sampler "adaptive", method contrast (samplers/adaptive.cpp): spp = maxSamples, minSamples in the mode's upper bits; both batches of a pixel are
+    // LD_HASH patterns, so the getters run in their low-discrepancy mode and the lane's own sample count (LdHash::w) says which
+    const bool adaptive = skind == HPT_SAMPLER_ADAPTIVE_HASH;
+    const int amin = adaptive ? HPT_SAMPLER_ADAPT_MIN(rd->sampler_mode) : 0;
+    if (adaptive && (rd->spp <= 0 || (rd->spp & (rd->spp - 1)) || amin < 2 || (amin & (amin - 1)) || amin >= rd->spp || amin > 1024)) {
+        hpt_set_error("adaptive sampler: minsamples and maxsamples (spp) are powers of two with 2 <= minsamples < maxsamples, minsamples <= 1024 (got %d .. %d)", amin, rd->spp); return HPT_E_INVALID; }
+    if (adaptive && rd->pipeline != HPT_PIPELINE_PERSISTENT) { hpt_set_error("Sampler \"adaptive\" runs on the persistent kernel"); return HPT_E_UNSUPPORTED; }
     if (skind == HPT_SAMPLER_HALTON_MT_REPLAY) { hpt_set_error("HALTON_MT_REPLAY is the oracle's pinning mode; the device runs Sampler \"halton\" as HPT_SAMPLER_HALTON_HASH"); return HPT_E_UNSUPPORTED; }
     // Sampler "halton" (samplers/halton.cpp): the arrays are the stratified mode's Latin hypercubes, the camera values Halton points of the
     // 32x32 super-tile the work item names (item_to_halton); any spp up to 65536 (the sample numbers of a window are ints)
@@ -446,9 +483,9 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode);
         if (xs <= 0 || rd->spp <= 0 || rd->spp % xs || rd->spp > 0xfff) { hpt_set_error("stratified sampler: spp = xsamples * ysamples, at most 4095 (got spp %d, xsamples %d)", rd->spp, xs); return HPT_E_INVALID; }
     }
-    if (rd->spp <= 0 || (!random_sampler && (rd->spp & (rd->spp - 1)))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42; Sampler \"random\" takes any)"); return HPT_E_INVALID; }
+    if (rd->spp <= 0 || (!random_sampler && !bestcand && (rd->spp & (rd->spp - 1)))) { hpt_set_error("spp must be a power of two (LDSampler rounds up, lowdiscrepancy.cpp:42; Sampler \"random\" takes any)"); return HPT_E_INVALID; }
     if (rd->x_count <= 0 || rd->y_count <= 0 || rd->maxdepth < 0) { hpt_set_error("bad film extent / maxdepth"); return HPT_E_INVALID; }
-    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY && !random_sampler) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
+    if (rd->sampler_mode != HPT_SAMPLER_LD_HASH && rd->sampler_mode != HPT_SAMPLER_MT_REPLAY && !random_sampler && !adaptive && !bestcand) { hpt_set_error("unknown sampler mode %d", rd->sampler_mode); return HPT_E_INVALID; }
     if (rd->sampler_mode == HPT_SAMPLER_MT_REPLAY) {
         if (rd->ntasks <= 0 || (rd->ntasks & (rd->ntasks - 1))) { hpt_set_error("MT_REPLAY needs ntasks = the reference's nTasks (a power of two, samplerrenderer.cpp:203-205)"); return HPT_E_INVALID; }
         if (rd->shard_count > 1) { hpt_set_error("MT_REPLAY is a single-device parity mode"); return HPT_E_UNSUPPORTED; }
@@ -480,6 +517,10 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     rp->random_sampler = random_sampler ? 1 : 0;
     rp->sampler_kind = halton ? 3 : stratified ? 2 : random_sampler ? 1 : 0;
     rp->sampler_w = (stratified || halton) ? HPT_STRAT_W : random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
+    rp->bc_table = rp->bc_shifts = nullptr; rp->bc_tw = 0.f; rp->bc_tx0 = rp->bc_ty0 = 0;
+    if (bestcand) rp->sampler_w = 0u;                     // the arrays of ONE pixel sample per table entry (LdHash::w = count - 1)
+    rp->adapt_min = amin;
+    if (adaptive) rp->sampler_w = (uint32_t)amin - 1u;    // a pixel starts with its first batch's pattern (Lane::finish_path_adaptive switches to spp - 1)
     rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
     if (stratified) {
         const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
@@ -519,7 +560,7 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         if (const char *e = getenv("HPT_SBUF_MAX_GB")) cap_gb = atof(e);
         const size_t need = (size_t)rp->sx_count * rp->sy_count * (size_t)rd->spp * 6;
         // (Sampler "halton": a window's samples are not a fixed count per pixel, so there is no slot for them in the record buffer: they splat)
-        if (!halton && !(fm && !strcmp(fm, "atomic")) && (double)need * 4.0 <= cap_gb * 1e9) {
+        if (!halton && !bestcand && !(fm && !strcmp(fm, "atomic")) && (double)need * 4.0 <= cap_gb * 1e9) {
             if (s->sbuf_floats < need) {
                 if (s->sbuf) (void)hipFree(s->sbuf);
                 s->sbuf = nullptr; s->sbuf_floats = 0;
@@ -536,6 +577,23 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
         rp->hx0 = rp->sx_start & ~31; rp->hy0 = rp->sy_start & ~31;
         rp->n_stx = (rp->sx_start + rp->sx_count - rp->hx0 + 31) / 32; rp->n_sty = (rp->sy_start + rp->sy_count - rp->hy0 + 31) / 32;
     }
+    if (bestcand) {   // the work grid is the grid of table tiles (BestCandidateSampler's constructor over the sample extent); their shifts, tabulated on the host
+        const BcGrid g = bc_grid(rd->spp, rp->sx_start, rp->sx_start + rp->sx_count, rp->sy_start, rp->sy_start + rp->sy_count);
+        if ((int64_t)g.nx * g.ny > (1 << 20)) { hpt_set_error("bestcandidate sampler: %d x %d table tiles exceed the 2^20 a work item can name", g.nx, g.ny); return HPT_E_UNSUPPORTED; }
+        if (memcmp(&g, &s->bc_grid_cached, sizeof(g)) != 0) {
+            std::vector<float> sh; bc_all_shifts(g, sh);
+            if (s->bc_shifts_floats < sh.size()) {
+                if (s->d_bc_shifts) (void)hipFree(s->d_bc_shifts);
+                s->d_bc_shifts = nullptr; s->bc_shifts_floats = 0;
+                if (hipMalloc((void **)&s->d_bc_shifts, sh.size() * sizeof(float)) != hipSuccess) { hpt_set_error("hipMalloc of the table-tile shifts failed"); return HPT_E_HIP; }
+                s->bc_shifts_floats = sh.size();
+            }
+            if (hipMemcpy(s->d_bc_shifts, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { hpt_set_error("upload of the table-tile shifts failed"); return HPT_E_HIP; }
+            s->bc_grid_cached = g;
+        }
+        rp->bc_table = s->d_bc_table; rp->bc_shifts = s->d_bc_shifts; rp->bc_tw = g.tw; rp->bc_tx0 = g.tx0; rp->bc_ty0 = g.ty0;
+        rp->n_stx = g.nx; rp->n_sty = g.ny;
+    }
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     int64_t local = (nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count;
     // A pixel's samples are split into work items of `chunk` samples.  A LARGE job (>= 32 M camera samples in this shard) takes ONE sample per
@@ -551,10 +609,14 @@ static int fill_params(const hpt_camera *cam, const hpt_render_desc *rd, RenderP
     if (nst * 1024 * (int64_t)rd->spp >= ((int64_t)32 << 20)) rp->chunk = 1;
     if (const char *e = getenv("HPT_CHUNK")) { int c = atoi(e); if (c > 0 && (c & (c - 1)) == 0 && c <= rd->spp) rp->chunk = c; }
     if (halton) rp->chunk = 1;     // the items of Sampler "halton" are single sample numbers of a window (item_to_halton)
+    if (bestcand) rp->chunk = 1;
+    if (adaptive) rp->chunk = amin;   // Sampler "adaptive": one item per pixel, begun with the first batch (the decision needs the whole batch on one lane)
     if (rp->chunk == 1) rp->n_heads = 8;
     if (const char *e = getenv("HPT_XCD_QUEUE")) rp->n_heads = atoi(e) == 0 ? 1 : 8;
     rp->items_per_pass = local * 1024;
     rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);   // the last chunk of a non-power-of-two spp is short (Lane::begin_pixel)
+    if (adaptive) rp->n_items = rp->items_per_pass;
+    if (bestcand) rp->n_items = rp->items_per_pass * 4;   // 4096 entries a tile = four passes of its 1024 items (item_to_bc)
     return HPT_OK;
 }
 
@@ -730,7 +792,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
                                  void *stream_v, hpt_stats *stats) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
@@ -759,7 +821,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     a.dl = dl ? 1 : 0;
     if (dl) cfg = 6;                                     // direct lighting is compiled for lock step + subtree stealing at HPT_DL_WAVES = 3 waves/SIMD only
-    const bool windowed = a.rp.sampler_kind == 3;        // Sampler "halton": the window samplers' kernels exist for configuration 5 (and direct lighting) only
+    const bool windowed = a.rp.sampler_kind == 3 || a.rp.adapt_min > 0 || a.rp.bc_table != nullptr;   // Sampler "halton" / "adaptive": the window samplers' kernels exist for configuration 5 (and direct lighting) only
     if (windowed && !dl) cfg = 5;
     if (cfg < 0 && !replay && rd->pipeline != HPT_PIPELINE_WAVEFRONT) {
         if (s->tune_cfg < 0 && (int64_t)a.rp.sx_count * a.rp.sy_count * rd->spp >= ((int64_t)32 << 20))
@@ -802,6 +864,16 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
             if (e == hipSuccess) s->dl_stack_floats = need;
         }
         a.dl_stack = s->dl_stack;
+    }
+    if (a.rp.adapt_min > 0 && e == hipSuccess) {          // Sampler "adaptive": three floats per first-batch sample and lane
+        const size_t need = (size_t)3 * (size_t)a.rp.adapt_min * (size_t)grid * HPT_BLOCK;
+        if (s->adapt_buf_floats < need) {
+            if (s->adapt_buf) (void)hipFree(s->adapt_buf);
+            s->adapt_buf = nullptr; s->adapt_buf_floats = 0;
+            e = hipMalloc((void **)&s->adapt_buf, need * sizeof(float));
+            if (e == hipSuccess) s->adapt_buf_floats = need;
+        }
+        a.adapt_buf = s->adapt_buf;
     }
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) a.rp.sbuf_xyzw = a.rp.sbuf_pos = nullptr;   // the wavefront pipeline keeps the one-pass (atomic) splat
     if (!replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT && e == hipSuccess) {
@@ -893,7 +965,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (tune_forced() >= 0) return tune_forced();
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
-    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);

@@ -265,6 +265,8 @@ HPT_FN double radical_inverse(int n, int base) {
     }
     return val;
 }
+// Sampler "bestcandidate": key of the table entries of tile (xTile, yTile) (definition: oracle/hpt_oracle.c bc_key)
+HPT_FN uint32_t bc_tile_key(int xTile, int yTile, uint32_t seed) { return hash3(hash3((uint32_t)xTile, (uint32_t)yTile, seed), 0x42455354u, 7u); }
 // key of the window = cell of the global 32x32 raster grid with origin (x0, y0) (multiples of 32, negative under a filter's margin)
 HPT_FN uint32_t halton_tile_key(int x0, int y0, uint32_t seed) { return hash3(((uint32_t)(x0 >> 5) & 0xffffu) | (((uint32_t)(y0 >> 5) & 0xffffu) << 16), seed, 0x48414c54u); }
 

@@ -31,6 +31,8 @@ struct PathKernelArgs {
     int32_t leaf_q, block_q;
     // the BVH4 walk (HPT_BVH4 builds): stack rows that take ordinary entries; above them one masked entry per level (trav_node4, hpt_device.h)
     int32_t cap_normal;
+    // Sampler "adaptive": the radiances of a pixel's first batch, parked until ReportResults has looked at them: [3 x minsamples][grid x 256] floats, or null
+    float *adapt_buf;
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
     return (size_t)a.stack_entries * HPT_BLOCK * 4;

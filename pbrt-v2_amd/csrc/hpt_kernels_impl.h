@@ -378,6 +378,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     if (DL && (MATS & MATS_EXT) && a.dl_stack) {   // the specular recursion's pending rays (hpt_path.h, Lane::node_done)
         lane.dls = a.dl_stack + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x; lane.dls_stride = (int64_t)gridDim.x * HPT_BLOCK; lane.dls_cap = a.dl_cap;
     }
+    if (WIN && a.adapt_buf) {      // Sampler "adaptive": the lane's column of parked first-batch radiances (Lane::finish_path_adaptive)
+        lane.abuf = a.adapt_buf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x; lane.abuf_stride = (int64_t)gridDim.x * HPT_BLOCK;
+    }
     bool exhausted = false;
     TravState ts;                  // this lane's walk, resumable across iterations (see the traversal phase)
     ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false;
@@ -433,7 +436,10 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (need && !over) {
                 const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
                 int x, y; uint32_t s0;
-                if (WIN) {                           // Sampler "halton": the item is a sample number of a super-tile's window
+                if (WIN && rp.bc_table) {            // Sampler "bestcandidate" (scalar branch): the item is an entry of the sample table in a table tile
+                    uint32_t tile;
+                    if (item_to_bc(rp, item, &tile, &s0)) (void)lane.begin_bc(rp, tile, s0);
+                } else if (WIN && rp.sampler_kind == 3) {   // Sampler "halton": the item is a sample number of a super-tile's window
                     if (item_to_halton(rp, item, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
                 } else if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     }                                                                                                               \
     hipError_t launch_path_##NAME(const PathKernelArgs &a, int grid, bool count, int cfg, hipStream_t s) {          \
         const size_t dyn_lds = path_kernel_dyn_lds(a);                                                              \
-        if (a.rp.sampler_kind == 3) {   /* window samplers: configuration 5 / the direct-lighting kernel, WIN = true */ \
+        if (a.rp.sampler_kind == 3 || a.rp.adapt_min > 0 || a.rp.bc_table) {   /* window samplers ("halton", "adaptive", "bestcandidate"): configuration 5 / the direct-lighting kernel, WIN = true */ \
             if (a.dl) {                                                                                             \
                 if (count) hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);    \
                 else hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);         \

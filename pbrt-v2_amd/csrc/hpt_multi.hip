@@ -150,6 +150,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     const size_t n_floats = (size_t)rd->x_count * rd->y_count * 4;
     // Sampler "halton" on a pixel extent that does not start on the global 32x32 grid: a shard's windows are not its film tiles — sum as well
     if (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31)) wide_filter = 1;
+    if (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_BESTCANDIDATE_HASH) wide_filter = 1;   // Sampler "bestcandidate": the shards are table tiles, not film tiles
     if (wide_filter) {                                   // partial sums over the whole frame: one sum-reduce to rank 0
         NCCL_OK(r->Reduce(d_film, d_film, n_floats, ncclFloat32, ncclSum, 0, c->comm, stream));
         return HPT_OK;
@@ -279,6 +280,12 @@ extern "C" int hpt_multi_set_camera_motion(hpt_multi *m, const hpt_instance *c2w
     return HPT_OK;
 }
 
+extern "C" int hpt_multi_set_sample_table(hpt_multi *m, const float *table, int n_entries) {
+    if (!m) { hpt_set_error("null handle"); return HPT_E_INVALID; }
+    for (int i = 0; i < m->n; ++i) { int rc = hpt_scene_set_sample_table(m->scenes[(size_t)i], table, n_entries); if (rc != HPT_OK) return rc; }
+    return HPT_OK;
+}
+
 extern "C" int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out) {
     if (!m || !out || shard < 0 || shard >= m->n) { hpt_set_error("bad shard"); return HPT_E_INVALID; }
     *out = m->scenes[(size_t)shard];
@@ -294,7 +301,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
     const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
     const bool use_rccl = !m->comms.empty();
     // (Sampler "halton" on a pixel extent off the global 32x32 grid: a shard's windows are not its film tiles — partial films are summed)
-    const bool wide = m->wide || (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31));
+    const bool wide = m->wide || (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31))
+                      || HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_BESTCANDIDATE_HASH;       // (its shards are table tiles, not film tiles)
     // buffers (grown on demand, kept with the handle)
     if (m->film_bytes < bytes || m->tiles_cap < (size_t)n_tiles) {
         for (int i = 0; i < n; ++i) {

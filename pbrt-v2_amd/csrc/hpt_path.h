@@ -42,6 +42,12 @@ struct RenderParams {
     uint32_t seed;
     int32_t shard_rank, shard_count;
     int32_t n_stx, n_sty;      // super-tiles (32x32 px) covering the sample extent
+    // Sampler "bestcandidate" (samplers/bestcandidate.cpp:50-91): the reference's 4096 x 5 table (hpt_scene_set_sample_table; nullptr: another
+    // sampler), the three shifts of every table tile of this render's grid (n_stx x n_sty tiles from tile (bc_tx0, bc_ty0); hpt_bc.h), tableWidth
+    const float *bc_table, *bc_shifts;
+    float bc_tw;
+    int32_t bc_tx0, bc_ty0;
+    int32_t adapt_min;         // Sampler "adaptive" (method contrast): minSamples, the size of a pixel's first batch (spp = maxSamples); 0: another sampler
     int32_t hx0, hy0;          // Sampler "halton": origin of the super-tile grid = the sample extent's corner floored to the GLOBAL 32x32 raster grid
                                // (its windows are cells of that grid, so that a crop renders the full frame's samples); otherwise sx_start, sy_start
     int32_t has_motion;        // scene has animated instances or a moving camera: rays carry a time sample
@@ -174,6 +180,21 @@ HPT_FN bool item_to_halton(const RenderParams &rp, int64_t item, int *x0, int *y
     *x0 = rp.hx0 + (int)(st % rp.n_stx) * 32; *y0 = rp.hy0 + (int)(st / rp.n_stx) * 32;
     return true;
 }
+// Sampler "bestcandidate": item -> (table tile of this render's grid, table entry): the 4096 entries of a tile are its 1024 items of four passes
+HPT_FN bool item_to_bc(const RenderParams &rp, int64_t item, uint32_t *tile, uint32_t *off) {
+    const int64_t pass = item / rp.items_per_pass;
+    item -= pass * rp.items_per_pass;
+    const int64_t st = (item >> 10) * rp.shard_count + rp.shard_rank;
+    if (st >= (int64_t)rp.n_stx * rp.n_sty) return false;
+    *tile = (uint32_t)st; *off = (uint32_t)pass * 1024u + (uint32_t)(item & 1023);
+    return true;
+}
+// raster position of table entry `off` in table tile `tile` (bestcandidate.cpp:66-67)
+HPT_FN void bc_image(const RenderParams &rp, uint32_t tile, uint32_t off, float *ix, float *iy) {
+    const int xTile = rp.bc_tx0 + (int)(tile % (uint32_t)rp.n_stx), yTile = rp.bc_ty0 + (int)(tile / (uint32_t)rp.n_stx);
+    const float *t = rp.bc_table + 5 * (int64_t)off;
+    *ix = ((float)xTile + t[0]) * rp.bc_tw; *iy = ((float)yTile + t[1]) * rp.bc_tw;
+}
 // image position of sample number k of the window at (x0, y0): origin + 32 * (radical inverse base 3, base 2) (halton.cpp:57-62)
 HPT_FN void halton_image(uint32_t k, int x0, int y0, float *ix, float *iy) {
     const float u = (float)radical_inverse((int)k, 3), v = (float)radical_inverse((int)k, 2);
@@ -281,13 +302,21 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // product of f * |wi.n| / pdf along its branch; the same Sample serves every node, as in the reference.
     int depth, nsp, dls_cap;
     float *dls; int64_t dls_stride;
+    // Sampler "adaptive" (window-sampler kernels only): this lane's column of PathKernelArgs::adapt_buf, component c of sample j at abuf[(3 j + c) * abuf_stride]
+    float *abuf; int64_t abuf_stride;
     // The camera sample is complete: its radiance goes to the film and the lane starts its next sample — finish_path(), which the callers of
     // on_hit() / shade_finish() run ONCE per round through flush() instead of the four places of the state machine that can end a path
     // (each an inlined copy of the film update and the camera-ray set-up: the path kernels are 30-50 k instructions).
     bool fin;
 
-    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; fin = false; }
-    HPT_MFN void flush(const RenderParams &rp, float *film, WorkCounters *wc) { if (fin) { fin = false; finish_path(rp, film, wc); } }
+    HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; abuf = nullptr; abuf_stride = 0; fin = false; }
+    HPT_MFN void flush(const RenderParams &rp, float *film, WorkCounters *wc) {
+        if (fin) {
+            fin = false;
+            if (Smp::windowed && rp.adapt_min > 0) finish_path_adaptive(rp, film, wc);
+            else finish_path(rp, film, wc);
+        }
+    }
 
     // samplerrenderer.cpp:90-111 for one camera sample
     HPT_MFN void begin_sample(const RenderParams &rp) {
@@ -321,6 +350,19 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         if (ix >= (float)x1 || iy >= (float)y1 || ix < (float)rp.sx_start || iy < (float)rp.sy_start) return false;
         px = (int)floorf(ix); py = (int)floorf(iy); si = k; s_end = k + 1u; cold.film_zero();
         smp.begin_tile(rp, x0, y0);
+        begin_sample(rp);
+        return true;
+    }
+
+    // Sampler "bestcandidate": entry `off` of the table in table tile `tile`; false: outside the sample extent (bestcandidate.cpp:77-81).
+    // si carries (tile, entry) for the camera getters (LdHashSrcT::tag); the arrays are the LD_HASH construction for ONE pixel sample
+    // (LdHash::w = 0) under the tile's key with the entry's number as the sample index.
+    HPT_MFN bool begin_bc(const RenderParams &rp, uint32_t tile, uint32_t off) {
+        float ix, iy;
+        bc_image(rp, tile, off, &ix, &iy);
+        if (ix < (float)rp.sx_start || ix >= (float)(rp.sx_start + rp.sx_count) || iy < (float)rp.sy_start || iy >= (float)(rp.sy_start + rp.sy_count)) return false;
+        px = (int)floorf(ix); py = (int)floorf(iy); si = tile * 4096u + off; s_end = si + 1u; cold.film_zero();
+        smp.begin_bc_tile(rp, rp.bc_tx0 + (int)(tile % (uint32_t)rp.n_stx), rp.bc_ty0 + (int)(tile / (uint32_t)rp.n_stx));
         begin_sample(rp);
         return true;
     }
@@ -377,6 +419,97 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         film_atomic_add(f + 0, fX); film_atomic_add(f + 1, fY); film_atomic_add(f + 2, fZ); film_atomic_add(f + 3, fW);
         stage = ST_IDLE;
         smp.end_pixel(rp);
+    }
+
+    // ---- Sampler "adaptive", method "contrast" (samplers/adaptive.cpp:100-160; window-sampler kernels) ------------------------------------
+    // One camera sample to the film (ImageFilm::AddSample, film/image.cpp:77-137): the film half of finish_path, for a sample whose number and
+    // image position are given.
+    HPT_MFN void film_one(const RenderParams &rp, float *film, f3 Ls, float imgx, float imgy, uint32_t sample) {
+        float X = 0.412453f * Ls.x + 0.357580f * Ls.y + 0.180423f * Ls.z; // RGBToXYZ (spectrum.h:58-62)
+        float Y = 0.212671f * Ls.x + 0.715160f * Ls.y + 0.072169f * Ls.z;
+        float Z = 0.019334f * Ls.x + 0.119193f * Ls.y + 0.950227f * Ls.z;
+        if (rp.ftable) {
+            if (rp.sbuf_xyzw) {
+                const int64_t slot = ((int64_t)(py - rp.sy_start) * rp.sx_count + (px - rp.sx_start)) * rp.spp + (int64_t)sample;
+                float *r4 = rp.sbuf_xyzw + 4 * slot;
+                r4[0] = X; r4[1] = Y; r4[2] = Z; r4[3] = 1.f;
+                rp.sbuf_pos[2 * slot] = imgx; rp.sbuf_pos[2 * slot + 1] = imgy;
+            } else
+                film_splat_table(rp, film, imgx, imgy, X, Y, Z);
+            return;
+        }
+        float dimageX = imgx - 0.5f, dimageY = imgy - 0.5f;
+        int x0 = (int)ceilf(dimageX - 0.5f), x1 = (int)floorf(dimageX + 0.5f);
+        int y0 = (int)ceilf(dimageY - 0.5f), y1 = (int)floorf(dimageY + 0.5f);
+        if (x0 < rp.x_start) x0 = rp.x_start;
+        if (x1 > rp.x_start + rp.x_count - 1) x1 = rp.x_start + rp.x_count - 1;
+        if (y0 < rp.y_start) y0 = rp.y_start;
+        if (y1 > rp.y_start + rp.y_count - 1) y1 = rp.y_start + rp.y_count - 1;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                if (x == px && y == py) cold.film_add(X, Y, Z, 1.f);
+                else {
+                    float *f = film + 4 * ((int64_t)(y - rp.y_start) * rp.x_count + (x - rp.x_start));
+                    film_atomic_add(f + 0, X); film_atomic_add(f + 1, Y); film_atomic_add(f + 2, Z); film_atomic_add(f + 3, 1.f);
+                }
+            }
+    }
+    HPT_MFN void pixel_done(const RenderParams &rp, float *film) {
+        if (!rp.ftable) {
+            float *f = film + 4 * ((int64_t)(py - rp.y_start) * rp.x_count + (px - rp.x_start));
+            float fX, fY, fZ, fW;
+            cold.film_get(&fX, &fY, &fZ, &fW);
+            film_atomic_add(f + 0, fX); film_atomic_add(f + 1, fY); film_atomic_add(f + 2, fZ); film_atomic_add(f + 3, fW);
+        }
+        stage = ST_IDLE;
+        smp.end_pixel(rp);
+    }
+    // A camera sample of an adaptively sampled pixel is complete.  First batch (s_end == minSamples; maxSamples is always larger, adaptive.cpp:71-75):
+    // its radiance is parked in the lane's column of adapt_buf; after the batch's last sample ReportResults decides (needsSupersampling: any
+    // luminance further than half the batch's mean from it) — supersample: the batch is dropped and the pixel starts again with maxSamples
+    // samples, the LD_HASH pattern of the pixel for that count; else the batch goes to the film in sample order.  Second batch: straight to the film.
+    HPT_MFN void finish_path_adaptive(const RenderParams &rp, float *film, WorkCounters *wc) {
+        f3 Ls = cold.L();
+        bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
+        if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
+        if (bad) { Ls = S(0.f); if (wc) wc->bad++; else if (rp.bad_counter) count_bad_sample(rp.bad_counter); }
+        if (wc) wc->samples++;
+        const uint32_t lo = (uint32_t)rp.adapt_min;
+        if (s_end == lo) {
+            float *b = abuf + (int64_t)(3u * si) * abuf_stride;
+            b[0] = Ls.x; b[abuf_stride] = Ls.y; b[2 * abuf_stride] = Ls.z;
+            ++si;
+            if (si < s_end) { begin_sample(rp); return; }
+            float Lavg = 0.f;                                           // adaptive.cpp:151-154
+            for (uint32_t j = 0; j < lo; ++j) { const float *c = abuf + (int64_t)(3u * j) * abuf_stride; Lavg += sy(mk3(c[0], c[abuf_stride], c[2 * abuf_stride])); }
+            Lavg /= (float)lo;
+            bool needs = false;
+            for (uint32_t j = 0; j < lo; ++j) {                         // adaptive.cpp:155-158
+                const float *c = abuf + (int64_t)(3u * j) * abuf_stride;
+                if (fabsf(sy(mk3(c[0], c[abuf_stride], c[2 * abuf_stride])) - Lavg) / Lavg > 0.5f) needs = true;
+            }
+            if (needs) {                                                // ReportResults -> false: nothing of this batch reaches the film
+                si = 0; s_end = (uint32_t)rp.spp;
+                smp.set_count((uint32_t)rp.spp);
+                begin_sample(rp);
+                return;
+            }
+            for (uint32_t j = 0; j < lo; ++j) {
+                const float *c = abuf + (int64_t)(3u * j) * abuf_stride;
+                smp.begin_sample(j);
+                float ia, ib;
+                smp.image(rp, px, py, &ia, &ib);
+                film_one(rp, film, mk3(c[0], c[abuf_stride], c[2 * abuf_stride]), px + ia, py + ib, j);
+            }
+            pixel_done(rp, film);
+            return;
+        }
+        float ia, ib;
+        smp.image(rp, px, py, &ia, &ib);
+        film_one(rp, film, Ls, px + ia, py + ib, si);
+        ++si;
+        if (si < s_end) { begin_sample(rp); return; }
+        pixel_done(rp, film);
     }
 
     HPT_MFN void after_mis(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
@@ -733,7 +866,15 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
 // inverses in the refill path — moved the register allocation of every kernel it was compiled into (same-box A/B, profiles/r03_ab.md run Q:
 // killeroo -1.9 %), so it lives in kernel instantiations of its own (hpt_path_kernel<..., WIN = true>) and the default sampler's kernels are,
 // instruction for instruction, what they were without it.
+// what the camera getters of the window samplers need beside the hash state: Lane::si (table tile and entry of Sampler "bestcandidate") —
+// a field only the WINDOWED instantiation has
+template <bool ON> struct WinTag { HPT_MFN void set(uint32_t) {} HPT_MFN uint32_t get() const { return 0u; } };
+template <> struct WinTag<true> { uint32_t v; HPT_MFN void set(uint32_t x) { v = x; } HPT_MFN uint32_t get() const { return v; } };
 template <bool WINDOWED> struct LdHashSrcT {
+    static constexpr bool windowed = WINDOWED;
+    WinTag<WINDOWED> tag;
+    HPT_MFN void begin_bc_tile(const RenderParams &rp, int xTile, int yTile) { h.pk = bc_tile_key(xTile, yTile, rp.seed); h.w = 0u; }
+    HPT_MFN void set_count(uint32_t n) { h.w = n - 1u; }       // Sampler "adaptive": the pixel's pattern for another sample count
     LdHash h;
     uint32_t dcount;
     HPT_MFN void begin_pixel(const RenderParams &rp, int x, int y) {
@@ -742,7 +883,8 @@ template <bool WINDOWED> struct LdHashSrcT {
         h.w = rp.sampler_w;
     }
     HPT_MFN void begin_tile(const RenderParams &rp, int x0, int y0) { h.pk = halton_tile_key(x0, y0, rp.seed); h.w = rp.sampler_w; }   // Sampler "halton": the window's key
-    HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; }
+    // (window-sampler kernels: a sample count of one — w == 0 — is Sampler "bestcandidate", whose i carries the tile above the entry's 12 bits)
+    HPT_MFN void begin_sample(uint32_t i) { h.i = i; dcount = 0; tag.set(i); if (WINDOWED && h.w == 0u) h.i = i & 4095u; }
     HPT_MFN void end_pixel(const RenderParams &) {}
     HPT_MFN float one(int j) const { return h.one(j); }
     HPT_MFN void two(int j, float *a, float *b) const { h.two(j, a, b); }
@@ -750,6 +892,12 @@ template <bool WINDOWED> struct LdHashSrcT {
     // (px, py): the lane's pixel — under Sampler "halton" it names the window (its cell of the global 32x32 grid), and the offsets returned are those of
     // the window's Halton point h.i inside the pixel: (origin + 32 u) - px is exact, and so is px + that
     HPT_MFN void image(const RenderParams &rp, int px, int py, float *a, float *b) const {
+        if (WINDOWED && rp.bc_table) {
+            float ix, iy;
+            bc_image(rp, tag.get() >> 12, tag.get() & 4095u, &ix, &iy);
+            *a = ix - (float)px; *b = iy - (float)py;
+            return;
+        }
         if (WINDOWED && rp.sampler_kind == 3) {
             float ix, iy;
             halton_image(h.i, px & ~31, py & ~31, &ix, &iy);
@@ -764,12 +912,22 @@ template <bool WINDOWED> struct LdHashSrcT {
         h.strat2(h.i, 0u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
     }
     HPT_MFN void lens(const RenderParams &rp, float *a, float *b) const {
+        if (WINDOWED && rp.bc_table) {                              // WRAP(sampleOffsets[1, 2] + sampleTable[..][3, 4]) (bestcandidate.cpp:70-73)
+            const float *t = rp.bc_table + 5 * (int64_t)(tag.get() & 4095u), *sh = rp.bc_shifts + 3 * (int64_t)(tag.get() >> 12);
+            const float u = sh[1] + t[3], v = sh[2] + t[4];
+            *a = u >= 1.f ? u - 1.f : u; *b = v >= 1.f ? v - 1.f : v;
+            return;
+        }
         if (rp.sampler_kind == 0) { h.lens(a, b); return; }
         if (rp.sampler_kind == 1) { *a = h.rnd(2u, 0u); *b = h.rnd(3u, 0u); return; }
         if (WINDOWED && rp.sampler_kind == 3) { *a = (float)radical_inverse((int)h.i + 1, 5); *b = (float)radical_inverse((int)h.i + 1, 7); return; }   // halton.cpp:68-69 (the incremented number)
         h.strat2(perm_n(h.i, (uint32_t)rp.strat_n, hash3(h.pk, 1u, 2u)), 2u, rp.strat_jitter != 0, rp.strat_fxs, rp.strat_dx, rp.strat_dy, a, b);
     }
     HPT_MFN float time01(const RenderParams &rp) const {
+        if (WINDOWED && rp.bc_table) {                              // WRAP(sampleOffsets[0] + sampleTable[..][2]) (bestcandidate.cpp:68-69)
+            const float t = rp.bc_shifts[3 * (int64_t)(tag.get() >> 12)] + rp.bc_table[5 * (int64_t)(tag.get() & 4095u) + 2];
+            return t >= 1.f ? t - 1.f : t;
+        }
         if (rp.sampler_kind == 0) return h.time01();
         if (rp.sampler_kind == 1) return h.rnd(4u, 0u);
         if (WINDOWED && rp.sampler_kind == 3) return (float)radical_inverse((int)h.i + 1, 11);   // halton.cpp:70

@@ -120,7 +120,10 @@ struct MtReplaySrc {
     HPT_MFN void two(int j, float *a, float *b) { *a = at(off_2d(j) + 2 * i); *b = at(off_2d(j) + 2 * i + 1); }
     HPT_MFN void image(const RenderParams &, float *a, float *b) { *a = at(2 * i); *b = at(2 * i + 1); }
     HPT_MFN void image(const RenderParams &rp, int, int, float *a, float *b) { image(rp, a, b); }
-    HPT_MFN void begin_tile(const RenderParams &, int, int) {}   // (Sampler "halton" has no replay mode on the device)
+    static constexpr bool windowed = false;
+    HPT_MFN void set_count(uint32_t) {}
+    HPT_MFN void begin_tile(const RenderParams &, int, int) {}
+    HPT_MFN void begin_bc_tile(const RenderParams &, int, int) {}   // (Sampler "halton" has no replay mode on the device)
     HPT_MFN void lens(const RenderParams &, float *a, float *b) { *a = at(2u * n + 2 * i); *b = at(2u * n + 2 * i + 1); }
     HPT_MFN float time01(const RenderParams &) { return at(4u * n + i); }
     // the replay parity mode covers the path integrator only (the direct-lighting sample layout is not tabulated)

@@ -54,6 +54,7 @@
 #include "samplers/stratified.h"
 #include "samplers/halton.h"
 #include "samplers/adaptive.h"
+#include "samplers/bestcandidate.h"
 #include "shapes/disk.h"
 #include "shapes/sphere.h"
 #include "shapes/trianglemesh.h"
@@ -597,7 +598,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     const StratifiedSampler *strat = dynamic_cast<const StratifiedSampler *>(sampler);
     const HaltonSampler *halt = dynamic_cast<const HaltonSampler *>(sampler);
     const AdaptiveSampler *adapt = dynamic_cast<const AdaptiveSampler *>(sampler);
-    if (!lds && !rnds && !strat && !halt && !adapt) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\", \"stratified\", \"halton\" or \"adaptive\"");
+    const BestCandidateSampler *bcs = dynamic_cast<const BestCandidateSampler *>(sampler);
+    if (!lds && !rnds && !strat && !halt && !adapt && !bcs) Severe("hip renderer: Sampler must be \"lowdiscrepancy\", \"random\", \"stratified\", \"halton\", \"adaptive\" or \"bestcandidate\"");
     if (adapt && adapt->method != AdaptiveSampler::ADAPTIVE_CONTRAST_THRESHOLD) Severe("hip renderer: Sampler \"adaptive\" with method \"shapeid\" is outside the scope (the device carries no Intersection ids); use \"contrast\"");
     const PathIntegrator *path = dynamic_cast<const PathIntegrator *>(surfaceIntegrator);
     const DirectLightingIntegrator *direct = dynamic_cast<const DirectLightingIntegrator *>(surfaceIntegrator);
@@ -628,7 +630,8 @@ void HipPathRenderer::Render(const Scene *scene) {
     rd.xres = film->xResolution; rd.yres = film->yResolution;
     rd.x_start = film->xPixelStart; rd.x_count = film->xPixelCount;
     rd.y_start = film->yPixelStart; rd.y_count = film->yPixelCount;
-    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : halt ? halt->samplesPerPixel : adapt ? adapt->maxSamples : strat->xPixelSamples * strat->yPixelSamples;
+    rd.spp = lds ? lds->nPixelSamples : rnds ? rnds->nSamples : halt ? halt->samplesPerPixel : adapt ? adapt->maxSamples : bcs ? bcs->samplesPerPixel
+                 : strat->xPixelSamples * strat->yPixelSamples;
     rd.maxdepth = path ? path->maxDepth : direct->maxDepth;
     rd.integrator = path ? HPT_INTEGRATOR_PATH
                          : (direct->strategy == SAMPLE_ALL_UNIFORM ? HPT_INTEGRATOR_DIRECT_ALL : HPT_INTEGRATOR_DIRECT_ONE);
@@ -639,6 +642,7 @@ void HipPathRenderer::Render(const Scene *scene) {
                                                  strat->xPixelSamples, strat->jitterSamples);
     }
     if (adapt) rd.sampler_mode = HPT_SAMPLER_ADAPTIVE(samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_ADAPTIVE_MT_REPLAY : HPT_SAMPLER_ADAPTIVE_HASH, adapt->minSamples);   // samplers/adaptive.cpp:44-83 (both counts already powers of two)
+    if (bcs) rd.sampler_mode = samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY : HPT_SAMPLER_BESTCANDIDATE_HASH;   // samplers/bestcandidate.cpp:50-91
     if (halt) rd.sampler_mode = samplerMode == HPT_SAMPLER_MT_REPLAY ? HPT_SAMPLER_HALTON_MT_REPLAY : HPT_SAMPLER_HALTON_HASH;   // samplers/halton.cpp:54-80
     rd.seed = seed;
     // nTasks exactly as SamplerRenderer::Render computes it (samplerrenderer.cpp:203-205)
@@ -654,6 +658,12 @@ void HipPathRenderer::Render(const Scene *scene) {
             FILE *mf = fopen(mpath.c_str(), "wb");
             if (!mf || fwrite(&camMotion, sizeof(camMotion), 1, mf) != 1) Severe("hip renderer: cannot write %s", mpath.c_str());
             fclose(mf);
+        }
+        if (bcs) {           // sidecar: the sampler's table (BestCandidateSampler::sampleTable: 4096 x 5 floats)
+            string tpath = dumpPath + ".sampletable";
+            FILE *tf = fopen(tpath.c_str(), "wb");
+            if (!tf || fwrite(&BestCandidateSampler::sampleTable[0][0], sizeof(float), 5 * SAMPLE_TABLE_SIZE, tf) != 5 * SAMPLE_TABLE_SIZE) Severe("hip renderer: cannot write %s", tpath.c_str());
+            fclose(tf);
         }
         if (!defaultBox) {   // sidecar: 258 floats {xwidth, ywidth, table[256]} = hpt_filter
             string fpath = dumpPath + ".filter";
@@ -682,6 +692,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         if (!hm) Severe("hip renderer: %s", hpt_last_error());
         if (!defaultBox && hpt_multi_set_filter(hm, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         if (movingCamera && hpt_multi_set_camera_motion(hm, &camMotion) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        if (bcs && hpt_multi_set_sample_table(hm, &BestCandidateSampler::sampleTable[0][0], SAMPLE_TABLE_SIZE) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         std::vector<hpt_stats> sts(devs.size());
         if (hpt_multi_render(hm, &cam, &rd, &xyzw[0], &sts[0]) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         hpt_multi_destroy(hm);
@@ -695,6 +706,7 @@ void HipPathRenderer::Render(const Scene *scene) {
         t_create = NowS();
         if (!defaultBox && hpt_scene_set_filter(hs, &flt) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         if (movingCamera && hpt_scene_set_camera_motion(hs, &camMotion) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
+        if (bcs && hpt_scene_set_sample_table(hs, &BestCandidateSampler::sampleTable[0][0], SAMPLE_TABLE_SIZE) != HPT_OK) Severe("hip renderer: %s", hpt_last_error());
         // kernel configuration of a job big enough to repay it (what hpt_render would do on its own: here as a step of its own, timed):
         // probe renders, or the cached choice for this scene
         if ((int64_t)rd.x_count * rd.y_count * rd.spp >= ((int64_t)32 << 20) && hpt_scene_tune(hs, &cam, &rd) < 0)

@@ -24,6 +24,7 @@ EXPORTS = [
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
     "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
+    "hpt_scene_set_sample_table", "hpt_multi_set_sample_table",
 ]
 
 
@@ -58,6 +59,8 @@ def lib():
         L.hpt_scene_tune.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc)]
         L.hpt_scene_set_filter.argtypes = [C.c_void_p, C.POINTER(abi.Filter)]
         L.hpt_scene_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
+        L.hpt_scene_set_sample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hpt_multi_set_sample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hpt_multi_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
         L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
@@ -130,6 +133,14 @@ class DeviceScene:
     def set_camera_motion(self, c2w):
         """A moving camera: CameraToWorld as an AnimatedTransform (abi.Instance record; None = static camera)."""
         _check(lib().hpt_scene_set_camera_motion(self.h, C.byref(c2w) if c2w is not None else None))
+
+    def set_sample_table(self, table):
+        """Sampler "bestcandidate": the reference's sample table, (4096, 5) float32 (BestCandidateSampler::sampleTable; None removes it)."""
+        if table is None:
+            _check(lib().hpt_scene_set_sample_table(self.h, None, 0))
+            return
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        _check(lib().hpt_scene_set_sample_table(self.h, t.ctypes.data, t.shape[0]))
 
     def set_filter(self, flt):
         """ImageFilm's reconstruction filter for the following renders (abi.Filter; None = box of width 0.5)."""

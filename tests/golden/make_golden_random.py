@@ -41,7 +41,7 @@ def sub(text, xres, yres, spp, out_pfm, integrator=None, sampler=None):
     else:
         text = re.sub(r'Film "image"', 'Film "image" "string filename" "%s"' % out_pfm, text, count=1)
     text = re.sub(r'Sampler "lowdiscrepancy" "integer pixelsamples" \[\d+\]', sampler or ('Sampler "random" "integer pixelsamples" [%d]' % spp), text)
-    assert 'Sampler "random"' in text or 'Sampler "stratified"' in text or 'Sampler "halton"' in text or 'Sampler "adaptive"' in text
+    assert 'Sampler "random"' in text or 'Sampler "stratified"' in text or 'Sampler "halton"' in text or 'Sampler "adaptive"' in text or 'Sampler "bestcandidate"' in text
     if integrator:
         text = text.replace('SurfaceIntegrator "directlighting"', integrator)
     text = text.replace('Include "geometry/', 'Include "%s/geometry/' % REF)
@@ -68,7 +68,7 @@ def run_case(name, pbrt_text, tmp, geometry_blob):
                 leaf = (sc.ipool[m.kd_bits_off:m.kd_bits_off + m.kd_nnodes] & 3) == 3
                 sc.fpool[m.kd_split_off:m.kd_split_off + m.kd_nnodes][leaf] = 0.0
     assert np.array_equal(v.fpool, g.fpool) and np.array_equal(v.ipool, g.ipool), "geometry differs from " + geometry_blob
-    assert abi.sampler_kind(v.render.sampler_mode) in (abi.HPT_SAMPLER_RANDOM_HASH, abi.HPT_SAMPLER_STRATIFIED_HASH, abi.HPT_SAMPLER_HALTON_HASH, abi.HPT_SAMPLER_ADAPTIVE_HASH)
+    assert abi.sampler_kind(v.render.sampler_mode) in (abi.HPT_SAMPLER_RANDOM_HASH, abi.HPT_SAMPLER_STRATIFIED_HASH, abi.HPT_SAMPLER_HALTON_HASH, abi.HPT_SAMPLER_ADAPTIVE_HASH, abi.HPT_SAMPLER_BESTCANDIDATE_HASH)
     np.savez(os.path.join(HERE, name + ".view.npz"), camera=np.frombuffer(bytes(v.camera), dtype=np.uint8),
              render=np.frombuffer(bytes(v.render), dtype=np.uint8), lights=np.frombuffer(bytes(v.lights), dtype=np.uint8))
     print(name, "integrator", v.render.integrator, "sampler mode", hex(v.render.sampler_mode), "spp", v.render.spp, "nsamples", [l.nsamples for l in v.lights], ref.shape)

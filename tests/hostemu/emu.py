@@ -30,6 +30,8 @@ def lib():
         L.emu_set_filter.restype = None
         L.emu_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
         L.emu_set_camera_motion.restype = None
+        L.emu_set_sample_table.argtypes = [C.c_void_p]
+        L.emu_set_sample_table.restype = None
         L.emu_set_two_pass.argtypes = [C.c_int]
         L.emu_set_two_pass.restype = None
         L.emu_sampler.argtypes = [C.POINTER(abi.RenderDesc), C.c_int, C.c_int, C.c_void_p]
@@ -51,11 +53,13 @@ class EmuScene:
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2]),
                 "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5]), "tree_hash": int(out[6])}
 
-    def render(self, cam, rd, flt=None, two_pass=False, cam_motion=None):
+    def render(self, cam, rd, flt=None, two_pass=False, cam_motion=None, sample_table=None):
         """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the
         one-pass atomic splat"""
         lib().emu_set_filter(C.byref(flt) if flt is not None else None)
         lib().emu_set_two_pass(1 if two_pass else 0)
+        tbl = np.ascontiguousarray(sample_table, dtype=np.float32) if sample_table is not None else None   # Sampler "bestcandidate": the reference's 4096 x 5 table
+        lib().emu_set_sample_table(tbl.ctypes.data if tbl is not None else None)
         lib().emu_set_camera_motion(C.byref(cam_motion) if cam_motion is not None else None)
         film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
         stats = np.zeros(6, dtype=np.uint64)

@@ -14,6 +14,7 @@
 #include "../../pbrt-v2_amd/csrc/hpt_flatten.h"
 #include "../../pbrt-v2_amd/csrc/hpt_path.h"
 #include "../../pbrt-v2_amd/csrc/hpt_replay.h"
+#include "../../pbrt-v2_amd/csrc/hpt_bc.h"
 
 void hpt_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 
@@ -67,6 +68,8 @@ extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
 static hpt_filter g_filter; static bool g_filter_set = false;
 static bool g_two_pass = false;   // the device's two-pass film (sample records + film_gather_pixel) instead of the atomic splat
 extern "C" void emu_set_filter(const hpt_filter *f) { g_filter_set = f != nullptr; if (f) g_filter = *f; }
+static std::vector<float> g_bc_table, g_bc_shifts;      // Sampler "bestcandidate": the reference's sample table (tests: a fixture) and the shifts of the render's table tiles
+extern "C" void emu_set_sample_table(const float *t) { if (t) g_bc_table.assign(t, t + 5 * HPT_SAMPLE_TABLE_SIZE); else g_bc_table.clear(); }
 extern "C" void emu_set_two_pass(int on) { g_two_pass = on != 0; }
 static hpt_instance g_cam_motion; static bool g_cam_motion_set = false;      // hpt_scene_set_camera_motion's stand-in (process-wide; NULL = static camera)
 extern "C" void emu_set_camera_motion(const hpt_instance *c) { g_cam_motion_set = c != nullptr; if (c) g_cam_motion = *c; }
@@ -97,6 +100,10 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
       rp->sampler_kind = halton ? 3 : strat ? 2 : rp->random_sampler ? 1 : 0;
       rp->sampler_w = strat ? HPT_STRAT_W : rp->random_sampler ? HPT_RANDOM_W : (uint32_t)rd->spp - 1u;
       rp->strat_n = rd->spp; rp->strat_jitter = 0; rp->strat_fxs = rp->strat_dx = rp->strat_dy = rp->strat_dt = 1.f;
+      rp->bc_table = rp->bc_shifts = nullptr; rp->bc_tw = 0.f; rp->bc_tx0 = rp->bc_ty0 = 0;
+      if (skind == HPT_SAMPLER_BESTCANDIDATE_HASH) { rp->random_sampler = 0; rp->sampler_kind = 0; rp->sampler_w = 0u; }
+      rp->adapt_min = skind == HPT_SAMPLER_ADAPTIVE_HASH ? HPT_SAMPLER_ADAPT_MIN(rd->sampler_mode) : 0;
+      if (rp->adapt_min > 0) { rp->random_sampler = 0; rp->sampler_kind = 0; rp->sampler_w = (uint32_t)rp->adapt_min - 1u; }   // both batches are LD_HASH patterns
       if (strat && !halton) {
           const int xs = HPT_SAMPLER_STRAT_XS(rd->sampler_mode), ys = rd->spp / xs;
           rp->strat_jitter = HPT_SAMPLER_STRAT_JITTER(rd->sampler_mode);
@@ -122,11 +129,22 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
         rp->hx0 = rp->sx_start & ~31; rp->hy0 = rp->sy_start & ~31;
         rp->n_stx = (rp->sx_start + rp->sx_count - rp->hx0 + 31) / 32; rp->n_sty = (rp->sy_start + rp->sy_count - rp->hy0 + 31) / 32;
     }
+    const bool bestcand = HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_BESTCANDIDATE_HASH && !g_bc_table.empty();
+    if (bestcand) {   // as fill_params of csrc/hpt_api.hip
+        const BcGrid g = bc_grid(rd->spp, rp->sx_start, rp->sx_start + rp->sx_count, rp->sy_start, rp->sy_start + rp->sy_count);
+        bc_all_shifts(g, g_bc_shifts);
+        rp->bc_table = g_bc_table.data(); rp->bc_shifts = g_bc_shifts.data(); rp->bc_tw = g.tw; rp->bc_tx0 = g.tx0; rp->bc_ty0 = g.ty0;
+        rp->n_stx = g.nx; rp->n_sty = g.ny;
+    }
     int64_t nst = (int64_t)rp->n_stx * rp->n_sty;
     rp->chunk = rd->spp < 64 ? rd->spp : 64;
     if (rp->sampler_kind == 3) rp->chunk = 1;     // Sampler "halton": one-sample items (a window's sample numbers)
+    if (rp->adapt_min > 0) rp->chunk = rp->adapt_min;
+    if (bestcand) rp->chunk = 1;
     rp->items_per_pass = ((nst - rp->shard_rank + rp->shard_count - 1) / rp->shard_count) * 1024;
     rp->n_items = rp->items_per_pass * ((rd->spp + rp->chunk - 1) / rp->chunk);
+    if (rp->adapt_min > 0) rp->n_items = rp->items_per_pass;
+    if (bestcand) rp->n_items = rp->items_per_pass * 4;
 }
 
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
@@ -153,12 +171,16 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
 #pragma omp for schedule(dynamic, 64)
         for (int64_t item = 0; item < rp.n_items; ++item) {
             int x, y; uint32_t s0;
-            const bool halton = rp.sampler_kind == 3;
-            if (halton ? !item_to_halton(rp, item, &x, &y, &s0) : !item_to_pixel(rp, item, &x, &y, &s0)) continue;
+            const bool halton = rp.sampler_kind == 3, bc = rp.bc_table != nullptr;
+            uint32_t tile = 0;
+            if (bc ? !item_to_bc(rp, item, &tile, &s0) : halton ? !item_to_halton(rp, item, &x, &y, &s0) : !item_to_pixel(rp, item, &x, &y, &s0)) continue;
             Lane<LdHashWinSrc, true, MATS_FULL, DL> lane; lane.init();
             std::vector<float> dls((size_t)(rd->maxdepth + 2) * HPT_DLS_FLOATS, 0.f);
             if (DL) { lane.dls = dls.data(); lane.dls_stride = 1; lane.dls_cap = rd->maxdepth + 1; }
-            if (halton) { if (!lane.begin_halton(rp, x, y, s0)) continue; }
+            std::vector<float> ab((size_t)3 * (rp.adapt_min > 0 ? rp.adapt_min : 1), 0.f);
+            lane.abuf = ab.data(); lane.abuf_stride = 1;
+            if (bc) { if (!lane.begin_bc(rp, tile, s0)) continue; }
+            else if (halton) { if (!lane.begin_halton(rp, x, y, s0)) continue; }
             else lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             while (lane.stage != ST_IDLE) {
                 Hit hit;

@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import CASES, DL_CASES, FILTER_CASES, HALTON_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sub_windows
+from tests.util import ADAPTIVE_CASES, BESTCANDIDATE_CASES, CASES, DL_CASES, FILTER_CASES, HALTON_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, bsdf_inputs, hash_rd, load_case, load_ref, random_rays, sample_table, sub_windows
 
 film = importlib.import_module("pbrt-v2_amd.film")
 hpt = importlib.import_module("pbrt-v2_amd.hpt")
@@ -708,6 +708,94 @@ def test_halton_sampler_matches_oracle_sample_for_sample(name):
     rd.sampler_mode, rd.pipeline = abi.HPT_SAMPLER_HALTON_HASH, abi.HPT_PIPELINE_WAVEFRONT
     with pytest.raises(hpt.HptError):
         d.render(s.camera, rd)
+
+
+@pytest.mark.parametrize("name", list(ADAPTIVE_CASES))
+def test_adaptive_sampler_matches_oracle_pixel_for_pixel(name):
+    """SURVEY.md §8f-4's tail, `Sampler "adaptive"`, method "contrast" (HPT_SAMPLER_ADAPTIVE_HASH; samplers/adaptive.cpp:100-160): one work item per
+    pixel; the first batch's radiances are parked in HBM, the lane takes ReportResults' decision from their luminances in the reference's float
+    order, and either starts the pixel again with maxSamples (the first batch never reaches the film) or adds the batch in sample order — 2 .. 8
+    samples on the path integrator, 4 .. 16 under direct lighting, 2 .. 4 on the animated scene.  The film weights say which pixels were
+    supersampled; a decision that sits on the threshold may fall the other way within the rounding of the two sides' radiances.  The oracle is
+    pinned bit-identical to the reference binary on these scenes in ADAPTIVE_MT_REPLAY mode."""
+    s = load_case(name)
+    d, o = hpt.DeviceScene(s), orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    lo = (rd.sampler_mode >> 8) & 0xfff
+    rd.seed = 5
+    f, _ = d.render(s.camera, rd)
+    rd.count_work = 1
+    _, st = d.render(s.camera, rd)
+    fo, so = o.render(s.camera, rd)
+    w = fo[..., 3]
+    assert (w == lo).sum() > 0 and (w == rd.spp).sum() > 0 and st.bad_samples == 0
+    assert (f[..., 3] != w).mean() < 2e-3
+    assert abs(int(st.camera_samples) - int(so[0])) <= 2e-3 * so[0]
+    assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 2e-3
+    # under a 2 x 2 gaussian filter: two-pass film (a dropped batch leaves no record) and the atomic splat
+    rd.count_work = 0
+    flt = abi.make_filter("gaussian")
+    d.set_filter(flt)
+    ff, _ = d.render(s.camera, rd)
+    ffo, _ = o.render(s.camera, rd, flt=flt)
+    assert film.rmse(film.xyzw_to_rgb(ff), film.xyzw_to_rgb(ffo)) < 2e-3
+    d.set_filter(None)
+    # shards partition the pixels
+    acc = np.zeros_like(f)
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        fr, _ = d.render(s.camera, rd)
+        acc += fr
+    assert np.allclose(acc, f, rtol=1e-4, atol=1e-4)
+    rd.shard_rank, rd.shard_count = 0, 1
+    for bad_mode in ((rd.sampler_mode & ~0x7f) | abi.HPT_SAMPLER_ADAPTIVE_MT_REPLAY, abi.adaptive_mode(abi.HPT_SAMPLER_ADAPTIVE_HASH, rd.spp),
+                     abi.adaptive_mode(abi.HPT_SAMPLER_ADAPTIVE_HASH, 3)):
+        rd.sampler_mode = bad_mode
+        with pytest.raises(hpt.HptError):
+            d.render(s.camera, rd)
+
+
+@pytest.mark.parametrize("name", list(BESTCANDIDATE_CASES))
+def test_bestcandidate_sampler_matches_oracle_sample_for_sample(name):
+    """SURVEY.md §8f-4's tail, `Sampler "bestcandidate"` (HPT_SAMPLER_BESTCANDIDATE_HASH; samplers/bestcandidate.cpp:50-91): the production kernel
+    pulls entries of the reference's sample table (hpt_scene_set_sample_table) in the table tiles of the render, reads the tiles' shifts the
+    library tabulated on the host, rejects what falls outside the sample extent — 4 spp path, 3 spp direct lighting (5 light samples rounded up
+    to 8), 2 spp with motion blur, 2 spp under a gaussian filter (negative tile coordinates).  The camera samples are exactly the reference's;
+    the oracle is pinned bit-identical to the reference binary on these scenes in BESTCANDIDATE_MT_REPLAY mode."""
+    s = load_case(name)
+    flt, tbl = getattr(s, "filter", None), sample_table()
+    d, o = hpt.DeviceScene(s), orc.OracleScene(s)
+    rd = abi.copy_struct(s.render)
+    rd.seed = 5
+    with pytest.raises(hpt.HptError):          # no table yet
+        d.render(s.camera, rd)
+    d.set_sample_table(tbl)
+    if flt is not None:
+        d.set_filter(flt)
+    f, _ = d.render(s.camera, rd)
+    rd.count_work = 1
+    _, st = d.render(s.camera, rd)
+    fo, so = o.render(s.camera, rd, flt=flt, sample_table=tbl)
+    assert st.camera_samples == so[0] > 0 and st.bad_samples == 0
+    assert abs(int(st.closest_rays) - int(so[1])) <= 8 and abs(int(st.shadow_rays) - int(so[2])) <= 8
+    if flt is None:
+        assert np.array_equal(f[..., 3], fo[..., 3])
+    else:
+        assert np.allclose(f[..., 3], fo[..., 3], rtol=1e-5, atol=1e-5)
+    assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3
+    rd.count_work = 0
+    acc = np.zeros_like(f)
+    for r in range(3):
+        rd.shard_rank, rd.shard_count = r, 3
+        fr, _ = d.render(s.camera, rd)
+        acc += fr
+    assert np.allclose(acc, f, rtol=1e-4, atol=1e-4)
+    rd.shard_rank, rd.shard_count = 0, 1
+    rd.sampler_mode = abi.HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY
+    with pytest.raises(hpt.HptError):
+        d.render(s.camera, rd)
+    with pytest.raises(hpt.HptError):
+        d.set_sample_table(tbl[:100])
 
 
 def test_halton_sampler_at_a_bench_sized_job(dev):

@@ -4,7 +4,7 @@ stored as golden fixtures by tests/golden/make_golden.py.  Bar: bit-identical.""
 import numpy as np
 import pytest
 
-from tests.util import ADAPTIVE_CASES, CASES, DL_CASES, FILTER_CASES, HALTON_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref
+from tests.util import ADAPTIVE_CASES, BESTCANDIDATE_CASES, CASES, DL_CASES, FILTER_CASES, HALTON_CASES, R2_CASES, R2_VIEW_CASES, RANDOM_CASES, STRATIFIED_CASES, abi, load_case, load_ref, sample_table
 import importlib
 
 film = importlib.import_module("pbrt-v2_amd.film")
@@ -143,6 +143,26 @@ def test_oracle_replays_adaptive_sampler_reference_image_bit_exact(name):
     n_lo, n_hi = int((w == lo).sum()), int((w == rd.spp).sum())
     assert n_lo > 0 and n_hi > 0 and n_lo + n_hi >= 0.99 * w.size
     assert abs(int(st[0]) - (lo * w.size + rd.spp * n_hi)) <= 0.01 * st[0]        # evaluated: every pixel's first batch + the second of the supersampled ones
+
+
+@pytest.mark.parametrize("name", list(BESTCANDIDATE_CASES))
+def test_oracle_replays_bestcandidate_sampler_reference_image_bit_exact(name):
+    """SURVEY.md §8f-4's tail: `Sampler "bestcandidate"` (samplers/bestcandidate.cpp:50-91) — the reference's 64 x 64 sample table (the fixture
+    dumped from the reference build) tiled in squares of 64 / sqrt(pixelsamples) pixels over every sampler window, three shifts per tile from
+    a generator seeded with the tile's coordinates, rejection outside the window, LDShuffleScrambled arrays per accepted entry (5 light samples
+    rounded up to 8 in `bdl`), 3 spp (tiles of 36.95 pixels) and tiles with negative coordinates under a gaussian filter's margin."""
+    s = load_case(name)
+    rd = abi.copy_struct(s.render)
+    assert rd.sampler_mode == abi.HPT_SAMPLER_BESTCANDIDATE_HASH
+    rd.sampler_mode = abi.HPT_SAMPLER_BESTCANDIDATE_MT_REPLAY
+    f, st = orc.OracleScene(s).render(s.camera, rd, nthreads=1, flt=getattr(s, "filter", None), sample_table=sample_table())
+    img, ref = film.xyzw_to_rgb(f), load_ref(name)
+    assert img.shape == ref.shape and st[5] == 0 and st[0] > 0
+    assert np.array_equal(img, ref), "max |d| = %g, rmse = %g" % (np.abs(img - ref).max(), film.rmse(img, ref))
+    if name == "bk":       # 4 spp: tiles of 32 pixels, 96 = 3 tiles — every entry of the nine tiles that meet the image lands inside
+        assert st[0] == 9 * 4096 == rd.x_count * rd.y_count * rd.spp
+    with pytest.raises(RuntimeError):       # no table, no render
+        orc.OracleScene(s).render(s.camera, rd, nthreads=1)
 
 
 def test_oracle_replays_exr_environment_map_reference_image_bit_exact():

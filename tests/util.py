@@ -2,6 +2,7 @@
 surface, the test-only CPU emulation of the device code.  `-m gpu`: parity tests proper, through
 the C ABI of libhpt.so on cuda:0 (an MI355X)."""
 import importlib
+import gzip
 import os
 import sys
 
@@ -81,12 +82,14 @@ def load_case(name):
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
         return s
-    if name in ADAPTIVE_CASES:   # Sampler "adaptive" cases (tests/golden/make_golden_adaptive.py)
-        s = abi.Scene.load(os.path.join(GOLDEN, ADAPTIVE_CASES[name]))
+    if name in ADAPTIVE_CASES or name in BESTCANDIDATE_CASES:   # Sampler "adaptive" / "bestcandidate" cases (tests/golden/make_golden_adaptive.py, make_golden_bestcandidate.py)
+        s = abi.Scene.load(os.path.join(GOLDEN, ADAPTIVE_CASES.get(name) or BESTCANDIDATE_CASES[name]))
         v = np.load(os.path.join(GOLDEN, name + ".view.npz"))
         s.camera = abi.Camera.from_buffer_copy(v["camera"].tobytes())
         s.render = abi.RenderDesc.from_buffer_copy(v["render"].tobytes())
         s.lights = abi.lights_from_bytes(v["lights"].tobytes(), len(s.lights))
+        if "filter" in v.files:
+            s.filter = abi.filter_from_array(v["filter"])
         return s
     if name in HALTON_CASES:   # Sampler "halton" cases (tests/golden/make_golden_halton.py): as the random / stratified ones; `hgauss` with the film's filter
         s = abi.Scene.load(os.path.join(GOLDEN, HALTON_CASES[name]))
@@ -129,6 +132,17 @@ RANDOM_CASES = {"rk": "killeroo_cfg1.hpts.gz", "rdl": "killeroo_cfg1.hpts.gz", "
 STRATIFIED_CASES = {"sk": "killeroo_cfg1.hpts.gz", "sdl": "killeroo_cfg1.hpts.gz", "sanim": "anim_killeroos.hpts.gz"}
 # Sampler "halton" (tests/golden/make_golden_halton.py): 3 spp, path; 2 spp, direct lighting with 5 light samples; 4 spp on the animated scene (time
 # sample, windows that are not square); 2 spp under PixelFilter "gaussian" (windows cut from the sample extent)
+# Sampler "bestcandidate" (tests/golden/make_golden_bestcandidate.py): 4 spp path; 3 spp direct lighting, 5 -> 8 light samples; 2 spp on the animated scene;
+# 2 spp under PixelFilter "gaussian" (table tiles with negative coordinates)
+BESTCANDIDATE_CASES = {"bk": "killeroo_cfg1.hpts.gz", "bdl": "killeroo_cfg1.hpts.gz", "banim": "anim_killeroos.hpts.gz", "bgauss": "killeroo_cfg1.hpts.gz"}
+
+
+def sample_table():
+    """BestCandidateSampler::sampleTable of the reference build (4096 x 5 float32), dumped by the host plugin (make_golden_bestcandidate.py)"""
+    with gzip.open(os.path.join(GOLDEN, "bestcandidate_table.npy.gz"), "rb") as f:
+        return np.load(f)
+
+
 # Sampler "adaptive", method "contrast" (tests/golden/make_golden_adaptive.py): 2 .. 8 samples, path; 4 .. 16, direct lighting; 2 .. 4 on the animated scene
 ADAPTIVE_CASES = {"ak": "killeroo_cfg1.hpts.gz", "adl": "killeroo_cfg1.hpts.gz", "aanim": "anim_killeroos.hpts.gz"}
 HALTON_CASES = {"hk": "killeroo_cfg1.hpts.gz", "hdl": "killeroo_cfg1.hpts.gz", "hanim": "anim_killeroos.hpts.gz", "hgauss": "killeroo_cfg1.hpts.gz"}
