@@ -411,6 +411,10 @@ void hpt_multi_destroy(hpt_multi *m);
 int hpt_multi_set_filter(hpt_multi *m, const hpt_filter *filter);
 int hpt_multi_set_camera_motion(hpt_multi *m, const hpt_instance *camera_to_world);   /* hpt_scene_set_camera_motion on every shard */
 int hpt_multi_set_sample_table(hpt_multi *m, const float *table, int n_entries);         /* hpt_scene_set_sample_table on every shard */
+/* Dynamic hand-out: with HPT_MULTI_CHUNKS=<k> (2 .. 16) in the environment and the box filter, hpt_multi_render cuts the frame into
+ * n_devices x k round-robin sub-shards and every device pulls the next one from a host-side atomic counter when its kernel has drained; the
+ * film exchange is then the sum.  out[i] = sub-shards device i rendered in the last frame (1 each under the static split). */
+int hpt_multi_chunks_taken(hpt_multi *m, int *out_n_devices);
 int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out);     /* the shard's scene handle (hpt_scene_tune, hpt_scene_get_info) */
 int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc *rd, float *film_xyzw_host, hpt_stats *stats);
 

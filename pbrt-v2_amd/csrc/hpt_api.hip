@@ -790,6 +790,9 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
 
 extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film,
                                  void *stream_v, hpt_stats *stats) {
+    return hpt_render_device_into(s, cam, rd, d_film, stream_v, stats, true);
+}
+int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film, void *stream_v, hpt_stats *stats, bool clear_film) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
     a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
@@ -831,7 +834,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
     if (cfg < 0) cfg = 5;                                // untuned (small job): lock step + subtree stealing, the usual winner
     if (rd->count_work && !dl) cfg = 5;                  // the instrumented build is the lock-step + stealing walk (hpt_kernels_impl.h)
     if (e == hipSuccess) e = hipMemsetAsync(d_scr, 0, sizeof(Scratch), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
+    if (e == hipSuccess && clear_film) e = hipMemsetAsync(d_film, 0, sizeof(float) * 4 * (size_t)rd->x_count * rd->y_count, stream);
     if (e == hipSuccess && a.rp.n_items == 0) {           // a shard that owns no tile (tiny image, many shards): an empty film
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }

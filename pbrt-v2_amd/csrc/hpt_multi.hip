@@ -211,6 +211,7 @@ struct hpt_multi {
     size_t film_bytes = 0, tiles_cap = 0;
     void *stage = nullptr; size_t stage_bytes = 0;   // peer-copy path under a wide filter: one shard's film on the root's device while it is added
     bool wide = false;
+    std::vector<int> chunks_taken;      // last frame: sub-shards each device rendered (dynamic hand-out, HPT_MULTI_CHUNKS; 1 each otherwise)
 };
 
 extern "C" void hpt_multi_destroy(hpt_multi *m) {
@@ -286,6 +287,12 @@ extern "C" int hpt_multi_set_sample_table(hpt_multi *m, const float *table, int 
     return HPT_OK;
 }
 
+extern "C" int hpt_multi_chunks_taken(hpt_multi *m, int *out_n_devices) {
+    if (!m || !out_n_devices) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    for (int i = 0; i < m->n; ++i) out_n_devices[i] = i < (int)m->chunks_taken.size() ? m->chunks_taken[(size_t)i] : 0;
+    return HPT_OK;
+}
+
 extern "C" int hpt_multi_scene(hpt_multi *m, int shard, hpt_scene **out) {
     if (!m || !out || shard < 0 || shard >= m->n) { hpt_set_error("bad shard"); return HPT_E_INVALID; }
     *out = m->scenes[(size_t)shard];
@@ -301,7 +308,12 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
     const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
     const bool use_rccl = !m->comms.empty();
     // (Sampler "halton" on a pixel extent off the global 32x32 grid: a shard's windows are not its film tiles — partial films are summed)
-    const bool wide = m->wide || (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31))
+    // HPT_MULTI_CHUNKS=<k> (2 .. 16): dynamic hand-out of n x k sub-shards (below); box filter only (the two-pass film of a table filter writes whole pixels)
+    int chunks = 1;
+    if (const char *e = getenv("HPT_MULTI_CHUNKS")) { chunks = atoi(e); if (chunks < 1) chunks = 1; if (chunks > 16) chunks = 16; }
+    const bool dynamic = chunks > 1 && n > 1 && !m->wide;
+    m->chunks_taken.assign((size_t)n, dynamic ? 0 : 1);
+    const bool wide = m->wide || dynamic || (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31))
                       || HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_BESTCANDIDATE_HASH;       // (its shards are table tiles, not film tiles)
     // buffers (grown on demand, kept with the handle)
     if (m->film_bytes < bytes || m->tiles_cap < (size_t)n_tiles) {
@@ -322,9 +334,34 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
     std::vector<std::string> errs((size_t)n);
     std::vector<hpt_stats> st((size_t)n);
     std::vector<std::thread> th;
+    std::atomic<int> next_chunk(0);
     for (int i = 0; i < n; ++i)
         th.emplace_back([&, i]() {
             hpt_render_desc r = *rd;
+            if (dynamic) {
+                // Dynamic hand-out (SURVEY.md §8e "optional dynamic balancing: host-side atomic tile counter per node"): the frame is cut into
+                // n x chunks round-robin sub-shards and every device's thread pulls the next one when its kernel has drained, so a device that
+                // got cheap tiles — or is faster — takes more of them and the frame ends with the slowest SUB-shard's tail, not the slowest shard's.
+                // A device's sub-shards are disjoint tile sets of one film (cleared once, then added to); the exchange is the sum.
+                int rc = hipSetDevice(m->devices[(size_t)i]) == hipSuccess && hipMemsetAsync(m->films[(size_t)i], 0, bytes, m->streams[(size_t)i]) == hipSuccess ? HPT_OK : HPT_E_HIP;
+                hpt_stats acc; memset(&acc, 0, sizeof(acc));
+                int taken = 0;
+                for (;;) {
+                    const int c = next_chunk.fetch_add(1);
+                    if (c >= n * chunks || rc != HPT_OK) break;
+                    r.shard_rank = c; r.shard_count = n * chunks;
+                    hpt_stats one; memset(&one, 0, sizeof(one));
+                    rc = hpt_render_device_into(m->scenes[(size_t)i], cam, &r, m->films[(size_t)i], m->streams[(size_t)i], &one, false);
+                    const double ms = acc.kernel_ms + one.kernel_ms;
+                    const uint64_t cs = acc.camera_samples + one.camera_samples, bs = acc.bad_samples + one.bad_samples, cr = acc.closest_rays + one.closest_rays,
+                                   sr = acc.shadow_rays + one.shadow_rays, nv = acc.nodes_visited + one.nodes_visited, tt = acc.tris_tested + one.tris_tested;
+                    acc = one; acc.kernel_ms = ms; acc.camera_samples = cs; acc.bad_samples = bs; acc.closest_rays = cr; acc.shadow_rays = sr; acc.nodes_visited = nv; acc.tris_tested = tt;
+                    ++taken;
+                }
+                if (rc != HPT_OK) errs[(size_t)i] = hpt_last_error();
+                st[(size_t)i] = acc; rcs[(size_t)i] = rc; m->chunks_taken[(size_t)i] = taken;
+                return;
+            }
             r.shard_rank = i; r.shard_count = n;
             int rc = hpt_render_device(m->scenes[(size_t)i], cam, &r, m->films[(size_t)i], m->streams[(size_t)i], &st[(size_t)i]);
             const int mine = local_tiles(n_tiles, i, n);   // (0 for a frame smaller than an earlier one of this handle: nothing to pack)

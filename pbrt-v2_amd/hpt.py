@@ -24,7 +24,7 @@ EXPORTS = [
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
     "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
-    "hpt_scene_set_sample_table", "hpt_multi_set_sample_table",
+    "hpt_scene_set_sample_table", "hpt_multi_set_sample_table", "hpt_multi_chunks_taken",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
         L.hpt_scene_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
         L.hpt_scene_set_sample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hpt_multi_set_sample_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hpt_multi_chunks_taken.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.hpt_multi_set_camera_motion.argtypes = [C.c_void_p, C.POINTER(abi.Instance)]
         L.hpt_test_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.hpt_test_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
@@ -220,6 +221,16 @@ class MultiScene:
         st = (abi.Stats * len(self.devices))()
         _check(lib().hpt_multi_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, C.byref(st)))
         return film, list(st)
+
+    def chunks_taken(self):
+        """sub-shards every device rendered in the last frame (dynamic hand-out, HPT_MULTI_CHUNKS; 1 each under the static split)"""
+        out = (C.c_int * len(self.devices))()
+        _check(lib().hpt_multi_chunks_taken(self.h, out))
+        return list(out)
+
+    def set_sample_table(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        _check(lib().hpt_multi_set_sample_table(self.h, t.ctypes.data, t.shape[0]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -42,6 +42,30 @@ def test_sharded_render_in_the_library_equals_the_single_device_frame(name, shar
     m.close()
 
 
+def test_dynamic_hand_out_of_sub_shards_renders_the_same_frame(monkeypatch):
+    """SURVEY.md §8e "optional dynamic balancing: host-side atomic tile counter per node": HPT_MULTI_CHUNKS=4 cuts the frame into n x 4 round-robin
+    sub-shards that the devices' host threads pull from an atomic counter; a device's sub-shards accumulate in one film, the exchange is the sum.
+    Same frame as the single-device render; every sub-shard rendered exactly once; under a table filter the static split is kept."""
+    s = load_case("k8")
+    rd = hash_rd(s, seed=4)
+    single, st1 = hpt.DeviceScene(s).render(s.camera, rd)
+    monkeypatch.setenv("HPT_MULTI_CHUNKS", "4")
+    m = hpt.MultiScene(s, [0, 0, 0])
+    multi, sts = m.render(s.camera, rd)
+    taken = m.chunks_taken()
+    assert sum(taken) == 12 and all(t >= 0 for t in taken)
+    assert sum(int(t.camera_samples) for t in sts) == st1.camera_samples
+    assert np.array_equal(multi[..., 3], single[..., 3]) and film.rmse(film.xyzw_to_rgb(multi), film.xyzw_to_rgb(single)) < 1e-5
+    m.set_filter(abi.make_filter("gaussian"))
+    multi_f, _ = m.render(s.camera, rd)
+    assert m.chunks_taken() == [1, 1, 1]
+    d = hpt.DeviceScene(s)
+    d.set_filter(abi.make_filter("gaussian"))
+    single_f, _ = d.render(s.camera, rd)
+    assert film.rmse(film.xyzw_to_rgb(multi_f), film.xyzw_to_rgb(single_f)) < 1e-4
+    m.close()
+
+
 def test_one_shard_multi_handle_and_odd_image_sizes():
     s = load_case("env")
     rd = hash_rd(s, seed=2)
