@@ -22,7 +22,8 @@ Workloads (all 1920x1080, path maxdepth 8; lowdiscrepancy-structured sampler, bo
   killeroo-dl  killeroo-simple.pbrt with the integrator it selects itself (directlighting, 8 light samples), 64 spp/GPU
   metal    BASELINE.json configs[4]: scenes/metal.pbrt as shipped, 3840x2160, 128 spp/GPU (1024 spp over 8 GPUs)
 The default run (N = 1, no --workload) prints the headline line for bunny and, under `workloads`, the same measurement for
-killeroo, anim and soup at the spp BASELINE.json names (fewer steps each).  Geometry comes from the committed blobs
+killeroo, anim, soup, metal (4K) and the 4 M-triangle soup at the spp BASELINE.json names (fewer steps each), then one short line each for
+killeroo-simple.pbrt as shipped (direct lighting), under PixelFilter "gaussian" and under Sampler "halton".  Geometry comes from the committed blobs
 (dumped from the reference's own parser by host/hip_renderer.cpp, tests/golden/make_golden.py) — the reference tree does
 not exist on the GPU box.  Multi-GPU is weak scaling: every rank traces the same number of samples (spp = N x spp_per_gpu
 over the same frame, pixel tiles sharded round-robin, scene replicated); `strong` adds the fixed frame split N ways.
@@ -674,6 +675,15 @@ def main():
                 if w == "metal" and not args.no_cpu_baseline:   # configs[4]'s own CPU line: pbrt-v2 (OpenEXR build) on metal.pbrt at 4K
                     ref = cpu_baseline_reference(w, sc_w)
                     extras[-1]["cpu_baseline"] = ref or cpu_baseline_port(sc_w)
+            # the widenings of SURVEY.md §8f on the north-star scene, one short line each: killeroo-simple.pbrt as shipped (DirectLightingIntegrator, 8
+            # light samples per camera sample), under PixelFilter "gaussian" (two-pass film), and under Sampler "halton" (window-sampler kernels)
+            keep = (args.sampler, args.filter)
+            for w, smp, fl in (("killeroo-dl", "lowdiscrepancy", "box"), ("killeroo", "lowdiscrepancy", "gaussian"), ("killeroo", "halton", "box")):
+                args.sampler, args.filter = smp, fl
+                o, _, _ = measure(args, w, 0, min(3, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm)
+                extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "kernel", "rmse_vs_oracle", "verify", "roofline") if k in o})
+                extras[-1]["workload"] = "%s%s%s" % (w, "" if fl == "box" else ", PixelFilter %s" % fl, "" if smp == "lowdiscrepancy" else ", Sampler %s" % smp)
+            args.sampler, args.filter = keep
         else:
             # strong scaling (north_star's ">= 6x at 8 GPUs" is a statement about a FIXED frame): the 256-spp 1M-triangle frame of configs[2],
             # the north-star target scene (killeroo 64 spp) and configs[3] (anim 128 spp), each split N ways
