@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 7   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights) and 6 (no mesh tangents) still load */
+#define HPT_VERSION 8   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights), 6 (no mesh tangents) and 7 (no animated spheres / disks: the same records, hpt_instance.quadric1 was padding) still load */
 
 enum {
     HPT_OK = 0,
@@ -122,10 +122,17 @@ typedef struct hpt_mesh {
  * (core/primitive.h:104-125, created by pbrtShape for an animated CTM, core/api.cpp:1012-1044).
  * Its meshes are built with identity ObjectToWorld (api.cpp:1019-1021), i.e. their P are in the
  * instance's own space; rays reach them through WorldToPrimitive interpolated at the ray's time
- * (AnimatedTransform::Interpolate, core/transform.cpp:371-396). */
+ * (AnimatedTransform::Interpolate, core/transform.cpp:371-396).
+ * Version 8: an animated SPHERE or DISK.  Such a shape CanIntersect(), so pbrtShape neither refines it nor builds a BVHAccel: the
+ * TransformedPrimitive holds the bare GeometricPrimitive (api.cpp:1032-1042) — quadric1 names its hpt_quadric record (identity o2w, no area
+ * light: api.cpp:1014-1021).  TransformedPrimitive::Intersect carries the whole differential geometry back to the world — p, nn, dpdu,
+ * dpdv and, unlike a triangle's zeros, dndu / dndv (core/primitive.cpp:104-117) — so textures and bump maps on it see the moving frame. */
 typedef struct hpt_instance {
     int32_t actually_animated;   /* AnimatedTransform::actuallyAnimated               */
-    int32_t pad;
+    int32_t quadric1;            /* version 8: the instance's primitive is ONE sphere / disk (a shape that CanIntersect() stays a bare
+                                  * GeometricPrimitive under the TransformedPrimitive, core/api.cpp:1032-1042): 1 + its index in
+                                  * `quadrics`; that record has identity o2w (api.cpp:1019-1021) and no area light (api.cpp:1014-1016),
+                                  * and is not a primitive of the world.  0: the meshes with hpt_mesh.instance == this index         */
     float start_time, end_time;  /* RenderOptions::transformStartTime / EndTime       */
     float bounds[6];             /* TransformedPrimitive::WorldBound() (MotionBounds) */
     float T[2][3];               /* AnimatedTransform::Decompose of start / end       */

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 7
+HPT_VERSION = 8
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
@@ -69,7 +69,7 @@ class Mesh(C.Structure):
 
 
 class Instance(C.Structure):
-    _fields_ = [("actually_animated", i32), ("pad", i32), ("start_time", f32), ("end_time", f32),
+    _fields_ = [("actually_animated", i32), ("quadric1", i32), ("start_time", f32), ("end_time", f32),
                 ("bounds", f32 * 6), ("T", (f32 * 3) * 2), ("R", (f32 * 4) * 2), ("S", M16 * 2),
                 ("w2p_m", M16 * 2), ("w2p_minv", M16 * 2)]
 
@@ -349,8 +349,8 @@ class Scene:
         with _open(path, "rb") as f:
             raw = f.read()
         h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
-        if h.magic != HPT_MAGIC or h.version not in (5, 6, HPT_VERSION):
-            raise ValueError(f"{path}: not an HPTS v5 / v6 / v{HPT_VERSION} blob")
+        if h.magic != HPT_MAGIC or h.version not in (5, 6, 7, HPT_VERSION):
+            raise ValueError(f"{path}: not an HPTS v5 .. v{HPT_VERSION} blob")
         v5 = h.version == 5          # round-1 fixtures: smaller material / light records, no texture table
         mat_t, light_t = (MaterialV5, LightV5) if v5 else (Material, Light)
         mesh_t = MeshV6 if h.version < 7 else Mesh       # versions 5 / 6: mesh records without s_off

@@ -285,6 +285,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     }
     for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0 || desc->meshes[m].s_off >= 0) ext = true;   // (explicit tangents: the extension set's shading geometry)
     for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
+    int n_inst_quadrics = 0;
+    for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; ++n_inst_quadrics; }   // animated spheres / disks: the extension set's walk and shading geometry
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
     if (ext) s->mats = MATS_FULL;
     // The code object of the scene's kernel set (one fat binary per set, 2-9 MB) loads on first use — 20 ms that the first render would
@@ -362,6 +364,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.instances = upload(s, &arena, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
+    s->d.n_inst_quadrics = n_inst_quadrics;
     s->stack_bound4 = 0; s->depth4 = 0;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
         s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);

@@ -148,6 +148,21 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 return HPT_E_UNSUPPORTED;
             }
         }
+    for (int k = 0; k < d->n_instances; ++k) {     // version 8: an animated sphere / disk (hpt_instance.quadric1)
+        const int32_t q1 = d->instances[k].quadric1;
+        if (q1 == 0) continue;
+        if (q1 < 0 || q1 > d->n_quadrics) { hpt_set_error("instance %d: quadric1 out of range", k); return HPT_E_INVALID; }
+        const hpt_quadric &qu = d->quadrics[q1 - 1];
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (qu.arealight >= 0 || memcmp(qu.o2w, ident, sizeof(ident)) != 0 || memcmp(qu.o2w_inv, ident, sizeof(ident)) != 0) {
+            hpt_set_error("instance %d: an animated quadric has identity ObjectToWorld and no area light (core/api.cpp:1014-1021)", k);
+            return HPT_E_INVALID;
+        }
+        for (int j = 0; j < k; ++j)
+            if (d->instances[j].quadric1 == q1) { hpt_set_error("instance %d: quadric %d already belongs to instance %d", k, q1 - 1, j); return HPT_E_INVALID; }
+        for (int m = 0; m < d->n_meshes; ++m)
+            if (d->meshes[m].instance == k) { hpt_set_error("instance %d: both a quadric and mesh %d", k, m); return HPT_E_INVALID; }
+    }
     for (int q = 0; q < d->n_quadrics; ++q) {
         const hpt_quadric &qu = d->quadrics[q];
         if ((qu.kind != HPT_QUADRIC_SPHERE && qu.kind != HPT_QUADRIC_DISK) || qu.material < 0 ||
@@ -301,8 +316,8 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     const long fsize = ftell(f);
     rewind(f);
     hpt_blob *b = (hpt_blob *)calloc(1, sizeof(hpt_blob));
-    if (fsize < (long)sizeof(b->h) || fread(&b->h, sizeof(b->h), 1, f) != 1 || b->h.magic != HPT_MAGIC || (b->h.version != 5 && b->h.version != 6 && b->h.version != HPT_VERSION)) {
-        hpt_set_error("%s: not an HPTS v5 / v6 / v%d blob", path, HPT_VERSION);
+    if (fsize < (long)sizeof(b->h) || fread(&b->h, sizeof(b->h), 1, f) != 1 || b->h.magic != HPT_MAGIC || (b->h.version < 5 || b->h.version > HPT_VERSION)) {
+        hpt_set_error("%s: not an HPTS v5 .. v%d blob", path, HPT_VERSION);
         fclose(f); free(b); return NULL;
     }
     const hpt_blob_header &h = b->h;

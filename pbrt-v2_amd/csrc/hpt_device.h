@@ -306,7 +306,8 @@ struct DScene {
     // the same trees, four children per node (collapse_bvh4, hpt_bvh.h): 128-byte nodes = 8 f4; roots as node indices.  nullptr: not built
     const f4 *nodes4;
     const int32_t *inst_root4;
-    int32_t world_root4, pad4;
+    int32_t world_root4;
+    int32_t n_inst_quadrics;        // instances whose primitive is one sphere / disk (hpt_instance.quadric1 > 0): those quadrics are not primitives of the world
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
@@ -585,17 +586,35 @@ struct TravState {
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
-HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world) {
+// QI (the extension set's walks): animated spheres / disks — an instance whose primitive is ONE quadric (hpt_instance.quadric1, core/api.cpp:1032-1042)
+// is tested here when the walk enters the instance (world = false, inst = its index; `ray` is in the instance's space and the quadric's
+// ObjectToWorld is the identity), and is skipped among the quadrics of the world.
+template <bool QI = false>
+HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world, int inst = -1) {
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
     // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
     for (int q = 0; world && q < sc.n_quadrics; ++q) {
+        if (QI && sc.n_inst_quadrics > 0) {
+            bool owned = false;
+            for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
+            if (owned) continue;
+        }
         float t;
         if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
             ts.hit.prim = sc.n_tris + q;
             if (anyhit) { ts.node = HPT_TRAV_EMPTY; break; }
             ts.hit.t = t; ray.maxt = t;
+        }
+    }
+    if (QI && !world && inst >= 0) {
+        const int q1 = sc.instances[inst].quadric1;
+        float t;
+        if (q1 > 0 && quadric_intersect(sc.quadrics[q1 - 1], ray, &t, nullptr)) {
+            ts.hit.prim = sc.n_tris + q1 - 1;
+            if (anyhit) ts.node = HPT_TRAV_EMPTY;
+            else { ts.hit.t = t; ray.maxt = t; }
         }
     }
     if (root < 0) ts.node = HPT_TRAV_EMPTY;
@@ -756,7 +775,7 @@ template <bool COUNT, bool INST, bool ALPHA = false, bool WIDE = false>
 HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
                      const float *xf_cache = nullptr, int64_t xf_stride = 0) {
     TravState ts;
-    trav_begin(sc, ts, ray, anyhit, WIDE ? sc.world_root4 : sc.world_root, true);
+    trav_begin<ALPHA>(sc, ts, ray, anyhit, WIDE ? sc.world_root4 : sc.world_root, true);
     while (!ts.done()) trav_step<COUNT, ALPHA, WIDE>(sc, ts, ray, stack, stride, cnt);
     *hit = ts.hit;
     if (anyhit && hit->prim >= 0) return true;
@@ -770,7 +789,7 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         Ray r2;
         r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
-        trav_begin(sc, t2, r2, anyhit, WIDE ? sc.inst_root4[k] : sc.inst_root[k], false);
+        trav_begin<ALPHA>(sc, t2, r2, anyhit, WIDE ? sc.inst_root4[k] : sc.inst_root[k], false, k);
         while (!t2.done()) trav_step<COUNT, ALPHA, WIDE>(sc, t2, r2, stack, stride, cnt);
         if (t2.hit.prim >= 0) {
             *hit = t2.hit; hit->inst = k;
@@ -1771,8 +1790,24 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
     if (hit.prim >= sc.n_tris) {
         const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
         float t; DGeom d3;
+        // an animated sphere / disk (hpt_instance.quadric1): the geometry in the instance's space from the transformed ray, then carried
+        // to the world by PrimitiveToWorld = Inverse(w2p) — p, nn, dpdu, dpdv, dndu, dndv (core/primitive.cpp:104-117)
+        Xf w2p;
+        const bool inInstance = INST && hit.inst >= 0;
+        if (inInstance) {
+            w2p = anim_interpolate(sc.instances[hit.inst], time, true);
+            ray.o = xf_point_affine(w2p.m.m, wray.o); ray.d = xf_vec(w2p.m.m, wray.d);
+        }
         quadric_intersect(q, ray, &t, &d3, &dg);      // Shape::GetShadingGeometry's default: dgShading = dg (core/shape.h:59) with the quadric's own u, v, dpdv, dndu, dndv
         dg.p = d3.p; dg.nn = d3.nn; dg.dpdu = d3.dpdu;
+        if (inInstance && !a34_is_identity(w2p.m)) {
+            dg.p = xf_point_affine(w2p.minv.m, dg.p);
+            dg.nn = normalize(xf_normal(w2p.m.m, dg.nn));
+            dg.dpdu = xf_vec(w2p.minv.m, dg.dpdu);
+            dg.dpdv = xf_vec(w2p.minv.m, dg.dpdv);
+            dg.dndu = xf_normal(w2p.m.m, dg.dndu);
+            dg.dndv = xf_normal(w2p.m.m, dg.dndv);
+        }
         compute_differentials(&dg, rdiff);
         *rayEps = 5e-4f * hit.t;
         *arealight = q.arealight;

@@ -151,6 +151,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
+#ifdef HPT_PRIO_WALK   /* A/B switch (profiles/r03_ab.md, run U): issue priority of the wave while it walks — the latency-bound phase — over the waves of the SIMD that shade */
+    __builtin_amdgcn_s_setprio(HPT_PRIO_WALK);
+#endif
     #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
     #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
     // the two pointers the loop dereferences, as scalar registers of their own: as fields of the kernel-argument block they live in a
@@ -181,7 +184,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     int seg = (INST && has_ray) ? -1 : n_inst, cur_inst = -1;
     bool more_b = TWO && has_ray && has_b;                          // the owner's second ray is still to come
     bool cur_any = anyhit;                                          // kind of the owner's CURRENT ray (the second one is closest-hit)
-    if (has_ray) trav_begin(sc, ts, r, anyhit, world_root, true);
+    if (has_ray) trav_begin<ALPHA>(sc, ts, r, anyhit, world_root, true);
     else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
@@ -272,12 +275,13 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
 #else
                     const int32_t iroot = sc.inst_root[seg];
 #endif
-                    if (iroot >= 0 && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
+                    // (the extension set: an instance may be one animated sphere / disk instead of a tree — trav_begin tests it)
+                    if ((iroot >= 0 || (ALPHA && in.quadric1 > 0)) && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
                         A34 w2p;
                         if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
                         else w2p = anim_interpolate(in, time, false).m;
                         r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
-                        trav_begin(sc, ts, r, cur_any, iroot, false);
+                        trav_begin<ALPHA>(sc, ts, r, cur_any, iroot, false, seg);
                         cur_inst = seg; sb = 0;
                     }
                 }
@@ -287,7 +291,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 more_b = false; cur_any = false;
                 seg = INST ? -1 : n_inst;
                 r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
-                trav_begin(sc, ts, r, false, world_root, true);
+                trav_begin<ALPHA>(sc, ts, r, false, world_root, true);
                 cur_inst = -1; sb = 0;
             }
         }
@@ -342,6 +346,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         }
     }
     HPT_WAVE_SYNC();
+#ifdef HPT_PRIO_WALK
+    __builtin_amdgcn_s_setprio(0);
+#endif
     #undef HPT_AUX
     #undef HPT_WAVE_SYNC
 }
@@ -494,7 +501,13 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #ifdef HPT_PHASE_TIMERS
             if (phase == ST_EXTEND) HPT_PT(1) else HPT_PT(2)
 #endif
+#ifdef HPT_PRIO_SHADE
+            __builtin_amdgcn_s_setprio(HPT_PRIO_SHADE);
+#endif
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv, MERGE ? &hitb : nullptr);
+#ifdef HPT_PRIO_SHADE
+            __builtin_amdgcn_s_setprio(0);
+#endif
         } else if (INST || EE == 0) {
             // ---- one traversal phase: each lane traces its own pending ray to completion -----------------
             if (mine) {
@@ -535,7 +548,13 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         HPT_PT(3)
         // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
         if (MATS & MATS_MEASURED) {
+#ifdef HPT_PRIO_QUERY
+            __builtin_amdgcn_s_setprio(HPT_PRIO_QUERY);
+#endif
             if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
+#ifdef HPT_PRIO_QUERY
+            __builtin_amdgcn_s_setprio(0);
+#endif
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
                 for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
         }

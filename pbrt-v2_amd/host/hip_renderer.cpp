@@ -363,8 +363,13 @@ struct Flattener {
                 for (size_t i = 0; i < b->primitives.size(); ++i) todo.push_back(b->primitives[i].GetPtr());
             } else if (const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(p)) {
                 const Triangle *tri = dynamic_cast<const Triangle *>(gp->shape.GetPtr());
-                if (!tri) Severe("hip renderer: animated instances of non-triangle shapes are outside the hot-path scope");
-                AddTriangle(tri, gp, idx);
+                if (tri) { AddTriangle(tri, gp, idx); continue; }
+                // an animated sphere / disk: a shape that CanIntersect() stays the bare GeometricPrimitive under the TransformedPrimitive
+                // (core/api.cpp:1032-1042), with identity ObjectToWorld and no area light (api.cpp:1014-1021): hpt_instance.quadric1
+                if (p != tp->primitive.GetPtr() || quadricIndex.find(gp->shape.GetPtr()) != quadricIndex.end())
+                    Severe("hip renderer: an animated quadric inside an aggregate, or shared between instances, is outside the hot-path scope");
+                AddQuadric(gp->shape.GetPtr(), gp);
+                instances[idx].quadric1 = 1 + quadricIndex[gp->shape.GetPtr()];
             } else
                 Severe("hip renderer: nested instances are outside the hot-path scope");
         }

@@ -47,6 +47,7 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->instances.assign(desc->instances, desc->instances + desc->n_instances);
     s->d.instances = s->instances.data(); s->d.inst_root = s->fs.inst_root.data();
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
+    for (int k = 0; k < desc->n_instances; ++k) s->d.n_inst_quadrics += desc->instances[k].quadric1 > 0;
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
     s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4;
     return s;
@@ -251,7 +252,7 @@ extern "C" int emu_render_replay(const emu_scene *s, const hpt_camera *cam, cons
 static bool traverse4_cap(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int cap, int *max_sp) {
     TravCounters tc = {0, 0};
     TravState ts;
-    trav_begin(sc, ts, ray, anyhit, sc.world_root4, true);
+    trav_begin<true>(sc, ts, ray, anyhit, sc.world_root4, true);
     auto walk = [&](TravState &w, Ray &r) {
         while (!w.done()) {
             if (w.node >= 0) trav_node4<false>(sc.nodes4, w, r, stack, 1, &tc, cap);
@@ -269,7 +270,7 @@ static bool traverse4_cap(const DScene &sc, Ray &ray, float time, bool anyhit, H
         A34 w2p = anim_interpolate(in, time, false).m;
         Ray r2; r2.o = xf_point_affine(w2p.m, ray.o); r2.d = xf_vec(w2p.m, ray.d); r2.mint = ray.mint; r2.maxt = ray.maxt;
         TravState t2;
-        trav_begin(sc, t2, r2, anyhit, sc.inst_root4[k], false);
+        trav_begin<true>(sc, t2, r2, anyhit, sc.inst_root4[k], false, k);
         walk(t2, r2);
         if (t2.hit.prim >= 0) { *hit = t2.hit; hit->inst = k; ray.maxt = r2.maxt; if (anyhit) return true; }
     }

@@ -66,6 +66,26 @@ def test_invalid_descriptors_are_rejected(cases, tmp_path):
     assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -3
 
 
+def test_animated_quadric_records_are_validated(tmp_path):
+    """ABI 8, hpt_instance.quadric1 (an animated sphere / disk: TransformedPrimitive over a bare GeometricPrimitive, core/api.cpp:1032-1042):
+    the record it names must exist, carry the identity ObjectToWorld and no area light (api.cpp:1014-1021), and belong to one instance;
+    version-7 blobs — the same records with the field as padding — still load."""
+    good = os.path.join(ROOT, "tests", "golden", "aquad.hpts.gz")
+    save = lambda s: hpt.lib().hpt_blob_save(str(tmp_path / "q.hpts").encode(), C.byref(s.desc), None, None)
+    s = abi.Scene.load(good)
+    assert sorted(i.quadric1 for i in s.instances) == [0, 1, 2] and save(s) == 0, hpt.last_error()
+    s = abi.Scene.load(good); s.instances[0].quadric1 = len(s.quadrics) + 1
+    assert save(s) == -2 and "quadric1" in hpt.last_error()
+    s = abi.Scene.load(good); s.quadrics[s.instances[0].quadric1 - 1].o2w[3] = 0.5
+    assert save(s) == -2 and "identity" in hpt.last_error()
+    s = abi.Scene.load(good); s.instances[1].quadric1 = s.instances[0].quadric1
+    assert save(s) == -2 and "already belongs" in hpt.last_error()
+    s = abi.Scene.load(good); s.instances[2].quadric1 = s.instances[0].quadric1; s.instances[0].quadric1 = 0
+    assert save(s) == -2 and "both a quadric and mesh" in hpt.last_error()
+    old = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "acam.hpts.gz"))       # a version-7 blob with an (ordinary) animated instance
+    assert len(old.instances) == 1 and old.instances[0].quadric1 == 0 and save(old) == 0
+
+
 def test_warmup_validates_its_argument_before_any_runtime_work():
     """hpt_warmup (include/hpt.h): a negative device is refused on the calling thread — no thread is started, no HIP call made."""
     assert hpt.lib().hpt_warmup(-1) == -2

@@ -154,7 +154,7 @@ def test_warmup_thread_starts_the_runtime_for_a_fresh_process(cases, dev, tmp_pa
     assert np.array_equal(np.load(out), fd)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -881,6 +881,41 @@ def test_pbrt_binary_reads_an_exr_environment_map_end_to_end(tmp_path):
     assert (np.abs(got - want).max(axis=2) > 1e-4).mean() < 1e-3 and film.rmse(got, want) < 1e-3
 
 
+def test_shipped_anim_moving_reflection_scene_end_to_end(tmp_path):
+    """scenes/anim-moving-reflection.pbrt, the file AS SHIPPED (byte for byte: oracle/_ref/scenes, copied by `make -C oracle ref-scenes`), through
+    pbrt_hip: an ANIMATED SPHERE (TransformedPrimitive over a bare GeometricPrimitive, core/api.cpp:1032-1042 — ABI 8, hpt_instance.quadric1)
+    with an .exr-textured plastic, a mirror triangle under it, the 1000 x 500 grace environment map, DirectLightingIntegrator by default,
+    500 x 500 at 64 spp.  The image pbrt_hip writes (--outfile, the reference's own option) against the oracle — pinned bit-identical to the
+    reference binary on this scene at 100 x 100, tests/test_oracle_pin.py [aquaddl] — rendering, sample for sample, the blob the plugin dumps
+    from the same file."""
+    import os
+    import shutil
+    import subprocess
+    from tests.util import ROOT
+    exe = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+    src = os.path.join(ROOT, "oracle", "_ref", "scenes")
+    if not os.path.exists(exe) or not os.path.exists(os.path.join(src, "anim-moving-reflection.pbrt")):
+        pytest.skip("pbrt_hip / the shipped scene files are built / copied from /root/reference in the build container only")
+    shutil.copy(os.path.join(src, "anim-moving-reflection.pbrt"), str(tmp_path / "anim-moving-reflection.pbrt"))
+    os.symlink(os.path.join(src, "textures"), str(tmp_path / "textures"))
+    out, blob = str(tmp_path / "got.pfm"), str(tmp_path / "scene.hpts")
+    env = dict(os.environ, PBRT_RENDERER_HIP="1")
+    subprocess.check_call([exe, "--quiet", "--outfile", out, "anim-moving-reflection.pbrt"], cwd=str(tmp_path), env=env)
+    subprocess.check_call([exe, "--quiet", "--outfile", str(tmp_path / "unused.pfm"), "anim-moving-reflection.pbrt"], cwd=str(tmp_path),
+                          env=dict(env, HPT_DUMP_SCENE=blob, HPT_HOST_BVH="1"))
+    s = abi.Scene.load(blob)
+    assert len(s.instances) == 1 and s.instances[0].quadric1 == 1 and s.instances[0].actually_animated
+    rd = abi.copy_struct(s.render)
+    assert (rd.x_count, rd.y_count, rd.spp) == (500, 500, 64) and rd.integrator == abi.HPT_INTEGRATOR_DIRECT_ALL
+    rd.sampler_mode, rd.seed = abi.HPT_SAMPLER_LD_HASH, 0
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    got, want = film.read_pfm(out), film.xyzw_to_rgb(fo)
+    assert got.shape == want.shape and so[0] == 500 * 500 * 64
+    err = film.rmse(got, want)
+    assert err < 1e-3, err
+    assert np.isclose(got, want, rtol=1e-3, atol=1e-4).all(axis=2).mean() > 0.99
+
+
 def test_exr_environment_map_matches_oracle_sample_for_sample():
     """SURVEY.md §8f-3, first step: infinite light with a 32x16 HDR map read from .exr by the reference's own (vendored) OpenEXR;
     importance-sampled through the Distribution2D tables in the scene blob."""
@@ -898,7 +933,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)

@@ -51,6 +51,19 @@ def test_bvh_depth_is_bounded(pairs):
         assert info["max_depth"] <= 25 and info["n_nodes"] > 0
 
 
+# Animated spheres / disks under textures and bump maps: the device inverts the interpolated transform analytically (hpt_device.h, anim_interpolate:
+# equal to the reference's Gauss-Jordan inverse up to rounding), and dpdu / dpdv / dndu / dndv go through that inverse into the bump frame and the
+# EWA footprint, which carry a last-bit difference to ~1e-5 of a pixel's value (a few pixels per frame: 1e-4 .. 3e-3, where one of the 8 samples takes a discrete decision — a filter level, a grazing shadow ray — the other way).  Same rays, same film weights; bounded instead of bit-compared.
+INVERSE_ROUNDING_CASES = ("aquad", "aquaddl")
+
+
+def close_enough(name, io, ie):
+    if name in INVERSE_ROUNDING_CASES:
+        d = np.abs(io - ie).max(axis=2)
+        return differing_pixels(io, ie) < 1e-2 and float((d / np.maximum(np.abs(io).max(axis=2), 1e-3)).max()) < 1e-2 and film.rmse(io, ie) < 5e-6
+    return differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-6
+
+
 def differing_pixels(io, ie):
     """Share of pixels where the emulated device image differs from the oracle's.  Bit for bit — except that the value of a measured
     BRDF (bunny scenes) agrees with the reference's to the rounding of a short sum (grid order instead of kd-tree order, hpt_device.h),
@@ -99,7 +112,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,
@@ -114,7 +127,7 @@ def test_round2_features_render_matches_oracle(name):
     assert abs(int(so[1]) - int(se[1])) <= 4 and abs(int(so[2]) - int(se[2])) <= 4
     assert np.array_equal(fo[..., 3], fe[..., 3])
     io, ie = film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fe)
-    assert differing_pixels(io, ie) < 1e-3 and film.rmse(io, ie) < 1e-6     # (specdl / mirtex: the recursion's products are taken in another order)
+    assert close_enough(name, io, ie)     # (specdl / mirtex: the recursion's products are taken in another order)
 
 
 @pytest.mark.parametrize("name,material", [("on", 1), ("on", 2), ("spec", 1), ("spec", 2), ("spec", 4), ("merl", 0), ("tex", 2), ("tex", 3)])
@@ -222,7 +235,7 @@ def test_forked_tree_build_equals_the_serial_build(cases, name, monkeypatch):
     assert hashes["1"] == hashes["2"] == hashes["16"], hashes
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex"])
+@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad"])
 def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     """Round 3: the MT_REPLAY sampler source over the FULL material set (Lane<MtReplaySrc, true, MATS_FULL>) — Oren-Nayar, glass / mirror,
     triangle-mesh emitters, the regular half-angle BRDF, EWA / trilinear image textures with camera-ray differentials, bump mapping, alpha
@@ -237,7 +250,7 @@ def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     f, st = emu.EmuScene(s).render(s.camera, rd)
     img, ref = film.xyzw_to_rgb(f), load_ref(name)
     assert st[0] == rd.x_count * rd.y_count * rd.spp and st[5] == 0
-    assert differing_pixels(img, ref) < 1e-3 and film.rmse(img, ref) < 1e-6
+    assert close_enough(name, ref, img)
 
 
 def test_moving_camera_matches_the_reference_and_the_oracle():
