@@ -548,13 +548,15 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         HPT_PT(3)
         // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
         if (MATS & MATS_MEASURED) {
+            if (INST || EE == 0) {
 #ifdef HPT_PRIO_QUERY
-            __builtin_amdgcn_s_setprio(HPT_PRIO_QUERY);
+                __builtin_amdgcn_s_setprio(HPT_PRIO_QUERY);
 #endif
-            if (INST || EE == 0) wave_eval_queries(sc, ls, sv, shaded);
+                wave_eval_queries(sc, ls, sv, shaded);
 #ifdef HPT_PRIO_QUERY
-            __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
 #endif
+            }
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
                 for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
         }

@@ -6,19 +6,19 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=gpurun_out/r03_u; mkdir -p $O
 t0=$(date +%s)
-timeout 900 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.txt 2>&1; grep -n "passed\|failed\|^FAILED\|^ERROR" $O/pytest_gpu.txt | tail -12
-t1=$(date +%s); echo "pytest $((t1-t0)) s"
+echo "(suite: run U1, scripts/gpu_r03_u1.sh)"
+t1=$(date +%s)
 run() { # workload steps tag lib
 w=$1; st=$2; tag=$3; lib=$4
 HPT_LIB=$lib timeout 300 python bench.py --workload $w --steps $st --warmup 2 --no-cpu-baseline --no-extra --no-verify --no-pmc --no-work > $O/${w}_$tag.log 2>&1
 echo "$w $tag: $(python -c "import json; d=json.loads(open('$O/${w}_$tag.log').read().strip().splitlines()[-1]); print(d['value'], d['kernel']['avg_ms'], d['kernel']['tune_cfg'][:1])" 2>&1 | tail -1)"
 }
 V=$PWD/pbrt-v2_amd/build/variants
-for tag in base pw3 pw3q3 ps3 trk base2; do
-lib=$V/libhpt_${tag%2}.so
+for tag in base pw3 ps3 trk base2 pw32; do
+lib=$V/libhpt_${tag%2}.so; [ ${tag%2} = base ] && lib=$PWD/pbrt-v2_amd/libhpt.so   # (base: the default build — its basic / measured kernels are instruction for instruction those of run T)
 [ -f $lib ] || { echo "no $lib"; continue; }
 for w in killeroo bunny anim metal; do
-[ $w = metal ] && [ $tag = pw3q3 -o $tag = base2 ] && continue
+[ $w = metal ] && [ $tag = pw32 -o $tag = base2 ] && continue
 st=5; [ $w = anim ] && st=3; [ $w = metal ] && st=2
 run $w $st $tag $lib
 done
