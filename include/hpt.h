@@ -92,7 +92,8 @@ enum { HPT_TEXSLOT_KD = 0,        /* matte / plastic / substrate Kd; metal eta  
        HPT_N_TEXSLOTS = 8 };
 
 /* Light kinds: lights/point.cpp:50, lights/diffuse.cpp:69, lights/infinite.cpp:68 */
-enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3 };
+enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3,
+       HPT_LIGHT_SPOT = 4, HPT_LIGHT_DISTANT = 5 };   /* version 8: lights/spot.cpp, lights/distant.cpp (delta lights like POINT) */
 
 /* One TriangleMesh (shapes/trianglemesh.cpp:42).  Offsets index the float / int pools of the
  * scene descriptor, in ELEMENTS; -1 = attribute absent.
@@ -188,16 +189,16 @@ typedef struct hpt_material {
 typedef struct hpt_light {
     int32_t kind;
     int32_t quadric;   /* DIFFUSE_AREA: emitting quadric index (ShapeSet of one quadric), or -1: the shape set below */
-    float pos[3];      /* POINT: world-space position (point.cpp:43)                    */
-    float intensity[3];/* POINT: I ; DIFFUSE_AREA: Lemit ; INFINITE: unused             */
-    float area;        /* DIFFUSE_AREA: ShapeSet::Area()                                */
+    float pos[3];      /* POINT, SPOT: world-space position lightPos (point.cpp:43, spot.cpp:43); DISTANT: lightDir, normalized, world space (distant.cpp:43) */
+    float intensity[3];/* POINT, SPOT: I ; DIFFUSE_AREA: Lemit ; DISTANT: L ; INFINITE: unused */
+    float area;        /* DIFFUSE_AREA: ShapeSet::Area() ; SPOT: cosTotalWidth (spot.cpp:45) */
     /* INFINITE (lights/infinite.cpp:68-105): level-0 texels of the (pow2-resampled) radiance
      * MIPMap and the Distribution2D tables, copied from the reference objects:
      *   fpool[tex_off + 3*(v*w+u)]   RGB
      *   cond_func h*w, cond_cdf h*(w+1), cond_int h, marg_func h, marg_cdf h+1, marg_int 1 */
     int32_t env_w, env_h;
     int64_t tex_off, cond_func_off, cond_cdf_off, cond_int_off, marg_func_off, marg_cdf_off;
-    float marg_int;
+    float marg_int;    /* (SPOT: cosFalloffStart, spot.cpp:46; WorldToLight of SpotLight::Falloff is l2w_inv below) */
     int32_t nsamples;  /* Light::nSamples (core/light.h:60): light samples per camera sample of the
                         * direct-lighting integrator, strategy "all"; 0 reads as 1; ignored by the path integrator */
     float l2w[16];     /* LightToWorld->m    */

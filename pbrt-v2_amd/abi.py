@@ -18,7 +18,7 @@ HPT_TEX_CONSTANT, HPT_TEX_IMAGEMAP, HPT_TEX_SCALE, HPT_TEX_MIX = 1, 2, 3, 4
 HPT_WRAP_REPEAT, HPT_WRAP_BLACK, HPT_WRAP_CLAMP = 0, 1, 2
 TEXSLOT_KD, TEXSLOT_KS, TEXSLOT_ROUGH, TEXSLOT_ROUGH_V, TEXSLOT_BUMP, TEXSLOT_KT, TEXSLOT_INDEX = 0, 1, 2, 3, 4, 5, 6
 HPT_N_TEXSLOTS = 8
-HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE = 1, 2, 3
+HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE, HPT_LIGHT_SPOT, HPT_LIGHT_DISTANT = 1, 2, 3, 4, 5
 HPT_SAMPLER_LD_HASH, HPT_SAMPLER_MT_REPLAY, HPT_SAMPLER_RANDOM_HASH, HPT_SAMPLER_RANDOM_MT_REPLAY = 0, 1, 2, 3
 HPT_SAMPLER_STRATIFIED_HASH, HPT_SAMPLER_STRATIFIED_MT_REPLAY = 4, 5
 HPT_SAMPLER_HALTON_HASH, HPT_SAMPLER_HALTON_MT_REPLAY = 6, 7

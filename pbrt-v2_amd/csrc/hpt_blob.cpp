@@ -222,7 +222,9 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
     }
     for (int l = 0; l < d->n_lights; ++l) {
         const hpt_light &li = d->lights[l];
-        if (li.kind == HPT_LIGHT_POINT) {
+        if (li.kind == HPT_LIGHT_POINT || li.kind == HPT_LIGHT_DISTANT) {
+        } else if (li.kind == HPT_LIGHT_SPOT) {     // cosTotalWidth in `area`, cosFalloffStart in `marg_int`: width >= falloff start, i.e. cosTotalWidth <= cosFalloffStart
+            if (!(li.area <= li.marg_int) || li.area < -1.f || li.marg_int > 1.f) { hpt_set_error("light %d: spot light cone cosines out of order", l); return HPT_E_INVALID; }
         } else if (li.kind == HPT_LIGHT_DIFFUSE_AREA) {
             if (li.quadric >= 0) {
                 if (li.quadric >= d->n_quadrics || d->quadrics[li.quadric].arealight != l) {

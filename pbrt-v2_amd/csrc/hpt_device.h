@@ -2156,6 +2156,25 @@ HPT_FN_LIGHT f3 light_sample_L(const DScene &sc, const hpt_light &l, f3 p, float
         shadow->o = p; shadow->d = vdiv(lp - p, d); shadow->mint = pEps; shadow->maxt = d * (1.f - 0.f);
         return sdivf(mk3(l.intensity[0], l.intensity[1], l.intensity[2]), dist2(lp, p));
     }
+    if (EXT && l.kind == HPT_LIGHT_SPOT) {        // SpotLight::Sample_L / Falloff (lights/spot.cpp:50-70): cosTotalWidth in `area`, cosFalloffStart in `marg_int`
+        f3 lp = mk3(l.pos[0], l.pos[1], l.pos[2]);
+        *wi = normalize(lp - p);
+        *pdf = 1.f;
+        float d = len(p - lp);
+        shadow->o = p; shadow->d = vdiv(lp - p, d); shadow->mint = pEps; shadow->maxt = d * (1.f - 0.f);
+        f3 wl = normalize(xf_vec(l.l2w_inv, -*wi));
+        float costheta = wl.z, fall;
+        if (costheta < l.area) fall = 0.f;
+        else if (costheta > l.marg_int) fall = 1.f;
+        else { float delta = (costheta - l.area) / (l.marg_int - l.area); fall = delta * delta * delta * delta; }
+        return sdivf(mk3(l.intensity[0], l.intensity[1], l.intensity[2]) * fall, dist2(lp, p));
+    }
+    if (EXT && l.kind == HPT_LIGHT_DISTANT) {     // DistantLight::Sample_L (lights/distant.cpp:48-55): VisibilityTester::SetRay — an unbounded shadow ray
+        *wi = mk3(l.pos[0], l.pos[1], l.pos[2]);
+        *pdf = 1.f;
+        shadow->o = p; shadow->d = *wi; shadow->mint = pEps; shadow->maxt = HPT_INF;
+        return mk3(l.intensity[0], l.intensity[1], l.intensity[2]);
+    }
     if (l.kind == HPT_LIGHT_DIFFUSE_AREA) {
         f3 ns, ps;
         if (!EXT || l.quadric >= 0) ps = quadric_sample(sc.quadrics[l.quadric], p, u0, u1, &ns);

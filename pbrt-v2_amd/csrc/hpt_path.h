@@ -720,7 +720,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
             if (DL && lightPick >= 0) lightNum = lightPick;
             const hpt_light &light = sc.lights[lightNum];
-            const bool isDelta = light.kind == HPT_LIGHT_POINT;
+            const bool isDelta = light.kind == HPT_LIGHT_POINT || ((MATS & MATS_EXT) && (light.kind == HPT_LIGHT_SPOT || light.kind == HPT_LIGHT_DISTANT));   // Light::IsDeltaLight
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
             f3 Li = light_sample_L<(MATS & MATS_EXT) != 0>(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);

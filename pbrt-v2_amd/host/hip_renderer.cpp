@@ -44,6 +44,8 @@
 #include "lights/diffuse.h"
 #include "lights/infinite.h"
 #include "lights/point.h"
+#include "lights/spot.h"
+#include "lights/distant.h"
 #include "materials/matte.h"
 #include "materials/measured.h"
 #include "materials/metal.h"
@@ -392,6 +394,15 @@ struct Flattener {
                 r.kind = HPT_LIGHT_POINT;
                 r.pos[0] = pl->lightPos.x; r.pos[1] = pl->lightPos.y; r.pos[2] = pl->lightPos.z;
                 pl->Intensity.ToRGB(r.intensity);
+            } else if (const SpotLight *sl = dynamic_cast<const SpotLight *>(l)) {       // ABI 8 (lights/spot.cpp)
+                r.kind = HPT_LIGHT_SPOT;
+                r.pos[0] = sl->lightPos.x; r.pos[1] = sl->lightPos.y; r.pos[2] = sl->lightPos.z;
+                sl->Intensity.ToRGB(r.intensity);
+                r.area = sl->cosTotalWidth; r.marg_int = sl->cosFalloffStart;
+            } else if (const DistantLight *dsl = dynamic_cast<const DistantLight *>(l)) { // ABI 8 (lights/distant.cpp)
+                r.kind = HPT_LIGHT_DISTANT;
+                r.pos[0] = dsl->lightDir.x; r.pos[1] = dsl->lightDir.y; r.pos[2] = dsl->lightDir.z;
+                dsl->L.ToRGB(r.intensity);
             } else if (const DiffuseAreaLight *dl = dynamic_cast<const DiffuseAreaLight *>(l)) {
                 r.kind = HPT_LIGHT_DIFFUSE_AREA;
                 dl->Lemit.ToRGB(r.intensity);
@@ -426,7 +437,7 @@ struct Flattener {
                 r.marg_int = d2->pMarginal->funcInt;
             } else
                 Severe("hip renderer: light type outside the hot-path scope "
-                       "(supported: point, area/diffuse, infinite)");
+                       "(supported: point, spot, distant, area/diffuse, infinite)");
             lights[i] = r;
         }
     }

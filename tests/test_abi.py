@@ -86,6 +86,19 @@ def test_animated_quadric_records_are_validated(tmp_path):
     assert len(old.instances) == 1 and old.instances[0].quadric1 == 0 and save(old) == 0
 
 
+def test_spot_light_records_are_validated(tmp_path):
+    """ABI 8, HPT_LIGHT_SPOT: cosTotalWidth (`area`) <= cosFalloffStart (`marg_int`), both cosines; HPT_LIGHT_DISTANT needs nothing beyond its kind."""
+    good = os.path.join(ROOT, "tests", "golden", "lts.hpts.gz")
+    save = lambda s: hpt.lib().hpt_blob_save(str(tmp_path / "l.hpts").encode(), C.byref(s.desc), None, None)
+    s = abi.Scene.load(good)
+    assert sorted(l.kind for l in s.lights) == [abi.HPT_LIGHT_POINT, abi.HPT_LIGHT_SPOT, abi.HPT_LIGHT_SPOT, abi.HPT_LIGHT_DISTANT] and save(s) == 0
+    spot = [i for i, l in enumerate(s.lights) if l.kind == abi.HPT_LIGHT_SPOT][0]
+    s.lights[spot].area, s.lights[spot].marg_int = s.lights[spot].marg_int + 0.01, s.lights[spot].marg_int
+    assert save(s) == -2 and "spot light" in hpt.last_error()
+    s = abi.Scene.load(good); s.lights[spot].kind = 9
+    assert save(s) in (-2, -3)
+
+
 def test_warmup_validates_its_argument_before_any_runtime_work():
     """hpt_warmup (include/hpt.h): a negative device is refused on the calling thread — no thread is started, no HIP call made."""
     assert hpt.lib().hpt_warmup(-1) == -2

@@ -160,7 +160,10 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             # round 3 (tests/golden/make_golden_aquad.py): ANIMATED spheres / disks — TransformedPrimitive over a bare GeometricPrimitive (ABI 8,
             # hpt_instance.quadric1): textured + bump-mapped partial sphere, tilting annulus, a moving octahedron beside them, a mirror wall (path);
             # scenes/anim-moving-reflection.pbrt as shipped at 100 x 100 / 4 spp under the 32 x 16 stand-in map (direct lighting, its default)
-            "aquad": "aquad.hpts.gz", "aquaddl": "aquaddl.hpts.gz"}
+            "aquad": "aquad.hpts.gz", "aquaddl": "aquaddl.hpts.gz",
+            # round 3 (tests/golden/make_golden_lights.py): SpotLight (one under a rotated, non-uniformly scaled CTM; one hard-edged) and DistantLight
+            # beside a point light — delta lights, unbounded shadow rays — under the path integrator and under direct lighting "all" (ABI 8)
+            "lts": "lts.hpts.gz", "ltsdl": "ltsdl.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
