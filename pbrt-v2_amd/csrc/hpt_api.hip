@@ -704,7 +704,11 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
         // The stealing walk runs on the BVH4 (trav_node4): a walk that stacks every other hit child can hold up to stack_bound4 entries (30-39
         // on the shipped meshes, 9-15 observed).  If the rows a workgroup can have do not cover that, the first cap_normal rows take ordinary
         // entries and the levels above them one masked entry each: cap_normal + 2 + depth4 rows always suffice.
+#ifdef HPT_W5   /* (A/B switch: five workgroups per CU = 32 rows each) */
+        const int room = (cfg == 5 && !a->dl ? 32 : HPT_MAX_STACK_ROWS) - extra;
+#else
         const int room = HPT_MAX_STACK_ROWS - extra;
+#endif
         int rows = s->stack_bound4 + 1;
         if (rows > room) { rows = room; a->cap_normal = room - 2 - s->depth4; }
         if (const char *e = getenv("HPT_BVH4_CAP")) { const int c = atoi(e); if (c >= 0 && c + 2 + s->depth4 <= rows) a->cap_normal = c; }   // (tests: exercise the masked entries)

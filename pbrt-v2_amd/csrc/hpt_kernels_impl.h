@@ -597,7 +597,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #ifndef HPT_W34
 #define HPT_W34 3
 #endif
+#ifdef HPT_W5   /* A/B switch (profiles/r03_ab.md, run X): configuration 5 at FIVE waves per SIMD (96 VGPRs, 32 LDS rows a workgroup: hpt_api.hip, kernel_residency) */
+#define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 || (c) == 6 ? HPT_W34 : (c) == 5 ? 5 : 4)
+#else
 #define HPT_CFG_WAVES(c) ((c) == 2 || (c) == 4 || (c) == 6 ? HPT_W34 : 4)
+#endif
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_STEAL(c) ((c) >= 5)
