@@ -133,7 +133,11 @@ typedef struct hpt_instance {
     int32_t quadric1;            /* version 8: the instance's primitive is ONE sphere / disk (a shape that CanIntersect() stays a bare
                                   * GeometricPrimitive under the TransformedPrimitive, core/api.cpp:1032-1042): 1 + its index in
                                   * `quadrics`; that record has identity o2w (api.cpp:1019-1021) and no area light (api.cpp:1014-1016),
-                                  * and is not a primitive of the world.  0: the meshes with hpt_mesh.instance == this index         */
+                                  * and is not a primitive of the world.  0: the meshes with hpt_mesh.instance == this index.
+                                  * < 0 — object instancing (pbrtObjectInstance, core/api.cpp:1114-1147: several TransformedPrimitives over ONE
+                                  * aggregate): this instance shares the primitive of instance -quadric1 - 1, which owns it (its meshes name the
+                                  * owner).  An instanced mesh keeps its own ObjectToWorld (the CTM at its Shape statement): its P are in the
+                                  * instance's space, and Intersection::ObjectToWorld = Inverse(WorldToObject * w2p) (primitive.cpp:104-107)        */
     float start_time, end_time;  /* RenderOptions::transformStartTime / EndTime       */
     float bounds[6];             /* TransformedPrimitive::WorldBound() (MotionBounds) */
     float T[2][3];               /* AnimatedTransform::Decompose of start / end       */

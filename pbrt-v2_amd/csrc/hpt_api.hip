@@ -286,6 +286,11 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     for (int m = 0; m < desc->n_meshes; ++m) if (desc->meshes[m].alpha_tex > 0 || desc->meshes[m].arealight >= 0 || desc->meshes[m].s_off >= 0) ext = true;   // (explicit tangents: the extension set's shading geometry)
     for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0) ext = true;
     for (int l = 0; l < desc->n_lights; ++l) if (desc->lights[l].kind == HPT_LIGHT_SPOT || desc->lights[l].kind == HPT_LIGHT_DISTANT) ext = true;   // (ABI 8: their sampling code lives in the extension set only)
+    {   // object instancing with a mesh that keeps an ObjectToWorld of its own: the extension set's shading geometry (DMesh::o2w_general)
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int m = 0; m < desc->n_meshes; ++m)
+            if (desc->meshes[m].instance >= 0 && (memcmp(desc->meshes[m].o2w, ident, sizeof(ident)) != 0 || memcmp(desc->meshes[m].o2w_inv, ident, sizeof(ident)) != 0)) ext = true;
+    }
     int n_inst_quadrics = 0;
     for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; ++n_inst_quadrics; }   // animated spheres / disks: the extension set's walk and shading geometry
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family

@@ -151,6 +151,13 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
     for (int k = 0; k < d->n_instances; ++k) {     // version 8: an animated sphere / disk (hpt_instance.quadric1)
         const int32_t q1 = d->instances[k].quadric1;
         if (q1 == 0) continue;
+        if (q1 < 0) {      // object instancing: shares the primitive of an EARLIER instance that owns one (no chains)
+            const int owner = -q1 - 1;
+            if (owner >= k || d->instances[owner].quadric1 < 0) { hpt_set_error("instance %d: shares the primitive of instance %d, which is not an earlier owner", k, owner); return HPT_E_INVALID; }
+            for (int m = 0; m < d->n_meshes; ++m)
+                if (d->meshes[m].instance == k) { hpt_set_error("instance %d: shares a primitive and owns mesh %d", k, m); return HPT_E_INVALID; }
+            continue;
+        }
         if (q1 < 0 || q1 > d->n_quadrics) { hpt_set_error("instance %d: quadric1 out of range", k); return HPT_E_INVALID; }
         const hpt_quadric &qu = d->quadrics[q1 - 1];
         static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

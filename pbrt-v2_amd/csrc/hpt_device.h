@@ -283,7 +283,8 @@ struct DMesh {
     int32_t instance, alpha_tex;    // animated instance the mesh belongs to, or -1; 1 + float texture of TriangleMesh::alphaTexture, 0 = none
     float o2w_inv[12];              // rows 0..2 of ObjectToWorld->mInv (for normals)
     int64_t p_off;                  // vertex positions in fpool (area-light sampling addresses triangles by (mesh, triangle))
-    int32_t flip_ro, pad3;          // Shape::ReverseOrientation alone (Triangle::Sample flips its normal by it, trianglemesh.cpp:455)
+    int32_t flip_ro;                // Shape::ReverseOrientation alone (Triangle::Sample flips its normal by it, trianglemesh.cpp:455)
+    int32_t o2w_general;            // an instanced mesh with its own ObjectToWorld (object instancing): Intersection::ObjectToWorld is a product (shade_geometry_ext)
     int64_t s_off;                  // TriangleMesh::s (explicit tangents, object space) in fpool, -1 = absent
     float o2w[12];                  // rows 0..2 of ObjectToWorld->m (carries the tangents to world space)
 };
@@ -463,6 +464,13 @@ struct Xf { A34 m, minv; };
 HPT_FN f3 xf_point_affine(const float *m, f3 p) {   // Transform::operator()(Point) with w = 1 (transform.h:192-202)
     const float x = p.x, y = p.y, z = p.z;
     return mk3(m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]);
+}
+// rows 0..2 of Matrix4x4::Mul(a, b) (core/transform.h:75-84) for two affine matrices given by their rows 0..2 (last rows 0 0 0 1): the reference's
+// four-term sums, term for term (the fourth term is an exact zero, or a[i][3] * 1)
+HPT_FN void a34_mul(const float *a, const float *b, float *r) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            r[4 * i + j] = a[4 * i + 0] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j] + a[4 * i + 3] * (j == 3 ? 1.f : 0.f);
 }
 HPT_FN bool a34_is_identity(const A34 &a) {
     bool id = true;
@@ -1871,6 +1879,10 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
             else bb0 = 1.f - bb1 - bb2;
             float minv[12];
             for (int k = 0; k < 12; ++k) minv[k] = inInstance ? w2p.m.m[k] : me.o2w_inv[k];
+            // object instancing: isect->WorldToObject = WorldToObject * w2p (primitive.cpp:104-105; Transform::operator*, transform.cpp:286-290:
+            // m = Mul(m, t2.m), mInv = Mul(t2.mInv, mInv)) — the mesh's own WorldToObject is not the identity there
+            const bool general = inInstance && me.o2w_general;
+            if (general) a34_mul(me.o2w_inv, w2p.m.m, minv);
             f3 n0 = S(0.f), n1 = S(0.f), n2 = S(0.f);
             f3 ns = dg.nn;
             if (me.n_off >= 0) {
@@ -1888,6 +1900,7 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
                                 + mk3(Sv[3 * v2], Sv[3 * v2 + 1], Sv[3 * v2 + 2]) * bb2;
                 float mfw[12];
                 for (int k = 0; k < 12; ++k) mfw[k] = inInstance ? w2p.minv.m[k] : me.o2w[k];
+                if (general) a34_mul(w2p.minv.m, me.o2w, mfw);
                 ss = normalize(xf_vec(mfw, ssum));
             } else ss = normalize(dg.dpdu);
             f3 ts = cross(ss, ns);

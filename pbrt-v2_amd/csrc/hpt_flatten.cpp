@@ -50,7 +50,11 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         dm.prim_base = (int32_t)base; dm.material = me.material; dm.arealight = me.arealight;
         dm.flip = me.reverse_orientation ^ me.swaps_handedness;
         dm.instance = me.instance; dm.alpha_tex = me.alpha_tex;
-        dm.p_off = me.p_off; dm.flip_ro = me.reverse_orientation; dm.pad3 = 0;
+        dm.p_off = me.p_off; dm.flip_ro = me.reverse_orientation;
+        {   // an instanced mesh whose ObjectToWorld is not the identity (object instancing): obj2world of its shading geometry is a product
+            static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            dm.o2w_general = (me.instance >= 0 && (memcmp(me.o2w, ident, sizeof(ident)) != 0 || memcmp(me.o2w_inv, ident, sizeof(ident)) != 0)) ? 1 : 0;
+        }
         for (int k = 0; k < 12; ++k) { dm.o2w_inv[k] = me.o2w_inv[k]; dm.o2w[k] = me.o2w[k]; }
         dm.s_off = me.s_off;
         const float *P = desc->fpool + me.p_off;
@@ -123,6 +127,10 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             if (d4 > out->depth4) out->depth4 = d4;
         }
         tri_base += sub.size();
+    }
+    for (int g = 0; g < desc->n_instances; ++g) {     // object instancing: an instance that shares its owner's primitive walks the owner's trees
+        const int32_t q1 = desc->instances[g].quadric1;
+        if (q1 < 0) { out->inst_root[(size_t)g] = out->inst_root[(size_t)(-q1 - 1)]; out->inst_root4[(size_t)g] = out->inst_root4[(size_t)(-q1 - 1)]; }
     }
     const auto t_trees = std::chrono::steady_clock::now();
     // ---- measured-BRDF samples -> grid-ordered 32-byte records + cell table (hpt_device.h: kd_begin / kd_step) -------

@@ -98,6 +98,7 @@ struct Flattener {
     std::vector<hpt_texture> textures;
     std::map<const void *, int> textureIndex;
     std::map<const void *, int64_t> tableOffset;
+    std::map<const Primitive *, int> instanceOfPrimitive;   // aggregate (or bare shape) of a TransformedPrimitive -> the instance that owns it
     std::vector<int64_t> meshTriBase;          // global number of every mesh's first triangle (meshes in descriptor order)
     std::map<const TriangleMesh *, int> meshIndex;
     std::map<const Shape *, int> quadricIndex;
@@ -357,6 +358,11 @@ struct Flattener {
         r.bounds[3] = wb.pMax.x; r.bounds[4] = wb.pMax.y; r.bounds[5] = wb.pMax.z;
         int idx = (int)instances.size();
         instances.push_back(r);
+        // object instancing (pbrtObjectInstance, core/api.cpp:1114-1147): every use of an object is a TransformedPrimitive over the SAME aggregate;
+        // the first one owns its meshes, the others share them (hpt_instance.quadric1 < 0)
+        std::map<const Primitive *, int>::iterator shared = instanceOfPrimitive.find(tp->primitive.GetPtr());
+        if (shared != instanceOfPrimitive.end()) { instances[idx].quadric1 = -(shared->second + 1); return; }
+        instanceOfPrimitive[tp->primitive.GetPtr()] = idx;
         std::vector<const Primitive *> todo;
         todo.push_back(tp->primitive.GetPtr());
         while (!todo.empty()) {

@@ -86,6 +86,22 @@ def test_animated_quadric_records_are_validated(tmp_path):
     assert len(old.instances) == 1 and old.instances[0].quadric1 == 0 and save(old) == 0
 
 
+def test_shared_instance_records_are_validated(tmp_path):
+    """ABI 8, object instancing (hpt_instance.quadric1 < 0: the instance shares the primitive of instance -quadric1 - 1): the owner is an earlier
+    instance that owns a primitive itself (no chains), and a sharing instance owns no mesh."""
+    good = os.path.join(ROOT, "tests", "golden", "oinst.hpts.gz")
+    save = lambda s: hpt.lib().hpt_blob_save(str(tmp_path / "o.hpts").encode(), C.byref(s.desc), None, None)
+    s = abi.Scene.load(good)
+    assert [i.quadric1 for i in s.instances] == [0, -1, -1, -1, 0, -5] and save(s) == 0, hpt.last_error()
+    s = abi.Scene.load(good); s.instances[1].quadric1 = -3            # owner 2 is itself a sharing instance
+    assert save(s) == -2 and "earlier owner" in hpt.last_error()
+    s = abi.Scene.load(good); s.instances[1].quadric1 = -6            # owner 5 comes later
+    assert save(s) == -2 and "earlier owner" in hpt.last_error()
+    s = abi.Scene.load(good)
+    m = [i for i, me in enumerate(s.meshes) if me.instance == 4][0]; s.meshes[m].instance = 5
+    assert save(s) == -2 and "owns mesh" in hpt.last_error()
+
+
 def test_spot_light_records_are_validated(tmp_path):
     """ABI 8, HPT_LIGHT_SPOT: cosTotalWidth (`area`) <= cosFalloffStart (`marg_int`), both cosines; HPT_LIGHT_DISTANT needs nothing beyond its kind."""
     good = os.path.join(ROOT, "tests", "golden", "lts.hpts.gz")

@@ -163,7 +163,10 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             "aquad": "aquad.hpts.gz", "aquaddl": "aquaddl.hpts.gz",
             # round 3 (tests/golden/make_golden_lights.py): SpotLight (one under a rotated, non-uniformly scaled CTM; one hard-edged) and DistantLight
             # beside a point light — delta lights, unbounded shadow rays — under the path integrator and under direct lighting "all" (ABI 8)
-            "lts": "lts.hpts.gz", "ltsdl": "ltsdl.hpts.gz"}
+            "lts": "lts.hpts.gz", "ltsdl": "ltsdl.hpts.gz",
+            # round 3 (tests/golden/make_golden_oinst.py): OBJECT INSTANCING — two objects (meshes with their own ObjectToWorld, vertex normals, explicit
+            # tangents) instanced four + two times (static, scaled, mirrored, animated): TransformedPrimitives over shared aggregates (ABI 8, quadric1 < 0)
+            "oinst": "oinst.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
