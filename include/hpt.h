@@ -63,17 +63,14 @@ enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_M
  *             reference built (MIPMap ctor, mipmap.h:105-190), through a UVMapping2D (core/texture.cpp:44-57)
  *   SCALE     textures/scale.h:46-60                    tex1 * tex2
  *   MIX       textures/mix.h:46-62                      (1 - amount) * tex1 + amount * tex2
- *   CHECKERBOARD (version 8) textures/checkerboard.h:49-105, dimension 2 over a UVMapping2D (su, sv, du, dv below): tex1 where
- *             floor(s) + floor(t) is even, tex2 elsewhere; `wrap` holds the antialiasing method — 0 "none" (point sample),
- *             1 "closedform" (the box-filtered blend of :80-99 from the lookup's screen-space derivatives)
  * Other texture plugins and other mappings are outside the hot-path scope (the host wrapper refuses them). */
-enum { HPT_TEX_CONSTANT = 1, HPT_TEX_IMAGEMAP = 2, HPT_TEX_SCALE = 3, HPT_TEX_MIX = 4, HPT_TEX_CHECKERBOARD = 5 };
+enum { HPT_TEX_CONSTANT = 1, HPT_TEX_IMAGEMAP = 2, HPT_TEX_SCALE = 3, HPT_TEX_MIX = 4 };
 enum { HPT_WRAP_REPEAT = 0, HPT_WRAP_BLACK = 1, HPT_WRAP_CLAMP = 2 };   /* ImageWrap, core/mipmap.h:47-49 */
 typedef struct hpt_texture {
     int32_t kind;
     int32_t channels;      /* 1: Texture<float>, 3: Texture<Spectrum> (RGB) */
     float value[3];        /* CONSTANT */
-    int32_t tex1, tex2;    /* SCALE / MIX / CHECKERBOARD operands (texture indices) */
+    int32_t tex1, tex2;    /* SCALE / MIX operands (texture indices) */
     int32_t amount;        /* MIX: float texture index */
     /* IMAGEMAP: the MIPMap's pyramid, level after level in fpool: level l is max(1, width >> l) x max(1, height >> l) texels of
      * `channels` floats, row-major (t * w + s), starting right after level l - 1; level 0 at pyr_off */

@@ -14,7 +14,7 @@ HPT_VERSION = 8
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
 HPT_MAT_GLASS, HPT_MAT_MIRROR, HPT_MAT_MEASURED_REGULAR = 6, 7, 8
-HPT_TEX_CONSTANT, HPT_TEX_IMAGEMAP, HPT_TEX_SCALE, HPT_TEX_MIX, HPT_TEX_CHECKERBOARD = 1, 2, 3, 4, 5
+HPT_TEX_CONSTANT, HPT_TEX_IMAGEMAP, HPT_TEX_SCALE, HPT_TEX_MIX = 1, 2, 3, 4
 HPT_WRAP_REPEAT, HPT_WRAP_BLACK, HPT_WRAP_CLAMP = 0, 1, 2
 TEXSLOT_KD, TEXSLOT_KS, TEXSLOT_ROUGH, TEXSLOT_ROUGH_V, TEXSLOT_BUMP, TEXSLOT_KT, TEXSLOT_INDEX = 0, 1, 2, 3, 4, 5, 6
 HPT_N_TEXSLOTS = 8

@@ -245,7 +245,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         std::vector<int> depth((size_t)desc->n_textures, 0);
         for (int t = 0; t < desc->n_textures; ++t) {
             const hpt_texture &tx = desc->textures[t];
-            if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX || tx.kind == HPT_TEX_CHECKERBOARD) {
+            if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX) {
                 int d = depth[(size_t)tx.tex1] > depth[(size_t)tx.tex2] ? depth[(size_t)tx.tex1] : depth[(size_t)tx.tex2];
                 if (tx.kind == HPT_TEX_MIX && depth[(size_t)tx.amount] > d) d = depth[(size_t)tx.amount];
                 depth[(size_t)t] = d + 1;

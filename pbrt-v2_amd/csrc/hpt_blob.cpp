@@ -97,7 +97,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 hpt_set_error("texture %d: image pyramid out of range / not a power of two", t);
                 return HPT_E_INVALID;
             }
-        } else if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX || tx.kind == HPT_TEX_CHECKERBOARD) {
+        } else if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX) {
             // operands must come EARLIER in the table (the plugin emits them depth first): no cycles, bounded recursion
             if (tx.tex1 < 0 || tx.tex1 >= t || tx.tex2 < 0 || tx.tex2 >= t || (tx.kind == HPT_TEX_MIX && (tx.amount < 0 || tx.amount >= t || d->textures[tx.amount].channels != 1))) {
                 hpt_set_error("texture %d: operand textures must precede it in the table", t);
@@ -108,7 +108,6 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 hpt_set_error("texture %d: a float texture cannot take spectrum operands", t);
                 return HPT_E_INVALID;
             }
-            if (tx.kind == HPT_TEX_CHECKERBOARD && (tx.wrap < 0 || tx.wrap > 1)) { hpt_set_error("texture %d: checkerboard antialiasing method %d", t, tx.wrap); return HPT_E_INVALID; }
         } else { hpt_set_error("texture %d: unknown kind %d", t, tx.kind); return HPT_E_UNSUPPORTED; }
     }
     // global triangle numbers of the meshes (shape sets refer to them)

@@ -1507,8 +1507,6 @@ HPT_FN_NOINLINE TexV mip_lookup(const TexPools sc, const hpt_texture &t, float s
 // ... and a call costs its callee's saved registers (50 scratch stores + loads for a level of tex_eval), so the two leaf kinds never pay for a
 // level of their own: a constant is read in place and an image map goes straight to mip_lookup — scale(imagemap, constant), the bump map of
 // scenes/metal.pbrt, is two calls instead of four.
-// BUMPINT of textures/checkerboard.h:92-94: the integral of the 0 / 1 square wave of period 2 up to x
-HPT_FN float checker_bumpint(float x) { const int f = (int)floorf(x / 2); return f + 2.f * maxf((x / 2) - f - .5f, 0.f); }
 HPT_FN TexV tex_image(const TexPools sc, const hpt_texture &t, const TexUV dg) {
     return mip_lookup(sc, t, t.su * dg.u + t.du, t.sv * dg.v + t.dv, t.su * dg.dudx, t.sv * dg.dvdx, t.su * dg.dudy, t.sv * dg.dvdy);
 }
@@ -1545,19 +1543,6 @@ HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg) {
         if (sc.textures[t.tex1].channels < t.channels) a.c[1] = a.c[2] = a.c[0];   // a float operand of a spectrum texture acts on every channel
         if (sc.textures[t.tex2].channels < t.channels) b.c[1] = b.c[2] = b.c[0];
         if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k]; return r; }
-        if (t.kind == HPT_TEX_CHECKERBOARD) {      // Checkerboard2DTexture::Evaluate (textures/checkerboard.h:68-101) over UVMapping2D::Map (core/texture.cpp:48-57)
-            const float s = t.su * dg.u + t.du, tt = t.sv * dg.v + t.dv;
-            const TexV point = (((int)floorf(s) + (int)floorf(tt)) % 2 == 0) ? a : b;
-            if (t.wrap == 0) return point;                                          // aamode "none"
-            const float ds = maxf(fabsf(t.su * dg.dudx), fabsf(t.su * dg.dudy)), dt = maxf(fabsf(t.sv * dg.dvdx), fabsf(t.sv * dg.dvdy));
-            const float s0 = s - ds, s1 = s + ds, t0 = tt - dt, t1 = tt + dt;
-            if ((int)floorf(s0) == (int)floorf(s1) && (int)floorf(t0) == (int)floorf(t1)) return point;    // the filter lies inside one check
-            const float sint = (checker_bumpint(s1) - checker_bumpint(s0)) / (2.f * ds), tint = (checker_bumpint(t1) - checker_bumpint(t0)) / (2.f * dt);
-            float area2 = sint + tint - 2.f * sint * tint;
-            if (ds > 1.f || dt > 1.f) area2 = .5f;
-            for (int k = 0; k < 3; ++k) r.c[k] = (1.f - area2) * a.c[k] + area2 * b.c[k];
-            return r;
-        }
         const float amt = tex_node<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
         for (int k = 0; k < 3; ++k) r.c[k] = (1.f - amt) * a.c[k] + amt * b.c[k];
     }

@@ -66,7 +66,6 @@
 #include "textures/imagemap.h"
 #include "textures/scale.h"
 #include "textures/mix.h"
-#include "textures/checkerboard.h"
 #include "materials/glass.h"
 #include "materials/mirror.h"
 
@@ -168,17 +167,8 @@ struct Flattener {
             hpt_texture r; memset(&r, 0, sizeof(r));
             r.kind = HPT_TEX_MIX; r.channels = channels; r.tex1 = a; r.tex2 = b; r.amount = am;
             textures.push_back(r); idx = (int)textures.size() - 1;
-        } else if (const Checkerboard2DTexture<T> *cb = dynamic_cast<const Checkerboard2DTexture<T> *>(t)) {     // ABI 8 (textures/checkerboard.h:49-105)
-            const UVMapping2D *uv = dynamic_cast<const UVMapping2D *>(cb->mapping);
-            if (!uv) Severe("hip renderer: only \"uv\" texture mappings are inside the hot-path scope");
-            int a = AddTextureT<T, Tmem>(cb->tex1.GetPtr(), channels), b = AddTextureT<T, Tmem>(cb->tex2.GetPtr(), channels);
-            hpt_texture r; memset(&r, 0, sizeof(r));
-            r.kind = HPT_TEX_CHECKERBOARD; r.channels = channels; r.tex1 = a; r.tex2 = b; r.amount = -1;
-            r.su = uv->su; r.sv = uv->sv; r.du = uv->du; r.dv = uv->dv;
-            r.wrap = cb->aaMethod == Checkerboard2DTexture<T>::NONE ? 0 : 1;
-            textures.push_back(r); idx = (int)textures.size() - 1;
         } else
-            Severe("hip renderer: texture type outside the hot-path scope (supported: constant, imagemap and 2D checkerboard with uv mapping, scale, mix)");
+            Severe("hip renderer: texture type outside the hot-path scope (supported: constant, imagemap with uv mapping, scale, mix)");
         textureIndex[(const void *)t] = idx;
         return idx;
     }

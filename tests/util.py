@@ -166,10 +166,7 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             "lts": "lts.hpts.gz", "ltsdl": "ltsdl.hpts.gz",
             # round 3 (tests/golden/make_golden_oinst.py): OBJECT INSTANCING — two objects (meshes with their own ObjectToWorld, vertex normals, explicit
             # tangents) instanced four + two times (static, scaled, mirrored, animated): TransformedPrimitives over shared aggregates (ABI 8, quadric1 < 0)
-            "oinst": "oinst.hpts.gz",
-            # round 3 (tests/golden/make_golden_chk.py): Checkerboard2DTexture — closedform (box-filtered from the camera-ray differentials) and point
-            # sampled, spectrum and float (a roughness, a bump map), over constants and over textures (ABI 8, HPT_TEX_CHECKERBOARD)
-            "chk": "chk.hpts.gz"}
+            "oinst": "oinst.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
