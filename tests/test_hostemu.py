@@ -45,6 +45,32 @@ def test_intersect_matches_oracle(cases, pairs, name):
     assert (ao == ae).mean() > 0.9995
 
 
+@pytest.mark.parametrize("name", ["aquad", "oinst"])
+def test_instance_kinds_of_abi8_find_the_oracles_hits(name):
+    """ABI 8's instance kinds under aggregatetest-style rays (time 0: the start transforms), closest hit and any hit, on the BVH2 walk (traverse) and on
+    the four-wide walk the path kernel runs (trav_node4): `aquad` — a sphere and a disk that are instances' primitives (trav_begin<QI>: tested when
+    the walk enters the instance, skipped among the world's quadrics) beside a mesh instance and a world sphere; `oinst` — six instances over two
+    shared aggregates (inst_root / inst_root4 of a sharing instance are its owner's), one of them mirrored."""
+    from tests.util import load_case
+    s = load_case(name)
+    o, e = orc.OracleScene(s), emu.EmuScene(s, max_leaf=2)
+    rays = random_rays(s, 40000, seed=9)
+    ho, po = o.intersect(rays)
+    _, ao = o.intersect(rays, anyhit=True)
+    assert (po >= 0).mean() > 0.15
+    he, pe = e.intersect(rays)
+    same = po == pe
+    assert same.mean() > 0.9995 and np.array_equal(ho[same][:, :3], he[same][:, :3])
+    _, ae = e.intersect(rays, anyhit=True)
+    assert (ao == ae).mean() > 0.9995
+    for cap in (-1, 0):
+        h4, p4, _ = e.intersect4(rays, cap=cap)
+        same = po == p4
+        assert same.mean() > 0.9995 and np.array_equal(ho[same][:, :3], h4[same][:, :3])
+        _, a4, _ = e.intersect4(rays, anyhit=True, cap=cap)
+        assert (ao == a4).mean() > 0.9995
+
+
 def test_bvh_depth_is_bounded(pairs):
     for n, (_, e) in pairs.items():
         info = e.info()
