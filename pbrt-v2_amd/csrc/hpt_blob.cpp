@@ -154,6 +154,10 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
         if (q1 < 0) {      // object instancing: shares the primitive of an EARLIER instance that owns one (no chains)
             const int owner = -q1 - 1;
             if (owner >= k || d->instances[owner].quadric1 < 0) { hpt_set_error("instance %d: shares the primitive of instance %d, which is not an earlier owner", k, owner); return HPT_E_INVALID; }
+            if (d->instances[owner].quadric1 > 0) {     // (a sphere / disk instanced several times: the walk tests an instance's quadric through its own record only)
+                hpt_set_error("instance %d: shares the sphere / disk of instance %d — only aggregates of triangle meshes are shared", k, owner);
+                return HPT_E_UNSUPPORTED;
+            }
             for (int m = 0; m < d->n_meshes; ++m)
                 if (d->meshes[m].instance == k) { hpt_set_error("instance %d: shares a primitive and owns mesh %d", k, m); return HPT_E_INVALID; }
             continue;

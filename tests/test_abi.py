@@ -100,6 +100,12 @@ def test_shared_instance_records_are_validated(tmp_path):
     s = abi.Scene.load(good)
     m = [i for i, me in enumerate(s.meshes) if me.instance == 4][0]; s.meshes[m].instance = 5
     assert save(s) == -2 and "owns mesh" in hpt.last_error()
+    # a sphere instanced twice (ObjectInstance of a one-sphere object): refused, not rendered without it
+    q = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "aquad.hpts.gz"))
+    owner = [k for k, i in enumerate(q.instances) if i.quadric1 > 0][0]
+    later = [k for k in range(owner + 1, len(q.instances)) if q.instances[k].quadric1 > 0][0]
+    q.instances[later].quadric1 = -(owner + 1)
+    assert hpt.lib().hpt_blob_save(str(tmp_path / "q.hpts").encode(), C.byref(q.desc), None, None) == -3 and "only aggregates" in hpt.last_error()
 
 
 def test_spot_light_records_are_validated(tmp_path):
