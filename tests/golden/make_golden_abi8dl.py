@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Golden fixture `abi8dl`: everything ABI 8 added, TOGETHER, under DirectLightingIntegrator strategy "one" with its specular recursion — from the REAL
+reference (build container only).  A spot light, a distant light and a sphere area light (UniformSampleOneLight picks among them); an object of two
+meshes (vertex normals, own ObjectToWorld) instanced three times, once under an animated transform; an animated, textured partial sphere and an
+animated disk; a mirror wall and a glass sphere, so that SpecularReflect / SpecularTransmit rays (with their differentials) reach the instanced and the
+animated geometry again; 160 x 90, 4 spp, maxdepth 3.  CPU tests only (oracle pin, host emulation): each ingredient has its own GPU case.
+abi8dl.ref.npy.gz = the reference binary's image, abi8dl.hpts.gz = the blob pbrt_hip dumped from the same file.
+"""
+import gzip
+import importlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+abi = importlib.import_module("pbrt-v2_amd.abi")
+film = importlib.import_module("pbrt-v2_amd.film")
+PBRT = os.path.join(ROOT, "oracle", "_ref", "pbrt")
+PBRT_HIP = os.path.join(ROOT, "pbrt-v2_amd", "host", "_build", "pbrt_hip")
+
+SCENE = """LookAt 0 2.4 -7  0 0.8 0  0 1 0
+Camera "perspective" "float fov" [40] "float shutteropen" [0.05] "float shutterclose" [0.95]
+Film "image" "integer xresolution" [160] "integer yresolution" [90] "string filename" "%OUT%"
+Sampler "lowdiscrepancy" "integer pixelsamples" [4]
+SurfaceIntegrator "directlighting" "string strategy" "one" "integer maxdepth" [3]
+WorldBegin
+AttributeBegin
+Rotate 15 0 1 0
+LightSource "spot" "color I" [70 60 50] "point from" [-2.5 4.5 -2] "point to" [0 0 0.5] "float coneangle" [32] "float conedeltaangle" [10]
+AttributeEnd
+LightSource "distant" "color L" [0.8 0.8 1.0] "point from" [2 3 -3] "point to" [0 0 0]
+AttributeBegin
+AreaLightSource "area" "color L" [9 9 9] "integer nsamples" [1]
+Translate 3 3.5 -1
+Shape "sphere" "float radius" [0.4]
+AttributeEnd
+Texture "img" "color" "imagemap" "string filename" "%TEX%"
+ObjectBegin "gem"
+AttributeBegin
+Rotate 25 0 0 1
+Scale 1 1.25 0.85
+Material "plastic" "color Kd" [.25 .5 .7] "color Ks" [.5 .5 .5] "float roughness" [.05]
+Shape "trianglemesh" "integer indices" [0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5]
+  "point P" [0.55 0 0  -0.55 0 0  0 0.55 0  0 -0.55 0  0 0 0.55  0 0 -0.55] "normal N" [1 0 0  -1 0 0  0 1 0  0 -1 0  0 0 1  0 0 -1]
+Material "matte" "texture Kd" "img"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-0.5 -0.7 -0.5  0.5 -0.7 -0.5  0.5 -0.7 0.5  -0.5 -0.7 0.5] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+ObjectEnd
+AttributeBegin
+Translate -2.2 0.95 0.3
+ObjectInstance "gem"
+AttributeEnd
+AttributeBegin
+Translate 2.0 1.0 1.2
+Rotate 40 0 1 0
+Scale 1.1 0.8 1
+ObjectInstance "gem"
+AttributeEnd
+AttributeBegin
+Translate 0.9 0.9 -1.6
+ActiveTransform EndTime
+Translate 0.4 0.2 0
+Rotate 30 0 1 0
+ActiveTransform All
+ObjectInstance "gem"
+AttributeEnd
+AttributeBegin
+Material "plastic" "texture Kd" "img" "color Ks" [.4 .4 .4] "float roughness" [.03]
+Translate -0.6 0.7 -0.4
+ActiveTransform EndTime
+Translate -0.5 0.15 0.2
+Rotate 30 0 0 1
+Scale 1 1.3 .9
+ActiveTransform All
+Shape "sphere" "float radius" [.5] "float zmin" [-.42] "float phimax" [320]
+AttributeEnd
+AttributeBegin
+Material "matte" "color Kd" [.7 .6 .2]
+Translate -3.2 0.6 1.5
+ActiveTransform EndTime
+Rotate 35 1 0 0
+ActiveTransform All
+Rotate -80 1 0 0
+Shape "disk" "float radius" [.6] "float innerradius" [.15]
+AttributeEnd
+AttributeBegin
+Material "glass" "float index" [1.5]
+Translate 0.6 0.55 -3.0
+Shape "sphere" "float radius" [0.55]
+AttributeEnd
+AttributeBegin
+Material "matte" "color Kd" [.5 .5 .48]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6]
+AttributeEnd
+AttributeBegin
+Material "mirror"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 3  6 0 3  6 5 3  -6 5 3]
+AttributeEnd
+WorldEnd
+"""
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        sp, out, blob = os.path.join(tmp, "abi8dl.pbrt"), os.path.join(tmp, "abi8dl.pfm"), os.path.join(tmp, "abi8dl.hpts")
+        open(sp, "w").write(SCENE.replace("%OUT%", out).replace("%TEX%", os.path.join(HERE, "tex16x12.pfm")))
+        subprocess.check_call([PBRT, "--quiet", "--ncores", "1", sp], cwd=tmp, stderr=subprocess.DEVNULL)
+        subprocess.check_call([PBRT_HIP, "--quiet", "--ncores", "1", sp], cwd=tmp,
+                              env=dict(os.environ, HPT_DUMP_SCENE=blob, PBRT_RENDERER_HIP="1", HPT_HOST_BVH="1"), stderr=subprocess.DEVNULL)
+        with gzip.open(os.path.join(HERE, "abi8dl.ref.npy.gz"), "wb", compresslevel=9) as f:
+            np.save(f, film.read_pfm(out))
+        s = abi.Scene.load(blob)
+        q = [i.quadric1 for i in s.instances]
+        assert len(q) == 5 and sum(1 for v in q if v > 0) == 2 and sum(1 for v in q if v < 0) == 2, q
+        assert s.render.integrator == abi.HPT_INTEGRATOR_DIRECT_ONE and sorted(l.kind for l in s.lights) == [abi.HPT_LIGHT_DIFFUSE_AREA, abi.HPT_LIGHT_SPOT, abi.HPT_LIGHT_DISTANT]
+        s.save(os.path.join(HERE, "abi8dl.hpts.gz"))
+
+
+if __name__ == "__main__":
+    main()

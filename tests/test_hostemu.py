@@ -80,7 +80,7 @@ def test_bvh_depth_is_bounded(pairs):
 # Animated spheres / disks under textures and bump maps: the device inverts the interpolated transform analytically (hpt_device.h, anim_interpolate:
 # equal to the reference's Gauss-Jordan inverse up to rounding), and dpdu / dpdv / dndu / dndv go through that inverse into the bump frame and the
 # EWA footprint, which carry a last-bit difference to ~1e-5 of a pixel's value (a few pixels per frame: 1e-4 .. 3e-3, where one of the 8 samples takes a discrete decision — a filter level, a grazing shadow ray — the other way).  Same rays, same film weights; bounded instead of bit-compared.
-INVERSE_ROUNDING_CASES = ("aquad", "aquaddl")
+INVERSE_ROUNDING_CASES = ("aquad", "aquaddl", "abi8dl")
 
 
 def close_enough(name, io, ie):
@@ -138,7 +138,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,

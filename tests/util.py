@@ -166,7 +166,10 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             "lts": "lts.hpts.gz", "ltsdl": "ltsdl.hpts.gz",
             # round 3 (tests/golden/make_golden_oinst.py): OBJECT INSTANCING — two objects (meshes with their own ObjectToWorld, vertex normals, explicit
             # tangents) instanced four + two times (static, scaled, mirrored, animated): TransformedPrimitives over shared aggregates (ABI 8, quadric1 < 0)
-            "oinst": "oinst.hpts.gz"}
+            "oinst": "oinst.hpts.gz",
+            # round 3 (tests/golden/make_golden_abi8dl.py): everything ABI 8 added, together, under direct lighting "one" with the specular recursion
+            # (CPU tests only: each ingredient has its own GPU case)
+            "abi8dl": "abi8dl.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
