@@ -3,7 +3,7 @@
 reference (build container only).  A spot light, a distant light and a sphere area light (UniformSampleOneLight picks among them); an object of two
 meshes (vertex normals, own ObjectToWorld) instanced three times, once under an animated transform; an animated, textured partial sphere and an
 animated disk; a mirror wall and a glass sphere, so that SpecularReflect / SpecularTransmit rays (with their differentials) reach the instanced and the
-animated geometry again; 160 x 90, 4 spp, maxdepth 3.  CPU tests only (oracle pin, host emulation): each ingredient has its own GPU case.
+animated geometry again; 160 x 90, 4 spp, maxdepth 3.
 abi8dl.ref.npy.gz = the reference binary's image, abi8dl.hpts.gz = the blob pbrt_hip dumped from the same file.
 """
 import gzip
