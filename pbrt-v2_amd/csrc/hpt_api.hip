@@ -113,7 +113,7 @@ static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name,
         const int64_t id[2] = {(int64_t)sb.st_size, (int64_t)sb.st_mtime};
         h = fnv1a(h, id, sizeof(id));
     }
-    for (const char *v : {"HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
+    for (const char *v : {"HPT_LEAN_EXT", "HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
         if (const char *e = getenv(v)) { h = fnv1a(h, v, strlen(v)); h = fnv1a(h, e, strlen(e)); }
     return h;
 }
@@ -295,6 +295,16 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; ++n_inst_quadrics; }   // animated spheres / disks: the extension set's walk and shading geometry
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
     if (ext) s->mats = MATS_FULL;
+    // OPT-IN (HPT_LEAN_EXT=1): an extension-set scene that reaches none of the rare features runs the lean instantiation (MATS_LEAN, hpt_device.h;
+    // hpt_kernels_lean.hip) — no animated instances (there is no lean _i twin), no measured BRDF, no specular material, no shape-set / spot /
+    // distant light.  Not the default until it has been measured on the device.
+    if (ext && desc->n_instances == 0 && getenv("HPT_LEAN_EXT") && atoi(getenv("HPT_LEAN_EXT")) != 0) {
+        bool rare = s->has_specular;
+        for (int m = 0; m < desc->n_materials; ++m) rare = rare || desc->materials[m].kind == HPT_MAT_MEASURED_IRREG || desc->materials[m].kind == HPT_MAT_MEASURED_REGULAR;
+        for (int l = 0; l < desc->n_lights; ++l)
+            rare = rare || desc->lights[l].kind == HPT_LIGHT_SPOT || desc->lights[l].kind == HPT_LIGHT_DISTANT || (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0);
+        if (!rare) s->mats = MATS_LEAN;
+    }
     // The code object of the scene's kernel set (one fat binary per set, 2-9 MB) loads on first use — 20 ms that the first render would
     // wait for: load it now, on a thread of its own, while the host builds the trees (an occupancy query is a first use).
     const int pre_mats = s->mats; const bool pre_inst = desc->n_instances > 0;
@@ -457,6 +467,7 @@ extern "C" int hpt_scene_set_camera_motion(hpt_scene *s, const hpt_instance *c2w
     }
     if (!(c2w->end_time > c2w->start_time) && c2w->actually_animated) { hpt_set_error("camera motion: end time must follow start time"); return HPT_E_INVALID; }
     s->cam_xf = *c2w; s->cam_animated = true;
+    if (s->mats & MATS_NORARE) s->mats = MATS_FULL;      // (a moving camera runs the kernels with a time sample: the full set's _i twin; its LDS rows differ)
     return HPT_OK;
 }
 

@@ -823,7 +823,13 @@ enum { BX_NONE = 0, BX_LAMBERT = 1, BX_MICROFACET = 2, BX_IRREG = 3, BX_MICROFAC
 // MATS_EXT: everything round 2 added — Oren-Nayar, specular lobes (glass, mirror), the regular half-angle BRDF, textures with ray
 // differentials and bump mapping, alpha-textured triangles, triangle-mesh emitters.  Its own kernel set (hpt_kernels_ext.hip): the
 // scenes that need none of it keep the lean kernels.
-enum { MATS_PLASTIC = 1, MATS_MEASURED = 2, MATS_METAL = 4, MATS_SUBSTRATE = 8, MATS_ALL = 15, MATS_EXT = 16, MATS_FULL = 31 };
+enum { MATS_PLASTIC = 1, MATS_MEASURED = 2, MATS_METAL = 4, MATS_SUBSTRATE = 8, MATS_ALL = 15, MATS_EXT = 16, MATS_FULL = 31,
+       // an OPT-OUT bit (so that MATS_FULL's instantiations keep their template arguments and their code): an extension-set kernel compiled
+       // WITHOUT what few scenes reach — specular lobes (glass, mirror) and the direct-lighting recursion, the regular half-angle BRDF, area
+       // lights over shape sets (mesh emitters), spot / distant lights.  MATS_LEAN: textures, bump, Oren-Nayar, alpha, tangents over matte /
+       // plastic / metal / substrate — what scenes/metal.pbrt needs (profiles/r03_ab.md, runs V3 / Y: the full set is at the edge of its budget)
+       MATS_NORARE = 32, MATS_LEAN = MATS_PLASTIC | MATS_METAL | MATS_SUBSTRATE | MATS_EXT | MATS_NORARE };
+#define HPT_MATS_RARE(M) (((M) & MATS_EXT) != 0 && ((M) & MATS_NORARE) == 0)
 
 // BSDF value type (replaces the arena-allocated BSDF + BxDF objects of core/reflection.h:150-191)
 struct Bsdf {
@@ -1134,8 +1140,8 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
     int kind = b.kind(i);
     if (kind == BX_LAMBERT) return b.R(i) * HPT_INV_PI;              // reflection.cpp:173-175
     if (MATS & MATS_EXT) {
-        if (kind == BX_SPEC_REFL || kind == BX_SPEC_TRANS) return S(0.f);   // reflection.h:313-315, 340-342
-        if (kind == BX_REGULAR) return regular_halfangle_f(sc, b.mat, wo, wi);
+        if (HPT_MATS_RARE(MATS) && (kind == BX_SPEC_REFL || kind == BX_SPEC_TRANS)) return S(0.f);   // reflection.h:313-315, 340-342
+        if (HPT_MATS_RARE(MATS) && kind == BX_REGULAR) return regular_halfangle_f(sc, b.mat, wo, wi);
         if (kind == BX_OREN_NAYAR) {                                  // OrenNayar::f, reflection.cpp:178-201
             float sinthetai = sin_theta(wi), sinthetao = sin_theta(wo);
             float maxcos = 0.f;
@@ -1197,7 +1203,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
 }
 template <int MATS>
 HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
-    if ((MATS & MATS_EXT) && (b.kind(i) == BX_SPEC_REFL || b.kind(i) == BX_SPEC_TRANS)) return 0.f;   // reflection.h:318-320, 345-347
+    if (HPT_MATS_RARE(MATS) && (b.kind(i) == BX_SPEC_REFL || b.kind(i) == BX_SPEC_TRANS)) return 0.f;   // reflection.h:318-320, 345-347
     if ((MATS & MATS_SUBSTRATE) && b.kind(i) == BX_FRESNELBLEND) { // FresnelBlend::Pdf (reflection.cpp:465-468)
         if (!same_hemisphere(wo, wi)) return 0.f;
         return .5f * (abs_cos_theta(wi) * HPT_INV_PI + aniso_pdf_wh(b.exponent, b.ey, wo, normalize(wo + wi)));
@@ -1234,14 +1240,14 @@ HPT_FN void concentric_sample_disk(float u1, float u2, float *dx, float *dy) { /
 // (a SPECULAR lobe is the exception: its Sample_f value is the one BSDF::Sample_f returns — *fspec)
 template <int MATS>
 HPT_FN void bxdf_sample_dir(const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float u2, float *pdf, f3 *fspec) {
-    if ((MATS & MATS_EXT) && b.kind(i) == BX_SPEC_REFL) {           // SpecularReflection::Sample_f, reflection.cpp:138-145
+    if (HPT_MATS_RARE(MATS) && b.kind(i) == BX_SPEC_REFL) {           // SpecularReflection::Sample_f, reflection.cpp:138-145
         *wi = mk3(-wo.x, -wo.y, wo.z);
         *pdf = 1.f;
         const float F = b.exponent > 0.f ? fresnel_dielectric(wo.z, 1.f, b.exponent) : 1.f;    // FresnelDielectric(1, ior) / FresnelNoOp
         *fspec = sdivf(smul(S(F), b.R(i)), abs_cos_theta(*wi));
         return;
     }
-    if ((MATS & MATS_EXT) && b.kind(i) == BX_SPEC_TRANS) {          // SpecularTransmission::Sample_f, reflection.cpp:148-170
+    if (HPT_MATS_RARE(MATS) && b.kind(i) == BX_SPEC_TRANS) {          // SpecularTransmission::Sample_f, reflection.cpp:148-170
         const bool entering = wo.z > 0.f;
         float ei = 1.f, et = b.exponent;
         if (!entering) { float t = ei; ei = et; et = t; }
@@ -1353,7 +1359,7 @@ HPT_FN_BSDF f3 bsdf_sample_f(const DScene &sc, const Bsdf &b, f3 woW, f3 *wiW, f
                         int flags, int *sampledType, LaneStack ls) {
     f3 wo, wi, fs;
     if (!bsdf_sample_dir<MATS>(b, woW, &wo, &wi, wiW, u1, u2, uComp, pdf, flags, sampledType, &fs)) return S(0.f);
-    if ((MATS & MATS_EXT) && (*sampledType & BSDF_SPECULAR)) return fs;             // reflection.cpp:555: a specular lobe's own value
+    if (HPT_MATS_RARE(MATS) && (*sampledType & BSDF_SPECULAR)) return fs;             // reflection.cpp:555: a specular lobe's own value
     return bsdf_f_local<MATS>(sc, b, wo, wi, woW, *wiW, flags, ls);
 }
 // A BSDF made of the measured lobe alone (materials/measured.cpp:121-131): its f() is a kd-tree query, which the

@@ -34,7 +34,7 @@ int path_kernel_effective_cfg(int mats, int cfg) {
     return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // HPT_CFG_ALIAS under HPT_LEAN_SET (hpt_kernels_impl.h)
 }
 int path_kernel_cold_rows(int mats, bool dl) {       // must mirror launch_path_kernel's choice of instantiation (below)
-    const int set = (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
+    const int set = (mats & MATS_NORARE) ? MATS_LEAN : (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;
     return (HPT_PARK_MATS(set) && !dl) ? HPT_COLD_ROWS : 0;
 }
 
@@ -474,6 +474,8 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
     int occupancy_##NAME##_i(int, bool, size_t, int *, int *);
 HPT_DECL_SET(basic) HPT_DECL_SET(measured) HPT_DECL_SET(ext) HPT_DECL_SET(all)
 #undef HPT_DECL_SET
+hipError_t launch_path_lean(const PathKernelArgs &, int, bool, int, hipStream_t);     // hpt_kernels_lean.hip (no _i twin: scenes with instances run the full set)
+int occupancy_lean(int, bool, size_t, int *, int *);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present); every set exists without
 // (hpt_kernels_<set>.hip) and with (hpt_kernels_<set>_i.hip) animated instances
@@ -484,6 +486,7 @@ static int pick_variant(int mats) {
     return 2;
 }
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
+    if ((mats & MATS_NORARE) && !inst) return occupancy_lean(cfg, dl, dyn_lds, blocks_per_cu, vgprs);     // (hpt_api.hip sets the bit only for scenes without instances and clears it with a moving camera)
     switch (pick_variant(mats)) {
         case 0: return inst ? occupancy_basic_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_basic(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
         case 1: return inst ? occupancy_measured_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_measured(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
@@ -493,6 +496,7 @@ int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds,
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {
     const bool inst = a.sc.n_instances > 0 || a.rp.cam_animated != 0;   // (a moving camera: the kernels that carry a time sample)
+    if ((mats & MATS_NORARE) && !inst) return launch_path_lean(a, grid_blocks, count, cfg, stream);
     switch (pick_variant(mats)) {
         case 0: return inst ? launch_path_basic_i(a, grid_blocks, count, cfg, stream) : launch_path_basic(a, grid_blocks, count, cfg, stream);
         case 1: return inst ? launch_path_measured_i(a, grid_blocks, count, cfg, stream) : launch_path_measured(a, grid_blocks, count, cfg, stream);

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);
     ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
-    if (DL && (MATS & MATS_EXT) && a.dl_stack) {   // the specular recursion's pending rays (hpt_path.h, Lane::node_done)
+    if (DL && HPT_MATS_RARE(MATS) && a.dl_stack) {   // the specular recursion's pending rays (hpt_path.h, Lane::node_done)
         lane.dls = a.dl_stack + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x; lane.dls_stride = (int64_t)gridDim.x * HPT_BLOCK; lane.dls_cap = a.dl_cap;
     }
     if (WIN && a.adapt_buf) {      // Sampler "adaptive": the lane's column of parked first-batch radiances (Lane::finish_path_adaptive)

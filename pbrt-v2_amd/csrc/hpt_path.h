@@ -538,7 +538,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         } else after_mis(sc, rp, film, wc);
     }
 
-    static constexpr bool DL_REC = DL && (MATS & MATS_EXT) != 0;
+    static constexpr bool DL_REC = DL && HPT_MATS_RARE(MATS);
     HPT_MFN f3 node_weight(f3 v) const { return DL_REC ? smul(cold.beta(), v) : v; }
     // differentials of the ray the current vertex was reached by: the camera ray's, rebuilt from its sample (path: first hit only,
     // geometry.h:351-361); under the direct-lighting recursion the spawned ray's, kept in the lane's HBM column
@@ -654,7 +654,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                         quadric_intersect(q, ray, &t, &dg);
                         sees = dot(dg.nn, -wi_mis) > 0.f;       // Intersection::Le -> DiffuseAreaLight::L
                     }
-                } else if (MATS & MATS_EXT) {                   // a triangle of an emitting mesh
+                } else if (HPT_MATS_RARE(MATS)) {                   // a triangle of an emitting mesh
                     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
                     const f4 a = tp[0], bb = tp[1], c = tp[2];
                     const DMesh &me = sc.meshes[as_int(a.w) & HPT_TRI_MESH_MASK];
@@ -720,10 +720,10 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             if (lightNum > sc.n_lights - 1) lightNum = sc.n_lights - 1;
             if (DL && lightPick >= 0) lightNum = lightPick;
             const hpt_light &light = sc.lights[lightNum];
-            const bool isDelta = light.kind == HPT_LIGHT_POINT || ((MATS & MATS_EXT) && (light.kind == HPT_LIGHT_SPOT || light.kind == HPT_LIGHT_DISTANT));   // Light::IsDeltaLight
+            const bool isDelta = light.kind == HPT_LIGHT_POINT || (HPT_MATS_RARE(MATS) && (light.kind == HPT_LIGHT_SPOT || light.kind == HPT_LIGHT_DISTANT));   // Light::IsDeltaLight
             // EstimateDirect, light-sampling half (integrator.cpp:123-142): Ld = f * Li * (|wi.n| * w / pdf)
             f3 wi; float lightPdf, bsdfPdf;
-            f3 Li = light_sample_L<(MATS & MATS_EXT) != 0>(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
+            f3 Li = light_sample_L<HPT_MATS_RARE(MATS)>(sc, light, p, eps, ls0, ls1, &wi, &lightPdf, &shadow, ls2);
             HPT_SPT(2)
             if (lightPdf > 0.f && !sblack(Li)) {
                 if (defer) {
@@ -759,7 +759,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                     float weight = 1.f;
                     bool ok = true;
                     if (!(sampledType & BSDF_SPECULAR)) {
-                        lightPdf = light_pdf<(MATS & MATS_EXT) != 0>(sc, light, p, wi);
+                        lightPdf = light_pdf<HPT_MATS_RARE(MATS)>(sc, light, p, wi);
                         if (lightPdf == 0.f) ok = false;
                         else weight = power_heuristic(1, bsdfPdf, 1, lightPdf);
                     }
@@ -790,7 +790,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             if (bsdf_sample_dir<MATS>(bsdf, wo, &wo_l, &wi_l, &wi, ps0, ps1, ps2, &pdf, BSDF_ALL, &flags, &fspec)) {
                 wi_next = wi;
                 spec_next = (flags & BSDF_SPECULAR) != 0;
-                if ((MATS & MATS_EXT) && spec_next) term_next(fspec, absdot(wi, n), pdf);       // a specular lobe's Sample_f value (reflection.cpp:555)
+                if (HPT_MATS_RARE(MATS) && spec_next) term_next(fspec, absdot(wi, n), pdf);       // a specular lobe's Sample_f value (reflection.cpp:555)
                 else if (defer) {
                     sv->has[2] = bsdf_query_point(bsdf, wo_l, wi_l, wo, wi, BSDF_ALL, &sv->fq[2]);
                     sv->a3 = absdot(wi, n); sv->pdf3 = pdf;

@@ -150,7 +150,7 @@ static void fill_params(const hpt_camera *cam, const hpt_render_desc *rd, Render
 
 // Runs the work items of the shard one lane at a time (the kernel runs 64 per wave concurrently).
 // DL: the direct-lighting instantiation of the lane (rd->integrator != HPT_INTEGRATOR_PATH).
-template <bool DL>
+template <bool DL, int MATSV = MATS_FULL>
 static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
     RenderParams rp; fill_params(cam, rd, &rp);
     rp.has_motion = s->d.n_instances > 0 || rp.cam_animated;
@@ -175,7 +175,7 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
             const bool halton = rp.sampler_kind == 3, bc = rp.bc_table != nullptr;
             uint32_t tile = 0;
             if (bc ? !item_to_bc(rp, item, &tile, &s0) : halton ? !item_to_halton(rp, item, &x, &y, &s0) : !item_to_pixel(rp, item, &x, &y, &s0)) continue;
-            Lane<LdHashWinSrc, true, MATS_FULL, DL> lane; lane.init();
+            Lane<LdHashWinSrc, true, MATSV, DL> lane; lane.init();
             std::vector<float> dls((size_t)(rd->maxdepth + 2) * HPT_DLS_FLOATS, 0.f);
             if (DL) { lane.dls = dls.data(); lane.dls_stride = 1; lane.dls_cap = rd->maxdepth + 1; }
             std::vector<float> ab((size_t)3 * (rp.adapt_min > 0 ? rp.adapt_min : 1), 0.f);
@@ -202,6 +202,8 @@ static int emu_render_t(const emu_scene *s, const hpt_camera *cam, const hpt_ren
     return 0;
 }
 extern "C" int emu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *stats) {
+    if (getenv("HPT_EMU_LEAN"))     // tests: the lean extension set (MATS_LEAN, csrc/hpt_kernels_lean.hip) instead of the full one
+        return rd->integrator != HPT_INTEGRATOR_PATH ? emu_render_t<true, MATS_LEAN>(s, cam, rd, film, stats) : emu_render_t<false, MATS_LEAN>(s, cam, rd, film, stats);
     return rd->integrator != HPT_INTEGRATOR_PATH ? emu_render_t<true>(s, cam, rd, film, stats) : emu_render_t<false>(s, cam, rd, film, stats);
 }
 

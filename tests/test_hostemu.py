@@ -71,6 +71,25 @@ def test_instance_kinds_of_abi8_find_the_oracles_hits(name):
         assert (ao == a4).mean() > 0.9995
 
 
+@pytest.mark.parametrize("name", ["metal", "metalg", "tex", "on", "alpha", "tang", "qtex", "lens"])
+def test_lean_extension_set_renders_the_full_sets_film(name, monkeypatch):
+    """The lean extension set (MATS_LEAN, csrc/hpt_kernels_lean.hip: the extension kernels without specular lobes / the direct-lighting recursion,
+    the regular half-angle BRDF, shape-set area lights, spot / distant lights and the measured BRDF — opt-in on the device, HPT_LEAN_EXT=1) on every
+    fixture that reaches none of those: the same film as the full set, bit for bit, and the oracle's rays."""
+    from tests.util import load_case
+    s = load_case(name)
+    rd = hash_rd(s, seed=3)
+    e = emu.EmuScene(s)
+    full, sf = e.render(s.camera, rd)
+    monkeypatch.setenv("HPT_EMU_LEAN", "1")
+    lean, sl = e.render(s.camera, rd)
+    monkeypatch.delenv("HPT_EMU_LEAN")
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    assert np.array_equal(full, lean) and list(sf[:3]) == list(sl[:3])
+    assert sl[0] == so[0] and abs(int(sl[1]) - int(so[1])) <= 4 and abs(int(sl[2]) - int(so[2])) <= 4
+    assert film.rmse(film.xyzw_to_rgb(lean), film.xyzw_to_rgb(fo)) < 1e-6
+
+
 def test_bvh_depth_is_bounded(pairs):
     for n, (_, e) in pairs.items():
         info = e.info()
