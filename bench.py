@@ -177,24 +177,44 @@ def cpu_baseline_reference(workload, scene):
     oracle/Makefile) on the same scene file, same frame, on this host's cores: two-point fit t(spp_b) - t(spp_a) so that
     parsing and the BVH build drop out.  None when the binary / scene files did not travel."""
     exe = os.path.join(ROOT, "oracle", "_ref", "pbrt_exr" if workload == "metal" else "pbrt")   # metal.pbrt reads .exr maps: the reference built with its vendored OpenEXR
-    if workload not in REF_SCENE_FILE or not os.path.exists(exe) or \
-            not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "scenes", REF_SCENE_FILE[workload])):
+    synthetic = workload in ("soup", "soup4m")     # no scene file: the same triangles written as one, pbrt-v2_amd/scenes.py export_pbrt
+    if not os.path.exists(exe) or (not synthetic and (workload not in REF_SCENE_FILE or
+                                                      not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "scenes", REF_SCENE_FILE[workload])))):
         return None
     cores = usable_cores()
     rd = scene.render
-    a, b = (2, 16) if rd.xres * rd.yres <= 1920 * 1080 else (1, 4)     # ~10-30 s of CPU work
+    # ~10-30 s of CPU work on 16 cores: bunny 13 Msamples/s, anim ~8, metal 4K ~9, the 1 M-triangle soup ~2.5
+    a, b = {"soup": (1, 6), "soup4m": (1, 4), "anim": (2, 12)}.get(workload, (2, 16) if rd.xres * rd.yres <= 1920 * 1080 else (1, 4))
     ts = {}
     with tempfile.TemporaryDirectory() as tmp:
+        base = None
+        if synthetic:      # the geometry is ~110 MB of text per million triangles: written once, the header's sample count substituted
+            base = os.path.join(tmp, "base.pbrt")
+            scenes.export_pbrt(scene, base, os.path.join(tmp, "o.pfm"), spp=a, maxdepth=rd.maxdepth, xres=rd.xres, yres=rd.yres)
         for spp in (a, b):
             sf = os.path.join(tmp, "s%d.pbrt" % spp)
-            open(sf, "w").write(ref_scene_text(workload, rd.xres, rd.yres, spp, rd.maxdepth, os.path.join(tmp, "o.pfm")))
+            if synthetic:
+                if spp == a:
+                    os.rename(base, sf)
+                else:
+                    with open(os.path.join(tmp, "s%d.pbrt" % a)) as fi, open(sf, "w") as fo:
+                        head = fi.read(4096).replace('"integer pixelsamples" [%d]' % a, '"integer pixelsamples" [%d]' % b, 1)
+                        fo.write(head)
+                        while True:
+                            chunk = fi.read(1 << 24)
+                            if not chunk:
+                                break
+                            fo.write(chunk)
+            else:
+                open(sf, "w").write(ref_scene_text(workload, rd.xres, rd.yres, spp, rd.maxdepth, os.path.join(tmp, "o.pfm")))
             t = time.time()
             subprocess.check_call([exe, "--quiet", "--ncores", str(cores), sf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             ts[spp] = time.time() - t
     rate = (b - a) * rd.xres * rd.yres / max(ts[b] - ts[a], 1e-9)
     return {"value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
             "sample": "pbrt-v2 itself (oracle/_ref/%s --ncores %d) on %s at %dx%d, path maxdepth %d: (%d - %d) spp / (%.2f s - %.2f s) — "
-                      "two-point fit, parse + BVH build cancel" % (os.path.basename(exe), cores, REF_SCENE_FILE[workload], rd.xres, rd.yres, rd.maxdepth, b, a, ts[b], ts[a])}
+                      "two-point fit, parse + BVH build cancel" % (os.path.basename(exe), cores, "the same triangles as a .pbrt file" if synthetic else REF_SCENE_FILE[workload],
+                                                                     rd.xres, rd.yres, rd.maxdepth, b, a, ts[b], ts[a])}
 
 
 def end_to_end_pbrt_hip(workload, scene):
@@ -334,10 +354,15 @@ def reference_work(scene, rd):
 
 
 def achieved_peak(local):
-    """hpt_calib_hbm_triad: float4 triad over 3 x 1 GiB on this rank's device, best of 5 (report the achieved peak too)."""
+    """What this box streams from HBM (report the achieved peak too), 1 GiB per array — beyond the Infinity Cache —, best of 5:
+    the float4 COPY MI355X_MICROARCH.md calibrates with (6.29 TB/s there) is `achieved_peak`; the triad (rounds 1-3: 4.9-5.0 TB/s, which
+    flattered frac_of_achieved_peak) and a read-only stream are reported beside it."""
     if "gbs" not in _CALIB:
         try:
-            _CALIB["gbs"] = round(hpt.hbm_triad(local, 1 << 30, 5), 1)
+            _CALIB["copy"] = round(hpt.hbm_copy(local, 1 << 30, 5), 1)
+            _CALIB["triad"] = round(hpt.hbm_triad(local, 1 << 30, 5), 1)
+            _CALIB["read"] = round(hpt.hbm_read(local, 1 << 30, 5), 1)
+            _CALIB["gbs"] = max(_CALIB["copy"], _CALIB["triad"], _CALIB["read"])
         except Exception as e:                               # noqa: BLE001 — calibration only
             _CALIB["gbs"], _CALIB["error"] = None, str(e)
     return _CALIB["gbs"]
@@ -495,7 +520,7 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                    "scene_bytes_in_hbm": int(info.total_device_bytes)},
         "kernel": {"name": "hpt_path_kernel" if args.pipeline == "persistent" else "wf_advance_kernel + wf_trace_kernel (wavefront pipeline; vgprs/waves of the trace kernel)",
                    "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
-                   "block_threads": last.block_threads, "vgprs": last.vgprs, "waves_per_cu": last.resident_waves,
+                   "block_threads": last.block_threads, "vgprs": last.vgprs, "scratch_B": int(last.scratch_bytes), "waves_per_cu": last.resident_waves,
                    "occupancy": round(last.resident_waves / 32.0, 3),
                    "tune_cfg": "%d (%s)" % (last.tune_cfg, TUNE_NAMES[last.tune_cfg]),
                    "samples_per_launch": int(per_launch_samples)},
@@ -560,11 +585,14 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                            "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": (prof["bytes_per_launch"] * scale) if prof.get("bytes_per_launch") else None,
                            "traffic_source": prof.get("source"), "traffic_write_bytes": (prof["write_bytes"] * scale) if prof.get("write_bytes") else None,
-                           "algorithmic_bytes_per_sample": bps, "achieved_peak": achieved_peak(local),
+                           "algorithmic_bytes_per_sample": bps, "algorithmic_bytes": bps * per_launch_samples, "achieved_peak": achieved_peak(local),
                            "scene_bytes_in_hbm": int(info.total_device_bytes),
                            "numerator": "reference algorithm on the reference's tree, counted by the oracle in this run (work.reference)"}
+        out["roofline"]["achieved_peak_by"] = {k: _CALIB.get(k) for k in ("copy", "triad", "read")}
         if out["roofline"]["achieved_peak"]:
             out["roofline"]["frac_of_achieved_peak"] = round(achieved / out["roofline"]["achieved_peak"], 5)
+        if info.total_device_bytes < (256 << 20):
+            out["roofline"]["note"] = "scene %.0f MB is L2 / Infinity-Cache resident: frac is an algorithmic-throughput index, not HBM bandwidth use" % (info.total_device_bytes / 1e6)
     if prof.get("valu_wave_instructions_per_launch"):
         # second roofline for the cache-resident scenes (7 MB of scene data never leaves L2 / Infinity Cache): VALU issue.
         ipl = prof["valu_wave_instructions_per_launch"] * (per_launch_samples / float(prof["samples_per_launch"]) if prof.get("samples_per_launch") else 1.0)
@@ -577,6 +605,110 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                                 "lane_utilisation": prof.get("valu_lane_utilisation"),
                                 "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"), "source": prof.get("source")}
     return out, scene, flt
+
+# ---- the line the driver parses ----------------------------------------------------------------------------------------------------
+FINAL_LINE_MAX = 4000       # the driver keeps an ~8 KB tail of stdout: the LAST line must fit it with room to spare (a 24 KB line parsed as null)
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def _num(v, nd=4):
+    if isinstance(v, float):
+        return float("%.*g" % (nd + 2, v))
+    return v
+
+
+def _roofline_compact(r):
+    if not r:
+        return None
+    out = {k: _num(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_sample", "achieved_peak", "achieved_peak_copy", "frac_of_achieved_peak") if k in r}
+    if r.get("traffic") and r.get("algorithmic_bytes") :
+        out["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
+    if r.get("traffic_write_bytes") is not None:
+        out["traffic_write_bytes"] = _num(r["traffic_write_bytes"])
+    out["traffic_source"] = _short(r.get("traffic_source"), 60) if r.get("traffic_source") else None
+    return out
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses: the contract's keys + roofline + cpu_baseline, every other workload as one compact row.  Everything else
+    (verify text, work.what, end_to_end stages, setup) lives in the full record: an EARLIER stdout line and profiles-ready JSON at `full_path`."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype") if k in out}
+    c["data"] = _short(out.get("data", ""), 60)
+    cfg = out.get("config", {})
+    c["config"] = {"workload": _short(cfg.get("workload", ""), 160), "sharding": _short(cfg.get("sharding", ""), 120)}
+    k = out.get("kernel", {})
+    c["kernel"] = {"name": _short(k.get("name", ""), 40), "avg_ms": k.get("avg_ms"), "vgprs": k.get("vgprs"), "scratch_B": k.get("scratch_B"),
+                   "waves_per_cu": k.get("waves_per_cu"), "tune_cfg": int(str(k.get("tune_cfg", "0")).split()[0]) if k.get("tune_cfg") is not None else None}
+    if "rmse_vs_oracle" in out:
+        c["rmse_vs_oracle"] = _num(out["rmse_vs_oracle"], 3)
+        c["rmse_tolerance"] = 1e-3
+        c["sampler_note"] = "timed kernel: LD_HASH sampler vs oracle LD_HASH mode sample-for-sample; vs reference binary: MT_REPLAY kernel (tests)"
+    if "value_incl_d2h" in out:
+        c["value_incl_d2h"] = out["value_incl_d2h"]
+    if out.get("roofline"):
+        c["roofline"] = _roofline_compact(out["roofline"])
+        if out["roofline"].get("note"):
+            c["roofline"]["note"] = _short(out["roofline"]["note"], 110)
+    if out.get("roofline_valu"):
+        v = out["roofline_valu"]
+        c["roofline_valu"] = {"frac": v.get("frac"), "lane_utilisation": v.get("lane_utilisation"), "scratch_bytes_per_lane": v.get("scratch_bytes_per_lane")}
+    if out.get("cpu_baseline"):
+        b = out["cpu_baseline"]
+        c["cpu_baseline"] = {"value": b.get("value"), "unit": b.get("unit"), "cores": b.get("cores"), "kind": b.get("kind"), "sample": _short(b.get("sample", ""), 150)}
+    if out.get("end_to_end") and "wall_s" in out["end_to_end"]:
+        c["end_to_end_wall_s"] = out["end_to_end"]["wall_s"]
+    rows = []
+    for w in out.get("workloads", []):
+        r = w.get("roofline") or {}
+        row = {"workload": _short(w.get("workload", ""), 48), "value": w.get("value"), "ms_per_step": w.get("ms_per_step"),
+               "kernel_ms": (w.get("kernel") or {}).get("avg_ms"), "frac": _num(r.get("frac")),
+               "traffic_ratio": round(r["traffic"] / r["algorithmic_bytes"], 3) if r.get("traffic") and r.get("algorithmic_bytes") else None,
+               "rmse": _num(w.get("rmse_vs_oracle"), 3) if w.get("rmse_vs_oracle") is not None else None}
+        if w.get("scaling"):
+            row["scaling"] = w["scaling"]
+        if w.get("cpu_baseline"):
+            row["cpu"] = w["cpu_baseline"].get("value")
+            row["cpu_kind"] = w["cpu_baseline"].get("kind")
+        rows.append(row)
+    if rows:
+        c["workloads"] = rows
+    if out.get("film_exchange"):
+        c["film_exchange"] = _short(out["film_exchange"], 120)
+    if full_path:
+        c["full_record"] = full_path
+    line = json.dumps(c, separators=(",", ":"))
+    # belt and braces: shed the optional parts, least important first, until the line fits
+    for drop in ("sampler_note", "roofline_valu", "end_to_end_wall_s", "value_incl_d2h", "full_record"):
+        if len(line) <= FINAL_LINE_MAX:
+            break
+        c.pop(drop, None)
+        line = json.dumps(c, separators=(",", ":"))
+    while len(line) > FINAL_LINE_MAX and c.get("workloads"):
+        c["workloads"].pop()
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= FINAL_LINE_MAX, len(line)
+    return line
+
+
+def emit(out):
+    """Full record first (its own stdout line + gpurun_out/bench_full.json when writable), the compact line LAST."""
+    full_path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        full_path = os.path.join("gpurun_out", "bench_full.json")
+        with open(os.path.join(ROOT, full_path), "w") as f:
+            json.dump(out, f)
+    except OSError:
+        full_path = None
+    print("BENCH_FULL " + json.dumps(out))
+    sys.stdout.flush()
+    print(compact_line(out, full_path))
+    sys.stdout.flush()
 
 
 def main():
@@ -672,7 +804,7 @@ def main():
                 o, sc_w, _ = measure(args, w, 0, min(st, args.steps), min(wu, args.warmup), world, rank, local, dist, torch, comm)
                 extras.append({k: o[k] for k in ("value", "value_incl_d2h", "unit", "steps", "ms_per_step", "config", "kernel", "setup_s", "rmse_vs_oracle", "verify", "work", "roofline", "roofline_valu") if k in o})
                 extras[-1]["workload"] = w
-                if w == "metal" and not args.no_cpu_baseline:   # configs[4]'s own CPU line: pbrt-v2 (OpenEXR build) on metal.pbrt at 4K
+                if w in ("metal", "anim", "soup") and not args.no_cpu_baseline:   # configs[2] / [3] / [4]: pbrt-v2's own multithreaded CPU path on the same frame, in the same run (north_star)
                     ref = cpu_baseline_reference(w, sc_w)
                     extras[-1]["cpu_baseline"] = ref or cpu_baseline_port(sc_w)
             # the widenings of SURVEY.md §8f on the north-star scene, one short line each: killeroo-simple.pbrt as shipped (DirectLightingIntegrator, 8
@@ -705,7 +837,7 @@ def main():
             e2e = end_to_end_pbrt_hip(workload, scene)
             if e2e:
                 out["end_to_end"] = e2e
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

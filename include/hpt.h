@@ -333,7 +333,7 @@ typedef struct hpt_stats {
                                 * traversal, 2 = 3 waves/SIMD, 3 / 4 = 4 / 3 waves with the wave's lanes in lock
                                 * step (extension, shadow, MIS phases), 5 / 6 = 3 / 4 + idle lanes steal subtrees from the wave's long rays; picked per scene by a probe render,
                                 * HPT_TUNE=<n> pins it.  All configurations compute the same film. */
-    uint32_t pad;
+    uint32_t scratch_bytes;    /* private (scratch) memory per lane of the kernel that ran: its register spills (was padding before round 4) */
 } hpt_stats;
 
 typedef struct hpt_scene_info {
@@ -433,7 +433,11 @@ int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_render_desc 
 /* hpt_comm: one PROCESS per GPU (bench.py under torch.distributed.run; any launcher that can hand 128 bytes from rank 0 to the others).
  * hpt_comm_unique_id on rank 0 (ncclGetUniqueId), hpt_comm_create everywhere (ncclCommInitRank, collective), then after every
  * hpt_render_device of the rank's shard: hpt_comm_exchange_film on the same stream (asynchronous like an RCCL call) — afterwards rank 0's
- * d_film_xyzw holds the whole frame.  wide_filter != 0: the scene has a filter set (sum-reduce instead of the tile gather). */
+ * d_film_xyzw holds the whole frame.  wide_filter != 0: the scene has a filter set (sum-reduce instead of the tile gather).
+ * Transport: RCCL (ncclSend / ncclRecv / ncclReduce over xGMI) by default.  With HPT_COMM_TRANSPORT=host in rank 0's environment
+ * hpt_comm_unique_id returns an id that names POSIX shared-memory mailboxes instead, and every rank created from that id moves its packed
+ * tiles (or its film, wide filter) through them with hipMemcpy — the same pack / unpack / sum kernels and tile bookkeeping; blocking.  For
+ * hosts without RCCL and for running several ranks on ONE device, which RCCL refuses (round 4; tests/test_gpu_multi.py). */
 typedef struct hpt_comm hpt_comm;
 int hpt_comm_unique_id(void *out_128_bytes);
 hpt_comm *hpt_comm_create(const void *id_128_bytes, int rank, int world, int device);
@@ -471,6 +475,9 @@ int hpt_test_sampler(const hpt_render_desc *rd, int x, int y, float *out /* spp*
  * achieved-peak too").  float4 triad a = b + s * c over three arrays of bytes_per_array each (pass >= 1 GiB: far beyond the 256 MiB
  * Infinity Cache), best of `reps` launches; *gb_per_s = 3 * bytes_per_array / time.  bench.py reports it as roofline.achieved_peak. */
 int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps, double *gb_per_s);
+/* the same harness as a float4 COPY (a = b; MI355X_MICROARCH.md's own calibration: 6.29 TB/s) and as a float4 READ (sum of b): round 4 */
+int hpt_calib_hbm_copy(int device, size_t bytes_per_array, int reps, double *gb_per_s);
+int hpt_calib_hbm_read(int device, size_t bytes_per_array, int reps, double *gb_per_s);
 
 /* Bytes of one BVH node fetch of the walk that hpt_stats.nodes_visited counts (count_work): 64 — the BVH2 node with both children's
  * boxes — or 128 when this build's lock-step + stealing walk runs on the four-wide trees (two 64-byte lines per node). */

@@ -237,7 +237,7 @@ class Stats(C.Structure):
                 ("shadow_rays", u64), ("nodes_visited", u64), ("tris_tested", u64),
                 ("bad_samples", u64), ("resident_waves", u32), ("grid_blocks", u32),
                 ("block_threads", u32), ("vgprs", u32),
-                ("tune_cfg", u32), ("pad", u32)]
+                ("tune_cfg", u32), ("scratch_bytes", u32)]
 
 
 class SceneInfo(C.Structure):

@@ -79,8 +79,8 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
 // ---- on-disk cache of the kernel configuration ----------------------------------------------------------------------------------
 // hpt_scene_tune times every configuration on a probe of the frame: 0.13-1.6 s per scene (profiles/r03_*), a large share of a sub-second
 // render in a fresh process (pbrt_hip).  Which configuration wins is a property of (scene, view, job shape, device, this build of the
-// kernels), so the choice is remembered under $HPT_TUNE_CACHE (a directory; default $XDG_CACHE_HOME/hpt or ~/.cache/hpt; "0" / "off"
-// disables) in a file named by a hash of exactly those: counts and a strided sample of the scene's pools, camera, frame / sampler /
+// kernels), so the choice is remembered under $HPT_TUNE_CACHE (a directory the HOST names; unset, "0" or "off": no cache, nothing is written)
+// in a file named by a hash of exactly those: counts and a strided sample of the scene's pools, camera, frame / sampler /
 // integrator of the job, device name and CU count, size and mtime of the library file itself.  A stale or foreign entry can only cost
 // speed, never change an image (every configuration renders the same film).
 static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
@@ -103,6 +103,7 @@ static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name,
     if (d->n_materials) h = fnv1a(h, d->materials, sizeof(hpt_material) * (size_t)d->n_materials);
     if (d->n_lights) h = fnv1a(h, d->lights, sizeof(hpt_light) * (size_t)d->n_lights);
     if (d->n_instances) h = fnv1a(h, d->instances, sizeof(hpt_instance) * (size_t)d->n_instances);
+    if (d->n_textures) h = fnv1a(h, d->textures, sizeof(hpt_texture) * (size_t)d->n_textures);
     h = fnv_strided(h, d->fpool, d->n_f);
     h = fnv_strided(h, d->ipool, d->n_i);
     h = fnv1a(h, dev_name, strlen(dev_name));
@@ -120,11 +121,9 @@ static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name,
 static std::string tune_cache_path(const hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd) {
     const char *dir = getenv("HPT_TUNE_CACHE");
     if (dir && (!strcmp(dir, "0") || !strcmp(dir, "off"))) return std::string();
-    std::string base;
-    if (dir && *dir) base = dir;
-    else if (const char *x = getenv("XDG_CACHE_HOME")) base = std::string(x) + "/hpt";
-    else if (const char *hm = getenv("HOME")) base = std::string(hm) + "/.cache/hpt";
-    else return std::string();
+    // OPT-IN since round 4: a rendering library does not write under $HOME unasked.  The host names the directory.
+    if (!dir || !*dir) return std::string();
+    const std::string base = dir;
     uint64_t h = s->content_key;
     h = fnv1a(h, cam, sizeof(*cam));
     if (s->cam_animated) h = fnv1a(h, &s->cam_xf, sizeof(s->cam_xf));
@@ -295,10 +294,11 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; ++n_inst_quadrics; }   // animated spheres / disks: the extension set's walk and shading geometry
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
     if (ext) s->mats = MATS_FULL;
-    // OPT-IN (HPT_LEAN_EXT=1): an extension-set scene that reaches none of the rare features runs the lean instantiation (MATS_LEAN, hpt_device.h;
-    // hpt_kernels_lean.hip) — no animated instances (there is no lean _i twin), no measured BRDF, no specular material, no shape-set / spot /
-    // distant light.  Not the default until it has been measured on the device.
-    if (ext && desc->n_instances == 0 && getenv("HPT_LEAN_EXT") && atoi(getenv("HPT_LEAN_EXT")) != 0) {
+    // The kernel set follows what the scene can REACH (round 4; no switch needed): an extension-set scene that reaches none of the rare features
+    // runs the lean instantiation (MATS_LEAN, hpt_device.h; hpt_kernels_lean.hip) — no animated instances (there is no lean _i twin), no measured
+    // BRDF, no specular material, no shape-set / spot / distant light.  Measured in round 3 (profiles/r03_ab.md, run Z2): metal.pbrt at 4K +4.8 %.
+    // HPT_LEAN_EXT=0 keeps the full set (A/B).
+    if (ext && desc->n_instances == 0 && !(getenv("HPT_LEAN_EXT") && atoi(getenv("HPT_LEAN_EXT")) == 0)) {
         bool rare = s->has_specular;
         for (int m = 0; m < desc->n_materials; ++m) rare = rare || desc->materials[m].kind == HPT_MAT_MEASURED_IRREG || desc->materials[m].kind == HPT_MAT_MEASURED_REGULAR;
         for (int l = 0; l < desc->n_lights; ++l)
@@ -929,7 +929,7 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
             }
             stats->bad_samples = h_scr2.wc.bad;
             stats->grid_blocks = (uint32_t)wgrid; stats->block_threads = HPT_BLOCK;
-            stats->resident_waves = (uint32_t)(wbpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)wvg;
+            stats->resident_waves = (uint32_t)(wbpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)wvg & 1023u; stats->scratch_bytes = (uint32_t)wvg >> 10;
         }
         return HPT_OK;
     }
@@ -981,7 +981,7 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
         }
         if (!getenv("HPT_PHASE_TIMERS")) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:118-131: the host plugin reports them)
         stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
-        stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs;
+        stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs & 1023u; stats->scratch_bytes = (uint32_t)vgprs >> 10;
         stats->tune_cfg = replay ? 0u : (uint32_t)cfg;
     }
     return HPT_OK;
@@ -997,6 +997,9 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
     if (rc != HPT_OK) return rc;
+    // the window samplers ("halton", "adaptive", "bestcandidate") exist as configuration 5 only (launch_path_*): nothing to race, and a probe of
+    // configurations 0-4 would size the LDS rows for kernels that never run
+    if (a.rp.sampler_kind == 3 || a.rp.adapt_min > 0 || a.rp.bc_table != nullptr) return 5;
     a.sc = s->d;
     {   // a cached answer needs no probe film (a 33 MB allocation and its release: 20 ms of a 0.4 s job)
         const int c = tune_cache_load(tune_cache_path(s, cam, rd));

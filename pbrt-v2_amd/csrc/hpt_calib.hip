@@ -17,8 +17,37 @@ __global__ __launch_bounds__(256) void hpt_triad_kernel(float4 *__restrict__ a, 
     }
 }
 
-extern "C" int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps, double *gb_per_s) {
-    if (!gb_per_s || bytes_per_array < 4096 || reps < 1) { hpt_set_error("hpt_calib_hbm_triad: bad argument"); return HPT_E_INVALID; }
+// round 4: the triad undershoots what the box can stream (4.9-5.0 TB/s against the 6.29 TB/s MI355X_MICROARCH.md measures with a
+// float4 copy), which flattered `frac_of_achieved_peak`.  Two more shapes of the same harness: a float4 COPY (a = b: the guide's calibration,
+// one read + one write stream) and a float4 READ (a grid-stride sum: what the path kernel's traffic mostly is — node and triangle fetches —
+// with one store per workgroup).  Each workgroup owns a CONTIGUOUS slice (no grid-stride interleave: one DRAM page stream per workgroup).
+__global__ __launch_bounds__(256) void hpt_copy_kernel(float4 *__restrict__ a, const float4 *__restrict__ b, size_t n) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = (size_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    size_t i = i0 + threadIdx.x;
+    for (; i + 3 * 256 < i1; i += 4 * 256) {                  // four 16-B loads in flight per lane before the first store
+        const float4 x0 = b[i], x1 = b[i + 256], x2 = b[i + 512], x3 = b[i + 768];
+        a[i] = x0; a[i + 256] = x1; a[i + 512] = x2; a[i + 768] = x3;
+    }
+    for (; i < i1; i += 256) a[i] = b[i];
+}
+__global__ __launch_bounds__(256) void hpt_read_kernel(float4 *__restrict__ a, const float4 *__restrict__ b, size_t n) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = (size_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t i = i0 + threadIdx.x;
+    for (; i + 3 * 256 < i1; i += 4 * 256) {
+        const float4 x0 = b[i], x1 = b[i + 256], x2 = b[i + 512], x3 = b[i + 768];
+        s.x += x0.x + x1.x + x2.x + x3.x; s.y += x0.y + x1.y + x2.y + x3.y; s.z += x0.z + x1.z + x2.z + x3.z; s.w += x0.w + x1.w + x2.w + x3.w;
+    }
+    for (; i < i1; i += 256) { const float4 x = b[i]; s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w; }
+    if (s.x + s.y + s.z + s.w == 12345.678f) a[blockIdx.x * 256 + threadIdx.x] = s;      // (never true on zeroed input: keeps the loads alive)
+}
+
+static int calib_run(int device, size_t bytes_per_array, int reps, double *gb_per_s, int shape);
+extern "C" int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps, double *gb_per_s) { return calib_run(device, bytes_per_array, reps, gb_per_s, 0); }
+extern "C" int hpt_calib_hbm_copy(int device, size_t bytes_per_array, int reps, double *gb_per_s) { return calib_run(device, bytes_per_array, reps, gb_per_s, 1); }
+extern "C" int hpt_calib_hbm_read(int device, size_t bytes_per_array, int reps, double *gb_per_s) { return calib_run(device, bytes_per_array, reps, gb_per_s, 2); }
+static int calib_run(int device, size_t bytes_per_array, int reps, double *gb_per_s, int shape) {
+    if (!gb_per_s || bytes_per_array < 4096 || reps < 1) { hpt_set_error("hpt_calib_hbm_*: bad argument"); return HPT_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { hpt_set_error("no HIP device available"); return HPT_E_NODEVICE; }
     if (device < 0 || device >= ndev) { hpt_set_error("device %d out of range (have %d)", device, ndev); return HPT_E_INVALID; }
@@ -29,15 +58,18 @@ extern "C" int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps,
     float4 *buf[3] = {nullptr, nullptr, nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipSuccess;
-    for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc((void **)&buf[k], n * sizeof(float4));
-    for (int k = 1; k < 3 && e == hipSuccess; ++k) e = hipMemset(buf[k], 0, n * sizeof(float4));
+    const int narr = shape == 0 ? 3 : 2;
+    for (int k = 0; k < narr && e == hipSuccess; ++k) e = hipMalloc((void **)&buf[k], n * sizeof(float4));
+    for (int k = 0; k < narr && e == hipSuccess; ++k) e = hipMemset(buf[k], 0, n * sizeof(float4));
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     float best = 0.f;
     const int grid = prop.multiProcessorCount * 8;
     for (int r = 0; r <= reps && e == hipSuccess; ++r) {       // launch 0 warms up (page faults of the first touch)
         e = hipEventRecord(e0, nullptr);
-        if (e == hipSuccess) hipLaunchKernelGGL(hpt_triad_kernel, dim3(grid), dim3(256), 0, nullptr, buf[0], buf[1], buf[2], 0.5f, n);
+        if (e == hipSuccess && shape == 0) hipLaunchKernelGGL(hpt_triad_kernel, dim3(grid), dim3(256), 0, nullptr, buf[0], buf[1], buf[2], 0.5f, n);
+        if (e == hipSuccess && shape == 1) hipLaunchKernelGGL(hpt_copy_kernel, dim3(grid), dim3(256), 0, nullptr, buf[0], buf[1], n);
+        if (e == hipSuccess && shape == 2) hipLaunchKernelGGL(hpt_read_kernel, dim3(grid), dim3(256), 0, nullptr, buf[0], buf[1], n);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
@@ -48,7 +80,7 @@ extern "C" int hpt_calib_hbm_triad(int device, size_t bytes_per_array, int reps,
     for (int k = 0; k < 3; ++k) if (buf[k]) (void)hipFree(buf[k]);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (e != hipSuccess || best <= 0.f) { hpt_set_error("hpt_calib_hbm_triad failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
-    *gb_per_s = 3.0 * (double)(n * sizeof(float4)) / (best * 1e-3) / 1e9;
+    if (e != hipSuccess || best <= 0.f) { hpt_set_error("hpt_calib_hbm_* failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    *gb_per_s = (shape == 0 ? 3.0 : shape == 1 ? 2.0 : 1.0) * (double)(n * sizeof(float4)) / (best * 1e-3) / 1e9;
     return HPT_OK;
 }

@@ -56,7 +56,7 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
 bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
 int path_kernel_effective_cfg(int mats, int cfg);   /* the configuration that actually runs: the extension set builds 0, 5 and 6 only (HPT_LEAN_SET: 1, 2 -> 0; 3 -> 5; 4 -> 6) */
 int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
-int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);
+int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);   /* *vgprs = VGPRs | scratch bytes per lane << 10 */
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(int mats, const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream);   // second pass of the two-pass film (table filters)

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \
-        *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0;                                      \
+        *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? (fa.numRegs | ((int)fa.localSizeBytes << 10)) : 0;   /* (scratch bytes per lane above bit 10: hpt_stats.scratch_bytes) */ \
         *blocks_per_cu = nb;                                                                                        \
         return 0;                                                                                                   \
     }

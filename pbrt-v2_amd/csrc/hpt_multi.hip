@@ -20,8 +20,14 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,15 +107,86 @@ inline int local_tiles(int n_tiles, int rank, int count) { return (n_tiles - ran
 
 } // namespace
 
+// film += other (float4 per pixel): the wide-filter sum of partial films on the peer-copy path, shard after shard in rank order
+__global__ __launch_bounds__(256) void hpt_film_add_kernel(float4 *__restrict__ film, const float4 *__restrict__ other, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 a = film[i], b = other[i];
+        film[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+// ---- host-staged transport (HPT_COMM_TRANSPORT=host) ------------------------------------------------------------------------------------
+// The same exchange — same pack / unpack kernels, same tile bookkeeping, same wide-filter sum — with the hop between the processes done through
+// POSIX shared memory instead of ncclSend / ncclRecv / ncclReduce: every non-root rank owns one mailbox segment "/hpt<key>.<rank>" (header +
+// payload, created by its owner, grown on demand), copies its packed tiles (or, under a wide filter, its whole film) into it with hipMemcpy
+// and publishes the frame's sequence number; the root maps the mailboxes, waits for the sequence number, uploads the payload and
+// acknowledges, after which the owner may overwrite the mailbox.  What it is for: RCCL refuses two ranks on one device, so on a one-GPU box
+// hpt_comm's multi-rank logic could never run; with this transport two PROCESSES sharing the one device exercise it
+// (tests/test_gpu_multi.py).  It also serves hosts without RCCL.  Blocking (the call returns when this rank's part is done), unlike RCCL.
+struct HostBox {                       // one mailbox, mapped by its owner and by the root
+    struct Hdr { std::atomic<uint64_t> seq, ack, bytes; uint64_t pad[5]; };
+    int fd = -1; void *map = nullptr; size_t map_bytes = 0; std::string name; bool owner = false;
+    Hdr *hdr() const { return (Hdr *)map; }
+    char *payload() const { return (char *)map + sizeof(Hdr); }
+    void close_box() {
+        if (map) munmap(map, map_bytes);
+        if (fd >= 0) close(fd);
+        if (owner && !name.empty()) shm_unlink(name.c_str());
+        map = nullptr; fd = -1; map_bytes = 0;
+    }
+    // owner: create (or grow) to hold `payload_bytes`; root: (re)map to the segment's current size
+    bool open_box(const std::string &nm, bool own, size_t payload_bytes) {
+        name = nm; owner = own;
+        const size_t want = sizeof(Hdr) + payload_bytes;
+        if (fd < 0) {
+            fd = shm_open(nm.c_str(), own ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+            if (fd < 0) return false;
+        }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) return false;
+        size_t have = (size_t)sb.st_size;
+        if (own && have < want) { if (ftruncate(fd, (off_t)want) != 0) return false; have = want; }   // (growing keeps the header's contents)
+        if (have < sizeof(Hdr)) return false;
+        if (map && map_bytes == have) return true;
+        if (map) munmap(map, map_bytes);
+        map = mmap(nullptr, have, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (map == MAP_FAILED) { map = nullptr; return false; }
+        map_bytes = have;
+        return true;
+    }
+};
+static bool host_wait(const std::atomic<uint64_t> &v, uint64_t want, double timeout_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; v.load(std::memory_order_acquire) < want; ++spin) {
+        if ((spin & 63) == 63) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+            usleep(50);
+        } else sched_yield();
+    }
+    return true;
+}
+
 // ---- one process per GPU -----------------------------------------------------------------------------------------------------------------
 struct hpt_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     float4 *packed = nullptr; size_t packed_tiles = 0;      // send buffer (peers) / receive buffer for all peers' tiles (root)
+    // host-staged transport
+    bool host = false; std::string key; uint64_t frame = 0;
+    std::vector<HostBox> boxes;                              // non-root: [0] = its own mailbox; root: one per peer (index peer - 1)
+    void *d_stage = nullptr; size_t d_stage_bytes = 0;       // root, wide filter: a peer's film on the device while it is added
 };
+static bool comm_transport_is_host() { const char *e = getenv("HPT_COMM_TRANSPORT"); return e && !strcmp(e, "host"); }
+static double comm_timeout_s() { const char *e = getenv("HPT_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }
 
 extern "C" int hpt_comm_unique_id(void *out128) {
     if (!out128) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    if (comm_transport_is_host()) {     // the id names the mailboxes: "HPTHOST" + a key unique to this communicator
+        memset(out128, 0, 128);
+        snprintf((char *)out128, 128, "HPTHOST%08x%08x", (unsigned)getpid(), (unsigned)std::chrono::steady_clock::now().time_since_epoch().count());
+        return HPT_OK;
+    }
     Rccl *r = rccl();
     if (!r) { hpt_set_error("RCCL (librccl.so.1) is not available in this process"); return HPT_E_NODEVICE; }
     ncclUniqueId id;
@@ -119,9 +196,21 @@ extern "C" int hpt_comm_unique_id(void *out128) {
 }
 
 extern "C" hpt_comm *hpt_comm_create(const void *id128, int rank, int world, int device) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { hpt_set_error("bad communicator arguments"); return nullptr; }
+    if (!memcmp(id128, "HPTHOST", 7)) {                      // an id made by hpt_comm_unique_id under HPT_COMM_TRANSPORT=host (every rank follows the id, not its own environment)
+        if (hipSetDevice(device) != hipSuccess) { hpt_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+        hpt_comm *c = new hpt_comm();
+        c->rank = rank; c->world = world; c->device = device; c->host = true;
+        char k[32]; memset(k, 0, sizeof(k)); memcpy(k, (const char *)id128 + 7, 16);
+        c->key = std::string("/hpt") + k;
+        if (rank != 0) {                                     // the owner creates its mailbox now, so that the root finds it at the first exchange
+            c->boxes.resize(1);
+            if (!c->boxes[0].open_box(c->key + "." + std::to_string(rank), true, 4096)) { hpt_set_error("hpt_comm (host transport): shm_open(%s.%d) failed", c->key.c_str(), rank); delete c; return nullptr; }
+        } else c->boxes.resize((size_t)(world > 1 ? world - 1 : 0));
+        return c;
+    }
     Rccl *r = rccl();
     if (!r) { hpt_set_error("RCCL (librccl.so.1) is not available in this process"); return nullptr; }
-    if (!id128 || world < 1 || rank < 0 || rank >= world) { hpt_set_error("bad communicator arguments"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { hpt_set_error("hipSetDevice(%d) failed", device); return nullptr; }
     hpt_comm *c = new hpt_comm();
     c->rank = rank; c->world = world; c->device = device;
@@ -135,8 +224,43 @@ extern "C" void hpt_comm_destroy(hpt_comm *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->packed) (void)hipFree(c->packed);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    for (HostBox &b : c->boxes) b.close_box();
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     delete c;
+}
+
+// The host-staged hop of one exchange.  Non-root: `src` (device, `bytes`) -> own mailbox, publish.  Root: for each peer in rank order wait,
+// upload into dst(peer) and hand the device pointer to `consume` (unpack / add), acknowledge.
+static int host_send(hpt_comm *c, const void *d_src, size_t bytes, hipStream_t stream) {
+    HostBox &b = c->boxes[0];
+    const uint64_t f = ++c->frame;
+    if (f > 1 && !host_wait(b.hdr()->ack, f - 1, comm_timeout_s())) { hpt_set_error("hpt_comm (host transport): rank 0 did not take frame %llu of rank %d", (unsigned long long)(f - 1), c->rank); return HPT_E_HIP; }
+    if (!b.open_box(b.name, true, bytes)) { hpt_set_error("hpt_comm (host transport): cannot grow the mailbox to %zu bytes", bytes); return HPT_E_HIP; }
+    HIP_OK(hipStreamSynchronize(stream));
+    if (bytes) HIP_OK(hipMemcpy(b.payload(), d_src, bytes, hipMemcpyDeviceToHost));
+    b.hdr()->bytes.store(bytes, std::memory_order_relaxed);
+    b.hdr()->seq.store(f, std::memory_order_release);
+    return HPT_OK;
+}
+template <class F> static int host_recv_all(hpt_comm *c, F &&per_peer) {
+    const uint64_t f = ++c->frame;
+    for (int p = 1; p < c->world; ++p) {
+        HostBox &b = c->boxes[(size_t)p - 1];
+        const std::string nm = c->key + "." + std::to_string(p);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!b.open_box(nm, false, 0)) {                  // (the peer may not have created it yet)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) { hpt_set_error("hpt_comm (host transport): no mailbox %s", nm.c_str()); return HPT_E_HIP; }
+            usleep(200);
+        }
+        if (!host_wait(b.hdr()->seq, f, comm_timeout_s())) { hpt_set_error("hpt_comm (host transport): rank %d did not deliver frame %llu", p, (unsigned long long)f); return HPT_E_HIP; }
+        const size_t bytes = (size_t)b.hdr()->bytes.load(std::memory_order_relaxed);
+        if (!b.open_box(nm, false, 0) || b.map_bytes < sizeof(HostBox::Hdr) + bytes) { hpt_set_error("hpt_comm (host transport): mailbox %s is smaller than its payload", nm.c_str()); return HPT_E_HIP; }
+        const int rc = per_peer(p, b.payload(), bytes);
+        b.hdr()->ack.store(f, std::memory_order_release);
+        if (rc != HPT_OK) return rc;
+    }
+    return HPT_OK;
 }
 
 // The end-of-frame film exchange on `stream` (the stream the shard was rendered on; asynchronous, like an RCCL call).
@@ -144,13 +268,29 @@ extern "C" void hpt_comm_destroy(hpt_comm *c) {
 extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film, void *stream_v, int wide_filter) {
     if (!c || !rd || !d_film) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (c->world == 1) return HPT_OK;
-    Rccl *r = rccl();
+    Rccl *r = c->host ? nullptr : rccl();
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_OK(hipSetDevice(c->device));
     const size_t n_floats = (size_t)rd->x_count * rd->y_count * 4;
     // Sampler "halton" on a pixel extent that does not start on the global 32x32 grid: a shard's windows are not its film tiles — sum as well
     if (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_HALTON_HASH && ((rd->x_start | rd->y_start) & 31)) wide_filter = 1;
     if (HPT_SAMPLER_KIND(rd->sampler_mode) == HPT_SAMPLER_BESTCANDIDATE_HASH) wide_filter = 1;   // Sampler "bestcandidate": the shards are table tiles, not film tiles
+    if (wide_filter && c->host) {                        // host-staged sum: the peers' films added on the root's device, in rank order
+        if (c->rank != 0) return host_send(c, d_film, n_floats * sizeof(float), stream);
+        if (c->d_stage_bytes < n_floats * sizeof(float)) {
+            if (c->d_stage) (void)hipFree(c->d_stage);
+            c->d_stage = nullptr; c->d_stage_bytes = 0;
+            HIP_OK(hipMalloc(&c->d_stage, n_floats * sizeof(float)));
+            c->d_stage_bytes = n_floats * sizeof(float);
+        }
+        return host_recv_all(c, [&](int, const char *payload, size_t bytes) -> int {
+            if (bytes != n_floats * sizeof(float)) { hpt_set_error("hpt_comm (host transport): a peer's film has %zu bytes, expected %zu", bytes, n_floats * sizeof(float)); return HPT_E_INVALID; }
+            HIP_OK(hipMemcpyAsync(c->d_stage, payload, bytes, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(hpt_film_add_kernel, dim3(1024), dim3(256), 0, stream, (float4 *)d_film, (const float4 *)c->d_stage, n_floats / 4);
+            HIP_OK(hipStreamSynchronize(stream));            // the mailbox is released (acknowledged) when its bytes are on the device
+            return HPT_OK;
+        });
+    }
     if (wide_filter) {                                   // partial sums over the whole frame: one sum-reduce to rank 0
         NCCL_OK(r->Reduce(d_film, d_film, n_floats, ncclFloat32, ncclSum, 0, c->comm, stream));
         return HPT_OK;
@@ -166,19 +306,32 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     if (c->rank != 0) {
         const int mine = local_tiles(n_tiles, c->rank, c->world);
         if (mine > 0) hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, stream, (const float4 *)d_film, c->packed, rd->x_count, rd->y_count, n_stx, n_tiles, c->rank, c->world);
+        if (c->host) return host_send(c, c->packed, (size_t)mine * 1024 * sizeof(float4), stream);
         NCCL_OK(r->GroupStart());
         if (mine > 0) NCCL_OK(r->Send(c->packed, (size_t)mine * 4096, ncclFloat32, 0, c->comm, stream));
         NCCL_OK(r->GroupEnd());
         return HPT_OK;
     }
-    NCCL_OK(r->GroupStart());
     size_t off = 0;
-    for (int p = 1; p < c->world; ++p) {
-        const int n = local_tiles(n_tiles, p, c->world);
-        if (n > 0) NCCL_OK(r->Recv(c->packed + off * 1024, (size_t)n * 4096, ncclFloat32, p, c->comm, stream));
-        off += (size_t)n;
+    if (c->host) {
+        HIP_OK(hipStreamSynchronize(stream));               // (the receive buffer may still be read by the previous frame's unpack kernels)
+        const int rc = host_recv_all(c, [&](int p, const char *payload, size_t bytes) -> int {
+            const int n = local_tiles(n_tiles, p, c->world);
+            if (bytes != (size_t)n * 1024 * sizeof(float4)) { hpt_set_error("hpt_comm (host transport): rank %d sent %zu bytes for %d tiles", p, bytes, n); return HPT_E_INVALID; }
+            if (n > 0) HIP_OK(hipMemcpy(c->packed + off * 1024, payload, bytes, hipMemcpyHostToDevice));
+            off += (size_t)n;
+            return HPT_OK;
+        });
+        if (rc != HPT_OK) return rc;
+    } else {
+        NCCL_OK(r->GroupStart());
+        for (int p = 1; p < c->world; ++p) {
+            const int n = local_tiles(n_tiles, p, c->world);
+            if (n > 0) NCCL_OK(r->Recv(c->packed + off * 1024, (size_t)n * 4096, ncclFloat32, p, c->comm, stream));
+            off += (size_t)n;
+        }
+        NCCL_OK(r->GroupEnd());
     }
-    NCCL_OK(r->GroupEnd());
     off = 0;
     for (int p = 1; p < c->world; ++p) {
         const int n = local_tiles(n_tiles, p, c->world);
@@ -189,14 +342,6 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     return HPT_OK;
 }
 
-// film += other (float4 per pixel): the wide-filter sum of partial films on the peer-copy path, shard after shard in rank order
-__global__ __launch_bounds__(256) void hpt_film_add_kernel(float4 *__restrict__ film, const float4 *__restrict__ other, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 a = film[i], b = other[i];
-        film[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
-}
 
 // ---- one process, one host thread per GPU -----------------------------------------------------------------------------------------------------
 struct hpt_multi {

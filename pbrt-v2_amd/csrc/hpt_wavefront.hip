@@ -218,7 +218,7 @@ int wf_trace_occupancy(bool inst, int bvh_depth, int *blocks_per_cu, int *vgprs)
     if (e != hipSuccess) return -1;
     hipFuncAttributes fa;
     const void *fn = inst ? (const void *)wf_trace_kernel<false, true> : (const void *)wf_trace_kernel<false, false>;
-    *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0;
+    *vgprs = hipFuncGetAttributes(&fa, fn) == hipSuccess ? (fa.numRegs | ((int)fa.localSizeBytes << 10)) : 0;
     *blocks_per_cu = nb;
     return 0;
 }

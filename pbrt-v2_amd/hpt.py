@@ -23,7 +23,7 @@ EXPORTS = [
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
-    "hpt_calib_hbm_triad", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
+    "hpt_calib_hbm_triad", "hpt_calib_hbm_copy", "hpt_calib_hbm_read", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
     "hpt_scene_set_sample_table", "hpt_multi_set_sample_table", "hpt_multi_chunks_taken",
 ]
 
@@ -79,7 +79,8 @@ def lib():
         L.hpt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.hpt_comm_destroy.argtypes = [C.c_void_p]
         L.hpt_comm_exchange_film.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int]
-        L.hpt_calib_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        for f in (L.hpt_calib_hbm_triad, L.hpt_calib_hbm_copy, L.hpt_calib_hbm_read):
+            f.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.hpt_abi_sizes.argtypes = [C.c_void_p]
         sizes = (C.c_int32 * 10)()
         L.hpt_abi_sizes(sizes)
@@ -277,6 +278,20 @@ def hbm_triad(device=0, bytes_per_array=1 << 30, reps=5):
     """Achieved-peak HBM bandwidth of `device` in GB/s (hpt_calib_hbm_triad: float4 triad over 3 x bytes_per_array)."""
     v = C.c_double(0.0)
     _check(lib().hpt_calib_hbm_triad(device, bytes_per_array, reps, C.byref(v)))
+    return float(v.value)
+
+
+def hbm_copy(device=0, bytes_per_array=1 << 30, reps=5):
+    """float4 copy (read + write streams counted): the calibration MI355X_MICROARCH.md quotes (6.29 TB/s)"""
+    v = C.c_double(0.0)
+    _check(lib().hpt_calib_hbm_copy(device, bytes_per_array, reps, C.byref(v)))
+    return float(v.value)
+
+
+def hbm_read(device=0, bytes_per_array=1 << 30, reps=5):
+    """float4 read-only stream: the shape of the path kernel's traffic (node / triangle fetches)"""
+    v = C.c_double(0.0)
+    _check(lib().hpt_calib_hbm_read(device, bytes_per_array, reps, C.byref(v)))
     return float(v.value)
 
 

@@ -2,7 +2,7 @@
 # Round 3, run P: start time of the HIP runtime in a fresh process: back to back, after pauses, and with a few runtime switches.
 cd "$(dirname "$0")/.."
 O=gpurun_out/r03_p; mkdir -p $O
-B=scripts/calib/hip_init_time
+B=scripts/calib/_build/hip_init_time; mkdir -p scripts/calib/_build; [ -x $B ] || /opt/rocm/bin/hipcc -O2 scripts/calib/hip_init_time.cpp -o $B
 {
 echo "== back to back"; for i in 1 2 3 4 5 6; do $B; done
 echo "== 1 s pause before each"; for i in 1 2 3 4; do sleep 1; $B; done

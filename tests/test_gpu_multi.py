@@ -6,8 +6,11 @@ cannot run here; what can:
     and the library-side gather (hipMemcpyAsync between the shards) — against the single-shard frame;
   * RCCL itself through the library's dlopen binding: a communicator of one rank (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy);
   * the pbrt plugin's `gpus` path end to end.
+  * hpt_comm with world = 2 and 3 as separate PROCESSES on the one device over the host-staged transport (HPT_COMM_TRANSPORT=host:
+    the library's pack kernel, tile bookkeeping, unpack / wide-filter sum; shared memory in place of ncclSend / ncclRecv / ncclReduce).
 The N > 1 RCCL exchange proper is the driver's 8-GPU run (bench.py --gpus N calls hpt_comm_exchange_film on every rank).
 """
+import sys
 import importlib
 import os
 import subprocess
@@ -143,3 +146,40 @@ def test_pbrt_binary_shards_over_gpus_end_to_end(tmp_path):
     f, st = hpt.DeviceScene(s).render(s.camera, hash_rd(s, seed=0))
     want = film.xyzw_to_rgb(f)
     assert got.shape == want.shape and film.rmse(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("case,world,wide", [("k8", 2, 0), ("b8", 3, 0), ("k8", 2, 1)])
+def test_hpt_comm_runs_with_two_processes_over_the_host_transport(case, world, wide, tmp_path):
+    """hpt_comm's multi-rank logic (csrc/hpt_multi.hip: shard bookkeeping, hpt_pack_tiles_kernel, the per-peer offsets of
+    the root's receive buffer, hpt_unpack_tiles_kernel; under a wide filter the sum of full-frame films) executed with world > 1 — one process
+    per rank, all on device 0, the hop between them through shared memory (HPT_COMM_TRANSPORT=host).  Two frames: the mailboxes are reused.
+    The gathered frame must be the single-rank frame."""
+    env = dict(os.environ, HPT_COMM_TRANSPORT="host", HPT_COMM_TIMEOUT_S="60")
+    worker = os.path.join(ROOT, "tests", "workers", "comm_rank.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), case, str(wide), "2"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    s = load_case(case)
+    dev = hpt.DeviceScene(s)
+    if wide:
+        dev.set_filter(abi.make_filter("gaussian"))
+    for k in range(2):
+        rd = hash_rd(s, seed=4 + k)
+        single, _ = dev.render(s.camera, rd)
+        got = np.load(os.path.join(str(tmp_path), "frame%d.npy" % k))
+        if wide:
+            assert np.allclose(got[..., 3], single[..., 3], rtol=3e-5, atol=2e-5)
+            assert film.rmse(film.xyzw_to_rgb(got), film.xyzw_to_rgb(single)) < 1e-4
+        else:
+            assert np.array_equal(got[..., 3], single[..., 3])
+            assert (got == single).all(axis=2).mean() > 0.999
+            assert film.rmse(film.xyzw_to_rgb(got), film.xyzw_to_rgb(single)) < 1e-5

@@ -973,6 +973,21 @@ def test_round2_features_match_oracle_sample_for_sample(name):
         assert st2.tune_cfg == cfg and np.array_equal(f[..., 3], ref[..., 3]) and film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(ref)) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "on"])
+def test_kernel_set_picked_by_scene_features_renders_the_full_sets_film(name, monkeypatch):
+    """Round 4: hpt_scene_create picks the kernel instantiation from what the scene can reach — an extension-set scene without measured /
+    specular materials, shape-set / spot / distant lights and animated instances runs the LEAN set (csrc/hpt_kernels_lean.hip, MATS_LEAN).
+    Same lane state machine minus unreachable code: the film must be the full set's (HPT_LEAN_EXT=0), weights identical."""
+    s = load_case(name)
+    rd = hash_rd(s, seed=5)
+    f_lean, st = hpt.DeviceScene(s).render(s.camera, rd)
+    monkeypatch.setenv("HPT_LEAN_EXT", "0")
+    f_full, st_full = hpt.DeviceScene(s).render(s.camera, rd)
+    assert np.array_equal(f_lean[..., 3], f_full[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(f_lean), film.xyzw_to_rgb(f_full)) < 1e-5
+    assert st.bad_samples == 0 and st_full.bad_samples == 0
+
+
 @pytest.mark.parametrize("name,material", [("on", 1), ("on", 2), ("spec", 1), ("spec", 2), ("spec", 4), ("merl", 0), ("tex", 2), ("tex", 3)])
 def test_round2_bsdfs_match_oracle(name, material):
     s = load_case(name)
