@@ -69,6 +69,10 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
     const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
     a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
     if (a->retrace_min < 1) a->retrace_min = 1;
+    const char *rg = getenv("HPT_REGEN_MIN");
+    a->regen_min = rg ? atoi(rg) : 1;
+    if (a->regen_min < 1) a->regen_min = 1;
+    if (a->regen_min > 64) a->regen_min = 64;
     const char *lq = getenv("HPT_LEAF_Q"), *bq = getenv("HPT_LEAF_BLOCK_Q");     // eighths of the busy lanes (0: the leaf half runs every step, as before round 2)
     // a BVH that does not fit the caches (> 64 MB of nodes + triangle records: the 1 M-triangle soup) prefers earlier leaf phases — its node
     // steps wait for HBM, parked leaves pile up behind them — : same-box 2/1 against 4/8: soup 303 vs 296, the 7 MB scenes 1483 vs 1514 (bunny)

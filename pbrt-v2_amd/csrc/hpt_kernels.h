@@ -26,6 +26,9 @@ struct PathKernelArgs {
     // lock step + stealing: when at least retrace_min lanes' extension rays escaped, those lanes finish their path, take their next camera ray
     // and the wave walks again (at most retrace_max times per round) before it shades, so the shading block runs with more of its lanes
     int32_t retrace_min, retrace_max;
+    // lanes whose camera sample is complete wait (as subtree thieves) until regen_min lanes of their wave have finished before the wave runs
+    // finish_path + refill + camera-ray set-up for all of them at once (1: every round, the behaviour up to round 3)
+    int32_t regen_min;
     // lock step + stealing: the wave runs the leaf half of the walk when leaf_q eighths of its busy lanes have a leaf parked, or block_q eighths
     // can do nothing else (traverse_steal)
     int32_t leaf_q, block_q;

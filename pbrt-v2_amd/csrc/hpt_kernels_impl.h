@@ -425,7 +425,15 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     pend.prim = -1; pend.t = 0.f; pend.b1 = 0.f; pend.b2 = 0.f; pend.inst = -1;
     for (;;) {
         // ---- camera samples completed in the last round: to the film, next sample (the one place finish_path is compiled in) ----
-        lane.flush(rp, a.film, COUNT ? &wc : nullptr);
+        // Batched (round 4, regen_min): finish_path + the refill + the first camera ray are ~1.5 k instructions that used to run in every round
+        // with the handful of lanes that had just ended a path (and, with animated instances, two AnimatedTransform interpolations behind
+        // them).  A lane that has finished now WAITS — as a subtree thief in the walks — until regen_min lanes of the wave have finished,
+        // or nobody else is left to wait for.
+        {
+            const unsigned long long mfin = __ballot(lane.fin);
+            if (mfin != 0ull && (__popcll(mfin) >= a.regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull))
+                lane.flush(rp, a.film, COUNT ? &wc : nullptr);
+        }
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
         // Eight queue heads, one per XCD: the dispatcher is observed to put workgroup b on XCD b % 8 (a speed assumption only),
         // each XCD has its own 4 MiB L2, and head k hands out the k-th eighth of the frame's 32x32 tiles (all their sample
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             }
             if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }
-        const bool active = lane.stage != ST_IDLE;
+        const bool active = lane.stage != ST_IDLE && !lane.fin;      // (a finished lane waiting for its flush is idle)
         if (INST && xf_col && active && lane.time != xf_time) {
             xf_time = lane.time;
             for (int k = 0; k < sc.n_instances; ++k) {
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
             // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
-            const int my_phase = (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : (MERGE && lane.stage == ST_MIS) ? (int)ST_SHADOW : lane.stage;
+            const int my_phase = !active ? (int)ST_IDLE : (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : (MERGE && lane.stage == ST_MIS) ? (int)ST_SHADOW : lane.stage;
             while (__ballot(my_phase == phase) == 0ull) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
@@ -488,7 +496,8 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 // ray now (flush at the top of the loop; idle lanes pull new work there too) and the wave walks once more — the lanes that
                 // did hit keep their Hit and help as subtree thieves — so that the shading block below runs with more of the wave.
                 const bool miss = tr && hit.prim < 0;
-                if (retraced < a.retrace_max && __popcll(__ballot(miss)) >= a.retrace_min) {
+                const int n_miss = __popcll(__ballot(miss));
+                if (retraced < a.retrace_max && n_miss >= a.retrace_min && n_miss + __popcll(__ballot(lane.fin)) >= a.regen_min) {   // (the escaped lanes must get their flush at the top of the loop, or the re-walk has nobody to walk for)
                     if (miss) lane.extend_miss(sc, rp, a.film, COUNT ? &wc : nullptr);
                     else if (tr) { pend = hit; has_pend = true; }
                     ++retraced;

@@ -82,25 +82,62 @@ Rccl *rccl() {
 
 // ---- tiles <-> packed buffer -------------------------------------------------------------------------------------------------------
 // Shard `rank` of `count` owns the 32x32 super-tiles t = rank, rank + count, ... of the n_stx x n_sty grid over the film; its k-th tile
-// sits at floats [k * 4096, (k + 1) * 4096) of the packed buffer (pixels row-major inside the tile, pixels beyond the film's edge unused).
+// sits at float4s [k * HPT_TILE_PX, (k + 1) * HPT_TILE_PX) of the packed buffer.
+// Round 4: a tile record is 34 x 34 — the tile AND a one-pixel apron.  A camera sample whose image coordinate is an exact integer lands in
+// two pixels (ImageFilm::AddSample under the box filter, film/image.cpp:82-89; 1.2e-4 of the samples); when the second pixel belongs to a
+// tile of ANOTHER shard the contribution sits in the rendering shard's film, outside its own tiles, and a gather of 32 x 32 tiles lost it
+// (found by the two-process host-transport test: film weights of a 3-shard frame one short in single pixels).  The apron carries it: an
+// apron pixel q (in tile B, not this shard's) is included by exactly ONE of this shard's tiles around B — the first in the order left,
+// right, up, down, up-left, up-right, down-left, down-right of B whose apron contains q and which this shard owns — and the root ADDS the
+// records into its film (its own film holds its own spills there, zeros otherwise).  +13 % bytes, an exact frame.
+#define HPT_TILE_W 34
+#define HPT_TILE_PX (HPT_TILE_W * HPT_TILE_W)
+__device__ __forceinline__ bool apron_carrier_is(int bx, int by, int u, int v, int n_stx, int n_sty, int rank, int count, int want_dx, int want_dy) {
+    // neighbours of tile B = (bx, by) whose apron contains B's pixel (u, v), in priority order; true iff the first one owned by `rank` is (want_dx, want_dy)
+    const int dxs[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dys[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    for (int i = 0; i < 8; ++i) {
+        const int dx = dxs[i], dy = dys[i];
+        if ((dx < 0 && u != 0) || (dx > 0 && u != 31) || (dy < 0 && v != 0) || (dy > 0 && v != 31)) continue;
+        const int tx = bx + dx, ty = by + dy;
+        if (tx < 0 || ty < 0 || tx >= n_stx || ty >= n_sty) continue;
+        if ((ty * n_stx + tx) % count != rank) continue;
+        return dx == want_dx && dy == want_dy;
+    }
+    return false;
+}
 __global__ void hpt_pack_tiles_kernel(const float4 *film, float4 *packed, int x_count, int y_count, int n_stx, int n_tiles, int rank, int count) {
     const int k = blockIdx.x;                         // local tile
     const int t = k * count + rank;
     if (t >= n_tiles) return;
-    const int x0 = (t % n_stx) * 32, y0 = (t / n_stx) * 32;
-    for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
-        const int x = x0 + (p & 31), y = y0 + (p >> 5);
-        packed[(size_t)k * 1024 + p] = (x < x_count && y < y_count) ? film[(size_t)y * x_count + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ax = t % n_stx, ay = t / n_stx, x0 = ax * 32, y0 = ay * 32, n_sty = n_tiles / n_stx;
+    for (int p = threadIdx.x; p < HPT_TILE_PX; p += blockDim.x) {
+        const int lx = p % HPT_TILE_W - 1, ly = p / HPT_TILE_W - 1;
+        const int x = x0 + lx, y = y0 + ly;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 0 && y >= 0 && x < x_count && y < y_count) {
+            if (lx >= 0 && lx < 32 && ly >= 0 && ly < 32) val = film[(size_t)y * x_count + x];
+            else {
+                const int bx = x >> 5, by = y >> 5;
+                if ((by * n_stx + bx) % count != rank && apron_carrier_is(bx, by, x & 31, y & 31, n_stx, n_sty, rank, count, ax - bx, ay - by))
+                    val = film[(size_t)y * x_count + x];
+            }
+        }
+        packed[(size_t)k * HPT_TILE_PX + p] = val;
     }
 }
+// the root ADDS a peer's records (atomically: aprons of one launch overlap each other and other tiles' interiors)
 __global__ void hpt_unpack_tiles_kernel(float4 *film, const float4 *packed, int x_count, int y_count, int n_stx, int n_tiles, int rank, int count) {
     const int k = blockIdx.x;
     const int t = k * count + rank;
     if (t >= n_tiles) return;
     const int x0 = (t % n_stx) * 32, y0 = (t / n_stx) * 32;
-    for (int p = threadIdx.x; p < 1024; p += blockDim.x) {
-        const int x = x0 + (p & 31), y = y0 + (p >> 5);
-        if (x < x_count && y < y_count) film[(size_t)y * x_count + x] = packed[(size_t)k * 1024 + p];
+    for (int p = threadIdx.x; p < HPT_TILE_PX; p += blockDim.x) {
+        const int x = x0 + p % HPT_TILE_W - 1, y = y0 + p / HPT_TILE_W - 1;
+        if (x < 0 || y < 0 || x >= x_count || y >= y_count) continue;
+        const float4 v = packed[(size_t)k * HPT_TILE_PX + p];
+        if (v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f) continue;
+        float *f = (float *)&film[(size_t)y * x_count + x];
+        unsafeAtomicAdd(f + 0, v.x); unsafeAtomicAdd(f + 1, v.y); unsafeAtomicAdd(f + 2, v.z); unsafeAtomicAdd(f + 3, v.w);
     }
 }
 inline int local_tiles(int n_tiles, int rank, int count) { return (n_tiles - rank + count - 1) / count; }
@@ -300,15 +337,15 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     if (c->packed_tiles < need) {
         if (c->packed) (void)hipFree(c->packed);
         c->packed = nullptr; c->packed_tiles = 0;
-        HIP_OK(hipMalloc((void **)&c->packed, need * 1024 * sizeof(float4)));
+        HIP_OK(hipMalloc((void **)&c->packed, need * HPT_TILE_PX * sizeof(float4)));
         c->packed_tiles = need;
     }
     if (c->rank != 0) {
         const int mine = local_tiles(n_tiles, c->rank, c->world);
         if (mine > 0) hipLaunchKernelGGL(hpt_pack_tiles_kernel, dim3(mine), dim3(256), 0, stream, (const float4 *)d_film, c->packed, rd->x_count, rd->y_count, n_stx, n_tiles, c->rank, c->world);
-        if (c->host) return host_send(c, c->packed, (size_t)mine * 1024 * sizeof(float4), stream);
+        if (c->host) return host_send(c, c->packed, (size_t)mine * HPT_TILE_PX * sizeof(float4), stream);
         NCCL_OK(r->GroupStart());
-        if (mine > 0) NCCL_OK(r->Send(c->packed, (size_t)mine * 4096, ncclFloat32, 0, c->comm, stream));
+        if (mine > 0) NCCL_OK(r->Send(c->packed, (size_t)mine * HPT_TILE_PX * 4, ncclFloat32, 0, c->comm, stream));
         NCCL_OK(r->GroupEnd());
         return HPT_OK;
     }
@@ -317,8 +354,8 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
         HIP_OK(hipStreamSynchronize(stream));               // (the receive buffer may still be read by the previous frame's unpack kernels)
         const int rc = host_recv_all(c, [&](int p, const char *payload, size_t bytes) -> int {
             const int n = local_tiles(n_tiles, p, c->world);
-            if (bytes != (size_t)n * 1024 * sizeof(float4)) { hpt_set_error("hpt_comm (host transport): rank %d sent %zu bytes for %d tiles", p, bytes, n); return HPT_E_INVALID; }
-            if (n > 0) HIP_OK(hipMemcpy(c->packed + off * 1024, payload, bytes, hipMemcpyHostToDevice));
+            if (bytes != (size_t)n * HPT_TILE_PX * sizeof(float4)) { hpt_set_error("hpt_comm (host transport): rank %d sent %zu bytes for %d tiles", p, bytes, n); return HPT_E_INVALID; }
+            if (n > 0) HIP_OK(hipMemcpy(c->packed + off * HPT_TILE_PX, payload, bytes, hipMemcpyHostToDevice));
             off += (size_t)n;
             return HPT_OK;
         });
@@ -327,7 +364,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
         NCCL_OK(r->GroupStart());
         for (int p = 1; p < c->world; ++p) {
             const int n = local_tiles(n_tiles, p, c->world);
-            if (n > 0) NCCL_OK(r->Recv(c->packed + off * 1024, (size_t)n * 4096, ncclFloat32, p, c->comm, stream));
+            if (n > 0) NCCL_OK(r->Recv(c->packed + off * HPT_TILE_PX, (size_t)n * HPT_TILE_PX * 4, ncclFloat32, p, c->comm, stream));
             off += (size_t)n;
         }
         NCCL_OK(r->GroupEnd());
@@ -335,7 +372,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     off = 0;
     for (int p = 1; p < c->world; ++p) {
         const int n = local_tiles(n_tiles, p, c->world);
-        if (n > 0) hipLaunchKernelGGL(hpt_unpack_tiles_kernel, dim3(n), dim3(256), 0, stream, (float4 *)d_film, c->packed + off * 1024, rd->x_count, rd->y_count, n_stx, n_tiles, p, c->world);
+        if (n > 0) hipLaunchKernelGGL(hpt_unpack_tiles_kernel, dim3(n), dim3(256), 0, stream, (float4 *)d_film, c->packed + off * HPT_TILE_PX, rd->x_count, rd->y_count, n_stx, n_tiles, p, c->world);
         off += (size_t)n;
     }
     HIP_OK(hipGetLastError());
@@ -470,8 +507,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
             m->films[(size_t)i] = nullptr; m->packed[(size_t)i] = nullptr; m->recv[(size_t)i] = nullptr;
             HIP_OK(hipMalloc(&m->films[(size_t)i], bytes));
             const size_t mine = (size_t)local_tiles(n_tiles, i, n);
-            if (i > 0 && mine > 0) HIP_OK(hipMalloc((void **)&m->packed[(size_t)i], mine * 1024 * sizeof(float4)));
-            if (i > 0 && mine > 0) { HIP_OK(hipSetDevice(m->devices[0])); HIP_OK(hipMalloc((void **)&m->recv[(size_t)i], mine * 1024 * sizeof(float4))); }
+            if (i > 0 && mine > 0) HIP_OK(hipMalloc((void **)&m->packed[(size_t)i], mine * HPT_TILE_PX * sizeof(float4)));
+            if (i > 0 && mine > 0) { HIP_OK(hipSetDevice(m->devices[0])); HIP_OK(hipMalloc((void **)&m->recv[(size_t)i], mine * HPT_TILE_PX * sizeof(float4))); }
         }
         m->film_bytes = bytes; m->tiles_cap = (size_t)n_tiles;
     }
@@ -557,8 +594,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
                 for (int i = 1; i < n; ++i) {
                     const int mine = local_tiles(n_tiles, i, n);
                     if (mine <= 0) continue;
-                    NCCL_OK(r->Send(m->packed[(size_t)i], (size_t)mine * 4096, ncclFloat32, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
-                    NCCL_OK(r->Recv(m->recv[(size_t)i], (size_t)mine * 4096, ncclFloat32, i, m->comms[0], m->streams[0]));
+                    NCCL_OK(r->Send(m->packed[(size_t)i], (size_t)mine * HPT_TILE_PX * 4, ncclFloat32, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
+                    NCCL_OK(r->Recv(m->recv[(size_t)i], (size_t)mine * HPT_TILE_PX * 4, ncclFloat32, i, m->comms[0], m->streams[0]));
                 }
                 NCCL_OK(r->GroupEnd());
             } else {
@@ -566,8 +603,8 @@ extern "C" int hpt_multi_render(hpt_multi *m, const hpt_camera *cam, const hpt_r
                 for (int i = 1; i < n; ++i) {
                     const int mine = local_tiles(n_tiles, i, n);
                     if (mine <= 0) continue;
-                    if (m->devices[(size_t)i] == m->devices[0]) HIP_OK(hipMemcpyAsync(m->recv[(size_t)i], m->packed[(size_t)i], (size_t)mine * 1024 * sizeof(float4), hipMemcpyDeviceToDevice, m->streams[0]));
-                    else HIP_OK(hipMemcpyPeerAsync(m->recv[(size_t)i], m->devices[0], m->packed[(size_t)i], m->devices[(size_t)i], (size_t)mine * 1024 * sizeof(float4), m->streams[0]));
+                    if (m->devices[(size_t)i] == m->devices[0]) HIP_OK(hipMemcpyAsync(m->recv[(size_t)i], m->packed[(size_t)i], (size_t)mine * HPT_TILE_PX * sizeof(float4), hipMemcpyDeviceToDevice, m->streams[0]));
+                    else HIP_OK(hipMemcpyPeerAsync(m->recv[(size_t)i], m->devices[0], m->packed[(size_t)i], m->devices[(size_t)i], (size_t)mine * HPT_TILE_PX * sizeof(float4), m->streams[0]));
                 }
             }
             HIP_OK(hipSetDevice(m->devices[0]));

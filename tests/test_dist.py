@@ -84,9 +84,39 @@ def test_sharded_render_under_a_wide_filter_reduces_to_the_single_rank_film(tmp_
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
-def test_tile_roundtrip():
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_tile_records_with_aprons_carry_cross_shard_boundary_samples_exactly_once(world):
+    """Round 4 (found on the GPU by the two-process host-transport test): a camera sample on an exact pixel boundary lands in two pixels
+    (film/image.cpp:82-89); when the second pixel lies in a tile of another shard, a gather of bare 32 x 32 tiles dropped it.  Tile records
+    carry a one-pixel apron; each spilled pixel is carried by exactly ONE record of the spilling shard (apron_carrier).  Synthetic shard
+    films: own tiles filled, plus a spill into EVERY pixel adjacent (8-neighbourhood) to an own tile; the sum of the records must be the
+    sum of the films, pixel for pixel — no spill lost, none counted twice."""
     hdist = importlib.import_module("pbrt-v2_amd.dist")
-    f = torch.arange(45 * 70 * 4, dtype=torch.float32).reshape(45, 70, 4)
-    t = hdist.film_to_tiles(f)
-    assert t.shape == (2 * 3, 32 * 32 * 4)
-    assert torch.equal(hdist.tiles_to_film(t, 70, 45), f)
+    H, W = 100, 150          # 5 x 4 tiles, ragged at both edges
+    nx, ny = hdist.tile_grid(W, H)
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:H, 0:W]
+    owner = ((yy >> 5) * nx + (xx >> 5)) % world
+    total = np.zeros((H, W, 4), dtype=np.float64)
+    films = []
+    for r in range(world):
+        own = owner == r
+        near = np.zeros_like(own)                     # pixels within one pixel of an own pixel
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                sh = np.zeros_like(own)
+                ys, yd = slice(max(dy, 0), H + min(dy, 0)), slice(max(-dy, 0), H + min(-dy, 0))
+                xs, xd = slice(max(dx, 0), W + min(dx, 0)), slice(max(-dx, 0), W + min(-dx, 0))
+                sh[yd, xd] = own[ys, xs]
+                near |= sh
+        f = np.zeros((H, W, 4), dtype=np.float32)
+        vals = rng.integers(1, 9, size=(H, W, 4)).astype(np.float32)      # small integers: float sums are exact in any order
+        f[near] = vals[near]
+        films.append(f)
+        total += f
+    out = films[0].copy()
+    for r in range(1, world):
+        recs = hdist.film_to_records(films[r], r, world)
+        assert recs.shape == (len(range(r, nx * ny, world)), hdist.TW * hdist.TW * 4)
+        hdist.add_records(out, np.asarray(recs), r, world)
+    assert np.array_equal(out.astype(np.float64), total)
