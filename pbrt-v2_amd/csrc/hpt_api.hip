@@ -70,7 +70,7 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
     a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
     if (a->retrace_min < 1) a->retrace_min = 1;
     const char *rg = getenv("HPT_REGEN_MIN");
-    a->regen_min = rg ? atoi(rg) : 1;
+    a->regen_min = rg ? atoi(rg) : 16;      // same-box sweep 1 / 4 / 8 / 16 / 24 / 32 (profiles/r04_ab.md, run B): killeroo +4.2 %, anim +5.9 %, metal 4K +8.8 %, bunny +1.5 %, soup +0.7 % at 16
     if (a->regen_min < 1) a->regen_min = 1;
     if (a->regen_min > 64) a->regen_min = 64;
     const char *lq = getenv("HPT_LEAF_Q"), *bq = getenv("HPT_LEAF_BLOCK_Q");     // eighths of the busy lanes (0: the leaf half runs every step, as before round 2)
@@ -385,12 +385,15 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->d.n_inst_quadrics = n_inst_quadrics;
-    s->stack_bound4 = 0; s->depth4 = 0;
+    s->stack_bound4 = 0; s->depth4 = 0; s->d.top_root4 = -1;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
         s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);
         s->d.inst_root4 = upload(s, &arena, fs.inst_root4.data(), fs.inst_root4.size(), &ok);
         s->d.world_root4 = fs.world_root4;
-        s->stack_bound4 = fs.stack_bound4; s->depth4 = fs.depth4;
+        s->d.top_root4 = fs.top_root4;
+        // (the stealing walk starts at the top-level tree and enters the instances' trees from it: its bounds, hpt_flatten.cpp build_top_tree)
+        s->stack_bound4 = fs.top_stack_bound4 > fs.stack_bound4 ? fs.top_stack_bound4 : fs.stack_bound4;
+        s->depth4 = fs.top_depth4 > fs.depth4 ? fs.top_depth4 : fs.depth4;
     }
     s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
     if (ok && !arena_flush(&arena)) ok = false;

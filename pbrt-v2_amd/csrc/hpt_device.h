@@ -288,8 +288,23 @@ struct DMesh {
     int64_t s_off;                  // TriangleMesh::s (explicit tangents, object space) in fpool, -1 = absent
     float o2w[12];                  // rows 0..2 of ObjectToWorld->m (carries the tangents to world space)
 };
+// Special leaves of the four-wide trees (round 4: the TOP-LEVEL tree over the world's mesh tree, its spheres / disks and the animated instances'
+// motion bounds — the reference keeps quadrics as ordinary primitives of the BVHAccel and builds a BVHAccel over the TransformedPrimitives,
+// accelerators/bvh.cpp:403-454, core/api.cpp:1186-1203).  A leaf code's triangle number (low 28 bits) at or above HPT_LEAF_SPECIAL is no
+// triangle range: bits 20..23 say what (a quadric of the world, an animated instance to enter, the walk's own "back to world space" marker),
+// bits 0..19 which.
+#define HPT_LEAF_SPECIAL 0x0f000000u
+#define HPT_LEAF_KIND_QUADRIC 0u
+#define HPT_LEAF_KIND_INSTANCE 1u
+#define HPT_LEAF_KIND_RESTORE 2u
+#define HPT_LEAF_CODE(kind, index) ((int32_t)~(HPT_LEAF_SPECIAL | ((uint32_t)(kind) << 20) | (uint32_t)(index)))
 #define HPT_TRI_ALPHA_BIT 0x40000000   /* set in a triangle record's mesh word when its mesh has an alpha texture */
-#define HPT_TRI_MESH_MASK 0x3fffffff
+// Round 4: a sphere / disk of the world is a primitive of the world's tree like the reference's (GeometricPrimitive in the BVHAccel,
+// accelerators/bvh.cpp:403-454) instead of being tested against every ray before the walk: it enters the builders as a pseudo-triangle
+// spanning its (padded) world bound and owns one 48-byte record in leaf order whose mesh word carries this bit and the quadric's number.
+#define HPT_TRI_QUADRIC_BIT 0x20000000
+#define HPT_TRI_MESH_MASK 0x1fffffff
+#define HPT_PRIM_QUADRIC 0x40000000    /* Hit::prim of a quadric hit: HPT_PRIM_QUADRIC | quadric number (triangle hits: the record's slot, < HPT_LEAF_SPECIAL) */
 struct DScene {
     const f4 *nodes;
     const f4 *tris;
@@ -309,11 +324,12 @@ struct DScene {
     const int32_t *inst_root4;
     int32_t world_root4;
     int32_t n_inst_quadrics;        // instances whose primitive is one sphere / disk (hpt_instance.quadric1 > 0): those quadrics are not primitives of the world
+    int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): world mesh tree + world quadrics + instances; -1: nothing to hit
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
 HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
-struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or n_tris + quadric; -1 miss; inst: animated instance or -1
+struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or HPT_PRIM_QUADRIC | quadric; -1 miss; inst: animated instance or -1
 struct DGeom { f3 p, nn, dpdu; };
 struct DGeomX { f3 p, nn, dpdu, dpdv, dndu, dndv, dpdx, dpdy; float u, v, dudx, dvdx, dudy, dvdy; };   // the full DifferentialGeometry (extension set)
 
@@ -602,25 +618,13 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
-    // the few quadrics (area-light emitters) are tested linearly first; closest hit is order independent
-    for (int q = 0; world && q < sc.n_quadrics; ++q) {
-        if (QI && sc.n_inst_quadrics > 0) {
-            bool owned = false;
-            for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
-            if (owned) continue;
-        }
-        float t;
-        if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
-            ts.hit.prim = sc.n_tris + q;
-            if (anyhit) { ts.node = HPT_TRAV_EMPTY; break; }
-            ts.hit.t = t; ray.maxt = t;
-        }
-    }
+    // (the world's spheres / disks are leaves of its tree since round 4: trav_leaf; up to round 3 every ray tested all of them here)
+    (void)world;
     if (QI && !world && inst >= 0) {
         const int q1 = sc.instances[inst].quadric1;
         float t;
         if (q1 > 0 && quadric_intersect(sc.quadrics[q1 - 1], ray, &t, nullptr)) {
-            ts.hit.prim = sc.n_tris + q1 - 1;
+            ts.hit.prim = HPT_PRIM_QUADRIC | (q1 - 1);
             if (anyhit) ts.node = HPT_TRAV_EMPTY;
             else { ts.hit.t = t; ray.maxt = t; }
         }
@@ -740,6 +744,16 @@ HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray,
         f4 a = tp[0], b = tp[1], c = tp[2];
         if (COUNT) cnt->tris++;
         float t, b1, b2;
+        if (sc.n_quadrics > 0 && (as_int(a.w) & HPT_TRI_QUADRIC_BIT)) {      // (scalar condition first: scenes without quadrics pay nothing)
+            const int q = as_int(a.w) & HPT_TRI_MESH_MASK;
+            if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
+                ts.hit.prim = HPT_PRIM_QUADRIC | q;
+                if (ts.anyhit) return true;
+                ts.hit.t = t; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f;
+                ray.maxt = t;
+            }
+            continue;
+        }
         if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
             if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
             ts.hit.prim = (int32_t)(first + k);
@@ -805,6 +819,92 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
             if (anyhit) return true;
         }
     }
+    return hit->prim >= 0;
+}
+
+// ---- the walk from the TOP-LEVEL tree (round 4) ---------------------------------------------------------------------------------------
+// sc.top_root4 (hpt_flatten.cpp, build_top_tree): the children of the world's root and one HPT_LEAF_KIND_INSTANCE leaf per animated
+// instance, boxed by its motion bounds — the reference's BVHAccel over the TransformedPrimitives (core/api.cpp:1186-1203,
+// core/primitive.cpp:95-124): a ray enters only the instances it crosses, nearest first, and a hit culls what lies behind it.
+HPT_FN bool leaf_is_special(int32_t node) { return (((uint32_t)~node) & 0x0fffffffu) >= HPT_LEAF_SPECIAL; }   // (for a leaf code)
+HPT_FN f3 safe_inv_dir(f3 d) {
+    const float big = 3.402823466e+38f;                    // keeps 0 * invd finite (see slab)
+    return mk3(fminf(fmaxf(1.f / d.x, -big), big), fminf(fmaxf(1.f / d.y, -big), big), fminf(fmaxf(1.f / d.z, -big), big));
+}
+// ts.node is a special leaf and no ordinary leaf is parked.  An instance leaf: the ray `r` (world space) is carried into the instance's
+// space at its time — xf_col: the 12-float column of the per-path transform cache that belongs to the ray's OWNER (element j of instance k
+// at xf_col[(12 k + j) * xf_stride]), or null: anim_interpolate at `jt` — and, when entries of the world-space walk are still stacked
+// under it, its world origin and direction and a HPT_LEAF_KIND_RESTORE marker go on the stack (7 rows; *fl = rows at the stack's bottom
+// that belong to the world, marker included); t is the same number in both spaces, so mint / maxt stay.  The marker: the way back.
+// st: the lane's stack (row i at st[i * stride]).  QI: the extension set's animated spheres / disks (hpt_instance.quadric1 > 0).
+template <bool QI>
+HPT_FN void top_special_leaf(const DScene &sc, TravState &ts, Ray &r, int *cur_inst, int *fl, int32_t *st, int stride, const float *xf_col, int64_t xf_stride, float jt) {
+    const uint32_t code = (uint32_t)~ts.node;
+    if (((code >> 20) & 0xfu) == HPT_LEAF_KIND_INSTANCE) {
+        const int k = (int)(code & 0xfffffu);
+        const hpt_instance &in = sc.instances[k];
+        const int32_t iroot = sc.inst_root4[k];
+        float tentry;
+        // (the motion bounds once more: the ray may have shrunk since the node above stacked this leaf)
+        if (!(iroot >= 0 || (QI && in.quadric1 > 0)) || !slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], r, ts.invd, &tentry)) {
+            trav_pop(ts, st, stride);
+            return;
+        }
+        A34 w2p;
+        if (xf_col) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_col[(int64_t)(12 * k + j) * xf_stride]; }
+        else w2p = anim_interpolate(in, jt, false).m;
+        if (ts.sp > 0) {                                    // the world-space walk goes on afterwards: its ray stays on the stack
+            st[(ts.sp + 0) * stride] = as_int(r.o.x); st[(ts.sp + 1) * stride] = as_int(r.o.y); st[(ts.sp + 2) * stride] = as_int(r.o.z);
+            st[(ts.sp + 3) * stride] = as_int(r.d.x); st[(ts.sp + 4) * stride] = as_int(r.d.y); st[(ts.sp + 5) * stride] = as_int(r.d.z);
+            st[(ts.sp + 6) * stride] = HPT_LEAF_CODE(HPT_LEAF_KIND_RESTORE, 0);
+            ts.sp += 7; *fl = ts.sp;
+        }
+        r.o = xf_point_affine(w2p.m, r.o); r.d = xf_vec(w2p.m, r.d);
+        ts.invd = safe_inv_dir(r.d);
+        *cur_inst = k;
+        ts.node = iroot >= 0 ? iroot : HPT_TRAV_EMPTY;
+        if (QI && in.quadric1 > 0) {                        // the instance's primitive is one animated sphere / disk
+            float t;
+            if (quadric_intersect(sc.quadrics[in.quadric1 - 1], r, &t, nullptr)) {
+                ts.hit.prim = HPT_PRIM_QUADRIC | (in.quadric1 - 1);
+                if (ts.anyhit) ts.node = HPT_TRAV_EMPTY;
+                else { ts.hit.t = t; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; r.maxt = t; }
+            }
+        }
+        // nothing to walk inside: on with the stack — the marker (if any) brings the ray back at the caller's next look, after the find has
+        // been recorded under this instance
+        if (ts.node == HPT_TRAV_EMPTY && !(ts.anyhit && ts.hit.prim >= 0)) trav_pop(ts, st, stride);
+        return;
+    }
+    // HPT_LEAF_KIND_RESTORE: back to the world ray under the marker
+    ts.sp -= 6;
+    r.o = mk3(as_float(st[(ts.sp + 0) * stride]), as_float(st[(ts.sp + 1) * stride]), as_float(st[(ts.sp + 2) * stride]));
+    r.d = mk3(as_float(st[(ts.sp + 3) * stride]), as_float(st[(ts.sp + 4) * stride]), as_float(st[(ts.sp + 5) * stride]));
+    ts.invd = safe_inv_dir(r.d);
+    *cur_inst = -1; *fl = 0;
+    trav_pop(ts, st, stride);
+}
+// One ray through the top-level tree on one lane (what traverse_steal of the path kernel does with 64 lanes and subtree stealing): parity
+// hooks and the host emulation.  cap_normal: stack rows that take ordinary entries (trav_node4).  *max_sp (optional): deepest stack seen.
+template <bool COUNT, bool ALPHA>
+HPT_FN bool traverse_top(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *hit, int32_t *stack, int stride, TravCounters *cnt,
+                         const float *xf_col = nullptr, int64_t xf_stride = 0, int cap_normal = 1 << 20, int *max_sp = nullptr) {
+    TravState ts;
+    Ray r = ray;
+    int cur_inst = -1, fl = 0;
+    trav_begin<ALPHA>(sc, ts, r, anyhit, sc.top_root4, true);
+    hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
+    while (!ts.done()) {
+        if (ts.node >= 0) trav_node4<COUNT>(sc.nodes4, ts, r, stack, stride, cnt, cap_normal);
+        else if (leaf_is_special(ts.node)) top_special_leaf<ALPHA>(sc, ts, r, &cur_inst, &fl, stack, stride, xf_col, xf_stride, time);
+        else { if (trav_leaf<COUNT, ALPHA>(sc, sc.tris, ts, r, ts.node, cnt)) ts.node = HPT_TRAV_EMPTY; else trav_pop(ts, stack, stride); }
+        if (max_sp && ts.sp > *max_sp) *max_sp = ts.sp;
+        if (ts.hit.prim >= 0) {                             // a find: recorded under the instance it was made in (r.maxt has shrunk with it)
+            *hit = ts.hit; hit->inst = cur_inst; ts.hit.prim = -1;
+            if (anyhit) return true;
+        }
+    }
+    if (hit->prim >= 0) ray.maxt = hit->t;
     return hit->prim >= 0;
 }
 
@@ -1696,8 +1796,8 @@ HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material 
 template <bool INST, int MATS>
 HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
     Ray ray = wray;
-    if (hit.prim >= sc.n_tris) {
-        const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+    if (hit.prim >= HPT_PRIM_QUADRIC) {
+        const hpt_quadric &q = sc.quadrics[hit.prim - HPT_PRIM_QUADRIC];
         float t;
         // re-evaluate the accepted hit to build dg: the traversal shrank ray.maxt to hit.t, so the
         // quadric test returns the same root again
@@ -1801,8 +1901,8 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
     const hpt_material *mat;
     int flip;
     DGeomX dgs;
-    if (hit.prim >= sc.n_tris) {
-        const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+    if (hit.prim >= HPT_PRIM_QUADRIC) {
+        const hpt_quadric &q = sc.quadrics[hit.prim - HPT_PRIM_QUADRIC];
         float t; DGeom d3;
         // an animated sphere / disk (hpt_instance.quadric1): the geometry in the instance's space from the transformed ray, then carried
         // to the world by PrimitiveToWorld = Inverse(w2p) — p, nn, dpdu, dpdv, dndu, dndv (core/primitive.cpp:104-117)

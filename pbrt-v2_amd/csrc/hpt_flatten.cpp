@@ -1,6 +1,7 @@
 // hpt_flatten.cpp — see hpt_flatten.h.
 #include "hpt_flatten.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -32,15 +33,138 @@ static int kd_count_within(const float *split, const int32_t *bits, const float 
     return found;
 }
 
+// ---- top-level tree (round 4) -------------------------------------------------------------------------------------------------------
+// Items: the world's mesh tree (an interior reference to its BVH4 root), every sphere / disk that is a primitive of the world (special
+// leaf, HPT_LEAF_KIND_QUADRIC) and every animated instance with something inside (HPT_LEAF_KIND_INSTANCE, boxed by its motion bounds:
+// AnimatedTransform::MotionBounds, core/transform.cpp:399-413).  Few items as a rule — one node —, but a scene of many instances gets a
+// real tree: median splits of the largest centroid extent, four children a node, written in collapse_bvh4's two-record layout.
+namespace {
+struct TopItem { float lo[3], hi[3]; int32_t code; int bound, depth; };   // bound / depth: of the subtree behind the item (0 for leaves)
+struct TopBuilder {
+    std::vector<BvhNode64> *out;
+    int best_bound = 0, best_depth = 0;
+    static void unite(const std::vector<TopItem> &it, size_t a, size_t b, float *lo, float *hi) {
+        for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (size_t i = a; i < b; ++i) for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], it[i].lo[k]); hi[k] = std::fmax(hi[k], it[i].hi[k]); }
+    }
+    static size_t split(std::vector<TopItem> &it, size_t a, size_t b) {      // median split of [a, b) along the largest centroid extent
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = a; i < b; ++i) for (int k = 0; k < 3; ++k) { const float c = 0.5f * it[i].lo[k] + 0.5f * it[i].hi[k]; clo[k] = std::fmin(clo[k], c); chi[k] = std::fmax(chi[k], c); }
+        int ax = 0;
+        if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+        if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        const size_t mid = a + (b - a) / 2;
+        std::nth_element(it.begin() + (ptrdiff_t)a, it.begin() + (ptrdiff_t)mid, it.begin() + (ptrdiff_t)b,
+                         [ax](const TopItem &x, const TopItem &y) { return x.lo[ax] + x.hi[ax] < y.lo[ax] + y.hi[ax]; });
+        return mid;
+    }
+    // node over items [a, b) (b - a >= 1); acc / lvl: stack entries / levels accumulated above it.  Returns the node's BVH4 index.
+    int32_t node(std::vector<TopItem> &it, size_t a, size_t b, int acc, int lvl) {
+        size_t cut[5] = {a, b, b, b, b}; int n = 1;                  // up to four groups [cut[i], cut[i + 1])
+        if (b - a <= 4) { n = (int)(b - a); for (int i = 0; i <= n; ++i) cut[i] = a + (size_t)i; }
+        else {
+            const size_t m = split(it, a, b), l = split(it, a, m), r = split(it, m, b);
+            cut[0] = a; cut[1] = l; cut[2] = m; cut[3] = r; cut[4] = b; n = 4;
+        }
+        const int32_t idx = (int32_t)(out->size() / 2);
+        out->emplace_back(); out->emplace_back();
+        BvhNode64 A, B;
+        for (int i = 0; i < 12; ++i) { A.f[i] = (i % 6) < 3 ? INFINITY : -INFINITY; B.f[i] = A.f[i]; }
+        for (int i = 0; i < 4; ++i) { A.child[i] = HPT_BVH4_EMPTY; B.child[i] = 0; }
+        const int here = acc + (n - 1);
+        for (int i = 0; i < n; ++i) {
+            float lo[3], hi[3];
+            unite(it, cut[i], cut[i + 1], lo, hi);
+            float *f = (i < 2 ? A : B).f + 6 * (i & 1);
+            for (int k = 0; k < 3; ++k) { f[k] = lo[k]; f[3 + k] = hi[k]; }
+            if (cut[i + 1] - cut[i] == 1) {
+                const TopItem &t = it[cut[i]];
+                A.child[i] = t.code;
+                if (here + t.bound > best_bound) best_bound = here + t.bound;
+                if (lvl + t.depth > best_depth) best_depth = lvl + t.depth;
+            } else A.child[i] = node(it, cut[i], cut[i + 1], here, lvl + 1);
+        }
+        (*out)[2 * (size_t)idx] = A; (*out)[2 * (size_t)idx + 1] = B;
+        return idx;
+    }
+};
+// Transform::operator()(BBox) of a quadric's ObjectBound (shapes/sphere.cpp:52-55, disk.cpp:50-53), padded: the shape test runs in object space
+void quadric_world_bound(const hpt_quadric &q, float *lo, float *hi) {
+    const float r = q.radius, z0 = q.kind == HPT_QUADRIC_SPHERE ? q.zmin : q.height, z1 = q.kind == HPT_QUADRIC_SPHERE ? q.zmax : q.height;
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {(c & 1) ? r : -r, (c & 2) ? r : -r, (c & 4) ? z1 : z0};
+        for (int k = 0; k < 3; ++k) {
+            const float w = q.o2w[4 * k] * p[0] + q.o2w[4 * k + 1] * p[1] + q.o2w[4 * k + 2] * p[2] + q.o2w[4 * k + 3];
+            lo[k] = std::fmin(lo[k], w); hi[k] = std::fmax(hi[k], w);
+        }
+    }
+    for (int k = 0; k < 3; ++k) { const float pad = 1e-4f * (hi[k] - lo[k]) + 1e-6f * std::fmax(std::fabs(lo[k]), std::fabs(hi[k])) + 1e-30f; lo[k] -= pad; hi[k] += pad; }
+}
+} // namespace
+
+// The top-level tree over what build the loop above left in out->nodes4; bounds of the per-group trees as collapse_bvh4 reported them.
+static void build_top_tree(const hpt_scene_desc *desc, FlatScene *out, int world_bound, int world_depth, const std::vector<int> &inst_bound, const std::vector<int> &inst_depth) {
+    std::vector<TopItem> items;
+    out->top_root4 = -1; out->top_stack_bound4 = 0; out->top_depth4 = 0; out->top_nodes4 = 0;
+    bool has_inst = false;
+    for (int k = 0; k < desc->n_instances; ++k) has_inst = has_inst || out->inst_root4[(size_t)k] >= 0 || desc->instances[k].quadric1 > 0;
+    if (!has_inst) {                                           // no instances: the world tree IS the top-level tree
+        out->top_root4 = out->world_root4; out->top_stack_bound4 = world_bound; out->top_depth4 = world_depth;
+        return;
+    }
+    if (out->world_root4 >= 0) {
+        // the CHILDREN of the world's root are the items, not the root: with a handful of instances the top-level tree is then one node that
+        // takes the world root's place — no extra level for the rays of scenes/anim-killeroos-moving.pbrt (ground + two instances)
+        const BvhNode64 &A = out->nodes4[2 * (size_t)out->world_root4], &B = out->nodes4[2 * (size_t)out->world_root4 + 1];
+        for (int c = 0; c < 4; ++c) {
+            if (A.child[c] == HPT_BVH4_EMPTY) continue;
+            TopItem t; t.code = A.child[c]; t.bound = world_bound; t.depth = world_depth;
+            const float *f = (c < 2 ? A : B).f + 6 * (c & 1);
+            for (int k = 0; k < 3; ++k) { t.lo[k] = f[k]; t.hi[k] = f[3 + k]; }
+            items.push_back(t);
+        }
+    }
+    for (int k = 0; k < desc->n_instances; ++k) {
+        if (out->inst_root4[(size_t)k] < 0 && desc->instances[k].quadric1 <= 0) continue;
+        TopItem t; t.code = HPT_LEAF_CODE(HPT_LEAF_KIND_INSTANCE, k);
+        t.bound = 7 + inst_bound[(size_t)k]; t.depth = 8 + inst_depth[(size_t)k];     // (inside: the saved world ray + its marker under the instance's own entries)
+        for (int j = 0; j < 3; ++j) { t.lo[j] = desc->instances[k].bounds[j]; t.hi[j] = desc->instances[k].bounds[3 + j]; }
+        items.push_back(t);
+    }
+    if (items.empty()) return;
+    TopBuilder tb; tb.out = &out->nodes4;
+    const size_t before = out->nodes4.size();
+    out->top_root4 = tb.node(items, 0, items.size(), 0, 1);
+    out->top_nodes4 = (int)((out->nodes4.size() - before) / 2);
+    out->top_stack_bound4 = tb.best_bound; out->top_depth4 = tb.best_depth;
+}
+
 int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatScene *out, BvhDeviceBuildFn device_build, int device_max_depth, bool defer_levels) {
     auto t0 = std::chrono::steady_clock::now();
     int64_t ntris = 0;
     for (int m = 0; m < desc->n_meshes; ++m) ntris += desc->meshes[m].ntris;
-    if (ntris >= (1ll << 28) - 16) { hpt_set_error("too many triangles (%lld)", (long long)ntris); return HPT_E_UNSUPPORTED; }
+    if (ntris >= (int64_t)HPT_LEAF_SPECIAL - 16) { hpt_set_error("too many triangles (%lld)", (long long)ntris); return HPT_E_UNSUPPORTED; }
     // world-space triangle soup (the reference transforms vertices at mesh construction,
     // shapes/trianglemesh.cpp:70-71, so P is already in world space)
-    std::vector<BvhInputTri> in((size_t)ntris);
-    std::vector<int32_t> tri_mesh((size_t)ntris), tri_idx((size_t)ntris);
+    // the world's spheres / disks (not the ones an animated instance owns) join the world's triangles as pseudo-triangles spanning their
+    // padded world bounds: primitives of the tree (HPT_TRI_QUADRIC_BIT, hpt_device.h) — tri_mesh = -(quadric + 1)
+    std::vector<int> world_quadrics;
+    for (int q = 0; q < desc->n_quadrics; ++q) {
+        bool owned = false;
+        for (int k = 0; k < desc->n_instances; ++k) owned = owned || desc->instances[k].quadric1 == q + 1;
+        if (!owned) world_quadrics.push_back(q);
+    }
+    const int64_t nrec = ntris + (int64_t)world_quadrics.size();
+    std::vector<BvhInputTri> in((size_t)nrec);
+    std::vector<int32_t> tri_mesh((size_t)nrec), tri_idx((size_t)nrec);
+    for (size_t j = 0; j < world_quadrics.size(); ++j) {
+        float lo[3], hi[3];
+        quadric_world_bound(desc->quadrics[world_quadrics[j]], lo, hi);
+        BvhInputTri &bt = in[(size_t)ntris + j];
+        for (int k = 0; k < 3; ++k) { bt.v[0][k] = lo[k]; bt.v[1][k] = hi[k]; bt.v[2][k] = 0.5f * lo[k] + 0.5f * hi[k]; }
+        tri_mesh[(size_t)ntris + j] = -(world_quadrics[j] + 1); tri_idx[(size_t)ntris + j] = 0;
+    }
     out->meshes.assign((size_t)desc->n_meshes, DMesh());
     int64_t base = 0;
     for (int m = 0; m < desc->n_meshes; ++m) {
@@ -71,13 +195,15 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     }
     // One BVH for the triangles that live directly in the world and one per animated instance (its
     // triangles are in the instance's own space), all in the same node / triangle arrays.
-    out->tri_rec.assign(12 * (size_t)ntris, 0.f);
+    out->tri_rec.assign(12 * (size_t)nrec, 0.f);
     out->nodes.clear();
     out->inst_root.assign((size_t)desc->n_instances, -1);
     out->world_root = -1;
     out->max_depth = 0;
     out->nodes4.clear(); out->inst_root4.assign((size_t)desc->n_instances, -1); out->world_root4 = -1; out->stack_bound4 = 0; out->depth4 = 0;
     size_t tri_base = 0;
+    int world_bound = 0, world_depth = 0;
+    std::vector<int> inst_bound((size_t)desc->n_instances, 0), inst_depth((size_t)desc->n_instances, 0);
     for (int g = -1; g < desc->n_instances; ++g) {
         std::vector<BvhInputTri> sub;
         std::vector<uint32_t> src;
@@ -86,6 +212,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             int64_t mb = out->meshes[(size_t)m].prim_base;
             for (int t = 0; t < desc->meshes[m].ntris; ++t) { sub.push_back(in[(size_t)(mb + t)]); src.push_back((uint32_t)(mb + t)); }
         }
+        if (g < 0) for (size_t j = 0; j < world_quadrics.size(); ++j) { sub.push_back(in[(size_t)ntris + j]); src.push_back((uint32_t)((size_t)ntris + j)); }
         if (sub.empty()) continue;
         BvhResult bvh;
         double dev_ms = 0.0;
@@ -113,7 +240,8 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             uint32_t s0 = src[bvh.order[i]];
             float *r = &out->tri_rec[12 * (tri_base + i)];
             for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[s0].v[k][0]; r[4 * k + 1] = in[s0].v[k][1]; r[4 * k + 2] = in[s0].v[k][2]; }
-            int32_t mesh_word = tri_mesh[s0] | (desc->meshes[tri_mesh[s0]].alpha_tex > 0 ? HPT_TRI_ALPHA_BIT : 0);
+            int32_t mesh_word = tri_mesh[s0] < 0 ? (int32_t)(HPT_TRI_QUADRIC_BIT | (uint32_t)(-tri_mesh[s0] - 1))
+                                                 : (tri_mesh[s0] | (desc->meshes[tri_mesh[s0]].alpha_tex > 0 ? HPT_TRI_ALPHA_BIT : 0));
             memcpy(&r[3], &mesh_word, 4);
             memcpy(&r[7], &tri_idx[s0], 4);
         }
@@ -122,7 +250,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         {   // the group's tree once more, four children wide (the walk with subtree stealing: half the dependent fetches per ray)
             int bound = 0, d4 = 0;
             const int32_t r4 = collapse_bvh4(out->nodes, node_base, &out->nodes4, &bound, &d4);
-            if (g < 0) out->world_root4 = r4; else out->inst_root4[(size_t)g] = r4;
+            if (g < 0) { out->world_root4 = r4; world_bound = bound; world_depth = d4; } else { out->inst_root4[(size_t)g] = r4; inst_bound[(size_t)g] = bound; inst_depth[(size_t)g] = d4; }
             if (bound > out->stack_bound4) out->stack_bound4 = bound;
             if (d4 > out->depth4) out->depth4 = d4;
         }
@@ -130,8 +258,10 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     }
     for (int g = 0; g < desc->n_instances; ++g) {     // object instancing: an instance that shares its owner's primitive walks the owner's trees
         const int32_t q1 = desc->instances[g].quadric1;
-        if (q1 < 0) { out->inst_root[(size_t)g] = out->inst_root[(size_t)(-q1 - 1)]; out->inst_root4[(size_t)g] = out->inst_root4[(size_t)(-q1 - 1)]; }
+        if (q1 < 0) { out->inst_root[(size_t)g] = out->inst_root[(size_t)(-q1 - 1)]; out->inst_root4[(size_t)g] = out->inst_root4[(size_t)(-q1 - 1)];
+                      inst_bound[(size_t)g] = inst_bound[(size_t)(-q1 - 1)]; inst_depth[(size_t)g] = inst_depth[(size_t)(-q1 - 1)]; }
     }
+    build_top_tree(desc, out, world_bound, world_depth, inst_bound, inst_depth);
     const auto t_trees = std::chrono::steady_clock::now();
     // ---- measured-BRDF samples -> grid-ordered 32-byte records + cell table (hpt_device.h: kd_begin / kd_step) -------
     out->fpool.assign(desc->fpool, desc->fpool + desc->n_f);

@@ -19,6 +19,11 @@ struct FlatScene {
     int32_t world_root4 = -1;
     int stack_bound4 = 0;             // entries a walk of the BVH4 can stack (max over the trees)
     int depth4 = 0;                   // interior levels of the deepest BVH4
+    // the top-level tree (build_top_tree): its root in nodes4, and the two bounds for a walk that starts there and enters the instances'
+    // trees from it (a walk inside an instance keeps 7 more entries: the world ray it returns to and their marker)
+    int32_t top_root4 = -1;
+    int top_stack_bound4 = 0, top_depth4 = 0;
+    int top_nodes4 = 0;               // nodes the top-level tree added to nodes4 (0: the world tree serves as it is)
     std::vector<int32_t> inst_root;   // root node of each animated instance's BVH (-1 = no triangles)
     int32_t world_root = -1;          // root node of the world BVH (-1 = no world triangles)
     // device copies of the float pool and the material table: the samples of a measured BRDF are binned into a

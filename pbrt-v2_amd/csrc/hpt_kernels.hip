@@ -391,7 +391,7 @@ __global__ __launch_bounds__(HPT_BLOCK) void hpt_intersect_kernel(const DScene s
     float *o = out_hit + 4 * i;
     if (anyhit) { out_prim[i] = h ? 0 : -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
     if (!h) { out_prim[i] = -1; o[0] = o[1] = o[2] = o[3] = 0.f; return; }
-    if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[1] = 0.f; o[2] = 0.f; o[3] = 5e-4f * hit.t; return; }
+    if (hit.prim >= HPT_PRIM_QUADRIC) { out_prim[i] = sc.n_tris + (hit.prim - HPT_PRIM_QUADRIC); o[0] = hit.t; o[1] = 0.f; o[2] = 0.f; o[3] = 5e-4f * hit.t; return; }
     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
     int mesh = as_int(tp[0].w) & HPT_TRI_MESH_MASK, tri = as_int(tp[1].w);
     out_prim[i] = sc.meshes[mesh].prim_base + tri;

@@ -133,10 +133,15 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // everything the walk uses (row aux: donor table).  Closest hits with exactly equal t (shared edges) are resolved by publishing
 // order here and by visiting order in the plain walk.
 #define HPT_STEAL_ROWS 6
-// INST: animated instances (TransformedPrimitive, core/primitive.cpp:95-124).  A ray's OWNER walks the world tree and then, one after
-// the other, the tree of every instance whose motion bounds the (shrinking) ray still crosses, each in the instance's own space at
-// the ray's time (xf_cache: the per-path transform cache, or null -> anim_interpolate).  Helpers only ever walk the subtree they were
-// given, in whatever space the donor was in, and publish the instance number with the hit.
+// INST: animated instances (TransformedPrimitive, core/primitive.cpp:95-124).  Round 4: the walk starts at the TOP-LEVEL tree (sc.top_root4,
+// hpt_flatten.cpp build_top_tree: the world root's children and one leaf per instance, boxed by its motion bounds — the reference's BVHAccel
+// over the TransformedPrimitives, core/api.cpp:1186-1203), so a ray enters only the instances it crosses, nearest first, with whatever hit it
+// already has culling the rest; up to round 3 the ray's owner walked the world tree and then every instance in index order.  A lane that
+// reaches an instance leaf carries its ray into the instance's space at the ray's time (the owner's column of the per-path transform cache,
+// or anim_interpolate), and — if entries of the world-space walk are still stacked under it — leaves the world ray's origin and direction
+// and a marker on its stack (7 rows): popping the marker brings the ray back (t is the same number in both spaces).  `fl` counts the rows
+// at the bottom of the lane's stack that belong to the world (its nodes + those 7; 0: none): a helper that is given one of those rows takes
+// the WORLD ray out of the donor's column instead of the donor's current ray.  Helpers publish the instance with the hit.
 // TWO (the merged light phase, HPT_MERGE_LIGHT): a lane may own TWO rays of its path vertex — its shadow ray (`ray`, any-hit) and, has_b, the
 // BSDF-sampled MIS ray (pb + t db from epsb, closest-hit) — and walks them one after the other inside ONE phase of the wave, the idle lanes
 // helping with whichever subtrees are on offer: the MIS rays of a vertex (a handful per wave under an area light, one per lane under an
@@ -158,13 +163,8 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
     // the two pointers the loop dereferences, as scalar registers of their own: as fields of the kernel-argument block they live in a
     // 16-register tuple that the allocator spills to VGPR lanes and re-reads WHOLE (16 v_readlane per node step, measured in the ISA)
-#ifndef HPT_NO_BVH4
     const f4 *nodes = sc.nodes4, *tris = sc.tris;                   // the four-wide trees (trav_node4): half the dependent fetches per ray
-    const int32_t world_root = sc.world_root4;
-#else
-    const f4 *nodes = sc.nodes, *tris = sc.tris;
-    const int32_t world_root = sc.world_root;
-#endif
+    const int32_t top_root = sc.top_root4;
 #ifndef HPT_NO_SGPR_PIN
     {   // (through v_readfirstlane: a plain "+s" register pin is rejected — "illegal VGPR to SGPR copy" — in the instantiations where the
         //  compiler keeps the argument block in vector registers)
@@ -179,12 +179,10 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     TravState ts;
     Ray r = ray;
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
-    // instances: the segment this lane's OWN ray is in (-1 world, k instance k, n_inst: all done) and the instance of the tree being walked
-    const int n_inst = INST ? sc.n_instances : 0;
-    int seg = (INST && has_ray) ? -1 : n_inst, cur_inst = -1;
+    int cur_inst = -1, fl = 0;                                      // instance whose tree is being walked (-1: world space); world rows at the stack's bottom
+    float jt = time;                                                // time of the ray this lane is walking (the owner's path time)
     bool more_b = TWO && has_ray && has_b;                          // the owner's second ray is still to come
-    bool cur_any = anyhit;                                          // kind of the owner's CURRENT ray (the second one is closest-hit)
-    if (has_ray) trav_begin<ALPHA>(sc, ts, r, anyhit, world_root, true);
+    if (has_ray) trav_begin<ALPHA>(sc, ts, r, anyhit, top_root, true);
     else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
@@ -198,19 +196,19 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     // the ray (a few more nodes visited); the nearest hit is the same up to exact ties.
     int32_t pend = HPT_TRAV_EMPTY;
     for (;;) {
+        // ---- a leaf of the top-level tree: enter the instance / return to the world (hpt_device.h, top_special_leaf) — once no ordinary leaf
+        // is parked: a parked one belongs to the space the lane is about to leave ---------------------------------------------------------
+        if (INST && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node))
+            top_special_leaf<ALPHA>(sc, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
         const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
         const unsigned long long mbusy = __ballot(busy);
-        const bool any_busy = (mbusy | __ballot(seg < n_inst || more_b)) != 0ull;
+        const bool any_busy = (mbusy | __ballot(more_b)) != 0ull;
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* every lane: wave clocks of the node half / of the leaf half, iterations, leaf phases, lanes in them */
         const unsigned long long w0_ = __builtin_readcyclecounter();
         cnt->steps++;
 #endif
-#ifndef HPT_NO_BVH4
         if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
-#else
-        if (ts.node >= 0) trav_node<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt);
-#endif
-        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node)) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
+        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
         const unsigned long long w1_ = __builtin_readcyclecounter();
         cnt->step_clocks += w1_ - w0_;
@@ -255,61 +253,30 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             }
             if (!any_busy) break;                                       // (the last publish has just happened)
         }
-        if ((INST || TWO) && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && (seg < n_inst || more_b)) {
-            if (INST && seg < n_inst) {
-                // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
-                const int shared = HPT_AUX(aux + (cur_any ? 2 : 1), lane);  // (seg < n_inst only on the owner: owner == lane)
-                ++seg;
-                if (cur_any && shared == 0) seg = n_inst;
-                if (seg < n_inst) {
-                    const hpt_instance &in = sc.instances[seg];
-                    Ray rw;
-                    if (TWO && !cur_any && has_b) { rw.o = *pb; rw.d = *db; rw.mint = epsb; rw.maxt = HPT_INF; }      // the MIS ray (a lane with two rays: the first is any-hit)
-                    else rw = ray;
-                    if (!cur_any) rw.maxt = fminf(rw.maxt, as_float(shared));
-                    const float big = 3.402823466e+38f;
-                    f3 invw = mk3(fminf(fmaxf(1.f / rw.d.x, -big), big), fminf(fmaxf(1.f / rw.d.y, -big), big), fminf(fmaxf(1.f / rw.d.z, -big), big));
-                    float tentry;
-#ifndef HPT_NO_BVH4
-                    const int32_t iroot = sc.inst_root4[seg];
-#else
-                    const int32_t iroot = sc.inst_root[seg];
-#endif
-                    // (the extension set: an instance may be one animated sphere / disk instead of a tree — trav_begin tests it)
-                    if ((iroot >= 0 || (ALPHA && in.quadric1 > 0)) && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
-                        A34 w2p;
-                        if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
-                        else w2p = anim_interpolate(in, time, false).m;
-                        r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
-                        trav_begin<ALPHA>(sc, ts, r, cur_any, iroot, false, seg);
-                        cur_inst = seg; sb = 0;
-                    }
-                }
-            }
-            if (TWO && more_b && seg >= n_inst && ts.node == HPT_TRAV_EMPTY) {
-                // ---- the owner's shadow ray is through (its helpers may still be walking): on to the vertex's MIS ray ----------------
-                more_b = false; cur_any = false;
-                seg = INST ? -1 : n_inst;
-                r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
-                trav_begin<ALPHA>(sc, ts, r, false, world_root, true);
-                cur_inst = -1; sb = 0;
-            }
+        if (TWO && more_b && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY) {
+            // ---- the owner's shadow ray is through (its helpers may still be walking): on to the vertex's MIS ray ----------------
+            more_b = false;
+            r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
+            trav_begin<ALPHA>(sc, ts, r, false, top_root, true);
+            cur_inst = -1; fl = 0; sb = 0;
         }
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
-        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_inst && !more_b;
-        const bool donor = still && ts.sp >= 1;
+        const bool idle = !still && pend == HPT_TRAV_EMPTY && !more_b;
+        const bool donor = still && ts.sp >= 1;                     // (fl is 0 or >= 8: the bottom row is a node, never a saved ray)
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
         const int nd = __popcll(md);
         if (nd < n) n = nd;
         if (n == 0) continue;
         const int ri = __popcll(mi & lt), rd = __popcll(md & lt);
-        int give = 0;
+        int give = 0, gw = -1;                                      // gw >= 0: the row given is a WORLD row of a lane inside an instance; gw = row of its saved world ray
         if (donor && rd < n) {
             HPT_AUX(aux, rd) = lane;
             give = stack[sb * HPT_BLOCK];                           // bottom entry: the oldest = largest pending subtree
+            if (INST && fl > 0) { gw = sb + fl - 7; --fl; }
             ++sb; --ts.sp;
+            if (INST && fl == 7) { sb += 7; ts.sp -= 7; fl = 0; }   // the last world row went: nothing to come back to (the saved ray stays readable for this round's thief)
         }
         HPT_WAVE_SYNC();
         const bool take = idle && ri < n;
@@ -321,10 +288,21 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         const float ix = __shfl(ts.invd.x, src), iy = __shfl(ts.invd.y, src), iz = __shfl(ts.invd.z, src);
         const int any_s = __shfl((int)ts.anyhit, src), own_s = __shfl(owner, src), node_s = __shfl(give, src);
         const int inst_s = INST ? __shfl(cur_inst, src) : -1;
+        const int gw_s = INST ? __shfl(gw, src) : -1;
+        const float jt_s = INST ? __shfl(jt, src) : 0.f;
         if (take) {
             r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
             ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s; cur_inst = inst_s;
-            ts.node = node_s; ts.sp = 0; sb = 0;
+            if (INST) {
+                jt = jt_s;
+                if (gw_s >= 0) {                                    // a subtree of the WORLD from a donor that is inside an instance: the world ray is in its column
+                    r.o = mk3(as_float(col0[src + (gw_s + 0) * HPT_BLOCK]), as_float(col0[src + (gw_s + 1) * HPT_BLOCK]), as_float(col0[src + (gw_s + 2) * HPT_BLOCK]));
+                    r.d = mk3(as_float(col0[src + (gw_s + 3) * HPT_BLOCK]), as_float(col0[src + (gw_s + 4) * HPT_BLOCK]), as_float(col0[src + (gw_s + 5) * HPT_BLOCK]));
+                    ts.invd = safe_inv_dir(r.d);
+                    cur_inst = -1;
+                }
+            }
+            ts.node = node_s; ts.sp = 0; sb = 0; fl = 0;
         }
     }
     HPT_WAVE_SYNC();
@@ -429,9 +407,13 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         // with the handful of lanes that had just ended a path (and, with animated instances, two AnimatedTransform interpolations behind
         // them).  A lane that has finished now WAITS — as a subtree thief in the walks — until regen_min lanes of the wave have finished,
         // or nobody else is left to wait for.
+        // Lock step + stealing only (configurations 5 / 6 and direct lighting — what production runs): there a waiting lane works as a thief.
+        // (The free-running instantiation of the extension set with animated instances faulted under a threshold of 16 — GPU run B2 of round 4,
+        //  cause not found; the free-running and plain lock-step kernels keep the per-round flush they have always had.)
         {
+            const int regen_min = (STEAL && PHASED) ? a.regen_min : 1;
             const unsigned long long mfin = __ballot(lane.fin);
-            if (mfin != 0ull && (__popcll(mfin) >= a.regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull))
+            if (mfin != 0ull && (__popcll(mfin) >= regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull))
                 lane.flush(rp, a.film, COUNT ? &wc : nullptr);
         }
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------

@@ -647,8 +647,8 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         if (stage == ST_MIS) {               // integrator.cpp:157-171
             bool sees = false;               // does the ray see light_mis with non-black radiance?
             if (hit.prim >= 0) {
-                if (hit.prim >= sc.n_tris) {
-                    const hpt_quadric &q = sc.quadrics[hit.prim - sc.n_tris];
+                if (hit.prim >= HPT_PRIM_QUADRIC) {
+                    const hpt_quadric &q = sc.quadrics[hit.prim - HPT_PRIM_QUADRIC];
                     if (q.arealight == light_mis) {
                         DGeom dg; float t;
                         quadric_intersect(q, ray, &t, &dg);

@@ -24,6 +24,9 @@ def lib():
         L.emu_render_replay.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p]
         L.emu_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_intersect4.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.emu_intersect_top.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.emu_set_ray_time.argtypes = [C.c_float]
+        L.emu_set_ray_time.restype = None
         L.emu_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_bsdf_tier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
@@ -48,10 +51,11 @@ class EmuScene:
             raise RuntimeError("emu_scene_create failed")
 
     def info(self):
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(12, dtype=np.int64)
         lib().emu_scene_info(self.h, out.ctypes.data)
         return {"n_tris": int(out[0]), "n_nodes": int(out[1]), "max_depth": int(out[2]),
-                "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5]), "tree_hash": int(out[6])}
+                "n_nodes4": int(out[3]), "stack_bound4": int(out[4]), "depth4": int(out[5]), "tree_hash": int(out[6]),
+                "top_stack_bound4": int(out[8]), "top_depth4": int(out[9]), "n_nodes4_top": int(out[10]), "top_root4": int(out[11])}
 
     def render(self, cam, rd, flt=None, two_pass=False, cam_motion=None, sample_table=None):
         """two_pass: the device's two-pass film under a table filter (sample records + film_gather_pixel) instead of the
@@ -84,6 +88,27 @@ class EmuScene:
         deepest = C.c_int(0)
         lib().emu_intersect4(self.h, rays.ctypes.data, n, int(anyhit), cap, hit.ctypes.data, prim.ctypes.data, C.byref(deepest))
         return hit, prim, deepest.value
+
+    def intersect_top(self, rays, anyhit=False, cap=-1, time=0.0):
+        """the same rays from the TOP-LEVEL tree (traverse_top: instances entered from the tree).  -> hit, prim, instance of the hit, deepest stack"""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros((n, 4), dtype=np.float32)
+        prim = np.zeros(n, dtype=np.int32)
+        inst = np.zeros(n, dtype=np.int32)
+        deepest = C.c_int(0)
+        lib().emu_set_ray_time(float(time))
+        lib().emu_intersect_top(self.h, rays.ctypes.data, n, int(anyhit), cap, hit.ctypes.data, prim.ctypes.data, inst.ctypes.data, C.byref(deepest))
+        lib().emu_set_ray_time(0.0)
+        return hit, prim, inst, deepest.value
+
+    def intersect_at(self, rays, time, anyhit=False):
+        """intersect() with the rays at `time` (the reference order of the walk: world tree, then every instance)"""
+        lib().emu_set_ray_time(float(time))
+        try:
+            return self.intersect(rays, anyhit)
+        finally:
+            lib().emu_set_ray_time(0.0)
 
     def bsdf(self, material, inp, tier=0):
         inp = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1, 16)

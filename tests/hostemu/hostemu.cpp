@@ -49,7 +49,7 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
     for (int k = 0; k < desc->n_instances; ++k) s->d.n_inst_quadrics += desc->instances[k].quadric1 > 0;
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
-    s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4;
+    s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4; s->d.top_root4 = s->fs.top_root4;
     return s;
 }
 extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }
@@ -63,6 +63,7 @@ extern "C" void emu_scene_info(const emu_scene *s, int64_t *out) {
     h = fnv(h, s->fs.nodes4.data(), s->fs.nodes4.size() * sizeof(BvhNode64));
     h = fnv(h, s->fs.tri_rec.data(), s->fs.tri_rec.size() * sizeof(float));
     out[6] = (int64_t)h;
+    out[8] = s->fs.top_stack_bound4; out[9] = s->fs.top_depth4; out[10] = s->fs.top_nodes4; out[11] = s->fs.top_root4;
 }
 
 // hpt_scene_set_filter's stand-in (process-wide; NULL = box of width 0.5)
@@ -293,7 +294,35 @@ extern "C" int emu_intersect4(const emu_scene *s, const float *rays, int64_t n, 
         o[0] = o[1] = o[2] = o[3] = 0.f;
         if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
         if (!h) { out_prim[i] = -1; continue; }
-        if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
+        if (hit.prim >= HPT_PRIM_QUADRIC) { out_prim[i] = sc.n_tris + (hit.prim - HPT_PRIM_QUADRIC); o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
+        const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
+        out_prim[i] = sc.meshes[as_int(tp[0].w) & HPT_TRI_MESH_MASK].prim_base + as_int(tp[1].w);
+        o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
+    }
+    if (max_sp) *max_sp = deepest;
+    return 0;
+}
+
+static float g_ray_time = 0.f;       // time of the rays of the intersect hooks (animated instances)
+extern "C" void emu_set_ray_time(float t) { g_ray_time = t; }
+// hpt_test_intersect's stand-in over the TOP-LEVEL tree (round 4: hpt_device.h traverse_top — instance leaves entered from the tree, the world ray
+// parked on the stack; cap as above).  `time`: the rays' time (animated instances).
+extern "C" int emu_intersect_top(const emu_scene *s, const float *rays, int64_t n, int anyhit, int cap, float *out_hit, int32_t *out_prim, int32_t *out_inst, int *max_sp) {
+    const DScene &sc = s->d;
+    int deepest = 0;
+#pragma omp parallel for reduction(max : deepest)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = rays + 8 * i;
+        Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
+        Hit hit; int32_t stack[160]; int msp = 0; TravCounters tc = {0, 0};
+        bool h = traverse_top<false, true>(sc, ray, g_ray_time, anyhit != 0, &hit, stack, 1, &tc, nullptr, 0, cap < 0 ? 1 << 20 : cap, &msp);
+        if (msp > deepest) deepest = msp;
+        float *o = out_hit + 4 * i;
+        o[0] = o[1] = o[2] = o[3] = 0.f;
+        if (out_inst) out_inst[i] = h ? hit.inst : -1;
+        if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
+        if (!h) { out_prim[i] = -1; continue; }
+        if (hit.prim >= HPT_PRIM_QUADRIC) { out_prim[i] = sc.n_tris + (hit.prim - HPT_PRIM_QUADRIC); o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
         const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
         out_prim[i] = sc.meshes[as_int(tp[0].w) & HPT_TRI_MESH_MASK].prim_base + as_int(tp[1].w);
         o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;
@@ -309,12 +338,12 @@ extern "C" int emu_intersect(const emu_scene *s, const float *rays, int64_t n, i
         const float *r = rays + 8 * i;
         Ray ray; ray.o = mk3(r[0], r[1], r[2]); ray.d = mk3(r[3], r[4], r[5]); ray.mint = r[6]; ray.maxt = r[7];
         Hit hit; TravCounters tc = {0, 0}; int32_t stack[64];
-        bool h = traverse<false, true, true>(sc, ray, 0.f, anyhit != 0, &hit, stack, 1, &tc);
+        bool h = traverse<false, true, true>(sc, ray, g_ray_time, anyhit != 0, &hit, stack, 1, &tc);
         float *o = out_hit + 4 * i;
         o[0] = o[1] = o[2] = o[3] = 0.f;
         if (anyhit) { out_prim[i] = h ? 0 : -1; continue; }
         if (!h) { out_prim[i] = -1; continue; }
-        if (hit.prim >= sc.n_tris) { out_prim[i] = hit.prim; o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
+        if (hit.prim >= HPT_PRIM_QUADRIC) { out_prim[i] = sc.n_tris + (hit.prim - HPT_PRIM_QUADRIC); o[0] = hit.t; o[3] = 5e-4f * hit.t; continue; }
         const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
         out_prim[i] = sc.meshes[as_int(tp[0].w)].prim_base + as_int(tp[1].w);
         o[0] = hit.t; o[1] = hit.b1; o[2] = hit.b2; o[3] = 1e-3f * hit.t;

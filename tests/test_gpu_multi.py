@@ -116,18 +116,35 @@ def test_a_smaller_later_frame_leaves_shards_without_tiles():
     m.close()
 
 
+_RCCL_ONE_RANK = '''
+import importlib, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from tests.util import hash_rd, load_case
+hpt = importlib.import_module("pbrt-v2_amd.hpt")
+c = hpt.Comm(0, 1, 0, lambda uid: uid)
+s = load_case("env")
+rd = hash_rd(s, seed=2)
+f = torch.ones((rd.y_count, rd.x_count, 4), dtype=torch.float32, device="cuda")
+c.exchange_film(rd, f.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert float(f.min()) == 1.0
+c.close()
+print("rccl one rank ok")
+'''
+
+
 def test_rccl_binding_creates_a_communicator():
     """ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy through the library's dlopen binding (one rank: all one device can host);
-    a world of one exchanges nothing and leaves the film untouched."""
-    import torch
-    c = hpt.Comm(0, 1, 0, lambda uid: uid)
-    s = load_case("env")
-    rd = hash_rd(s, seed=2)
-    f = torch.ones((rd.y_count, rd.x_count, 4), dtype=torch.float32, device="cuda")
-    c.exchange_film(rd, f.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert float(f.min()) == 1.0
-    c.close()
+    a world of one exchanges nothing and leaves the film untouched.  In a process of its own: ncclCommInitRank has failed with "unhandled
+    cuda error" in pytest processes that had already driven hpt_multi's threads and RCCL (rounds 3 and 4: one run in three; never in a
+    fresh process — gpurun_out/r04_b2), which is RCCL's state, not the binding's.  One retry."""
+    last = None
+    for _ in range(2):
+        last = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT], capture_output=True, timeout=300)
+        if last.returncode == 0 and b"rccl one rank ok" in last.stdout:
+            return
+    raise AssertionError(last.stdout.decode(errors="replace")[-800:] + last.stderr.decode(errors="replace")[-1500:])
 
 
 def test_pbrt_binary_shards_over_gpus_end_to_end(tmp_path):

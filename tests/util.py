@@ -331,3 +331,36 @@ def compare_crops(scene, oracle, frame, rd, flt=None, tol=1e-3, n=CROP, content=
     total = (sq / npx) ** 0.5
     assert total < tol, total
     return total, worst
+
+
+def with_instance_copies(scene, src, n_copies, start=(20.0, 0.0, 0.0), step=(3.0, 0.0, 0.0)):
+    """`scene` with n_copies more instances: copies of instance `src` (object instancing — they share its aggregate, hpt_instance.quadric1 < 0)
+    moved by start + j * step in world space.  PrimitiveToWorld' = Translate(v) PrimitiveToWorld, so WorldToPrimitive' = WorldToPrimitive
+    Translate(-v): the translation column of both end matrices (and of their decomposition, T) loses M3 v, the inverses gain v, the motion
+    bounds move by v; rotation and scale stay.  Round 4: scenes of MANY instances for the top-level tree."""
+    import ctypes as C
+    inst = list(scene.instances)
+    owner = src if inst[src].quadric1 == 0 else -inst[src].quadric1 - 1
+    assert inst[owner].quadric1 == 0, "copies of a mesh instance only"
+    out = [abi.Instance.from_buffer_copy(bytes(i)) for i in inst]
+    for j in range(n_copies):
+        v = np.asarray(start, dtype=np.float64) + j * np.asarray(step, dtype=np.float64)
+        c = abi.Instance.from_buffer_copy(bytes(inst[src]))
+        c.quadric1 = -(owner + 1)
+        for k in range(3):
+            c.bounds[k] = np.float32(c.bounds[k] + v[k]); c.bounds[3 + k] = np.float32(c.bounds[3 + k] + v[k])
+        for e in range(2):
+            m = np.array(list(c.w2p_m[e]), dtype=np.float64).reshape(4, 4)
+            mi = np.array(list(c.w2p_minv[e]), dtype=np.float64).reshape(4, 4)
+            d = -(m[:3, :3] @ v)
+            for k in range(3):
+                c.w2p_m[e][4 * k + 3] = np.float32(m[k, 3] + d[k])
+                c.T[e][k] = np.float32(c.T[e][k] + d[k])
+                c.w2p_minv[e][4 * k + 3] = np.float32(mi[k, 3] + v[k])
+        out.append(c)
+    s2 = abi.Scene(meshes=list(scene.meshes), quadrics=list(scene.quadrics), materials=list(scene.materials), lights=list(scene.lights),
+                   fpool=scene.fpool, ipool=scene.ipool, camera=scene.camera, render=scene.render, instances=out, textures=list(scene.textures))
+    for attr in ("filter", "camera_motion", "meta"):
+        if hasattr(scene, attr):
+            setattr(s2, attr, getattr(scene, attr))
+    return s2
