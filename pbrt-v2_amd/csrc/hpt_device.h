@@ -324,7 +324,8 @@ struct DScene {
     const int32_t *inst_root4;
     int32_t world_root4;
     int32_t n_inst_quadrics;        // instances whose primitive is one sphere / disk (hpt_instance.quadric1 > 0): those quadrics are not primitives of the world
-    int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): world mesh tree + world quadrics + instances; -1: nothing to hit
+    int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
+    int32_t n_linear_quadrics;      // 0: the world's quadrics are primitives of its tree; n_quadrics: too many for that (HPT_MAX_LEAF_QUADRICS) — tested before the walk
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
@@ -618,8 +619,21 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
-    // (the world's spheres / disks are leaves of its tree since round 4: trav_leaf; up to round 3 every ray tested all of them here)
-    (void)world;
+    // The world's spheres / disks are primitives of its tree since round 4 (trav_leaf).  Only a scene with more of them than the stealing walk's
+    // deferral mask holds (HPT_MAX_LEAF_QUADRICS) keeps the linear test of rounds 1-3: n_linear_quadrics = n_quadrics there, 0 otherwise.
+    for (int q = 0; world && q < sc.n_linear_quadrics; ++q) {
+        if (QI && sc.n_inst_quadrics > 0) {
+            bool owned = false;
+            for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
+            if (owned) continue;
+        }
+        float t;
+        if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
+            ts.hit.prim = HPT_PRIM_QUADRIC | q;
+            if (anyhit) { ts.node = HPT_TRAV_EMPTY; break; }
+            ts.hit.t = t; ray.maxt = t;
+        }
+    }
     if (QI && !world && inst >= 0) {
         const int q1 = sc.instances[inst].quadric1;
         float t;
@@ -735,8 +749,14 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
 
 // trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
 // any-hit ray is done (occluded).
-template <bool COUNT, bool ALPHA>
-HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
+// QDEFER (the path kernel's stealing walk): a quadric's record only sets its bit in *qmask — the shape test (a square root, an atan2f, the partial-
+// sphere logic: ~350 instructions inlined) inside the leaf loop cost the whole walk its register allocation (nine scratch reloads per step,
+// every workload 7-12 % slower: round 4, GPU run C); the ray's owner tests the noted quadrics once, after the walk (deferred_quadrics).  A
+// primitive tested later only delays the shrinking of the ray.  Scenes with more than HPT_MAX_LEAF_QUADRICS world quadrics keep them out
+// of the tree (DScene::n_linear_quadrics: the linear test of rounds 1-3, trav_begin).
+#define HPT_MAX_LEAF_QUADRICS 16
+template <bool COUNT, bool ALPHA, bool QDEFER = false>
+HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt, uint32_t *qmask = nullptr) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     for (uint32_t k = 0; k < count; ++k) {
@@ -744,8 +764,9 @@ HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray,
         f4 a = tp[0], b = tp[1], c = tp[2];
         if (COUNT) cnt->tris++;
         float t, b1, b2;
-        if (sc.n_quadrics > 0 && (as_int(a.w) & HPT_TRI_QUADRIC_BIT)) {      // (scalar condition first: scenes without quadrics pay nothing)
+        if (as_int(a.w) & HPT_TRI_QUADRIC_BIT) {                 // a sphere / disk of the world (a pseudo-triangle record, hpt_flatten.cpp)
             const int q = as_int(a.w) & HPT_TRI_MESH_MASK;
+            if (QDEFER) { *qmask |= 1u << q; continue; }         // the stealing walk: noted, tested once the walk is over (traverse_steal)
             if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
                 ts.hit.prim = HPT_PRIM_QUADRIC | q;
                 if (ts.anyhit) return true;
@@ -822,6 +843,22 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
     return hit->prim >= 0;
 }
 
+// The quadrics a stealing walk noted for one ray (trav_leaf<..., QDEFER>): bit q = quadric q.  any: an any-hit ray — h->prim = 0 if one of them blocks it;
+// else the nearest of them that beats rr.maxt goes to *h (and shrinks rr).  World space.
+HPT_FN void deferred_quadrics(const DScene &sc, Ray &rr, uint32_t bits, bool any, Hit *h) {
+    while (bits != 0u) {
+        int q = 0;
+        while (!((bits >> q) & 1u)) ++q;
+        bits &= bits - 1u;
+        float t;
+        if (quadric_intersect(sc.quadrics[q], rr, &t, nullptr)) {
+            if (any) { h->prim = 0; return; }
+            h->prim = HPT_PRIM_QUADRIC | q; h->t = t; h->b1 = 0.f; h->b2 = 0.f; h->inst = -1;
+            rr.maxt = t;
+        }
+    }
+}
+
 // ---- the walk from the TOP-LEVEL tree (round 4) ---------------------------------------------------------------------------------------
 // sc.top_root4 (hpt_flatten.cpp, build_top_tree): the children of the world's root and one HPT_LEAF_KIND_INSTANCE leaf per animated
 // instance, boxed by its motion bounds — the reference's BVHAccel over the TransformedPrimitives (core/api.cpp:1186-1203,
@@ -837,8 +874,17 @@ HPT_FN f3 safe_inv_dir(f3 d) {
 // under it, its world origin and direction and a HPT_LEAF_KIND_RESTORE marker go on the stack (7 rows; *fl = rows at the stack's bottom
 // that belong to the world, marker included); t is the same number in both spaces, so mint / maxt stay.  The marker: the way back.
 // st: the lane's stack (row i at st[i * stride]).  QI: the extension set's animated spheres / disks (hpt_instance.quadric1 > 0).
+// Inlined.  (Out of line — HPT_TOP_NOINLINE, the three tables it reads passed BY VALUE so that no reference to the kernel-argument block escapes
+// (round 3, run G) — the walk's loop shrinks from 1640 to 900 VALU instructions, but the call makes the allocator spill ACROSS the loop: 37
+// scratch loads and 41 stores per iteration instead of 4 and 0, 432 instead of 300 B of scratch on anim's kernel.  Measured at compile time only.)
+struct TopTables { const hpt_instance *instances; const int32_t *inst_root4; const hpt_quadric *quadrics; };
+#if defined(__HIPCC__) && defined(HPT_TOP_NOINLINE)
+#define HPT_FN_TOP __device__ __noinline__
+#else
+#define HPT_FN_TOP HPT_FN
+#endif
 template <bool QI>
-HPT_FN void top_special_leaf(const DScene &sc, TravState &ts, Ray &r, int *cur_inst, int *fl, int32_t *st, int stride, const float *xf_col, int64_t xf_stride, float jt) {
+HPT_FN_TOP void top_special_leaf(TopTables sc, TravState &ts, Ray &r, int *cur_inst, int *fl, int32_t *st, int stride, const float *xf_col, int64_t xf_stride, float jt) {
     const uint32_t code = (uint32_t)~ts.node;
     if (((code >> 20) & 0xfu) == HPT_LEAF_KIND_INSTANCE) {
         const int k = (int)(code & 0xfffffu);
@@ -896,7 +942,7 @@ HPT_FN bool traverse_top(const DScene &sc, Ray &ray, float time, bool anyhit, Hi
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
     while (!ts.done()) {
         if (ts.node >= 0) trav_node4<COUNT>(sc.nodes4, ts, r, stack, stride, cnt, cap_normal);
-        else if (leaf_is_special(ts.node)) top_special_leaf<ALPHA>(sc, ts, r, &cur_inst, &fl, stack, stride, xf_col, xf_stride, time);
+        else if (leaf_is_special(ts.node)) { TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics; top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack, stride, xf_col, xf_stride, time); }
         else { if (trav_leaf<COUNT, ALPHA>(sc, sc.tris, ts, r, ts.node, cnt)) ts.node = HPT_TRAV_EMPTY; else trav_pop(ts, stack, stride); }
         if (max_sp && ts.sp > *max_sp) *max_sp = ts.sp;
         if (ts.hit.prim >= 0) {                             // a find: recorded under the instance it was made in (r.maxt has shrunk with it)

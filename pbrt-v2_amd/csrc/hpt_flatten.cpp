@@ -155,6 +155,9 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
         for (int k = 0; k < desc->n_instances; ++k) owned = owned || desc->instances[k].quadric1 == q + 1;
         if (!owned) world_quadrics.push_back(q);
     }
+    // more of them than the stealing walk's deferral mask holds: they stay out of the tree and are tested before the walk, as in rounds 1-3
+    out->n_linear_quadrics = 0;
+    if (desc->n_quadrics > HPT_MAX_LEAF_QUADRICS || getenv("HPT_QUADRIC_LINEAR")) { out->n_linear_quadrics = desc->n_quadrics; world_quadrics.clear(); }   // (HPT_QUADRIC_LINEAR: A/B switch)
     const int64_t nrec = ntris + (int64_t)world_quadrics.size();
     std::vector<BvhInputTri> in((size_t)nrec);
     std::vector<int32_t> tri_mesh((size_t)nrec), tri_idx((size_t)nrec);

@@ -132,7 +132,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // Must be called by ALL 64 lanes (has_ray = false for lanes with nothing to trace in this phase).  aux: five stack rows above
 // everything the walk uses (row aux: donor table).  Closest hits with exactly equal t (shared edges) are resolved by publishing
 // order here and by visiting order in the plain walk.
-#define HPT_STEAL_ROWS 6
+#define HPT_STEAL_ROWS 7
 // INST: animated instances (TransformedPrimitive, core/primitive.cpp:95-124).  Round 4: the walk starts at the TOP-LEVEL tree (sc.top_root4,
 // hpt_flatten.cpp build_top_tree: the world root's children and one leaf per instance, boxed by its motion bounds — the reference's BVHAccel
 // over the TransformedPrimitives, core/api.cpp:1186-1203), so a ray enters only the instances it crosses, nearest first, with whatever hit it
@@ -187,6 +187,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
     HPT_AUX(aux + 4, lane) = -1;
+    HPT_AUX(aux + 6, lane) = 0;                                     // quadrics the walks noted for this owner's rays (trav_leaf QDEFER): bits 0..15 any-hit ray, 16..31 closest-hit ray
     HPT_WAVE_SYNC();
     // Leaf batching.  Measured (profiles/r02i_phase_clocks.md): the leaf half of a step — the triangle tests, double-precision cross
     // products and all — takes 51-56 % of the step's time with 5-12 % of the lanes in it; whenever ANY lane reaches a leaf the whole wave
@@ -198,8 +199,10 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     for (;;) {
         // ---- a leaf of the top-level tree: enter the instance / return to the world (hpt_device.h, top_special_leaf) — once no ordinary leaf
         // is parked: a parked one belongs to the space the lane is about to leave ---------------------------------------------------------
-        if (INST && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node))
-            top_special_leaf<ALPHA>(sc, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
+        if (INST && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node)) {
+            TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics;
+            top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
+        }
         const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
         const unsigned long long mbusy = __ballot(busy);
         const bool any_busy = (mbusy | __ballot(more_b)) != 0ull;
@@ -220,8 +223,10 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
                 if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
                     if (has) {
-                        if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
+                        uint32_t qm = 0u;
+                        if (trav_leaf<COUNT, ALPHA, true>(sc, tris, ts, r, pend, cnt, &qm)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
                         pend = HPT_TRAV_EMPTY;
+                        if (qm != 0u) atomicOr((unsigned *)&HPT_AUX(aux + 6, owner), ts.anyhit ? qm : qm << 16);      // (rare: the leaf of a sphere / disk)
                     }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
                     cnt->leaf_clocks += __builtin_readcyclecounter() - w1_; cnt->leaf_lanes += (unsigned)nh; cnt->tris++;
@@ -321,6 +326,19 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             hit->t = as_float(shared); hit->b1 = as_float(HPT_AUX(aux + 2, lane)); hit->b2 = as_float(HPT_AUX(aux + 3, lane)); hit->prim = HPT_AUX(aux + 4, lane);
             if (INST) hit->inst = HPT_AUX(aux + 5, lane);
             ray.maxt = hit->t;
+        }
+    }
+    // ---- the spheres / disks whose leaves the walks reached: tested now, by the rays' owners, outside the loop (trav_leaf QDEFER) -------------
+    if (sc.n_quadrics > 0) {
+        const uint32_t qm = has_ray ? (uint32_t)HPT_AUX(aux + 6, lane) : 0u;
+        if (__ballot(qm != 0u) != 0ull) {
+            if (anyhit) {
+                if ((qm & 0xffffu) != 0u && hit->prim < 0) deferred_quadrics(sc, ray, qm & 0xffffu, true, hit);
+                if (TWO && has_b && (qm >> 16) != 0u) {
+                    Ray rb; rb.o = *pb; rb.d = *db; rb.mint = epsb; rb.maxt = hitb->prim >= 0 ? hitb->t : HPT_INF;
+                    deferred_quadrics(sc, rb, qm >> 16, false, hitb);
+                }
+            } else if ((qm >> 16) != 0u) deferred_quadrics(sc, ray, qm >> 16, false, hit);      // (shrinks ray.maxt with the find)
         }
     }
     HPT_WAVE_SYNC();

@@ -205,8 +205,9 @@ def test_wavefront_pipeline_equals_persistent(cases, dev, ora, name):
     assert sw.closest_rays == sp.closest_rays and sw.shadow_rays == sp.shadow_rays
     # (node fetches / triangle tests are a property of the WALK: the instrumented persistent kernel is the lock-step + stealing walk since
     #  round 3 — helpers walk stolen subtrees with the hit distance they had when they took them —, the wavefront trace kernel the plain one:
-    #  the same order of magnitude, not the same count)
-    assert 0.5 < sw.nodes_visited / sp.nodes_visited < 2.0 and 0.5 < sw.tris_tested / sp.tris_tested < 2.0
+    #  the same order of magnitude, not the same count; the persistent walk counts 128-byte four-wide nodes, the wavefront kernel 64-byte
+    #  two-wide ones: about two to one on a small scene — 2.02 on bunny once its disk light had become a primitive of the tree, round 4)
+    assert 0.5 < sw.nodes_visited / sp.nodes_visited < 2.6 and 0.5 < sw.tris_tested / sp.tris_tested < 2.0
     assert np.array_equal(fp[..., 3], fw[..., 3])
     assert np.allclose(fp, fw, rtol=1e-6, atol=1e-6)     # identical up to the order of the rare boundary spills
     fo, _ = ora[name].render(s.camera, rd)
