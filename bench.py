@@ -240,7 +240,10 @@ def end_to_end_pbrt_hip(workload, scene):
         def once(extra_env, pause=1.0):
             time.sleep(pause)
             t = time.time()
-            p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, env=dict(os.environ, HPT_TIMING="1", **extra_env))
+            # (the library remembers a scene's kernel configuration only where the HOST tells it to — HPT_TUNE_CACHE, opt-in since round 4: the first
+            #  run of this leg probes and fills the directory, the warm runs find the choice there, as a renderer started twice on a scene would)
+            p = subprocess.run([exe, "--quiet", sf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240,
+                               env=dict(os.environ, HPT_TIMING="1", HPT_TUNE_CACHE=os.path.join(tmp, "tune_cache"), **extra_env))
             dt_ = time.time() - t
             ok = p.returncode == 0 and os.path.exists(os.path.join(tmp, "o.pfm"))
             if ok: os.remove(os.path.join(tmp, "o.pfm"))

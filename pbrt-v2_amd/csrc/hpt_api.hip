@@ -50,6 +50,7 @@ struct hpt_scene {
     uint64_t content_key; // hash of the scene description (counts + a strided sample of the pools): keys the on-disk cache of tune_cfg
     int stack_entries;    // per-lane traversal stack entries this scene needs
     int stack_bound4, depth4;   // the four-wide trees: entries a walk can stack (hpt_bvh.h, collapse_bvh4), interior levels; 0: not built
+    int top_stack_bound4, top_depth4;   // the same for a walk that starts at the top-level tree and enters the instances from it (PathKernelArgs::top)
     float *inst_xf; size_t inst_xf_lanes;        // per-path instance-transform cache of the path kernel (animated instances)
     double device_build_ms; int device_built;   // HPT_BVH_BUILD=lbvh: kernel time of the device builder, groups it built
     float *d_ftable, *d_ftable_alloc; hpt_filter filter;
@@ -69,6 +70,8 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
     const char *m = getenv("HPT_RETRACE_MIN"), *x = getenv("HPT_RETRACE_MAX");
     a->retrace_min = m ? atoi(m) : 8; a->retrace_max = x ? atoi(x) : 4;
     if (a->retrace_min < 1) a->retrace_min = 1;
+    a->top = (s && s->d.n_instances > HPT_TOP_MIN_INSTANCES) ? 1 : 0;
+    if (const char *t = getenv("HPT_TOP")) a->top = (s && s->d.n_instances > 0 && atoi(t) != 0) ? 1 : 0;      // (A/B and tests)
     const char *rg = getenv("HPT_REGEN_MIN");
     a->regen_min = rg ? atoi(rg) : 16;      // same-box sweep 1 / 4 / 8 / 16 / 24 / 32 (profiles/r04_ab.md, run B): killeroo +4.2 %, anim +5.9 %, metal 4K +8.8 %, bunny +1.5 %, soup +0.7 % at 16
     if (a->regen_min < 1) a->regen_min = 1;
@@ -386,15 +389,16 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->d.n_inst_quadrics = n_inst_quadrics;
     s->d.n_linear_quadrics = fs.n_linear_quadrics;
-    s->stack_bound4 = 0; s->depth4 = 0; s->d.top_root4 = -1;
+    s->stack_bound4 = 0; s->depth4 = 0; s->top_stack_bound4 = 0; s->top_depth4 = 0; s->d.top_root4 = -1;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
         s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);
         s->d.inst_root4 = upload(s, &arena, fs.inst_root4.data(), fs.inst_root4.size(), &ok);
         s->d.world_root4 = fs.world_root4;
         s->d.top_root4 = fs.top_root4;
         // (the stealing walk starts at the top-level tree and enters the instances' trees from it: its bounds, hpt_flatten.cpp build_top_tree)
-        s->stack_bound4 = fs.top_stack_bound4 > fs.stack_bound4 ? fs.top_stack_bound4 : fs.stack_bound4;
-        s->depth4 = fs.top_depth4 > fs.depth4 ? fs.top_depth4 : fs.depth4;
+        s->stack_bound4 = fs.stack_bound4; s->depth4 = fs.depth4;
+        s->top_stack_bound4 = fs.top_stack_bound4 > fs.stack_bound4 ? fs.top_stack_bound4 : fs.stack_bound4;
+        s->top_depth4 = fs.top_depth4 > fs.depth4 ? fs.top_depth4 : fs.depth4;
     }
     s->d.ewa_lut = s->d.fpool ? s->d.fpool + fs.ewa_lut_off : nullptr;
     if (ok && !arena_flush(&arena)) ok = false;
@@ -724,7 +728,8 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
     const bool steal = path_kernel_effective_cfg(s->mats, cfg) >= 5 || a->dl;
     const int extra = (steal ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);
     a->cap_normal = 1 << 20;
-    if (steal && s->stack_bound4 > 0) {
+    const int bound4 = a->top ? s->top_stack_bound4 : s->stack_bound4, depth4 = a->top ? s->top_depth4 : s->depth4;
+    if (steal && bound4 > 0) {
         // The stealing walk runs on the BVH4 (trav_node4): a walk that stacks every other hit child can hold up to stack_bound4 entries (30-39
         // on the shipped meshes, 9-15 observed).  If the rows a workgroup can have do not cover that, the first cap_normal rows take ordinary
         // entries and the levels above them one masked entry each: cap_normal + 2 + depth4 rows always suffice.
@@ -733,9 +738,9 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
 #else
         const int room = HPT_MAX_STACK_ROWS - extra;
 #endif
-        int rows = s->stack_bound4 + 1;
-        if (rows > room) { rows = room; a->cap_normal = room - 2 - s->depth4; }
-        if (const char *e = getenv("HPT_BVH4_CAP")) { const int c = atoi(e); if (c >= 0 && c + 2 + s->depth4 <= rows) a->cap_normal = c; }   // (tests: exercise the masked entries)
+        int rows = bound4 + 1;
+        if (rows > room) { rows = room; a->cap_normal = room - 2 - depth4; }
+        if (const char *e = getenv("HPT_BVH4_CAP")) { const int c = atoi(e); if (c >= 0 && c + 2 + depth4 <= rows) a->cap_normal = c; }   // (tests: exercise the masked entries)
         else if (a->cap_normal < 6) return -1;                       // (a very deep tree: the caller falls back to the plain lock-step walk)
         if (rows < 12 && (s->mats & MATS_MEASURED)) rows = 12;       // the query queue of wave_eval_queries
         if (rows < 8) rows = 8;

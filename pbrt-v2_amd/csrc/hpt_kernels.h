@@ -29,6 +29,9 @@ struct PathKernelArgs {
     // lanes whose camera sample is complete wait (as subtree thieves) until regen_min lanes of their wave have finished before the wave runs
     // finish_path + refill + camera-ray set-up for all of them at once (1: every round, the behaviour up to round 3)
     int32_t regen_min;
+    // animated instances, lock step + stealing: 1 = walk from the top-level tree (DScene::top_root4: scenes of more than HPT_TOP_MIN_INSTANCES
+    // instances, or HPT_TOP=1), 0 = the ray's owner visits the instances one after the other behind the world tree
+    int32_t top;
     // lock step + stealing: the wave runs the leaf half of the walk when leaf_q eighths of its busy lanes have a leaf parked, or block_q eighths
     // can do nothing else (traverse_steal)
     int32_t leaf_q, block_q;
@@ -55,6 +58,7 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
 #define HPT_MAX_STACK_ROWS 40   /* dynamic LDS stack rows of the path kernel: 40 KiB a workgroup = 4 workgroups per CU */
 #define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
+#define HPT_TOP_MIN_INSTANCES 4 /* up to this many animated instances are visited serially (measured faster on two: profiles/r04_ab.md run D) */
 #define HPT_STEAL_STACK_ROWS 7  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
 bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
 int path_kernel_effective_cfg(int mats, int cfg);   /* the configuration that actually runs: the extension set builds 0, 5 and 6 only (HPT_LEAN_SET: 1, 2 -> 0; 3 -> 5; 4 -> 6) */

@@ -149,7 +149,10 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // Results live in different rows of the owner's column, so helpers of the first ray may still be walking when the owner starts the second:
 // any-hit rays raise the flag in row aux+2 (0 = occluded), closest-hit rays share t / prim / instance in rows aux+1 / aux+4 / aux+5.
 // `light`: a shadow / MIS phase — nobody needs barycentrics (rows aux+2, aux+3 are not written: aux+2 is the flag).
-template <bool COUNT, bool INST, bool ALPHA, bool TWO = false>
+// TOP: the walk from the top-level tree; false (scenes of a handful of instances: measured on anim-killeroos-moving, two instances, the serial
+// visit is 5-7 % faster — run D of round 4): the ray's OWNER walks the world tree and then, one after the other, the tree of every instance whose
+// motion bounds the (shrinking) ray still crosses, helpers only ever walk the subtree they were given.
+template <bool COUNT, bool INST, bool ALPHA, bool TWO = false, bool TOP = false>
 __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
                                                TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
                                                bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
@@ -164,7 +167,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     // the two pointers the loop dereferences, as scalar registers of their own: as fields of the kernel-argument block they live in a
     // 16-register tuple that the allocator spills to VGPR lanes and re-reads WHOLE (16 v_readlane per node step, measured in the ISA)
     const f4 *nodes = sc.nodes4, *tris = sc.tris;                   // the four-wide trees (trav_node4): half the dependent fetches per ray
-    const int32_t top_root = sc.top_root4;
+    const int32_t top_root = (INST && TOP) ? sc.top_root4 : sc.world_root4;
 #ifndef HPT_NO_SGPR_PIN
     {   // (through v_readfirstlane: a plain "+s" register pin is rejected — "illegal VGPR to SGPR copy" — in the instantiations where the
         //  compiler keeps the argument block in vector registers)
@@ -181,7 +184,11 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
     int cur_inst = -1, fl = 0;                                      // instance whose tree is being walked (-1: world space); world rows at the stack's bottom
     float jt = time;                                                // time of the ray this lane is walking (the owner's path time)
+    // !TOP: the segment this lane's OWN ray is in (-1 world, k instance k, n_seg: all done)
+    const int n_seg = (INST && !TOP) ? sc.n_instances : 0;
+    int seg = (INST && !TOP && has_ray) ? -1 : n_seg;
     bool more_b = TWO && has_ray && has_b;                          // the owner's second ray is still to come
+    bool cur_any = anyhit;                                          // kind of the owner's CURRENT ray (the second one is closest-hit)
     if (has_ray) trav_begin<ALPHA>(sc, ts, r, anyhit, top_root, true);
     else { ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f); }
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
@@ -199,19 +206,19 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     for (;;) {
         // ---- a leaf of the top-level tree: enter the instance / return to the world (hpt_device.h, top_special_leaf) — once no ordinary leaf
         // is parked: a parked one belongs to the space the lane is about to leave ---------------------------------------------------------
-        if (INST && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node)) {
+        if (INST && TOP && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node)) {
             TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics;
             top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
         }
         const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
         const unsigned long long mbusy = __ballot(busy);
-        const bool any_busy = (mbusy | __ballot(more_b)) != 0ull;
+        const bool any_busy = (mbusy | __ballot(seg < n_seg || more_b)) != 0ull;
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3   /* every lane: wave clocks of the node half / of the leaf half, iterations, leaf phases, lanes in them */
         const unsigned long long w0_ = __builtin_readcyclecounter();
         cnt->steps++;
 #endif
         if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
-        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
+        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && TOP && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
         const unsigned long long w1_ = __builtin_readcyclecounter();
         cnt->step_clocks += w1_ - w0_;
@@ -258,16 +265,44 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             }
             if (!any_busy) break;                                       // (the last publish has just happened)
         }
-        if (TWO && more_b && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY) {
-            // ---- the owner's shadow ray is through (its helpers may still be walking): on to the vertex's MIS ray ----------------
-            more_b = false;
-            r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
-            trav_begin<ALPHA>(sc, ts, r, false, top_root, true);
-            cur_inst = -1; fl = 0; sb = 0;
+        if (((INST && !TOP) || TWO) && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && (seg < n_seg || more_b)) {
+            if (INST && !TOP && seg < n_seg) {
+                // ---- the owner's ray leaves a tree: on to the next instance it can still reach ---------------------------------
+                const int shared = HPT_AUX(aux + (cur_any ? 2 : 1), lane);  // (seg < n_seg only on the owner: owner == lane)
+                ++seg;
+                if (cur_any && shared == 0) seg = n_seg;
+                if (seg < n_seg) {
+                    const hpt_instance &in = sc.instances[seg];
+                    Ray rw;
+                    if (TWO && !cur_any && has_b) { rw.o = *pb; rw.d = *db; rw.mint = epsb; rw.maxt = HPT_INF; }      // the MIS ray (a lane with two rays: the first is any-hit)
+                    else rw = ray;
+                    if (!cur_any) rw.maxt = fminf(rw.maxt, as_float(shared));
+                    const f3 invw = safe_inv_dir(rw.d);
+                    float tentry;
+                    const int32_t iroot = sc.inst_root4[seg];
+                    // (the extension set: an instance may be one animated sphere / disk instead of a tree — trav_begin tests it)
+                    if ((iroot >= 0 || (ALPHA && in.quadric1 > 0)) && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
+                        A34 w2p;
+                        if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
+                        else w2p = anim_interpolate(in, time, false).m;
+                        r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
+                        trav_begin<ALPHA>(sc, ts, r, cur_any, iroot, false, seg);
+                        cur_inst = seg; sb = 0;
+                    }
+                }
+            }
+            if (TWO && more_b && seg >= n_seg && ts.node == HPT_TRAV_EMPTY) {
+                // ---- the owner's shadow ray is through (its helpers may still be walking): on to the vertex's MIS ray ----------------
+                more_b = false; cur_any = false;
+                seg = (INST && !TOP) ? -1 : n_seg;
+                r.o = *pb; r.d = *db; r.mint = epsb; r.maxt = HPT_INF;
+                trav_begin<ALPHA>(sc, ts, r, false, top_root, true);
+                cur_inst = -1; fl = 0; sb = 0;
+            }
         }
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
-        const bool idle = !still && pend == HPT_TRAV_EMPTY && !more_b;
+        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_seg && !more_b;
         const bool donor = still && ts.sp >= 1;                     // (fl is 0 or >= 8: the bottom row is a node, never a saved ray)
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
@@ -279,9 +314,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         if (donor && rd < n) {
             HPT_AUX(aux, rd) = lane;
             give = stack[sb * HPT_BLOCK];                           // bottom entry: the oldest = largest pending subtree
-            if (INST && fl > 0) { gw = sb + fl - 7; --fl; }
+            if (INST && TOP && fl > 0) { gw = sb + fl - 7; --fl; }
             ++sb; --ts.sp;
-            if (INST && fl == 7) { sb += 7; ts.sp -= 7; fl = 0; }   // the last world row went: nothing to come back to (the saved ray stays readable for this round's thief)
+            if (INST && TOP && fl == 7) { sb += 7; ts.sp -= 7; fl = 0; }   // the last world row went: nothing to come back to (the saved ray stays readable for this round's thief)
         }
         HPT_WAVE_SYNC();
         const bool take = idle && ri < n;
@@ -293,12 +328,12 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         const float ix = __shfl(ts.invd.x, src), iy = __shfl(ts.invd.y, src), iz = __shfl(ts.invd.z, src);
         const int any_s = __shfl((int)ts.anyhit, src), own_s = __shfl(owner, src), node_s = __shfl(give, src);
         const int inst_s = INST ? __shfl(cur_inst, src) : -1;
-        const int gw_s = INST ? __shfl(gw, src) : -1;
-        const float jt_s = INST ? __shfl(jt, src) : 0.f;
+        const int gw_s = (INST && TOP) ? __shfl(gw, src) : -1;
+        const float jt_s = (INST && TOP) ? __shfl(jt, src) : 0.f;
         if (take) {
             r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
             ts.invd = mk3(ix, iy, iz); ts.anyhit = any_s != 0; owner = own_s; cur_inst = inst_s;
-            if (INST) {
+            if (INST && TOP) {
                 jt = jt_s;
                 if (gw_s >= 0) {                                    // a subtree of the WORLD from a donor that is inside an instance: the world ray is in its column
                     r.o = mk3(as_float(col0[src + (gw_s + 0) * HPT_BLOCK]), as_float(col0[src + (gw_s + 1) * HPT_BLOCK]), as_float(col0[src + (gw_s + 2) * HPT_BLOCK]));
@@ -362,7 +397,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
 // every live lane shades at once and each phase traces one kind of ray (all any-hit in the shadow phase).
 // WIN: the kernels of the window samplers (Sampler "halton": a work item is a sample number of a 32x32 window, item_to_halton) — instantiations
 // of their own so that the default sampler's kernels stay instruction for instruction what they were (LdHashSrcT, hpt_path.h)
-template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false, bool WIN = false>
+// TOP (lock step + stealing with animated instances): the walk starts at the top-level tree (traverse_steal; PathKernelArgs::top: scenes of more than
+// HPT_TOP_MIN_INSTANCES instances)
+template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false, bool WIN = false, bool TOP = false>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     extern __shared__ uint64_t dyn_lds[];      // traversal stacks — sized per scene (path_kernel_dyn_lds)
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
@@ -489,7 +526,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool has_b = MERGE && tr && anyhit && lane.has_mis;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; if (has_b) wc.closest++; }
             Hit hitb;
-            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0, MERGE>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal,
+            traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0, MERGE, TOP>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - HPT_STEAL_ROWS, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal,
                                                                         MERGE && phase != ST_EXTEND, has_b, &lane.p, &lane.wi_mis, lane.eps, &hitb);
             if (RETRACE && phase == ST_EXTEND) {
                 // Extension rays that escaped end their paths without shading.  If there are enough of them, they take their next camera
@@ -637,6 +674,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 // +1 %; the instanced kernels, at their register limit, lose 6 % with it — profiles/r02_ab.md) and build in parallel.  The
 // instrumented (COUNT) build exists for configuration 5 only (lock step + subtree stealing: the walk — and the tree — the production
 // configurations 5 / 6 run, so that its node counter counts the fetches of THAT walk); rays and samples do not depend on scheduling.
+#ifndef HPT_COUNT_WAVES
+#define HPT_COUNT_WAVES 4   /* waves per SIMD the instrumented (count_work) build of configuration 5 is compiled for */
+#endif
 #define HPT_DEFINE_PATH_LAUNCHER(NAME, MATS, INSTV)                                                                 \
     template <int CFG> static hipError_t launch_cfg_##NAME(const PathKernelArgs &a, int grid, size_t dyn_lds, hipStream_t s) { \
         hipLaunchKernelGGL((HPT_CFG_KERNEL(MATS, INSTV, CFG)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);             \
@@ -648,9 +688,19 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (a.dl) {                                                                                             \
                 if (count) hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);    \
                 else hipLaunchKernelGGL((HPT_DL_KERNEL_W(MATS, INSTV, false)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);         \
-            } else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, true, false, true, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); \
+            } else if (count) hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, HPT_COUNT_WAVES, 0, true, false, true, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); \
             else hipLaunchKernelGGL((hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);             \
             return hipGetLastError();                                                                               \
+        }                                                                                                           \
+        if constexpr (INSTV) if (a.top) {   /* many instances: the lock-step + stealing kernels that walk from the top-level tree (TOP = true) */ \
+            if (a.dl) {                                                                                             \
+                if (count) hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); \
+                else hipLaunchKernelGGL((hpt_path_kernel<false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);      \
+                return hipGetLastError();                                                                           \
+            }                                                                                                       \
+            if (count) { hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, HPT_COUNT_WAVES, 0, true, false, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); return hipGetLastError(); } \
+            if (HPT_CFG_ALIAS(cfg) == 5) { hipLaunchKernelGGL((hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); return hipGetLastError(); } \
+            if (HPT_CFG_ALIAS(cfg) == 6) { hipLaunchKernelGGL((hpt_path_kernel<false, INSTV, MATS, HPT_W34, 0, true, false, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a); return hipGetLastError(); } \
         }                                                                                                           \
         if (a.dl) {                                                                                                 \
             if (count) hipLaunchKernelGGL((HPT_DL_KERNEL(MATS, INSTV, true)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);          \
@@ -658,7 +708,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (count) {                                                                                                \
-            hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, 4, 0, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
+            hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, HPT_COUNT_WAVES, 0, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
         if (INSTV && cfg == 1) cfg = 0;                                                                             \

@@ -1123,3 +1123,27 @@ def test_sixty_four_instances_render_like_the_oracle_and_cost_no_more_than_a_han
     finally:
         del os.environ["HPT_TUNE"]
     assert t64 < 2.0 * t6 + 0.5, (t6, t64)
+
+
+@pytest.mark.parametrize("name", ["anim", "aquad", "oinst", "abi8dl"])
+def test_top_level_tree_walk_and_serial_instance_visit_render_the_same_film(name, monkeypatch):
+    """Round 4: scenes of up to HPT_TOP_MIN_INSTANCES (4) animated instances keep the serial visit behind the world tree (faster on two), larger ones
+    walk from the top-level tree (hpt_path_kernel<..., TOP = true>).  HPT_TOP forces either on any scene: both must render the oracle's film —
+    production and instrumented (count_work) builds, path and direct lighting."""
+    s = load_case(name)
+    rd = hash_rd(s, seed=7)
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    films = {}
+    for top in ("0", "1"):
+        monkeypatch.setenv("HPT_TOP", top)
+        d = hpt.DeviceScene(s)
+        for cw in (0, 1):
+            rd.count_work = cw
+            f, st = d.render(s.camera, rd)
+            assert st.bad_samples == 0 and np.array_equal(f[..., 3], fo[..., 3]), (top, cw)
+            assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3, (top, cw)
+            if cw:
+                assert st.camera_samples == so[0]
+                assert abs(int(st.closest_rays) - int(so[1])) <= max(8, so[1] // 2000) and abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 2000)
+        films[top] = f
+    assert film.rmse(film.xyzw_to_rgb(films["0"]), film.xyzw_to_rgb(films["1"])) < 1e-4
