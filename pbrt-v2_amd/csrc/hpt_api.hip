@@ -388,7 +388,6 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
     s->d.n_inst_quadrics = n_inst_quadrics;
-    s->d.n_linear_quadrics = fs.n_linear_quadrics;
     s->stack_bound4 = 0; s->depth4 = 0; s->top_stack_bound4 = 0; s->top_depth4 = 0; s->d.top_root4 = -1;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
         s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);

@@ -299,11 +299,7 @@ struct DMesh {
 #define HPT_LEAF_KIND_RESTORE 2u
 #define HPT_LEAF_CODE(kind, index) ((int32_t)~(HPT_LEAF_SPECIAL | ((uint32_t)(kind) << 20) | (uint32_t)(index)))
 #define HPT_TRI_ALPHA_BIT 0x40000000   /* set in a triangle record's mesh word when its mesh has an alpha texture */
-// Round 4: a sphere / disk of the world is a primitive of the world's tree like the reference's (GeometricPrimitive in the BVHAccel,
-// accelerators/bvh.cpp:403-454) instead of being tested against every ray before the walk: it enters the builders as a pseudo-triangle
-// spanning its (padded) world bound and owns one 48-byte record in leaf order whose mesh word carries this bit and the quadric's number.
-#define HPT_TRI_QUADRIC_BIT 0x20000000
-#define HPT_TRI_MESH_MASK 0x1fffffff
+#define HPT_TRI_MESH_MASK 0x3fffffff
 #define HPT_PRIM_QUADRIC 0x40000000    /* Hit::prim of a quadric hit: HPT_PRIM_QUADRIC | quadric number (triangle hits: the record's slot, < HPT_LEAF_SPECIAL) */
 struct DScene {
     const f4 *nodes;
@@ -325,7 +321,6 @@ struct DScene {
     int32_t world_root4;
     int32_t n_inst_quadrics;        // instances whose primitive is one sphere / disk (hpt_instance.quadric1 > 0): those quadrics are not primitives of the world
     int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
-    int32_t n_linear_quadrics;      // 0: the world's quadrics are primitives of its tree; n_quadrics: too many for that (HPT_MAX_LEAF_QUADRICS) — tested before the walk
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
@@ -619,9 +614,12 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
-    // The world's spheres / disks are primitives of its tree since round 4 (trav_leaf).  Only a scene with more of them than the stealing walk's
-    // deferral mask holds (HPT_MAX_LEAF_QUADRICS) keeps the linear test of rounds 1-3: n_linear_quadrics = n_quadrics there, 0 otherwise.
-    for (int q = 0; world && q < sc.n_linear_quadrics; ++q) {
+    // The few quadrics (area-light emitters) are tested linearly first; closest hit is order independent.  (Round 4 built them into the world's
+    // tree as pseudo-triangle records — the reference keeps them in the BVHAccel, accelerators/bvh.cpp:403-454 — twice: with the shape test in
+    // the leaf loop every workload lost 7-12 % (nine scratch reloads per step of the walk), with the test deferred to after the walk the films of
+    // the instanced extension-set kernels came out wrong in some instantiations and right in others — the red channel of the radiance zeroed:
+    // the compiler's problem or mine, not found — and the gain was mixed anyway: killeroo +1.7 %, bunny -2.6 %.  profiles/r04_ab.md, runs C-E.)
+    for (int q = 0; world && q < sc.n_quadrics; ++q) {
         if (QI && sc.n_inst_quadrics > 0) {
             bool owned = false;
             for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
@@ -749,14 +747,8 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
 
 // trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
 // any-hit ray is done (occluded).
-// QDEFER (the path kernel's stealing walk): a quadric's record only sets its bit in *qmask — the shape test (a square root, an atan2f, the partial-
-// sphere logic: ~350 instructions inlined) inside the leaf loop cost the whole walk its register allocation (nine scratch reloads per step,
-// every workload 7-12 % slower: round 4, GPU run C); the ray's owner tests the noted quadrics once, after the walk (deferred_quadrics).  A
-// primitive tested later only delays the shrinking of the ray.  Scenes with more than HPT_MAX_LEAF_QUADRICS world quadrics keep them out
-// of the tree (DScene::n_linear_quadrics: the linear test of rounds 1-3, trav_begin).
-#define HPT_MAX_LEAF_QUADRICS 16
-template <bool COUNT, bool ALPHA, bool QDEFER = false>
-HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt, uint32_t *qmask = nullptr) {
+template <bool COUNT, bool ALPHA>
+HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     for (uint32_t k = 0; k < count; ++k) {
@@ -764,17 +756,6 @@ HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray,
         f4 a = tp[0], b = tp[1], c = tp[2];
         if (COUNT) cnt->tris++;
         float t, b1, b2;
-        if (as_int(a.w) & HPT_TRI_QUADRIC_BIT) {                 // a sphere / disk of the world (a pseudo-triangle record, hpt_flatten.cpp)
-            const int q = as_int(a.w) & HPT_TRI_MESH_MASK;
-            if (QDEFER) { *qmask |= 1u << q; continue; }         // the stealing walk: noted, tested once the walk is over (traverse_steal)
-            if (quadric_intersect(sc.quadrics[q], ray, &t, nullptr)) {
-                ts.hit.prim = HPT_PRIM_QUADRIC | q;
-                if (ts.anyhit) return true;
-                ts.hit.t = t; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f;
-                ray.maxt = t;
-            }
-            continue;
-        }
         if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
             if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
             ts.hit.prim = (int32_t)(first + k);
@@ -841,22 +822,6 @@ HPT_FN bool traverse(const DScene &sc, Ray &ray, float time, bool anyhit, Hit *h
         }
     }
     return hit->prim >= 0;
-}
-
-// The quadrics a stealing walk noted for one ray (trav_leaf<..., QDEFER>): bit q = quadric q.  any: an any-hit ray — h->prim = 0 if one of them blocks it;
-// else the nearest of them that beats rr.maxt goes to *h (and shrinks rr).  World space.
-HPT_FN void deferred_quadrics(const DScene &sc, Ray &rr, uint32_t bits, bool any, Hit *h) {
-    while (bits != 0u) {
-        int q = 0;
-        while (!((bits >> q) & 1u)) ++q;
-        bits &= bits - 1u;
-        float t;
-        if (quadric_intersect(sc.quadrics[q], rr, &t, nullptr)) {
-            if (any) { h->prim = 0; return; }
-            h->prim = HPT_PRIM_QUADRIC | q; h->t = t; h->b1 = 0.f; h->b2 = 0.f; h->inst = -1;
-            rr.maxt = t;
-        }
-    }
 }
 
 // ---- the walk from the TOP-LEVEL tree (round 4) ---------------------------------------------------------------------------------------
@@ -940,6 +905,10 @@ HPT_FN bool traverse_top(const DScene &sc, Ray &ray, float time, bool anyhit, Hi
     int cur_inst = -1, fl = 0;
     trav_begin<ALPHA>(sc, ts, r, anyhit, sc.top_root4, true);
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
+    if (ts.hit.prim >= 0) {                                 // (a quadric of the world: trav_begin's linear test)
+        *hit = ts.hit; hit->inst = -1; ts.hit.prim = -1;
+        if (anyhit) return true;
+    }
     while (!ts.done()) {
         if (ts.node >= 0) trav_node4<COUNT>(sc.nodes4, ts, r, stack, stride, cnt, cap_normal);
         else if (leaf_is_special(ts.node)) { TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics; top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack, stride, xf_col, xf_stride, time); }

@@ -88,19 +88,6 @@ struct TopBuilder {
         return idx;
     }
 };
-// Transform::operator()(BBox) of a quadric's ObjectBound (shapes/sphere.cpp:52-55, disk.cpp:50-53), padded: the shape test runs in object space
-void quadric_world_bound(const hpt_quadric &q, float *lo, float *hi) {
-    const float r = q.radius, z0 = q.kind == HPT_QUADRIC_SPHERE ? q.zmin : q.height, z1 = q.kind == HPT_QUADRIC_SPHERE ? q.zmax : q.height;
-    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-    for (int c = 0; c < 8; ++c) {
-        const float p[3] = {(c & 1) ? r : -r, (c & 2) ? r : -r, (c & 4) ? z1 : z0};
-        for (int k = 0; k < 3; ++k) {
-            const float w = q.o2w[4 * k] * p[0] + q.o2w[4 * k + 1] * p[1] + q.o2w[4 * k + 2] * p[2] + q.o2w[4 * k + 3];
-            lo[k] = std::fmin(lo[k], w); hi[k] = std::fmax(hi[k], w);
-        }
-    }
-    for (int k = 0; k < 3; ++k) { const float pad = 1e-4f * (hi[k] - lo[k]) + 1e-6f * std::fmax(std::fabs(lo[k]), std::fabs(hi[k])) + 1e-30f; lo[k] -= pad; hi[k] += pad; }
-}
 } // namespace
 
 // The top-level tree over what build the loop above left in out->nodes4; bounds of the per-group trees as collapse_bvh4 reported them.
@@ -147,27 +134,8 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     if (ntris >= (int64_t)HPT_LEAF_SPECIAL - 16) { hpt_set_error("too many triangles (%lld)", (long long)ntris); return HPT_E_UNSUPPORTED; }
     // world-space triangle soup (the reference transforms vertices at mesh construction,
     // shapes/trianglemesh.cpp:70-71, so P is already in world space)
-    // the world's spheres / disks (not the ones an animated instance owns) join the world's triangles as pseudo-triangles spanning their
-    // padded world bounds: primitives of the tree (HPT_TRI_QUADRIC_BIT, hpt_device.h) — tri_mesh = -(quadric + 1)
-    std::vector<int> world_quadrics;
-    for (int q = 0; q < desc->n_quadrics; ++q) {
-        bool owned = false;
-        for (int k = 0; k < desc->n_instances; ++k) owned = owned || desc->instances[k].quadric1 == q + 1;
-        if (!owned) world_quadrics.push_back(q);
-    }
-    // more of them than the stealing walk's deferral mask holds: they stay out of the tree and are tested before the walk, as in rounds 1-3
-    out->n_linear_quadrics = 0;
-    if (desc->n_quadrics > HPT_MAX_LEAF_QUADRICS || getenv("HPT_QUADRIC_LINEAR")) { out->n_linear_quadrics = desc->n_quadrics; world_quadrics.clear(); }   // (HPT_QUADRIC_LINEAR: A/B switch)
-    const int64_t nrec = ntris + (int64_t)world_quadrics.size();
-    std::vector<BvhInputTri> in((size_t)nrec);
-    std::vector<int32_t> tri_mesh((size_t)nrec), tri_idx((size_t)nrec);
-    for (size_t j = 0; j < world_quadrics.size(); ++j) {
-        float lo[3], hi[3];
-        quadric_world_bound(desc->quadrics[world_quadrics[j]], lo, hi);
-        BvhInputTri &bt = in[(size_t)ntris + j];
-        for (int k = 0; k < 3; ++k) { bt.v[0][k] = lo[k]; bt.v[1][k] = hi[k]; bt.v[2][k] = 0.5f * lo[k] + 0.5f * hi[k]; }
-        tri_mesh[(size_t)ntris + j] = -(world_quadrics[j] + 1); tri_idx[(size_t)ntris + j] = 0;
-    }
+    std::vector<BvhInputTri> in((size_t)ntris);
+    std::vector<int32_t> tri_mesh((size_t)ntris), tri_idx((size_t)ntris);
     out->meshes.assign((size_t)desc->n_meshes, DMesh());
     int64_t base = 0;
     for (int m = 0; m < desc->n_meshes; ++m) {
@@ -198,7 +166,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
     }
     // One BVH for the triangles that live directly in the world and one per animated instance (its
     // triangles are in the instance's own space), all in the same node / triangle arrays.
-    out->tri_rec.assign(12 * (size_t)nrec, 0.f);
+    out->tri_rec.assign(12 * (size_t)ntris, 0.f);
     out->nodes.clear();
     out->inst_root.assign((size_t)desc->n_instances, -1);
     out->world_root = -1;
@@ -215,7 +183,6 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             int64_t mb = out->meshes[(size_t)m].prim_base;
             for (int t = 0; t < desc->meshes[m].ntris; ++t) { sub.push_back(in[(size_t)(mb + t)]); src.push_back((uint32_t)(mb + t)); }
         }
-        if (g < 0) for (size_t j = 0; j < world_quadrics.size(); ++j) { sub.push_back(in[(size_t)ntris + j]); src.push_back((uint32_t)((size_t)ntris + j)); }
         if (sub.empty()) continue;
         BvhResult bvh;
         double dev_ms = 0.0;
@@ -243,8 +210,7 @@ int flatten_scene(const hpt_scene_desc *desc, int max_leaf, int max_depth, FlatS
             uint32_t s0 = src[bvh.order[i]];
             float *r = &out->tri_rec[12 * (tri_base + i)];
             for (int k = 0; k < 3; ++k) { r[4 * k + 0] = in[s0].v[k][0]; r[4 * k + 1] = in[s0].v[k][1]; r[4 * k + 2] = in[s0].v[k][2]; }
-            int32_t mesh_word = tri_mesh[s0] < 0 ? (int32_t)(HPT_TRI_QUADRIC_BIT | (uint32_t)(-tri_mesh[s0] - 1))
-                                                 : (tri_mesh[s0] | (desc->meshes[tri_mesh[s0]].alpha_tex > 0 ? HPT_TRI_ALPHA_BIT : 0));
+            int32_t mesh_word = tri_mesh[s0] | (desc->meshes[tri_mesh[s0]].alpha_tex > 0 ? HPT_TRI_ALPHA_BIT : 0);
             memcpy(&r[3], &mesh_word, 4);
             memcpy(&r[7], &tri_idx[s0], 4);
         }

@@ -23,7 +23,6 @@ struct FlatScene {
     // trees from it (a walk inside an instance keeps 7 more entries: the world ray it returns to and their marker)
     int32_t top_root4 = -1;
     int top_stack_bound4 = 0, top_depth4 = 0;
-    int n_linear_quadrics = 0;        // DScene::n_linear_quadrics
     int top_nodes4 = 0;               // nodes the top-level tree added to nodes4 (0: the world tree serves as it is)
     std::vector<int32_t> inst_root;   // root node of each animated instance's BVH (-1 = no triangles)
     int32_t world_root = -1;          // root node of the world BVH (-1 = no world triangles)

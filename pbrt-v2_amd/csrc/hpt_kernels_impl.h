@@ -132,7 +132,7 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // Must be called by ALL 64 lanes (has_ray = false for lanes with nothing to trace in this phase).  aux: five stack rows above
 // everything the walk uses (row aux: donor table).  Closest hits with exactly equal t (shared edges) are resolved by publishing
 // order here and by visiting order in the plain walk.
-#define HPT_STEAL_ROWS 7
+#define HPT_STEAL_ROWS 6
 // INST: animated instances (TransformedPrimitive, core/primitive.cpp:95-124).  Round 4: the walk starts at the TOP-LEVEL tree (sc.top_root4,
 // hpt_flatten.cpp build_top_tree: the world root's children and one leaf per instance, boxed by its motion bounds — the reference's BVHAccel
 // over the TransformedPrimitives, core/api.cpp:1186-1203), so a ray enters only the instances it crosses, nearest first, with whatever hit it
@@ -194,7 +194,6 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     HPT_AUX(aux + 1, lane) = as_int(more_b ? HPT_INF : r.maxt);     // r.maxt >= 0: float order == unsigned order of the bits
     HPT_AUX(aux + 2, lane) = 1;                                     // any-hit flag (0 = occluded); an extension phase overwrites it with b1
     HPT_AUX(aux + 4, lane) = -1;
-    HPT_AUX(aux + 6, lane) = 0;                                     // quadrics the walks noted for this owner's rays (trav_leaf QDEFER): bits 0..15 any-hit ray, 16..31 closest-hit ray
     HPT_WAVE_SYNC();
     // Leaf batching.  Measured (profiles/r02i_phase_clocks.md): the leaf half of a step — the triangle tests, double-precision cross
     // products and all — takes 51-56 % of the step's time with 5-12 % of the lanes in it; whenever ANY lane reaches a leaf the whole wave
@@ -230,10 +229,8 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                 const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
                 if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
                     if (has) {
-                        uint32_t qm = 0u;
-                        if (trav_leaf<COUNT, ALPHA, true>(sc, tris, ts, r, pend, cnt, &qm)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
+                        if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
                         pend = HPT_TRAV_EMPTY;
-                        if (qm != 0u) atomicOr((unsigned *)&HPT_AUX(aux + 6, owner), ts.anyhit ? qm : qm << 16);      // (rare: the leaf of a sphere / disk)
                     }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
                     cnt->leaf_clocks += __builtin_readcyclecounter() - w1_; cnt->leaf_lanes += (unsigned)nh; cnt->tris++;
@@ -363,19 +360,6 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             ray.maxt = hit->t;
         }
     }
-    // ---- the spheres / disks whose leaves the walks reached: tested now, by the rays' owners, outside the loop (trav_leaf QDEFER) -------------
-    if (sc.n_quadrics > 0) {
-        const uint32_t qm = has_ray ? (uint32_t)HPT_AUX(aux + 6, lane) : 0u;
-        if (__ballot(qm != 0u) != 0ull) {
-            if (anyhit) {
-                if ((qm & 0xffffu) != 0u && hit->prim < 0) deferred_quadrics(sc, ray, qm & 0xffffu, true, hit);
-                if (TWO && has_b && (qm >> 16) != 0u) {
-                    Ray rb; rb.o = *pb; rb.d = *db; rb.mint = epsb; rb.maxt = hitb->prim >= 0 ? hitb->t : HPT_INF;
-                    deferred_quadrics(sc, rb, qm >> 16, false, hitb);
-                }
-            } else if ((qm >> 16) != 0u) deferred_quadrics(sc, ray, qm >> 16, false, hit);      // (shrinks ray.maxt with the find)
-        }
-    }
     HPT_WAVE_SYNC();
 #ifdef HPT_PRIO_WALK
     __builtin_amdgcn_s_setprio(0);
@@ -466,7 +450,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         // (The free-running instantiation of the extension set with animated instances faulted under a threshold of 16 — GPU run B2 of round 4,
         //  cause not found; the free-running and plain lock-step kernels keep the per-round flush they have always had.)
         {
+#ifdef HPT_DBG_NO_REGEN
+            const int regen_min = 1;
+#else
             const int regen_min = (STEAL && PHASED) ? a.regen_min : 1;
+#endif
             const unsigned long long mfin = __ballot(lane.fin);
             if (mfin != 0ull && (__popcll(mfin) >= regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull))
                 lane.flush(rp, a.film, COUNT ? &wc : nullptr);

@@ -49,7 +49,7 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
     for (int k = 0; k < desc->n_instances; ++k) s->d.n_inst_quadrics += desc->instances[k].quadric1 > 0;
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
-    s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4; s->d.top_root4 = s->fs.top_root4; s->d.n_linear_quadrics = s->fs.n_linear_quadrics;
+    s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4; s->d.top_root4 = s->fs.top_root4;
     return s;
 }
 extern "C" void emu_scene_destroy(emu_scene *s) { delete s; }

@@ -1147,3 +1147,18 @@ def test_top_level_tree_walk_and_serial_instance_visit_render_the_same_film(name
                 assert abs(int(st.closest_rays) - int(so[1])) <= max(8, so[1] // 2000) and abs(int(st.shadow_rays) - int(so[2])) <= max(8, so[2] // 2000)
         films[top] = f
     assert film.rmse(film.xyzw_to_rgb(films["0"]), film.xyzw_to_rgb(films["1"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["aquad", "oinst", "oinst64", "abi8dl", "aquaddl", "anim"])
+def test_every_instantiation_an_instanced_scene_can_run_renders_the_oracles_film(name):
+    """scripts/gpu_matrix.py as a test: kernel configuration 0 / 5 / 6 x serial instance visit / top-level walk (HPT_TOP) x production / instrumented build,
+    every combination against the oracle.  Round 4 found the instanced extension-set kernels (the largest instantiations: 0.5-1 MB of code, ~1.2 KB of scratch a
+    lane) wrong in ONE instantiation or another after every edit of the kernel source — the red channel of the radiance zeroed in half the lanes, a memory
+    fault in the free-running kernel — while the host emulation of the same headers is clean under MemorySanitizer: a build of those kernels is good when
+    this passes, whatever changed."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_matrix.py"), name], capture_output=True, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "matrix: 0 of" in out, out[-2000:] + p.stderr.decode(errors="replace")[-1500:]
