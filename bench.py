@@ -495,7 +495,7 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_samples = rd.x_count * rd.y_count * rd.spp * steps
@@ -516,7 +516,7 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                                   rd.spp // world if strong else spp_per_gpu, rd.spp,
                                   {"random": "RANDOM_HASH", "stratified": "STRATIFIED_HASH (8 strata wide, jittered)", "halton": "HALTON_HASH (32 x 32 pixel windows)"}.get(args.sampler, "LD_HASH"),
                                   "box" if flt is None else "%s %g x %g" % (args.filter, flt.xwidth, flt.ywidth)),
-                   "sharding": ("32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s per frame in the library (hpt_comm_exchange_film: RCCL)" % (world, "gather (ncclSend / ncclRecv of packed tiles)" if flt is None else "sum-reduce (ncclReduce)"))
+                   "sharding": ("32x32 pixel tiles round-robin over %d GPU(s), scene replicated, one film-tile %s per frame in the library (hpt_comm_exchange_film: %s)" % (world, "gather (send / recv of packed tile records)" if flt is None else "sum-reduce", "host-staged shared memory, ONE-DEVICE DRY RUN" if os.environ.get("HPT_COMM_TRANSPORT") == "host" else "RCCL"))
                                if (comm is not None or world == 1) else
                                ("32x32 pixel tiles round-robin over %d GPU(s), scene replicated, film exchange through torch.distributed (pbrt-v2_amd/dist.py) — FALLBACK: %s" % (world, _EXCHANGE.get("fallback"))),
                    "prims": int(info.n_tris + info.n_quadrics), "bvh2_nodes_64B": int(info.n_bvh_nodes),
@@ -750,10 +750,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available() or hpt.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+    # Dry run of the N > 1 code path on a ONE-GPU box (HPT_BENCH_ONE_DEVICE=1; tests and scripts/gpu_r04_j.sh): every rank uses device 0, the timing
+    # barrier / all-reduce go over gloo, and the library's film exchange over its host-staged transport (RCCL refuses two ranks on one device).  The
+    # numbers of such a run measure nothing — N processes share one GPU — the LINE, the sharding and the exchange are what it checks.
+    one_device = world > 1 and os.environ.get("HPT_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
+        os.environ["HPT_COMM_TRANSPORT"] = "host"
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_device else "nccl", rank=rank, world_size=world)
     comm = None
     if world > 1:
         def bcast(uid):                                  # torch.distributed only carries the 128-byte ncclUniqueId and the timing barrier
@@ -768,7 +775,7 @@ def main():
             comm = hpt.Comm(rank, world, local, bcast)
         except Exception as e:                           # noqa: BLE001 — any failure of the set-up takes the fallback
             err = "%s: %s" % (type(e).__name__, e)
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if one_device else "cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if comm is not None:
