@@ -725,7 +725,7 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
     // (the extension set runs configurations 3 / 4 as 5 / 6: the rows must be those of the kernel that runs — round 2 sized them for the
     //  plain lock-step walk and the stealing rows overlapped the top of the traversal stacks)
     const bool steal = path_kernel_effective_cfg(s->mats, cfg) >= 5 || a->dl;
-    const int extra = (steal ? HPT_STEAL_STACK_ROWS : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);
+    const int extra = (steal ? path_kernel_steal_rows(a->dl != 0) : 0) + path_kernel_cold_rows(s->mats, a->dl != 0);
     a->cap_normal = 1 << 20;
     const int bound4 = a->top ? s->top_stack_bound4 : s->stack_bound4, depth4 = a->top ? s->top_depth4 : s->depth4;
     if (steal && bound4 > 0) {

@@ -60,6 +60,7 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_TOP_MIN_INSTANCES 4 /* up to this many animated instances are visited serially (measured faster on two: profiles/r04_ab.md run D) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
+int path_kernel_steal_rows(bool dl);   /* LDS rows the lock-step + stealing kernels of THIS build keep above their traversal stacks (HPT_STEAL_ROWS; a -DHPT_FUSE build's path kernels: HPT_STEAL3_ROWS) */
 bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
 int path_kernel_effective_cfg(int mats, int cfg);   /* the configuration that actually runs: the extension set builds 0, 5 and 6 only (HPT_LEAN_SET: 1, 2 -> 0; 3 -> 5; 4 -> 6) */
 int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */

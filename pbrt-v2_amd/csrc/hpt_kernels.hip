@@ -29,6 +29,14 @@ bool path_kernel_wide_bvh() {
     return false;
 #endif
 }
+int path_kernel_steal_rows(bool dl) {
+#ifdef HPT_FUSE
+    return dl ? HPT_STEAL_ROWS : HPT_STEAL3_ROWS;
+#else
+    (void)dl;
+    return HPT_STEAL_ROWS;
+#endif
+}
 int path_kernel_effective_cfg(int mats, int cfg) {
     if (!(mats & MATS_EXT)) return cfg;
     return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // HPT_CFG_ALIAS under HPT_LEAN_SET (hpt_kernels_impl.h)
