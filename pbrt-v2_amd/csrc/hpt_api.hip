@@ -121,7 +121,7 @@ static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name,
         const int64_t id[2] = {(int64_t)sb.st_size, (int64_t)sb.st_mtime};
         h = fnv1a(h, id, sizeof(id));
     }
-    for (const char *v : {"HPT_LEAN_EXT", "HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
+    for (const char *v : {"HPT_LEAN_EXT", "HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_BINS", "HPT_BVH_CT", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
         if (const char *e = getenv(v)) { h = fnv1a(h, v, strlen(v)); h = fnv1a(h, e, strlen(e)); }
     return h;
 }
@@ -297,8 +297,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         for (int m = 0; m < desc->n_meshes; ++m)
             if (desc->meshes[m].instance >= 0 && (memcmp(desc->meshes[m].o2w, ident, sizeof(ident)) != 0 || memcmp(desc->meshes[m].o2w_inv, ident, sizeof(ident)) != 0)) ext = true;
     }
-    int n_inst_quadrics = 0;
-    for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; ++n_inst_quadrics; }   // animated spheres / disks: the extension set's walk and shading geometry
+    uint32_t inst_quadric_mask = 0u;
+    for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) { ext = true; inst_quadric_mask |= 1u << std::min(desc->instances[k].quadric1 - 1, 31); }   // animated spheres / disks: the extension set's walk and shading geometry
     // anything round 2 added runs on the extension kernel set (hpt_kernels_ext.hip), which carries every material family
     if (ext) s->mats = MATS_FULL;
     // The kernel set follows what the scene can REACH (round 4; no switch needed): an extension-set scene that reaches none of the rare features
@@ -387,7 +387,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.instances = upload(s, &arena, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;
-    s->d.n_inst_quadrics = n_inst_quadrics;
+    s->d.inst_quadric_mask = inst_quadric_mask;
     s->stack_bound4 = 0; s->depth4 = 0; s->top_stack_bound4 = 0; s->top_depth4 = 0; s->d.top_root4 = -1;
     if (path_kernel_wide_bvh() && !fs.nodes4.empty()) {      // the stealing walk of this build walks the collapsed trees
         s->d.nodes4 = (const f4 *)upload(s, &arena, fs.nodes4.data(), fs.nodes4.size(), &ok);

@@ -46,6 +46,7 @@ struct Builder {
     std::vector<uint32_t> order;
     int maxLeaf, maxDepth, deepest;
     int nbins = 16;     // SAH bins per axis (HPT_BVH_BINS, 4..64)
+    float ct = 1.f;     // cost of a node visit in units of a triangle test (HPT_BVH_CT, 0.05..16)
 
     static int ceil_log2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 
@@ -122,7 +123,7 @@ struct Builder {
                     if (cost < bestCost) { bestCost = cost; bestDim = d; bestSplit = b; }
                 }
             }
-            const float Ct = 1.0f, Ci = 1.0f;
+            const float Ct = ct, Ci = 1.0f;
             float leafCost = Ci * n;
             float splitCost = bestDim >= 0 ? Ct + Ci * bestCost / std::max(bb.area(), 1e-30f) : std::numeric_limits<float>::infinity();
             if ((int)n <= maxLeaf && leafCost <= splitCost) return make_leaf(start, end);
@@ -152,7 +153,7 @@ struct Builder {
         int32_t c0, c1;
         if (par > 0 && n >= 4096) {
             Builder L, R;
-            for (Builder *b : {&L, &R}) { b->tris = tris; b->boxes = boxes; b->cent = cent; b->idx = idx; b->maxLeaf = maxLeaf; b->maxDepth = maxDepth; b->deepest = 0; b->nbins = nbins; }
+            for (Builder *b : {&L, &R}) { b->tris = tris; b->boxes = boxes; b->cent = cent; b->idx = idx; b->maxLeaf = maxLeaf; b->maxDepth = maxDepth; b->deepest = 0; b->nbins = nbins; b->ct = ct; }
             L.nodes.reserve(mid - start); L.order.reserve(mid - start); R.nodes.reserve(end - mid); R.order.reserve(end - mid);
             std::thread left([&] { c0 = L.build(start, mid, depth + 1, &b0, par - 1); });
             c1 = R.build(mid, end, depth + 1, &b1, par - 1);
@@ -243,6 +244,7 @@ void build_bvh(const BvhInputTri *tris, size_t n, int maxLeaf, int maxDepth, Bvh
     Builder b;
     b.tris = tris; b.maxLeaf = std::min(std::max(maxLeaf, 1), 8); b.maxDepth = maxDepth; b.deepest = 0;
     if (const char *e = getenv("HPT_BVH_BINS")) { int v = atoi(e); if (v >= 4 && v <= 64) b.nbins = v; }
+    if (const char *e = getenv("HPT_BVH_CT")) { float v = (float)atof(e); if (v >= 0.05f && v <= 16.f) b.ct = v; }
     std::vector<Box> boxes(n); std::vector<float> cent(3 * n); std::vector<uint32_t> idx(n);
     for (size_t i = 0; i < n; ++i) {
         Box bx; bx.reset();

@@ -319,7 +319,7 @@ struct DScene {
     const f4 *nodes4;
     const int32_t *inst_root4;
     int32_t world_root4;
-    int32_t n_inst_quadrics;        // instances whose primitive is one sphere / disk (hpt_instance.quadric1 > 0): those quadrics are not primitives of the world
+    uint32_t inst_quadric_mask;     // bit q (q < 31): quadric q is the primitive of an instance (hpt_instance.quadric1 == q + 1), not a primitive of the world; bit 31: an owned quadric has index >= 31 (those are looked up in the instance table)
     int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
 };
 
@@ -620,9 +620,10 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     // the instanced extension-set kernels came out wrong in some instantiations and right in others — the red channel of the radiance zeroed:
     // the compiler's problem or mine, not found — and the gain was mixed anyway: killeroo +1.7 %, bunny -2.6 %.  profiles/r04_ab.md, runs C-E.)
     for (int q = 0; world && q < sc.n_quadrics; ++q) {
-        if (QI && sc.n_inst_quadrics > 0) {
-            bool owned = false;
-            for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
+        if (QI && sc.inst_quadric_mask != 0u) {
+            bool owned = q < 31 && ((sc.inst_quadric_mask >> q) & 1u) != 0u;
+            if (q >= 31 && (sc.inst_quadric_mask >> 31) != 0u)
+                for (int k = 0; k < sc.n_instances; ++k) owned |= sc.instances[k].quadric1 == q + 1;
             if (owned) continue;
         }
         float t;

@@ -591,6 +591,10 @@ HipPathRenderer::HipPathRenderer(Sampler *s, Camera *c, SurfaceIntegrator *si,
         samplerMode = !strcmp(e, "mtreplay") ? HPT_SAMPLER_MT_REPLAY : HPT_SAMPLER_LD_HASH;
     dumpPath = params.FindOneString("dumpscene", "");
     if (const char *e = getenv("HPT_DUMP_SCENE")) dumpPath = e;
+    // "string tunecache" ["<dir>"]: the directory the library may remember this scene's kernel configuration in (the library writes nothing
+    // unasked: $HPT_TUNE_CACHE, which this sets when the environment has not)
+    std::string tc = params.FindOneString("tunecache", "");
+    if (tc != "") setenv("HPT_TUNE_CACHE", tc.c_str(), 0);
 }
 
 HipPathRenderer::~HipPathRenderer() {

@@ -1162,3 +1162,24 @@ def test_every_instantiation_an_instanced_scene_can_run_renders_the_oracles_film
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_matrix.py"), name], capture_output=True, timeout=600)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "matrix: 0 of" in out, out[-2000:] + p.stderr.decode(errors="replace")[-1500:]
+
+
+@pytest.mark.parametrize("name", ["k8", "b8", "anim", "metal"])
+def test_regeneration_batch_size_does_not_change_the_film(name, monkeypatch):
+    """Round 4: lanes whose camera sample is complete wait (stealing subtrees) until HPT_REGEN_MIN lanes of their wave have finished (default 16), then the wave
+    refills them together.  When a lane is refilled decides nothing about WHAT it renders — samples are numbered by the work counter, not by the lane — so every
+    threshold must give the oracle's film: 1 (round 3's behaviour), the default, and 64 (a wave refills only when nobody is left walking)."""
+    s = load_case(name)
+    rd = hash_rd(s, seed=11)
+    fo, _ = orc.OracleScene(s).render(s.camera, rd)
+    monkeypatch.setenv("HPT_TUNE", "5")
+    d = hpt.DeviceScene(s)
+    films = {}
+    for v in ("1", "16", "64"):
+        monkeypatch.setenv("HPT_REGEN_MIN", v)
+        f, st = d.render(s.camera, rd)
+        assert st.bad_samples == 0 and np.array_equal(f[..., 3], fo[..., 3]), v
+        assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3, v
+        films[v] = f
+    for v in ("1", "64"):
+        assert film.rmse(film.xyzw_to_rgb(films[v]), film.xyzw_to_rgb(films["16"])) < 1e-4, v
