@@ -41,6 +41,9 @@ struct PathKernelArgs {
     float *adapt_buf;
 };
 inline size_t path_kernel_dyn_lds(const PathKernelArgs &a) {
+#ifdef HPT_LDS_PAD_ENV   /* (diagnostic builds: HPT_LDS_PAD_KB of unused LDS per workgroup lower the residency without touching the kernel — occupancy and register budget apart) */
+    if (const char *e = getenv("HPT_LDS_PAD_KB")) return (size_t)a.stack_entries * HPT_BLOCK * 4 + (size_t)atoi(e) * 1024;
+#endif
     return (size_t)a.stack_entries * HPT_BLOCK * 4;
 }
 
