@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Stress of tests/test_gpu_parity.py::test_kernel_configurations_render_the_same_film: the seven kernel configurations on the small fixtures, many times over; prints
+every render whose film weights are not the expected sample counts (which configuration, how many pixels, by how much) or whose radiance is off.
+usage: stress_cfgs.py [cases=env,ms] [reps=20]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import importlib  # noqa: E402
+
+hpt = importlib.import_module("pbrt-v2_amd.hpt")
+from tests.util import hash_rd, load_case  # noqa: E402
+
+
+def main():
+    cases = (sys.argv[1] if len(sys.argv) > 1 else "env,ms").split(",")
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    bad = 0
+    for name in cases:
+        s = load_case(name)
+        rd = hash_rd(s, seed=9)
+        d = hpt.DeviceScene(s)
+        ref = None
+        for rep in range(reps):
+            for cfg in range(7):
+                os.environ["HPT_TUNE"] = str(cfg)
+                f, st = d.render(s.camera, rd)
+                if ref is None:
+                    ref = f
+                    print(name, "reference: cfg 0, weights", float(f[..., 3].min()), float(f[..., 3].max()), "spp", rd.spp)
+                w = f[..., 3] - ref[..., 3]
+                dv = np.abs(f[..., :3] - ref[..., :3]).max()
+                if np.any(w != 0) or st.bad_samples or not np.allclose(f, ref, rtol=1e-6, atol=1e-6):
+                    bad += 1
+                    ys, xs = np.nonzero(w)
+                    print("DEVIATION", name, "rep", rep, "cfg", cfg, "pixels", len(ys), "weight diff sum", float(w.sum()), "min/max", float(w.min()), float(w.max()),
+                          "first", [(int(y), int(x), float(w[y, x])) for y, x in list(zip(ys, xs))[:6]], "max |dXYZ|", float(dv), "bad_samples", int(st.bad_samples))
+        d.close()
+    print("stress: %d deviating renders" % bad)
+    os.environ.pop("HPT_TUNE", None)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
