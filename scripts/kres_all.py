@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -munsafe-fp-atomics".split()
 ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 TUS = {"hpt_kernels_basic": ILP, "hpt_kernels_basic_i": [], "hpt_kernels_measured": ILP + ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"], "hpt_kernels_measured_i": [],
-       "hpt_kernels_all": [], "hpt_kernels_all_i": [], "hpt_kernels_ext": ILP, "hpt_kernels_ext_i": [], "hpt_kernels_lean": ILP}
+       "hpt_kernels_all": [], "hpt_kernels_all_i": [], "hpt_kernels_ext": ILP, "hpt_kernels_ext_i": [], "hpt_kernels_lean": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 
 
 def run(tu):
