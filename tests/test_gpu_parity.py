@@ -1184,3 +1184,28 @@ def test_regeneration_batch_size_does_not_change_the_film(name, monkeypatch):
         films[v] = f
     for v in ("1", "64"):
         assert film.rmse(film.xyzw_to_rgb(films[v]), film.xyzw_to_rgb(films["16"])) < 1e-4, v
+
+
+def test_owned_quadrics_past_the_mask_bits_are_found_in_the_instance_table(monkeypatch):
+    """Round 4: the device knows which quadrics are instances' primitives from a bit per quadric (DScene::inst_quadric_mask, indices < 31) and looks the others up
+    in the instance table.  `aquad` behind 33 more world spheres puts its two owned quadrics at indices 33 and 34: the intersect hook and the rendered film (free-running
+    and lock-step + stealing kernels, serial instance visit and top-level walk) against the oracle."""
+    from tests.util import with_quadric_padding
+    s = with_quadric_padding(load_case("aquad"), 33)
+    o, d = orc.OracleScene(s), hpt.DeviceScene(s)
+    rays = random_rays(s, 100000, seed=5)
+    ho, po = o.intersect(rays)
+    hd, pd = d.intersect(rays)
+    same = po == pd
+    assert same.mean() > 0.9995 and np.array_equal(ho[same], hd[same])
+    _, ao = o.intersect(rays, anyhit=True)
+    _, ad = d.intersect(rays, anyhit=True)
+    assert (ao == ad).mean() > 0.9995
+    rd = hash_rd(s, seed=4)
+    fo, _ = o.render(s.camera, rd)
+    for cfg, top in (("0", "0"), ("5", "0"), ("5", "1")):
+        monkeypatch.setenv("HPT_TUNE", cfg)
+        monkeypatch.setenv("HPT_TOP", top)
+        f, st = hpt.DeviceScene(s).render(s.camera, rd)
+        assert st.bad_samples == 0 and np.array_equal(f[..., 3], fo[..., 3]), (cfg, top)
+        assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3, (cfg, top)

@@ -45,14 +45,15 @@ def test_intersect_matches_oracle(cases, pairs, name):
     assert (ao == ae).mean() > 0.9995
 
 
-@pytest.mark.parametrize("name", ["aquad", "oinst"])
+@pytest.mark.parametrize("name", ["aquad", "oinst", "aquad+33"])
 def test_instance_kinds_of_abi8_find_the_oracles_hits(name):
     """ABI 8's instance kinds under aggregatetest-style rays (time 0: the start transforms), closest hit and any hit, on the BVH2 walk (traverse) and on
     the four-wide walk the path kernel runs (trav_node4): `aquad` — a sphere and a disk that are instances' primitives (trav_begin<QI>: tested when
     the walk enters the instance, skipped among the world's quadrics) beside a mesh instance and a world sphere; `oinst` — six instances over two
-    shared aggregates (inst_root / inst_root4 of a sharing instance are its owner's), one of them mirrored."""
-    from tests.util import load_case
-    s = load_case(name)
+    shared aggregates (inst_root / inst_root4 of a sharing instance are its owner's), one of them mirrored; `aquad+33` — aquad behind 33 more world spheres, so
+    that the quadrics its instances own have indices past the 31 bits of DScene::inst_quadric_mask (the instance-table lookup of trav_begin)."""
+    from tests.util import load_case, with_quadric_padding
+    s = with_quadric_padding(load_case("aquad"), 33) if name == "aquad+33" else load_case(name)
     o, e = orc.OracleScene(s), emu.EmuScene(s, max_leaf=2)
     rays = random_rays(s, 40000, seed=9)
     ho, po = o.intersect(rays)

@@ -364,3 +364,35 @@ def with_instance_copies(scene, src, n_copies, start=(20.0, 0.0, 0.0), step=(3.0
         if hasattr(scene, attr):
             setattr(s2, attr, getattr(scene, attr))
     return s2
+
+
+def with_quadric_padding(scene, n_pad, at=(100.0, 100.0, 100.0), step=(3.0, 0.0, 0.0)):
+    """`scene` with n_pad small world spheres (copies of its last world quadric without its emission, far outside the scene) placed BEFORE its own quadrics, so that
+    the quadrics instances own get indices >= n_pad: hpt_instance.quadric1 and hpt_light.quadric move with them.  Round 4: the device keeps a bit per owned quadric
+    (DScene::inst_quadric_mask) for indices < 31 and looks the rest up in the instance table."""
+    owned = {i.quadric1 - 1 for i in scene.instances if i.quadric1 > 0}
+    src = max(k for k in range(len(scene.quadrics)) if k not in owned)
+    pads = []
+    for j in range(n_pad):
+        q = abi.Quadric.from_buffer_copy(bytes(scene.quadrics[src]))
+        q.arealight = -1
+        v = np.asarray(at, dtype=np.float64) + j * np.asarray(step, dtype=np.float64)
+        m = np.eye(4); m[:3, 3] = v
+        mi = np.eye(4); mi[:3, 3] = -v
+        for k in range(16):
+            q.o2w[k] = np.float32(m.flat[k]); q.o2w_inv[k] = np.float32(mi.flat[k])
+        pads.append(q)
+    inst = [abi.Instance.from_buffer_copy(bytes(i)) for i in scene.instances]
+    for i in inst:
+        if i.quadric1 > 0:
+            i.quadric1 += n_pad
+    lights = [type(l).from_buffer_copy(bytes(l)) for l in scene.lights]
+    for l in lights:
+        if l.kind == abi.HPT_LIGHT_DIFFUSE_AREA and l.quadric >= 0:
+            l.quadric += n_pad
+    s2 = abi.Scene(meshes=list(scene.meshes), quadrics=pads + list(scene.quadrics), materials=list(scene.materials), lights=lights,
+                   fpool=scene.fpool, ipool=scene.ipool, camera=scene.camera, render=scene.render, instances=inst, textures=list(scene.textures))
+    for attr in ("filter", "camera_motion", "meta"):
+        if hasattr(scene, attr):
+            setattr(s2, attr, getattr(scene, attr))
+    return s2
