@@ -1057,7 +1057,7 @@ struct LaneStack {
     int qrow = 0;         // first stack row of the wave's query queue (path kernel only)
 };
 #define HPT_KD_GRID 64
-#define HPT_BG_X 16       /* sample grid: cells along sin*sin in [0,1] */
+#define HPT_BG_X 64       /* sample grid: cells along sin*sin in [0,1] (round 4: 64, was 16 — a row of the box is one range of the cell table whatever its cells' width, so narrow cells along x trim a fifth of the samples a query tests for free: bunny +2.7 %, run AA) */
 #define HPT_BG_Y 16       /*              dphi/pi in [0,1]            */
 #define HPT_BG_Z 32       /*              cos*cos in [-1,1]           */
 HPT_FN int bg_cell_x(float v) { int c = (int)(v * (float)HPT_BG_X); return c < 0 ? 0 : c > HPT_BG_X - 1 ? HPT_BG_X - 1 : c; }
@@ -1111,6 +1111,7 @@ HPT_FN void kd_begin(const float *fpool, const hpt_material *m, f3 mpt, KdWalk *
 // returns true when the query is finished: *out = IrregIsotropicBRDF::f
 HPT_FN bool kd_step(KdWalk *w, f3 *out) {
     if (w->j >= w->jend) {                               // this row's range is used up: on to the next row of the box
+        // (skipping EMPTY rows inside the step — about one row in seven — was measured: bunny 1941 against 1974 Msamples/s, run AA of round 4: the loop costs more than the steps it saves)
         ++w->iy;
         if (w->iy > w->y1) { w->iy = w->y0; ++w->iz; }
         if (w->iz <= w->z1) {
