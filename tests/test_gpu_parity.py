@@ -1209,3 +1209,20 @@ def test_owned_quadrics_past_the_mask_bits_are_found_in_the_instance_table(monke
         f, st = hpt.DeviceScene(s).render(s.camera, rd)
         assert st.bad_samples == 0 and np.array_equal(f[..., 3], fo[..., 3]), (cfg, top)
         assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3, (cfg, top)
+
+
+def test_tune_leaves_the_window_samplers_alone(monkeypatch):
+    """ADVICE (round 3): hpt_scene_tune probed configurations 0-4 for Sampler "halton" / "adaptive" / "bestcandidate" jobs, whose kernels exist as configuration 5 only
+    (the LDS rows of the probe were those of kernels that never run).  It now answers 5 without a probe, whatever the job's size, and the render runs configuration 5."""
+    import time
+    monkeypatch.delenv("HPT_TUNE", raising=False)
+    s = load_case("hk")
+    d = hpt.DeviceScene(s)
+    rd = abi.copy_struct(s.render)
+    big = abi.copy_struct(rd)
+    big.spp = 4096                                     # a job far past the 32 M-sample threshold of the autotuner
+    t0 = time.perf_counter()
+    assert d.tune(s.camera, big) == 5
+    assert time.perf_counter() - t0 < 0.5              # no probe renders
+    _, st = d.render(s.camera, rd)
+    assert st.tune_cfg == 5 and st.bad_samples == 0
