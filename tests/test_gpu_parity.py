@@ -1211,18 +1211,24 @@ def test_owned_quadrics_past_the_mask_bits_are_found_in_the_instance_table(monke
         assert film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)) < 1e-3, (cfg, top)
 
 
-def test_tune_leaves_the_window_samplers_alone(monkeypatch):
+def test_tune_leaves_the_window_samplers_alone(monkeypatch, capfd):
     """ADVICE (round 3): hpt_scene_tune probed configurations 0-4 for Sampler "halton" / "adaptive" / "bestcandidate" jobs, whose kernels exist as configuration 5 only
-    (the LDS rows of the probe were those of kernels that never run).  It now answers 5 without a probe, whatever the job's size, and the render runs configuration 5."""
-    import time
+    (the LDS rows of the probe were those of kernels that never run).  It now answers 5 without a probe, whatever the job's size (HPT_TUNE_VERBOSE prints a line per
+    probe render: there must be none), and the render runs configuration 5; the same scene under its LD sampler does probe."""
     monkeypatch.delenv("HPT_TUNE", raising=False)
+    monkeypatch.setenv("HPT_TUNE_VERBOSE", "1")
     s = load_case("hk")
     d = hpt.DeviceScene(s)
     rd = abi.copy_struct(s.render)
     big = abi.copy_struct(rd)
     big.spp = 4096                                     # a job far past the 32 M-sample threshold of the autotuner
-    t0 = time.perf_counter()
+    capfd.readouterr()
     assert d.tune(s.camera, big) == 5
-    assert time.perf_counter() - t0 < 0.5              # no probe renders
+    assert "hpt autotune" not in capfd.readouterr().err
     _, st = d.render(s.camera, rd)
     assert st.tune_cfg == 5 and st.bad_samples == 0
+    ld = hash_rd(s, seed=1)
+    ld.spp = 4096
+    capfd.readouterr()
+    assert 0 <= hpt.DeviceScene(s).tune(s.camera, ld) < 7
+    assert "hpt autotune" in capfd.readouterr().err
