@@ -40,7 +40,9 @@ enum {
     HPT_E_INVALID = -2,    /* malformed descriptor */
     HPT_E_UNSUPPORTED = -3,/* scene uses a feature outside the hot-path scope */
     HPT_E_IO = -4,
-    HPT_E_HIP = -5
+    HPT_E_HIP = -5,
+    HPT_E_INTERNAL = -6    /* the library caught itself: the camera samples a frame's kernels completed are not the job's (every sample reaches the
+                              film exactly once, renderers/samplerrenderer.cpp:60-164), or a check of the debug build failed.  The film is not to be used. */
 };
 
 /* ---- scene description (flattened pbrt Scene) ------------------------------------------ */
@@ -482,6 +484,10 @@ int hpt_calib_hbm_read(int device, size_t bytes_per_array, int reps, double *gb_
 /* Bytes of one BVH node fetch of the walk that hpt_stats.nodes_visited counts (count_work): 64 — the BVH2 node with both children's
  * boxes — or 128 when this build's lock-step + stealing walk runs on the four-wide trees (two 64-byte lines per node). */
 int hpt_kernel_node_bytes(void);
+
+/* sizeof() of the ABI's records as THIS library was compiled: {hpt_mesh, hpt_quadric, hpt_material, hpt_light, hpt_camera, hpt_render_desc,
+ * hpt_stats, hpt_blob_header, hpt_instance, hpt_texture} — a binding (ctypes, cgo, JNI) checks its own layouts against it before the first call. */
+void hpt_abi_sizes(int32_t out[10]);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ using namespace hpt;
         }                                                                                   \
     } while (0)
 
-struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; };   // one work-queue head per XCD
+struct RenderScratch { unsigned long long next_item[8]; hpt::WorkCounters wc; unsigned dbg[HPT_DBG_WORDS]; };   // one work-queue head per XCD; the counters; the debug build's failure record
 
 struct hpt_scene {
     int device;
@@ -121,7 +121,7 @@ static uint64_t scene_content_key(const hpt_scene_desc *d, const char *dev_name,
         const int64_t id[2] = {(int64_t)sb.st_size, (int64_t)sb.st_mtime};
         h = fnv1a(h, id, sizeof(id));
     }
-    for (const char *v : {"HPT_LEAN_EXT", "HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_BINS", "HPT_BVH_CT", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q"})
+    for (const char *v : {"HPT_LEAN_EXT", "HPT_BVH_BUILD", "HPT_BVH_MAXLEAF", "HPT_BVH_BINS", "HPT_BVH_CT", "HPT_BVH_DEVICE_MIN", "HPT_CHUNK", "HPT_XCD_QUEUE", "HPT_RETRACE_MIN", "HPT_RETRACE_MAX", "HPT_LEAF_Q", "HPT_LEAF_BLOCK_Q", "HPT_TOP", "HPT_REGEN_MIN"})
         if (const char *e = getenv(v)) { h = fnv1a(h, v, strlen(v)); h = fnv1a(h, e, strlen(e)); }
     return h;
 }
@@ -418,6 +418,9 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     }
     s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
     s->d.n_nodes = (int32_t)fs.nodes.size();
+#ifdef HPT_DEBUG_CHECKS
+    s->d.n_nodes4 = (int32_t)(fs.nodes4.size() / 2); s->d.n_meshes = (int32_t)fs.meshes.size(); s->d.n_materials = (int32_t)fs.materials.size(); s->d.n_textures = desc->n_textures;
+#endif
     // what every frame needs besides the film: allocated once, so that a render call neither allocates nor frees (hipFree synchronises the device)
     if (ok && (hipMalloc(&s->d_scr, sizeof(RenderScratch)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) ok = false;
     if (!ok) { hpt_set_error("device allocation / upload failed: %s", hipGetErrorString(hipGetLastError())); hpt_scene_destroy(s); return nullptr; }
@@ -747,7 +750,9 @@ static int kernel_residency(const hpt_scene *s, int cfg, PathKernelArgs *a, int 
     } else
         a->stack_entries = s->stack_entries + extra;   // [walk stack][stealing rows][cold rows]
     if (a->stack_entries > HPT_MAX_STACK_ROWS) return -1;            // (configuration 5 on a very deep tree: the caller skips it)
-    if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs) != 0) return -1;
+    // (the instantiation that will run: the top-level walk and the window samplers have kernels of their own — ADVICE r04)
+    const bool win = a->rp.sampler_kind == 3 || a->rp.adapt_min > 0 || a->rp.bc_table != nullptr;
+    if (path_kernel_occupancy(s->mats, inst, cfg, a->dl != 0, path_kernel_dyn_lds(*a), bpc, vgprs, a->top != 0, win) != 0) return -1;
     if (*bpc < 1) *bpc = 1;
     return 0;
 }
@@ -831,7 +836,7 @@ extern "C" int hpt_render_device(hpt_scene *s, const hpt_camera *cam, const hpt_
 int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, void *d_film, void *stream_v, hpt_stats *stats, bool clear_film) {
     if (!s || !d_film) { hpt_set_error("null scene / film"); return HPT_E_INVALID; }
     PathKernelArgs a;
-    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.dbg = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);     // before fill_params: it may (re)allocate the scene's sample-record buffer
     int rc = fill_params(cam, rd, &a.rp, s);
@@ -845,6 +850,7 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
     a.next_item = d_scr->next_item;
     a.counters = &d_scr->wc;
     a.rp.bad_counter = (unsigned long long *)&d_scr->wc.bad;   // the production kernels count bad radiance values there (one atomic on the rare path)
+    a.dbg = d_scr->dbg;
     const bool replay = rd->sampler_mode == HPT_SAMPLER_MT_REPLAY;
     if ((s->mats & MATS_EXT) && !replay && rd->pipeline == HPT_PIPELINE_WAVEFRONT) {
         hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel (the wavefront pipeline covers the round-1 feature set)");
@@ -969,6 +975,39 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
     if (ra.mt) (void)hipFree(ra.mt);
     if (ra.buf) (void)hipFree(ra.buf);
     if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
+    if (h_scr.dbg[0] != 0u) {         // a `make debug` build: the first check that failed in this frame's kernels (codes: hpt_device.h, HPT_CK_*)
+        static const char *const names[] = {"?", "STACK_ROW", "STACK_NEG", "EXEC", "SHFL_SRC", "NODE", "TRI", "PRIM", "QUEUE", "INST", "ITEM", "PIXEL", "STATE", "MATERIAL", "XF"};
+        const unsigned c = h_scr.dbg[0];
+        hpt_set_error("debug check %u (%s) failed in the path kernel: values %d %d %d %d, workgroup %u thread %u; %u failures in all (configuration %d, mats %d, instances %d, top %d, integrator %d, sampler kind %d)",
+                      c, c < sizeof(names) / sizeof(names[0]) ? names[c] : "?", (int)h_scr.dbg[1], (int)h_scr.dbg[2], (int)h_scr.dbg[3], (int)h_scr.dbg[4], h_scr.dbg[5], h_scr.dbg[6],
+                      h_scr.dbg[15], cfg, s->mats, s->d.n_instances, a.top, rd->integrator, a.rp.sampler_kind);
+        return HPT_E_INTERNAL;
+    }
+    // the job's camera samples: this shard's pixels inside the sample extent x spp
+    uint64_t job_samples = 0;
+    {
+        uint64_t px = 0;
+        const int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
+        for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
+            int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
+            int w = a.rp.sx_count - x0; if (w > 32) w = 32;
+            int h = a.rp.sy_count - y0; if (h > 32) h = 32;
+            px += (uint64_t)w * (uint64_t)h;
+        }
+        job_samples = px * (uint64_t)rd->spp;
+        if (const char *t = getenv("HPT_TEST_CONSERVATION_DELTA")) job_samples += (uint64_t)atoll(t);   // (tests: a job size the kernels cannot meet — the check must fire)
+    }
+    // Sample conservation (renderers/samplerrenderer.cpp:60-164: every camera sample of the job is traced and reaches film->AddSample exactly
+    // once).  Every path kernel counts the camera samples it completes (hpt_kernels_impl.h, n_flushed); for the samplers whose samples belong
+    // to pixels the total is known before the launch.  (The window samplers reject points outside the extent and the adaptive sampler renders
+    // some pixels twice: their count is reported, not checked.  A -DHPT_PHASE_TIMERS build keeps wave clocks in these words.)
+    if (!replay && !windowed && !getenv("HPT_PHASE_TIMERS") && h_scr.wc.samples != job_samples) {
+        hpt_set_error("sample conservation violated: the kernels completed %llu camera samples, the job has %llu (configuration %d, %d x %d pixels from (%d, %d), %d spp, shard %d of %d, "
+                      "material set %d, %d instances, top-level walk %d, integrator %d, sampler kind %d, work items of %d samples, regeneration threshold %d)",
+                      (unsigned long long)h_scr.wc.samples, (unsigned long long)job_samples, cfg, a.rp.sx_count, a.rp.sy_count, a.rp.sx_start, a.rp.sy_start, rd->spp, a.rp.shard_rank, a.rp.shard_count,
+                      s->mats, s->d.n_instances, a.top, rd->integrator, a.rp.sampler_kind, a.rp.chunk, a.regen_min);
+        return HPT_E_INTERNAL;
+    }
     if (getenv("HPT_PHASE_TIMERS"))   // a -DHPT_PHASE_TIMERS kernel build leaves wave clocks per loop section in the work counters
         fprintf(stderr, "hpt phase clocks (refill, extension walk, shadow+MIS walk, on_hit, BRDF queries, shade_finish): %llu %llu %llu %llu %llu %llu  kernel %.3f ms cfg %d\n",
                 (unsigned long long)h_scr.wc.samples, (unsigned long long)h_scr.wc.closest, (unsigned long long)h_scr.wc.shadow, (unsigned long long)h_scr.wc.nodes,
@@ -976,16 +1015,8 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
-        // samples of this shard: pixels inside the extent x spp (also counted on device when count_work)
-        uint64_t px = 0;
-        int64_t nst = (int64_t)a.rp.n_stx * a.rp.n_sty;
-        for (int64_t st = a.rp.shard_rank; st < nst; st += a.rp.shard_count) {
-            int x0 = (int)(st % a.rp.n_stx) * 32, y0 = (int)(st / a.rp.n_stx) * 32;
-            int w = a.rp.sx_count - x0; if (w > 32) w = 32;
-            int h = a.rp.sy_count - y0; if (h > 32) h = 32;
-            px += (uint64_t)w * (uint64_t)h;
-        }
-        stats->camera_samples = px * (uint64_t)rd->spp;
+        // samples of this shard (checked above against the kernels' own count; the window samplers report what the kernels counted)
+        stats->camera_samples = (windowed && !getenv("HPT_PHASE_TIMERS")) ? h_scr.wc.samples : job_samples;
         if (rd->count_work || replay) {
             stats->camera_samples = h_scr.wc.samples;
             stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
@@ -1004,7 +1035,7 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
     if (tune_forced() >= 0) return tune_forced();
     if (rd->integrator != HPT_INTEGRATOR_PATH) return 6;    // direct lighting: one configuration
     PathKernelArgs a;
-    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
+    a.dl = 0; a.dl_stack = nullptr; a.dl_cap = 0; a.inst_xf = nullptr; a.adapt_buf = nullptr; a.dbg = nullptr; a.stack_entries = s ? s->stack_entries : HPT_STACK_DEPTH;
     retrace_defaults(&a, s);
     HIP_CHECK_RET(hipSetDevice(s->device), HPT_E_HIP);
     int rc = fill_params(cam, rd, &a.rp, s);
@@ -1019,11 +1050,11 @@ extern "C" int hpt_scene_tune(hpt_scene *s, const hpt_camera *cam, const hpt_ren
         int bpc = 0, vg = 0;
         if (c >= 0 && kernel_residency(s, c, &a2, &bpc, &vg) == 0) { s->tune_cfg = c; return c; }
     }
-    struct Scratch { unsigned long long next_item[8]; WorkCounters wc; };   // one work-queue head per XCD
+    typedef RenderScratch Scratch;
     DevBuf<Scratch> scr;
     DevBuf<float> filmbuf;
     if (!scr.alloc(1) || !filmbuf.alloc((size_t)4 * rd->x_count * rd->y_count)) { hpt_set_error("hipMalloc failed"); return HPT_E_HIP; }
-    a.next_item = scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p;
+    a.next_item = scr.p->next_item; a.counters = &scr.p->wc; a.film = filmbuf.p; a.dbg = scr.p->dbg;
     hipError_t e = autotune(s, cam, rd, a, scr.p, sizeof(Scratch), nullptr);
     if (e != hipSuccess) { hpt_set_error("autotune failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
     return s->tune_cfg;

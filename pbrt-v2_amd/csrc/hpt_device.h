@@ -55,6 +55,57 @@ namespace hpt {
 #define HPT_FN_BSDF HPT_FN
 #endif
 
+// ---- debug build (`make debug`: -DHPT_DEBUG_CHECKS, round 5) ---------------------------------------------------------------------------
+// Every LDS row index, stack pointer, cross-lane source and table index of the path kernel asserted where it is used.  A failed check does
+// not trap (a trapped wave tells nothing): the FIRST failure's code and four values go into a 16-word record of the frame's scratch block
+// (PathKernelArgs::dbg -> RenderScratch::dbg), word 15 counts all failures, the offending index is clamped by the caller where it can be, the
+// kernel runs on, and hpt_render_device returns HPT_E_INTERNAL with the record in the message.  Production builds compile the checks away.
+#define HPT_DBG_WORDS 16
+enum {  // check codes (hpt_render_device prints the name)
+    HPT_CK_STACK_ROW = 1,      // a walk-stack write / read outside the rows the lane owns          v: sp, limit, sb, node
+    HPT_CK_STACK_NEG = 2,      // a negative stack pointer                                          v: sp, sb, fl, node
+    HPT_CK_EXEC = 3,           // a wave-level operation (shuffle, ballot protocol) under a partial EXEC mask   v: site, exec lo, exec hi
+    HPT_CK_SHFL_SRC = 4,       // a shuffle source lane outside 0..63 or a thief without a donor     v: src, ri, n
+    HPT_CK_NODE = 5,           // a BVH4 node index outside the node array                           v: index, n_nodes4, code
+    HPT_CK_TRI = 6,            // a triangle record outside the array                                v: first, count, n_tris
+    HPT_CK_PRIM = 7,           // a Hit::prim outside triangles / quadrics at shading time           v: prim, n_tris, n_quadrics, inst
+    HPT_CK_QUEUE = 8,          // the measured-BRDF query queue outside its rows                     v: idx, total, qrow
+    HPT_CK_INST = 9,           // an instance index outside the table                                v: index, n_instances
+    HPT_CK_ITEM = 10,          // a work item outside the job                                        v: item lo, item hi, n_items lo
+    HPT_CK_PIXEL = 11,         // a film pixel outside the extent                                    v: x, y
+    HPT_CK_STATE = 12,         // the lane state machine in a state it cannot be in                  v: site, stage, fin
+    HPT_CK_MATERIAL = 13,      // a mesh / material / texture index outside its table                v: site, index, count
+    HPT_CK_XF = 14,            // a transform-cache column outside the buffer                        v: lane column, lanes
+};
+#if defined(HPT_DEBUG_CHECKS) && defined(__HIPCC__)
+static __device__ unsigned *hpt_dbg_ptr;        // this translation unit's copy, set by the path kernel at entry (PathKernelArgs::dbg)
+__device__ __noinline__ static void hpt_dbg_fail(unsigned code, int v0, int v1, int v2, int v3) {
+    unsigned *r = hpt_dbg_ptr;
+    if (!r) return;
+    if (atomicCAS(&r[0], 0u, code) == 0u) {
+        r[1] = (unsigned)v0; r[2] = (unsigned)v1; r[3] = (unsigned)v2; r[4] = (unsigned)v3;
+        r[5] = blockIdx.x; r[6] = threadIdx.x;
+    }
+    atomicAdd(&r[15], 1u);
+}
+static __device__ int hpt_dbg_n_nodes4;         // (DScene::n_nodes4 of the running kernel, for trav_node4 — it only gets the node pointer)
+__device__ __forceinline__ int sc_n_nodes4_dbg(const void *) { return hpt_dbg_n_nodes4; }
+#define HPT_CHECK(cond, code, v0, v1, v2, v3) do { if (!(cond)) hpt::hpt_dbg_fail((code), (int)(v0), (int)(v1), (int)(v2), (int)(v3)); } while (0)
+// (every lane of the wave must be here: __ballot(true) counts the lanes that are)
+#define HPT_CHECK_FULL_EXEC(site) do { const unsigned long long e_ = __ballot(true); if (e_ != ~0ull) hpt::hpt_dbg_fail(hpt::HPT_CK_EXEC, (site), (int)(unsigned)e_, (int)(unsigned)(e_ >> 32), 0); } while (0)
+#elif defined(HPT_DEBUG_CHECKS)
+}
+#include <stdio.h>
+#include <stdlib.h>
+namespace hpt {
+static inline int sc_n_nodes4_dbg(const void *) { return 1 << 30; }
+#define HPT_CHECK(cond, code, v0, v1, v2, v3) do { if (!(cond)) { fprintf(stderr, "hpt debug check %d failed (%s): %d %d %d %d\n", (int)(code), #cond, (int)(v0), (int)(v1), (int)(v2), (int)(v3)); abort(); } } while (0)
+#define HPT_CHECK_FULL_EXEC(site) do {} while (0)
+#else
+#define HPT_CHECK(cond, code, v0, v1, v2, v3) do {} while (0)
+#define HPT_CHECK_FULL_EXEC(site) do {} while (0)
+#endif
+
 #define HPT_PI 3.14159265358979323846f       /* core/pbrt.h:190 — a FLOAT literal in pbrt */
 #define HPT_INV_PI 0.31830988618379067154f
 #define HPT_INV_TWOPI 0.15915494309189533577f
@@ -76,6 +127,34 @@ HPT_FN float absdot(f3 a, f3 b) { return fabsf(dot(a, b)); }
 HPT_FN f3 cross(f3 a, f3 b) { // geometry.h:475-484: evaluated in DOUBLE
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return mk3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
+}
+// The two cross products of the triangle test (the hot ones: trav_leaf is half of a node step's time, and an f64 instruction issues at the
+// 4-clock rate, a float add / mul / fma at the 2-clock rate — profiles/r02j_valu_rate.md).  HPT_CROSS_MODE:
+//   0 (default)  the reference's arithmetic, geometry.h:475-484: both products exact in double, ONE rounding of their difference to double,
+//                one to float — written with fma(a, b, -(c * d)), which is that same single rounding (3 f64 instructions fewer per cross
+//                than mul, mul, sub: bit-identical results);
+//   1            Kahan's difference of products in float (w = c d; e = fma(-c, d, w); f = fma(a, b, -w); f + e): 4 two-clock instructions a
+//                component instead of 7 four-clock ones, no 64-bit temporaries; within 1.5 ulp of the exact value, NOT bit-identical;
+//   2            an error-free float evaluation (two-product, two-sum, one final rounding): the exact value rounded once — agrees with the
+//                double-then-round result except when the exact value sits within 2^-29 relative of a rounding boundary; 13 two-clock
+//                instructions a component (no faster than mode 0 — it exists to measure what the 64-bit registers cost).
+#ifndef HPT_CROSS_MODE
+#define HPT_CROSS_MODE 0
+#endif
+HPT_FN float diff_of_products(float a, float b, float c, float d) {   // a b - c d
+#if HPT_CROSS_MODE == 1
+    const float w = c * d, e = __builtin_fmaf(-c, d, w), f = __builtin_fmaf(a, b, -w);
+    return f + e;
+#elif HPT_CROSS_MODE == 2
+    const float p1 = a * b, e1 = __builtin_fmaf(a, b, -p1), p2 = c * d, e2 = __builtin_fmaf(c, d, -p2);
+    const float s = p1 - p2, bv = s - p1, av = s - bv, dl = (p1 - av) + (-p2 - bv);   // two-sum: p1 - p2 = s + dl exactly
+    return s + (dl + (e1 - e2));
+#else
+    return (float)__builtin_fma((double)a, (double)b, -((double)c * (double)d));
+#endif
+}
+HPT_FN f3 cross_tri(f3 a, f3 b) {
+    return mk3(diff_of_products(a.y, b.z, a.z, b.y), diff_of_products(a.z, b.x, a.x, b.z), diff_of_products(a.x, b.y, a.y, b.x));
 }
 HPT_FN float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 HPT_FN float len(f3 a) { return sqrtf(len2(a)); }
@@ -321,6 +400,9 @@ struct DScene {
     int32_t world_root4;
     uint32_t inst_quadric_mask;     // bit q (q < 31): quadric q is the primitive of an instance (hpt_instance.quadric1 == q + 1), not a primitive of the world; bit 31: an owned quadric has index >= 31 (those are looked up in the instance table)
     int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
+#ifdef HPT_DEBUG_CHECKS             /* `make debug` only (the whole library is built with the flag): table sizes for the bounds checks */
+    int32_t n_nodes4, n_meshes, n_materials, n_textures;
+#endif
 };
 
 struct Ray { f3 o, d; float mint, maxt; };
@@ -335,14 +417,14 @@ HPT_FN float as_float(int32_t i) { union { float f; int32_t i; } u; u.i = i; ret
 // Triangle::Intersect core test (shapes/trianglemesh.cpp:127-160)
 HPT_FN bool tri_test(f3 p1, f3 p2, f3 p3, const Ray &ray, float *t_out, float *b1_out, float *b2_out) {
     f3 e1 = p2 - p1, e2 = p3 - p1;
-    f3 s1 = cross(ray.d, e2);
+    f3 s1 = cross_tri(ray.d, e2);
     float divisor = dot(s1, e1);
     if (divisor == 0.f) return false;
     float invDivisor = 1.f / divisor;
     f3 s = ray.o - p1;
     float b1 = dot(s, s1) * invDivisor;
     if (b1 < 0.f || b1 > 1.f) return false;
-    f3 s2 = cross(s, e1);
+    f3 s2 = cross_tri(s, e1);
     float b2 = dot(ray.d, s2) * invDivisor;
     if (b2 < 0.f || b1 + b2 > 1.f) return false;
     float t = dot(e2, s2) * invDivisor;
@@ -603,6 +685,14 @@ struct TravState {
     int32_t node;
     int sp;
     Hit hit;
+#ifdef HPT_DEBUG_CHECKS
+    int lim;        // rows this lane may use above its current stack base (traverse_steal: aux - sb; elsewhere unbounded)
+#define HPT_TS_SETLIM(ts, n) ((ts).lim = (n))
+#define HPT_TS_LIM(ts) ((ts).lim)
+#else
+#define HPT_TS_SETLIM(ts, n) ((void)0)
+#define HPT_TS_LIM(ts) (1 << 30)
+#endif
     HPT_MFN bool done() const { return node == HPT_TRAV_EMPTY; }
 };
 
@@ -614,6 +704,7 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
+    HPT_TS_SETLIM(ts, 1 << 30);
     // The few quadrics (area-light emitters) are tested linearly first; closest hit is order independent.  (Round 4 built them into the world's
     // tree as pseudo-triangle records — the reference keeps them in the BVHAccel, accelerators/bvh.cpp:403-454 — twice: with the shape test in
     // the leaf loop every workload lost 7-12 % (nine scratch reloads per step of the walk), with the test deferred to after the walk the films of
@@ -683,6 +774,7 @@ template <bool COUNT>
 HPT_FN void trav_node(const DScene &sc, TravState &ts, const Ray &ray, int32_t *stack, int stride, TravCounters *cnt) { trav_node<COUNT>(sc.nodes, ts, ray, stack, stride, cnt); }
 HPT_FN bool trav_is_leaf(int32_t node) { return node < 0 && node != HPT_TRAV_EMPTY; }
 HPT_FN void trav_pop(TravState &ts, const int32_t *stack, int stride) {
+    HPT_CHECK(ts.sp >= 0 && ts.sp <= HPT_TS_LIM(ts), HPT_CK_STACK_NEG, ts.sp, HPT_TS_LIM(ts), 0, ts.node);
     if (ts.sp > 0) { --ts.sp; ts.node = stack[ts.sp * stride]; }
     else ts.node = HPT_TRAV_EMPTY;
 }
@@ -707,6 +799,11 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
     const int32_t self = HPT_N4_INDEX(ts.node);
     uint32_t mask = HPT_N4_MASK(ts.node);
     if (mask == 0u) mask = 0xfu;
+    HPT_CHECK(ts.sp >= 0, HPT_CK_STACK_NEG, ts.sp, HPT_TS_LIM(ts), cap_normal, ts.node);
+#ifdef HPT_DEBUG_CHECKS
+    HPT_CHECK(self >= 0 && self < sc_n_nodes4_dbg(nodes4), HPT_CK_NODE, self, sc_n_nodes4_dbg(nodes4), ts.node, 0);
+#endif
+#define HPT_PUSH_CK() HPT_CHECK(ts.sp < HPT_TS_LIM(ts), HPT_CK_STACK_ROW, ts.sp, HPT_TS_LIM(ts), cap_normal, ts.node)
     const HPT_GLOBAL f4 *np = (const HPT_GLOBAL f4 *)nodes4 + 8 * (int64_t)self;
     const f4 a0 = np[0], a1 = np[1], a2 = np[2], cc = np[3], b0 = np[4], b1 = np[5], b2 = np[6];
     if (COUNT) cnt->nodes++;
@@ -730,16 +827,17 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
     // far to near onto the stack, the nearest next
     if (k1 != none) {
         if (ts.sp < cap_normal) {
-            if (k3 != none) { stack[ts.sp * stride] = pick4(k3, c0, c1, c2, c3); ++ts.sp; }
-            if (k2 != none) { stack[ts.sp * stride] = pick4(k2, c0, c1, c2, c3); ++ts.sp; }
-            stack[ts.sp * stride] = pick4(k1, c0, c1, c2, c3); ++ts.sp;
+            if (k3 != none) { HPT_PUSH_CK(); stack[ts.sp * stride] = pick4(k3, c0, c1, c2, c3); ++ts.sp; }
+            if (k2 != none) { HPT_PUSH_CK(); stack[ts.sp * stride] = pick4(k2, c0, c1, c2, c3); ++ts.sp; }
+            HPT_PUSH_CK(); stack[ts.sp * stride] = pick4(k1, c0, c1, c2, c3); ++ts.sp;
         } else {                                          // the rows above cap_normal: one entry for all of them (see above)
             uint32_t m = 1u << (k1 & 3u);
             if (k2 != none) m |= 1u << (k2 & 3u);
             if (k3 != none) m |= 1u << (k3 & 3u);
-            stack[ts.sp * stride] = self | (int32_t)(m << 26); ++ts.sp;
+            HPT_PUSH_CK(); stack[ts.sp * stride] = self | (int32_t)(m << 26); ++ts.sp;
         }
     }
+#undef HPT_PUSH_CK
     int32_t next;
     if (k0 != none) next = pick4(k0, c0, c1, c2, c3);
     else { next = HPT_TRAV_EMPTY; if (ts.sp > 0) { --ts.sp; next = stack[ts.sp * stride]; } }
@@ -752,6 +850,7 @@ template <bool COUNT, bool ALPHA>
 HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+    HPT_CHECK(first + count <= (uint32_t)sc.n_tris, HPT_CK_TRI, first, count, sc.n_tris, 0);
     for (uint32_t k = 0; k < count; ++k) {
         const HPT_GLOBAL f4 *tp = (const HPT_GLOBAL f4 *)tris + 3 * (int64_t)(first + k);
         f4 a = tp[0], b = tp[1], c = tp[2];
@@ -856,6 +955,7 @@ HPT_FN_TOP void top_special_leaf(TopTables sc, TravState &ts, Ray &r, int *cur_i
         const int k = (int)(code & 0xfffffu);
         const hpt_instance &in = sc.instances[k];
         const int32_t iroot = sc.inst_root4[k];
+        HPT_CHECK(ts.sp >= 0 && ts.sp + 7 <= HPT_TS_LIM(ts), HPT_CK_STACK_ROW, ts.sp, HPT_TS_LIM(ts), -7, ts.node);
         float tentry;
         // (the motion bounds once more: the ray may have shrunk since the node above stacked this leaf)
         if (!(iroot >= 0 || (QI && in.quadric1 > 0)) || !slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], r, ts.invd, &tentry)) {
@@ -889,6 +989,7 @@ HPT_FN_TOP void top_special_leaf(TopTables sc, TravState &ts, Ray &r, int *cur_i
         return;
     }
     // HPT_LEAF_KIND_RESTORE: back to the world ray under the marker
+    HPT_CHECK(ts.sp >= 6, HPT_CK_STACK_NEG, ts.sp, 6, *fl, ts.node);
     ts.sp -= 6;
     r.o = mk3(as_float(st[(ts.sp + 0) * stride]), as_float(st[(ts.sp + 1) * stride]), as_float(st[(ts.sp + 2) * stride]));
     r.d = mk3(as_float(st[(ts.sp + 3) * stride]), as_float(st[(ts.sp + 4) * stride]), as_float(st[(ts.sp + 5) * stride]));
@@ -1813,6 +1914,8 @@ HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material 
 template <bool INST, int MATS>
 HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, const Hit &hit, Bsdf *b, DGeom *dg, float *rayEps, int *arealight) {
     Ray ray = wray;
+    HPT_CHECK(hit.prim >= 0 && (hit.prim >= HPT_PRIM_QUADRIC ? hit.prim - HPT_PRIM_QUADRIC < sc.n_quadrics : hit.prim < sc.n_tris) && hit.inst >= -1 && hit.inst < (sc.n_instances > 0 ? sc.n_instances : 1),
+              HPT_CK_PRIM, hit.prim, sc.n_tris, sc.n_quadrics, hit.inst);
     if (hit.prim >= HPT_PRIM_QUADRIC) {
         const hpt_quadric &q = sc.quadrics[hit.prim - HPT_PRIM_QUADRIC];
         float t;
@@ -1828,6 +1931,9 @@ HPT_FN_SHADE void shade_geometry(const DScene &sc, const Ray &wray, float time, 
     const f4 *tp = sc.tris + 3 * (int64_t)hit.prim;
     f4 a = tp[0], bb = tp[1], c = tp[2];
     f3 p1 = mk3(a.x, a.y, a.z), p2 = mk3(bb.x, bb.y, bb.z), p3 = mk3(c.x, c.y, c.z);
+#ifdef HPT_DEBUG_CHECKS
+    HPT_CHECK((as_int(a.w) & HPT_TRI_MESH_MASK) < sc.n_meshes, HPT_CK_MATERIAL, 1, as_int(a.w) & HPT_TRI_MESH_MASK, sc.n_meshes, hit.prim);
+#endif
     const DMesh &me = sc.meshes[as_int(a.w) & HPT_TRI_MESH_MASK];
     int tri = as_int(bb.w);
     // hit inside an animated instance: redo the geometry in the instance's space with the transformed
@@ -1913,6 +2019,8 @@ template <bool INST>
 HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float time, const Hit &hit, const RayDiff &rdiff, Bsdf *b, DGeom *dgo,
                                      float *rayEps, int *arealight, DGeomX *dgs_out = nullptr) {
     Ray ray = wray;
+    HPT_CHECK(hit.prim >= 0 && (hit.prim >= HPT_PRIM_QUADRIC ? hit.prim - HPT_PRIM_QUADRIC < sc.n_quadrics : hit.prim < sc.n_tris) && hit.inst >= -1 && hit.inst < (sc.n_instances > 0 ? sc.n_instances : 1),
+              HPT_CK_PRIM, hit.prim, sc.n_tris, sc.n_quadrics, hit.inst);
     DGeomX dg;
     dg.dndu = dg.dndv = S(0.f);
     const hpt_material *mat;

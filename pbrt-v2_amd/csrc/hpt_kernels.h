@@ -16,7 +16,8 @@ struct PathKernelArgs {
     RenderParams rp;
     float *film;                    // x_count*y_count*4, zeroed before the launch
     unsigned long long *next_item;  // 8 work-queue heads (one per XCD, hpt_kernels_impl.h), zeroed before the launch
-    WorkCounters *counters;         // only written by the COUNT instantiation
+    WorkCounters *counters;         // COUNT instantiation: all of it; production: `samples` (camera samples completed — the conservation check of hpt_render_device) and `bad`
+    unsigned *dbg;                  // HPT_DBG_WORDS words of the frame's scratch block: the first failed check of a `make debug` build (hpt_device.h); unused otherwise
     // dynamic LDS of a workgroup: traversal stacks, stack_entries x 256 x 4 B
     int32_t stack_entries;          // per-lane stack entries this scene needs (BVH depth + 2; 12 query-queue rows with a measured BRDF)
     float *inst_xf;                 // animated instances: per-path transform cache, [12 x n_instances][grid x 256] floats, or null
@@ -63,11 +64,11 @@ inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_TOP_MIN_INSTANCES 4 /* up to this many animated instances are visited serially (measured faster on two: profiles/r04_ab.md run D) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
-int path_kernel_steal_rows(bool dl);   /* LDS rows the lock-step + stealing kernels of THIS build keep above their traversal stacks (HPT_STEAL_ROWS; a -DHPT_FUSE build's path kernels: HPT_STEAL3_ROWS) */
+int path_kernel_steal_rows(bool dl);   /* LDS rows the lock-step + stealing kernels of THIS build keep above their traversal stacks (HPT_STEAL_ROWS) */
 bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
 int path_kernel_effective_cfg(int mats, int cfg);   /* the configuration that actually runs: the extension set builds 0, 5 and 6 only (HPT_LEAN_SET: 1, 2 -> 0; 3 -> 5; 4 -> 6) */
 int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
-int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs);   /* *vgprs = VGPRs | scratch bytes per lane << 10 */
+int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs, bool top = false, bool win = false);   /* *vgprs = VGPRs | scratch bytes per lane << 10 */
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);
 hipError_t launch_replay_kernel(int mats, const PathKernelArgs &a, const ReplayArgs &ra, int bvh_depth, hipStream_t stream);
 hipError_t launch_film_gather(const RenderParams &rp, float *film, hipStream_t stream);   // second pass of the two-pass film (table filters)

@@ -22,21 +22,11 @@
 
 namespace hpt {
 
-bool path_kernel_wide_bvh() {
-#ifndef HPT_NO_BVH4
-    return true;
-#else
-    return false;
+#ifdef HPT_NO_BVH4
+#error "HPT_NO_BVH4 is gone: the stealing walk (traverse_steal) only exists on the four-wide trees"
 #endif
-}
-int path_kernel_steal_rows(bool dl) {
-#ifdef HPT_FUSE
-    return dl ? HPT_STEAL_ROWS : HPT_STEAL3_ROWS;
-#else
-    (void)dl;
-    return HPT_STEAL_ROWS;
-#endif
-}
+bool path_kernel_wide_bvh() { return true; }
+int path_kernel_steal_rows(bool dl) { (void)dl; return HPT_STEAL_ROWS; }
 int path_kernel_effective_cfg(int mats, int cfg) {
     if (!(mats & MATS_EXT)) return cfg;
     return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // HPT_CFG_ALIAS under HPT_LEAN_SET (hpt_kernels_impl.h)
@@ -478,12 +468,12 @@ __global__ void hpt_sampler_kernel(RenderParams rp, int x, int y, float *out) {
 #define HPT_DECL_SET(NAME)                                                              \
     hipError_t launch_path_##NAME(const PathKernelArgs &, int, bool, int, hipStream_t);     \
     hipError_t launch_path_##NAME##_i(const PathKernelArgs &, int, bool, int, hipStream_t); \
-    int occupancy_##NAME(int, bool, size_t, int *, int *);                                  \
-    int occupancy_##NAME##_i(int, bool, size_t, int *, int *);
+    int occupancy_##NAME(int, bool, size_t, int *, int *, bool, bool);                      \
+    int occupancy_##NAME##_i(int, bool, size_t, int *, int *, bool, bool);
 HPT_DECL_SET(basic) HPT_DECL_SET(measured) HPT_DECL_SET(ext) HPT_DECL_SET(all)
 #undef HPT_DECL_SET
 hipError_t launch_path_lean(const PathKernelArgs &, int, bool, int, hipStream_t);     // hpt_kernels_lean.hip (no _i twin: scenes with instances run the full set)
-int occupancy_lean(int, bool, size_t, int *, int *);
+int occupancy_lean(int, bool, size_t, int *, int *, bool, bool);
 
 // smallest compiled material set that covers the scene's (mats = MATS_* bits of the materials present); every set exists without
 // (hpt_kernels_<set>.hip) and with (hpt_kernels_<set>_i.hip) animated instances
@@ -493,13 +483,13 @@ static int pick_variant(int mats) {
     if ((mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0) return 1;
     return 2;
 }
-int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {
-    if ((mats & MATS_NORARE) && !inst) return occupancy_lean(cfg, dl, dyn_lds, blocks_per_cu, vgprs);     // (hpt_api.hip sets the bit only for scenes without instances and clears it with a moving camera)
+int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs, bool top, bool win) {
+    if ((mats & MATS_NORARE) && !inst) return occupancy_lean(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win);     // (hpt_api.hip sets the bit only for scenes without instances and clears it with a moving camera)
     switch (pick_variant(mats)) {
-        case 0: return inst ? occupancy_basic_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_basic(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        case 1: return inst ? occupancy_measured_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_measured(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        case 3: return inst ? occupancy_ext_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_ext(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
-        default: return inst ? occupancy_all_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs) : occupancy_all(cfg, dl, dyn_lds, blocks_per_cu, vgprs);
+        case 0: return inst ? occupancy_basic_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win) : occupancy_basic(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win);
+        case 1: return inst ? occupancy_measured_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win) : occupancy_measured(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win);
+        case 3: return inst ? occupancy_ext_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win) : occupancy_ext(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win);
+        default: return inst ? occupancy_all_i(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win) : occupancy_all(cfg, dl, dyn_lds, blocks_per_cu, vgprs, top, win);
     }
 }
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream) {

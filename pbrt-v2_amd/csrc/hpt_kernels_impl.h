@@ -29,6 +29,7 @@ __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
 // One atomicAdd per wave hands out consecutive work items to the lanes that need one.
 __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool need) {
+    HPT_CHECK_FULL_EXEC(3);
     unsigned long long mask = __ballot(need);
     if (mask == 0ull) return -1;
     int n = __popcll(mask);
@@ -100,6 +101,8 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
     if (shaded) for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
     return;
 #endif
+    HPT_CHECK_FULL_EXEC(5);
+    HPT_CHECK(ls.qrow >= 0 && total <= 192, HPT_CK_QUEUE, total, ls.qrow, 0, 0);
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int o0 = __popcll(m0 & lt), o1 = n0 + __popcll(m1 & lt), o2 = n0 + n1 + __popcll(m2 & lt);
@@ -179,6 +182,8 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     }
     leaf_q = __builtin_amdgcn_readfirstlane(leaf_q); block_q = __builtin_amdgcn_readfirstlane(block_q);   // (uniform by construction: kernel arguments)
 #endif
+    HPT_CHECK_FULL_EXEC(1);
+    HPT_CHECK(aux >= 8 && cap_normal >= 0, HPT_CK_STACK_ROW, aux, cap_normal, 0, 0);
     TravState ts;
     Ray r = ray;
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
@@ -203,12 +208,15 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     // the ray (a few more nodes visited); the nearest hit is the same up to exact ties.
     int32_t pend = HPT_TRAV_EMPTY;
     for (;;) {
+        HPT_TS_SETLIM(ts, aux - sb);
         // ---- a leaf of the top-level tree: enter the instance / return to the world (hpt_device.h, top_special_leaf) — once no ordinary leaf
         // is parked: a parked one belongs to the space the lane is about to leave ---------------------------------------------------------
         if (INST && TOP && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node)) {
             TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics;
             top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
         }
+        HPT_TS_SETLIM(ts, aux - sb);                              // (debug build: the rows this lane's walk may touch from its current base)
+        HPT_CHECK(sb >= 0 && sb <= aux && ts.sp >= 0, HPT_CK_STACK_NEG, ts.sp, sb, fl, ts.node);
         const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
         const unsigned long long mbusy = __ballot(busy);
         const bool any_busy = (mbusy | __ballot(seg < n_seg || more_b)) != 0ull;
@@ -300,7 +308,12 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
         const bool still = ts.node != HPT_TRAV_EMPTY;
         const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_seg && !more_b;
-        const bool donor = still && ts.sp >= 1;                     // (fl is 0 or >= 8: the bottom row is a node, never a saved ray)
+        // A donor gives its BOTTOM row, which must be a node.  With world rows under a saved ray (fl > 0) that holds while the marker is still
+        // stacked (fl >= 8).  A lane that has popped its marker but not yet acted on it (a leaf is parked: the restore waits for it) still
+        // counts the six ray rows in ts.sp: giving its last world row would leave ts.sp at -1 (right only by the luck of the row
+        // arithmetic) — such a lane does not donate until it is back in world space, one leaf phase later.
+        const bool on_marker = INST && TOP && trav_is_leaf(ts.node) && leaf_is_special(ts.node) && ((((uint32_t)~ts.node) >> 20) & 0xfu) == HPT_LEAF_KIND_RESTORE;
+        const bool donor = still && ts.sp >= 1 && !on_marker;
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
         const int nd = __popcll(md);
@@ -314,10 +327,13 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             if (INST && TOP && fl > 0) { gw = sb + fl - 7; --fl; }
             ++sb; --ts.sp;
             if (INST && TOP && fl == 7) { sb += 7; ts.sp -= 7; fl = 0; }   // the last world row went: nothing to come back to (the saved ray stays readable for this round's thief)
+            HPT_CHECK(ts.sp >= 0 && sb <= aux, HPT_CK_STACK_NEG, ts.sp, sb, fl, ts.node);
         }
         HPT_WAVE_SYNC();
         const bool take = idle && ri < n;
         const int src = take ? HPT_AUX(aux, ri) : lane;
+        HPT_CHECK_FULL_EXEC(2);
+        HPT_CHECK(src >= 0 && src < 64 && (!take || ((md >> src) & 1ull)), HPT_CK_SHFL_SRC, src, ri, n, take);
         // the donor's ray and bookkeeping, through cross-lane shuffles executed by every lane
         const float ox = __shfl(r.o.x, src), oy = __shfl(r.o.y, src), oz = __shfl(r.o.z, src);
         const float dx = __shfl(r.d.x, src), dy = __shfl(r.d.y, src), dz = __shfl(r.d.z, src);
@@ -368,195 +384,6 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     #undef HPT_WAVE_SYNC
 }
 
-// ---- FUSE (round 4, experimental: -DHPT_FUSE): ONE traversal phase per path vertex ----------------------------------------------------------
-// The three rays a shaded vertex leaves behind — shadow ray A (any-hit), BSDF-sampled MIS ray B (closest hit, nobody needs barycentrics) and continuation ray
-// C (closest hit with barycentrics) — do not depend on each other's results: the light terms only ADD to L (core/integrator.cpp:123-172), the throughput of
-// the continuation was fixed when the vertex was shaded (path.cpp:83-110).  Round 3 walked A and B in one phase; here a lane owns up to all three (a lane with a
-// camera ray only C) and walks them one after the other while the idle lanes steal subtrees of whichever ray is on offer: every live lane takes part in every
-// round, there is no phase to wait for, and a vertex costs one walk + one shading block instead of two walks.  Each ray kind has result rows of its own in the
-// owner's LDS column (helpers of A may still be walking when the owner starts B):
-//   aux+0 donor table | A: aux+1 flag (0 = occluded) | B: aux+2 t, +3 prim, +4 instance | C: aux+5 t, +6 b1, +7 b2, +8 prim, +9 instance
-#define HPT_STEAL3_ROWS 10
-template <bool COUNT, bool INST, bool ALPHA, bool TOP>
-__device__ __forceinline__ void traverse_steal3(const DScene &sc, const Ray &ra, bool has_a, const f3 &pb, const f3 &db, float epsb, bool has_b, const Ray &rc, bool has_c, float time,
-                                                bool *occluded, Hit *hitb, Hit *hitc, int32_t *stack, int aux, TravCounters *cnt, const float *xf_cache, int64_t xf_stride,
-                                                int leaf_q, int block_q, int cap_normal) {
-    const int lane = lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
-    #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
-    #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-    const f4 *nodes = sc.nodes4, *tris = sc.tris;
-    const int32_t top_root = (INST && TOP) ? sc.top_root4 : sc.world_root4;
-#ifndef HPT_NO_SGPR_PIN
-    {
-        uint64_t vn = (uint64_t)nodes, vt = (uint64_t)tris;
-        uint32_t nl = __builtin_amdgcn_readfirstlane((uint32_t)vn), nh = __builtin_amdgcn_readfirstlane((uint32_t)(vn >> 32));
-        uint32_t tl = __builtin_amdgcn_readfirstlane((uint32_t)vt), th = __builtin_amdgcn_readfirstlane((uint32_t)(vt >> 32));
-        asm volatile("" : "+s"(nl), "+s"(nh), "+s"(tl), "+s"(th));
-        nodes = (const f4 *)(((uint64_t)nh << 32) | nl); tris = (const f4 *)(((uint64_t)th << 32) | tl);
-    }
-    leaf_q = __builtin_amdgcn_readfirstlane(leaf_q); block_q = __builtin_amdgcn_readfirstlane(block_q);
-#endif
-    TravState ts;
-    Ray r = rc;
-    int owner = lane, sb = 0;
-    int jk = 2;                                                     // kind of the ray this lane is walking: 0 A (any-hit), 1 B, 2 C
-    int cur_inst = -1, fl = 0;
-    float jt = time;
-    const int n_seg = (INST && !TOP) ? sc.n_instances : 0;
-    int seg = n_seg;                                                // !TOP: the segment of this lane's OWN current ray (-1 world, k instance k, n_seg: done)
-    int own = (has_a ? 1 : 0) | (has_b ? 2 : 0) | (has_c ? 4 : 0);  // own rays still to start
-    int curk = 2;                                                   // kind of the own ray this lane is on (for the serial instance visit)
-    ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false; ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1; ts.invd = S(0.f);
-    HPT_AUX(aux + 1, lane) = 1;
-    HPT_AUX(aux + 2, lane) = as_int(HPT_INF); HPT_AUX(aux + 3, lane) = -1;
-    HPT_AUX(aux + 5, lane) = as_int(rc.maxt); HPT_AUX(aux + 8, lane) = -1;
-    HPT_WAVE_SYNC();
-    int32_t pend = HPT_TRAV_EMPTY;
-    for (;;) {
-        // ---- an owner without a walk takes up its next own ray (A, then B, then C) ------------------------------------------------------------
-        if (own != 0 && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && seg >= n_seg) {
-            curk = (own & 1) ? 0 : (own & 2) ? 1 : 2;
-            own &= ~(1 << curk);
-            if (curk == 0) r = ra;
-            else if (curk == 1) { r.o = pb; r.d = db; r.mint = epsb; r.maxt = HPT_INF; }
-            else r = rc;
-            trav_begin<ALPHA>(sc, ts, r, curk == 0, top_root, true);
-            jk = curk; owner = lane; cur_inst = -1; fl = 0; sb = 0; jt = time;
-            seg = (INST && !TOP) ? -1 : n_seg;
-        }
-        if (INST && TOP && pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && leaf_is_special(ts.node)) {
-            TopTables tt; tt.instances = sc.instances; tt.inst_root4 = sc.inst_root4; tt.quadrics = sc.quadrics;
-            top_special_leaf<ALPHA>(tt, ts, r, &cur_inst, &fl, stack + sb * HPT_BLOCK, HPT_BLOCK, xf_cache ? xf_cache + (owner - lane) : nullptr, xf_stride, jt);
-        }
-        const bool busy = ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY;
-        const unsigned long long mbusy = __ballot(busy);
-        const bool any_busy = (mbusy | __ballot(seg < n_seg || own != 0)) != 0ull;
-        if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
-        if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && TOP && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
-        {
-            const bool has = pend != HPT_TRAV_EMPTY;
-            const unsigned long long mh = __ballot(has);
-            if (mh != 0ull) {
-                const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
-                if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
-                    if (has) {
-                        if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
-                        pend = HPT_TRAV_EMPTY;
-                    }
-                }
-            }
-        }
-        const bool found = ts.hit.prim >= 0;
-        const bool any_found = __ballot(found) != 0ull;
-        if (any_found || !any_busy) {
-            // ---- publish finds, share the hit distance inside every group (owner + helpers of one ray) ------------------------
-            const int rt = jk == 1 ? aux + 2 : aux + 5;                // the ray kind's shared-t row (closest-hit kinds)
-            if (found) {
-                if (jk == 0) HPT_AUX(aux + 1, owner) = 0;
-                else atomicMin((unsigned *)&HPT_AUX(rt, owner), (unsigned)as_int(ts.hit.t));
-            }
-            HPT_WAVE_SYNC();
-            const int shared = HPT_AUX(jk == 0 ? aux + 1 : rt, owner);
-            if (found && jk != 0 && as_int(ts.hit.t) == shared) {      // this lane holds the group's nearest hit so far
-                if (jk == 2) { HPT_AUX(aux + 6, owner) = as_int(ts.hit.b1); HPT_AUX(aux + 7, owner) = as_int(ts.hit.b2); HPT_AUX(aux + 8, owner) = ts.hit.prim; if (INST) HPT_AUX(aux + 9, owner) = cur_inst; }
-                else { HPT_AUX(aux + 3, owner) = ts.hit.prim; if (INST) HPT_AUX(aux + 4, owner) = cur_inst; }
-            }
-            ts.hit.prim = -1;
-            if (ts.node != HPT_TRAV_EMPTY || pend != HPT_TRAV_EMPTY) {
-                if (jk == 0) { if (shared == 0) { ts.node = HPT_TRAV_EMPTY; pend = HPT_TRAV_EMPTY; } }
-                else r.maxt = fminf(r.maxt, as_float(shared));
-            }
-            if (!any_busy) break;
-        }
-        if (INST && !TOP && ts.node == HPT_TRAV_EMPTY && pend == HPT_TRAV_EMPTY && seg < n_seg) {
-            // ---- the owner's ray leaves a tree: on to the next instance it can still reach (serial visit) ------------------------------
-            const int shared = HPT_AUX(curk == 0 ? aux + 1 : curk == 1 ? aux + 2 : aux + 5, lane);
-            ++seg;
-            if (curk == 0 && shared == 0) seg = n_seg;
-            if (seg < n_seg) {
-                const hpt_instance &in = sc.instances[seg];
-                Ray rw;
-                if (curk == 0) rw = ra;
-                else if (curk == 1) { rw.o = pb; rw.d = db; rw.mint = epsb; rw.maxt = HPT_INF; }
-                else rw = rc;
-                if (curk != 0) rw.maxt = fminf(rw.maxt, as_float(shared));
-                const f3 invw = safe_inv_dir(rw.d);
-                float tentry;
-                const int32_t iroot = sc.inst_root4[seg];
-                if ((iroot >= 0 || (ALPHA && in.quadric1 > 0)) && slab(in.bounds[0], in.bounds[1], in.bounds[2], in.bounds[3], in.bounds[4], in.bounds[5], rw, invw, &tentry)) {
-                    A34 w2p;
-                    if (xf_cache) { for (int j = 0; j < 12; ++j) w2p.m[j] = xf_cache[(int64_t)(12 * seg + j) * xf_stride]; }
-                    else w2p = anim_interpolate(in, time, false).m;
-                    r.o = xf_point_affine(w2p.m, rw.o); r.d = xf_vec(w2p.m, rw.d); r.mint = rw.mint; r.maxt = rw.maxt;
-                    trav_begin<ALPHA>(sc, ts, r, curk == 0, iroot, false, seg);
-                    cur_inst = seg; sb = 0; jk = curk; owner = lane;
-                }
-            }
-        }
-        // ---- stealing: k-th idle lane takes the bottom stack entry of the k-th lane that has one to spare ---------------
-        const bool still = ts.node != HPT_TRAV_EMPTY;
-        const bool idle = !still && pend == HPT_TRAV_EMPTY && seg >= n_seg && own == 0;
-        const bool donor = still && ts.sp >= 1;
-        const unsigned long long mi = __ballot(idle), md = __ballot(donor);
-        int n = __popcll(mi);
-        const int nd = __popcll(md);
-        if (nd < n) n = nd;
-        if (n == 0) continue;
-        const int ri = __popcll(mi & lt), rd = __popcll(md & lt);
-        int give = 0, gw = -1;
-        if (donor && rd < n) {
-            HPT_AUX(aux, rd) = lane;
-            give = stack[sb * HPT_BLOCK];
-            if (INST && TOP && fl > 0) { gw = sb + fl - 7; --fl; }
-            ++sb; --ts.sp;
-            if (INST && TOP && fl == 7) { sb += 7; ts.sp -= 7; fl = 0; }
-        }
-        HPT_WAVE_SYNC();
-        const bool take = idle && ri < n;
-        const int src = take ? HPT_AUX(aux, ri) : lane;
-        const float ox = __shfl(r.o.x, src), oy = __shfl(r.o.y, src), oz = __shfl(r.o.z, src);
-        const float dx = __shfl(r.d.x, src), dy = __shfl(r.d.y, src), dz = __shfl(r.d.z, src);
-        const float mint = __shfl(r.mint, src), maxt = __shfl(r.maxt, src);
-        const float ix = __shfl(ts.invd.x, src), iy = __shfl(ts.invd.y, src), iz = __shfl(ts.invd.z, src);
-        const int jk_s = __shfl(jk, src), own_s = __shfl(owner, src), node_s = __shfl(give, src);
-        const int inst_s = INST ? __shfl(cur_inst, src) : -1;
-        const int gw_s = (INST && TOP) ? __shfl(gw, src) : -1;
-        const float jt_s = (INST && TOP) ? __shfl(jt, src) : 0.f;
-        if (take) {
-            r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.mint = mint; r.maxt = maxt;
-            ts.invd = mk3(ix, iy, iz); jk = jk_s; ts.anyhit = jk_s == 0; owner = own_s; cur_inst = inst_s;
-            if (INST && TOP) {
-                jt = jt_s;
-                if (gw_s >= 0) {
-                    r.o = mk3(as_float(col0[src + (gw_s + 0) * HPT_BLOCK]), as_float(col0[src + (gw_s + 1) * HPT_BLOCK]), as_float(col0[src + (gw_s + 2) * HPT_BLOCK]));
-                    r.d = mk3(as_float(col0[src + (gw_s + 3) * HPT_BLOCK]), as_float(col0[src + (gw_s + 4) * HPT_BLOCK]), as_float(col0[src + (gw_s + 5) * HPT_BLOCK]));
-                    ts.invd = safe_inv_dir(r.d);
-                    cur_inst = -1;
-                }
-            }
-            ts.node = node_s; ts.sp = 0; sb = 0; fl = 0;
-        }
-    }
-    HPT_WAVE_SYNC();
-    // ---- every owner collects the results of its rays ---------------------------------------------------------------------------------------
-    *occluded = has_a && HPT_AUX(aux + 1, lane) == 0;
-    hitb->prim = -1; hitb->t = 0.f; hitb->b1 = 0.f; hitb->b2 = 0.f; hitb->inst = -1;
-    hitc->prim = -1; hitc->t = 0.f; hitc->b1 = 0.f; hitc->b2 = 0.f; hitc->inst = -1;
-    if (has_b && HPT_AUX(aux + 3, lane) >= 0) {
-        hitb->t = as_float(HPT_AUX(aux + 2, lane)); hitb->prim = HPT_AUX(aux + 3, lane);
-        if (INST) hitb->inst = HPT_AUX(aux + 4, lane);
-    }
-    if (has_c && HPT_AUX(aux + 8, lane) >= 0) {
-        hitc->t = as_float(HPT_AUX(aux + 5, lane)); hitc->b1 = as_float(HPT_AUX(aux + 6, lane)); hitc->b2 = as_float(HPT_AUX(aux + 7, lane)); hitc->prim = HPT_AUX(aux + 8, lane);
-        if (INST) hitc->inst = HPT_AUX(aux + 9, lane);
-    }
-    HPT_WAVE_SYNC();
-    #undef HPT_AUX
-    #undef HPT_WAVE_SYNC
-}
-
 // WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
 // scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
@@ -578,6 +405,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     int32_t *stack = (int32_t *)dyn_lds + threadIdx.x;
     const DScene &sc = a.sc;
     const RenderParams &rp = a.rp;
+#ifdef HPT_DEBUG_CHECKS
+    hpt_dbg_ptr = a.dbg; hpt_dbg_n_nodes4 = a.sc.n_nodes4;      // (every lane stores the same two words)
+#endif
     LaneStack ls; ls.p = (HPT_LDS int32_t *)stack; ls.stride = HPT_BLOCK;
     // LDS rows of a lane's column: [walk stack][HPT_STEAL_ROWS, with stealing][HPT_COLD_ROWS] (hpt_api.hip, kernel_residency)
     // Cold lane state in LDS: for the material sets with a measured BRDF (same-box A/B, profiles/r02_ab.md: bunny +3.4 %; the
@@ -627,16 +457,15 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     constexpr bool MERGE = STEAL && PHASED;
 #endif
     constexpr int LAST_PHASE = MERGE ? (int)ST_SHADOW : (int)ST_MIS;
-    // one traversal phase per vertex (traverse_steal3): the path integrator's lock step + stealing kernels of a -DHPT_FUSE build
-#ifdef HPT_FUSE
-    constexpr bool FUSE = STEAL && PHASED && !DL;
-#else
-    constexpr bool FUSE = false;
-#endif
-    constexpr int STEAL_ROWS_K = FUSE ? HPT_STEAL3_ROWS : HPT_STEAL_ROWS;
+    constexpr int STEAL_ROWS_K = HPT_STEAL_ROWS;
     Hit pend; bool has_pend = false; int retraced = 0;
     pend.prim = -1; pend.t = 0.f; pend.b1 = 0.f; pend.b2 = 0.f; pend.inst = -1;
+    // Sample conservation (round 5; renderers/samplerrenderer.cpp:60-164: every camera sample reaches film->AddSample exactly once): the wave
+    // counts the camera samples it completes — a popcount of the flush's ballot in a scalar register, ONE atomic per wave at the end of the
+    // kernel — and hpt_render_device compares the frame's total with the job's size (HPT_E_INTERNAL when they differ).
+    unsigned n_flushed = 0u;
     for (;;) {
+        HPT_CHECK_FULL_EXEC(4);
         // ---- camera samples completed in the last round: to the film, next sample (the one place finish_path is compiled in) ----
         // Batched (round 4, regen_min): finish_path + the refill + the first camera ray are ~1.5 k instructions that used to run in every round
         // with the handful of lanes that had just ended a path (and, with animated instances, two AnimatedTransform interpolations behind
@@ -648,12 +477,17 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         {
 #ifdef HPT_DBG_NO_REGEN
             const int regen_min = 1;
+#elif defined(HPT_REGEN_ALL)   /* (diagnostic build: the batching in EVERY kernel — the state of round 4's run B2, whose free-running instanced extension kernel faulted) */
+            const int regen_min = a.regen_min;
 #else
             const int regen_min = (STEAL && PHASED) ? a.regen_min : 1;
 #endif
             const unsigned long long mfin = __ballot(lane.fin);
-            if (mfin != 0ull && (__popcll(mfin) >= regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull))
+            HPT_CHECK(!lane.fin || lane.stage != ST_IDLE, HPT_CK_STATE, 1, lane.stage, lane.fin, 0);
+            if (mfin != 0ull && (__popcll(mfin) >= regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull)) {
+                n_flushed += (unsigned)__popcll(mfin);
                 lane.flush(rp, a.film, COUNT ? &wc : nullptr);
+            }
         }
         // ---- refill: idle lanes pull the next (pixel, sample chunk) --------------------------------
         // Eight queue heads, one per XCD: the dispatcher is observed to put workgroup b on XCD b % 8 (a speed assumption only),
@@ -691,55 +525,22 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         }
         Hit hit;
         hit.prim = -1; hit.t = 0.f; hit.b1 = 0.f; hit.b2 = 0.f; hit.inst = -1;
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(active) == 0ull) {
+            HPT_CHECK(!lane.fin && lane.stage == ST_IDLE && !has_pend, HPT_CK_STATE, 2, lane.stage, lane.fin, has_pend);
+            break;
+        }
         // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for -------------
         bool mine = active, shaded = false;
         ShadeV sv;
         sv.has[0] = sv.has[1] = sv.has[2] = false;
-        if (PHASED && !FUSE) {
+        if (PHASED) {
             // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
             const int my_phase = !active ? (int)ST_IDLE : (DL && lane.stage == ST_SHADE) ? (int)ST_EXTEND : (MERGE && lane.stage == ST_MIS) ? (int)ST_SHADOW : lane.stage;
             while (__ballot(my_phase == phase) == 0ull) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
         HPT_PT(0)
-        if (FUSE) {
-            // ---- ONE traversal phase for the shadow, MIS and continuation rays of every live lane's vertex (or its camera ray) -------------------------
-            const bool tr = active && !has_pend;
-            const bool pendL = tr && (lane.stage == ST_SHADOW || lane.stage == ST_MIS);
-            const bool has_a = pendL && lane.stage == ST_SHADOW, has_b = pendL && lane.has_mis, has_c = tr && (pendL ? lane.has_next : true);
-            Ray rc = lane.ray;
-            if (pendL) { rc.o = lane.p; rc.d = lane.wi_next; rc.mint = lane.eps; rc.maxt = HPT_INF; }      // RayDifferential(p, wi, ray, eps), path.cpp:100
-            if (COUNT) { if (has_a) wc.shadow++; if (has_b) wc.closest++; if (has_c) wc.closest++; }
-            bool occ = false;
-            Hit hitb, hitc;
-            traverse_steal3<COUNT, INST, (MATS & MATS_EXT) != 0, TOP>(sc, lane.ray, has_a, lane.p, lane.wi_mis, lane.eps, has_b, rc, has_c, lane.time, &occ, &hitb, &hitc, stack,
-                                                                      top - STEAL_ROWS_K, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal);
-            // the light results of the vertex through the state machine's own code (on_hit for ST_SHADOW / ST_MIS): L += beta * Ld * nLights, then the continuation
-            // ray becomes the lane's ray (ST_EXTEND) — or the path is over (fin)
-            if (pendL) {
-                Hit ha; ha.prim = occ ? 0 : -1; ha.t = 0.f; ha.b1 = 0.f; ha.b2 = 0.f; ha.inst = -1;
-                if (lane.stage == ST_SHADOW) (void)lane.on_hit(sc, rp, ha, a.film, COUNT ? &wc : nullptr, ls, &sv, &hitb);
-                else (void)lane.on_hit(sc, rp, hitb, a.film, COUNT ? &wc : nullptr, ls, &sv);
-            }
-            if (tr && !lane.fin && hitc.prim >= 0) lane.ray.maxt = hitc.t;      // (the traversal shrinks a ray to its hit, core/primitive.cpp:174)
-            if (tr) hit = hitc;
-            if (RETRACE) {
-                // lanes that will not shade this round — the path ended with the light terms, or the continuation / camera ray escaped — finish now and
-                // the wave walks again for their next camera rays while the lanes that did hit keep their Hit (as in the two-phase loop)
-                const bool ended = tr && (lane.fin || hit.prim < 0);
-                const int n_end = __popcll(__ballot(ended));
-                if (retraced < a.retrace_max && n_end >= a.retrace_min && __popcll(__ballot(lane.fin || ended)) >= a.regen_min) {
-                    if (tr && !lane.fin) { if (hit.prim < 0) lane.extend_miss(sc, rp, a.film, COUNT ? &wc : nullptr); else { pend = hit; has_pend = true; } }
-                    ++retraced;
-                    continue;
-                }
-                if (has_pend) { hit = pend; has_pend = false; }
-                retraced = 0;
-            }
-            mine = active && !lane.fin;
-            if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv, nullptr);      // ST_EXTEND: an escaped ray ends the path, a hit is prepared for shading
-        } else if (STEAL && PHASED) {
+        if (STEAL && PHASED) {
             // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
             const bool tr = mine && (!DL || lane.stage != ST_SHADE) && !(RETRACE && has_pend);
             const bool anyhit = lane.stage == ST_SHADOW;
@@ -829,7 +630,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         HPT_PT(4)
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
         HPT_PT(5)
-        if (PHASED && !FUSE) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
+        if (PHASED) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
     }
 #ifdef HPT_PHASE_TIMERS
 #if HPT_PHASE_TIMERS == 3   /* the walk: lane-summed clocks of whole steps / of their leaf parts, steps, steps that were at a leaf */
@@ -845,6 +646,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         atomicAdd((unsigned long long *)&a.counters->shadow, pt[2]); atomicAdd((unsigned long long *)&a.counters->nodes, pt[3]);
         atomicAdd((unsigned long long *)&a.counters->tris, pt[4]); atomicAdd((unsigned long long *)&a.counters->bad, pt[5]);
     }
+#endif
+#ifndef HPT_PHASE_TIMERS
+    if (!COUNT && (threadIdx.x & 63) == 0 && n_flushed != 0u) atomicAdd((unsigned long long *)&a.counters->samples, (unsigned long long)n_flushed);
 #endif
     if (COUNT) {
         wc.nodes = tc.nodes; wc.tris = tc.tris;
@@ -943,11 +747,18 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         }                                                                                                           \
     }                                                                                                               \
     template <int CFG> static const void *fn_cfg_##NAME() { return (const void *)HPT_CFG_KERNEL(MATS, INSTV, CFG); } \
-    int occupancy_##NAME(int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs) {                         \
+    /* the function that launch_path_##NAME runs for (cfg, dl, top, win) without the instrumented build: same selection, same order */ \
+    int occupancy_##NAME(int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs, bool top, bool win) {     \
         if (INSTV && cfg == 1) cfg = 0;                                                                             \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>() : cfg == 2 ? fn_cfg_##NAME<2>() : cfg == 3 ? fn_cfg_##NAME<3>() \
                        : cfg == 4 ? fn_cfg_##NAME<4>() : cfg == 5 ? fn_cfg_##NAME<5>() : cfg == 6 ? fn_cfg_##NAME<6>() : fn_cfg_##NAME<0>(); \
         if (dl) fn = (const void *)HPT_DL_KERNEL(MATS, INSTV, false);                                               \
+        if (win) fn = dl ? (const void *)HPT_DL_KERNEL_W(MATS, INSTV, false) : (const void *)hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, true>; \
+        else if constexpr (INSTV) if (top) {                                                                        \
+            if (dl) fn = (const void *)hpt_path_kernel<false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, false, true>; \
+            else if (HPT_CFG_ALIAS(cfg) == 5) fn = (const void *)hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, false, true>; \
+            else if (HPT_CFG_ALIAS(cfg) == 6) fn = (const void *)hpt_path_kernel<false, INSTV, MATS, HPT_W34, 0, true, false, true, false, true>; \
+        }                                                                                                           \
         int nb = 0;                                                                                                 \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HPT_BLOCK, dyn_lds) != hipSuccess) return -1;           \
         hipFuncAttributes fa;                                                                                       \

@@ -370,6 +370,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // ImageFilm::AddSample with the box filter (film/image.cpp:77-137) + the radiance sanity
     // checks of samplerrenderer.cpp:118-131; then advance to the next sample / flush the pixel.
     HPT_MFN void finish_path(const RenderParams &rp, float *film, WorkCounters *wc) {
+        HPT_CHECK(stage != ST_IDLE && si < s_end, HPT_CK_STATE, 3, stage, si, s_end);
         f3 Ls = cold.L();
         bool bad = (Ls.x != Ls.x) || (Ls.y != Ls.y) || (Ls.z != Ls.z);
         if (!bad) { float yv = sy(Ls); bad = ((double)yv < -1e-5) || yv == HPT_INF || yv == -HPT_INF; }
@@ -413,6 +414,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         if (wc) wc->samples++;
         ++si;
         if (si < s_end) { begin_sample(rp); return; }
+        HPT_CHECK(px >= rp.x_start && px < rp.x_start + rp.x_count && py >= rp.y_start && py < rp.y_start + rp.y_count, HPT_CK_PIXEL, px, py, si, s_end);
         float *f = film + 4 * ((int64_t)(py - rp.y_start) * rp.x_count + (px - rp.x_start));
         float fX, fY, fZ, fW;
         cold.film_get(&fX, &fY, &fZ, &fW);

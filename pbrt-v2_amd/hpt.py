@@ -24,8 +24,9 @@ EXPORTS = [
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
     "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
     "hpt_calib_hbm_triad", "hpt_calib_hbm_copy", "hpt_calib_hbm_read", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
-    "hpt_scene_set_sample_table", "hpt_multi_set_sample_table", "hpt_multi_chunks_taken",
+    "hpt_scene_set_sample_table", "hpt_multi_set_sample_table", "hpt_multi_chunks_taken", "hpt_abi_sizes",
 ]
+E_INTERNAL = -6   # include/hpt.h HPT_E_INTERNAL: the library caught itself (sample conservation, a check of the debug build)
 
 
 class HptError(RuntimeError):

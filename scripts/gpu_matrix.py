@@ -41,7 +41,12 @@ def main():
                         os.environ.pop("HPT_TUNE", None)
                     r = abi.copy_struct(rd)
                     r.count_work = cw
-                    f, st = hpt.DeviceScene(s).render(s.camera, r)
+                    try:
+                        f, st = hpt.DeviceScene(s).render(s.camera, r)
+                    except hpt.HptError as e:      # (HPT_E_INTERNAL: sample conservation, or a check of the debug build — the message names it)
+                        total += 1; bad += 1
+                        print("ERROR %-8s top %s count %d cfg %s: %s" % (name, top, cw, cfg, e)); sys.stdout.flush()
+                        continue
                     a = film.xyzw_to_rgb(f)
                     rmse = float(film.rmse(a, b))
                     ok = rmse < 1e-3 and np.array_equal(f[..., 3], fo[..., 3]) and st.bad_samples == 0

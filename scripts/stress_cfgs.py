@@ -27,7 +27,12 @@ def main():
         for rep in range(reps):
             for cfg in range(7):
                 os.environ["HPT_TUNE"] = str(cfg)
-                f, st = d.render(s.camera, rd)
+                try:
+                    f, st = d.render(s.camera, rd)
+                except hpt.HptError as e:          # (HPT_E_INTERNAL: the conservation check or the debug build caught it where it happened)
+                    bad += 1
+                    print("ERROR", name, "rep", rep, "cfg", cfg, e); sys.stdout.flush()
+                    continue
                 if ref is None:
                     ref = f
                     print(name, "reference: cfg 0, weights", float(f[..., 3].min()), float(f[..., 3].max()), "spp", rd.spp)

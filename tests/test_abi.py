@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """The export list is generated from include/hpt.h (pbrt-v2_amd/Makefile, build/hpt.map): no hpt:: internal, launcher or kernel stub is
+    part of the dynamic surface — a host that binds the library sees the C ABI and nothing else."""
+    import subprocess
+    path = os.environ.get("HPT_LIB") or os.path.join(ROOT, "pbrt-v2_amd", "libhpt.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    defined = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TDBRWVi")
+    assert defined == header_symbols(), sorted(set(defined) ^ set(header_symbols()))
+
+
 def test_struct_layouts_match_compiled_library():
     sizes = (C.c_int32 * 10)()
     hpt.lib().hpt_abi_sizes(sizes)

@@ -51,9 +51,38 @@ def test_intersect_matches_oracle(cases, dev, ora, name):
     same = po == pd
     assert same.mean() > 0.9995, same.mean()
     assert np.array_equal(ho[same], hd[same])
+    # the rays on which the primitive differs are TIES, nothing else: both sides hit, and at the same distance to an ulp (a point on an edge
+    # two triangles share belongs to whichever the walk reaches first; the trees differ).  Anything further apart is a wrong hit.
+    diff = ~same
+    assert (po[diff] >= 0).all() and (pd[diff] >= 0).all(), (po[diff][:8], pd[diff][:8])
+    ulps = np.abs(ho[diff, 0].view(np.int32).astype(np.int64) - hd[diff, 0].view(np.int32).astype(np.int64))
+    assert (ulps <= 1).all(), (int(diff.sum()), ulps.max(), ho[diff, 0][:8], hd[diff, 0][:8])
     _, ao = ora[name].intersect(rays, anyhit=True)
     _, ad = dev[name].intersect(rays, anyhit=True)
     assert (ao == ad).mean() > 0.9995
+
+
+def test_every_render_checks_sample_conservation(cases, dev, monkeypatch):
+    """renderers/samplerrenderer.cpp:60-164: every camera sample of the job is traced and reaches the film exactly once.  The path kernels count
+    the camera samples they complete (one atomic per wave) and hpt_render_device compares the total with the job's size: a lost or repeated
+    sample is HPT_E_INTERNAL where it happens, not a film that differs (round 4, run T).  Here: every tuning configuration reports the job's
+    count, and a job size the kernels cannot meet (test hook) is refused with the configuration in the message."""
+    for name in ("env", "anim", "b8"):
+        s = cases[name]
+        rd = hash_rd(s, seed=3)
+        n = rd.x_count * rd.y_count * rd.spp
+        for cfg in range(7):
+            monkeypatch.setenv("HPT_TUNE", str(cfg))
+            _, st = dev[name].render(s.camera, rd)
+            assert st.camera_samples == n and st.tune_cfg == cfg
+    monkeypatch.setenv("HPT_TUNE", "5")
+    monkeypatch.setenv("HPT_TEST_CONSERVATION_DELTA", "1")
+    with pytest.raises(hpt.HptError) as e:
+        dev["env"].render(cases["env"].camera, hash_rd(cases["env"], seed=3))
+    assert "sample conservation" in str(e.value) and "configuration 5" in str(e.value) and str(hpt.E_INTERNAL) in str(e.value)
+    monkeypatch.delenv("HPT_TEST_CONSERVATION_DELTA")
+    _, st = dev["env"].render(cases["env"].camera, hash_rd(cases["env"], seed=3))
+    assert st.bad_samples == 0
 
 
 def test_intersect_edge_cases(cases, dev, ora):
