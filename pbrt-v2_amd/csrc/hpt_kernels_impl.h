@@ -384,6 +384,37 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     #undef HPT_WAVE_SYNC
 }
 
+// ---- `make shadow` (-DHPT_DEBUG_CHECKS -DHPT_DEBUG_SHADOW, round 5): which block of the loop changes lane state it must not touch? ----------------
+// The wrong films of rounds 4 / 5 have ONE component of one f3 of the lane state off in some lanes, in one instantiation or another, whatever
+// run-time path is switched off (profiles/r05_ab.md).  A lane's path state is invariant across the blocks of the loop that do not own it: the
+// traversal phase (all of it but ray.maxt), the measured-BRDF queries, the flush / refill of OTHER lanes, the shading of other lanes.  The
+// shadow build copies that state into registers of its own before each such block (through an empty asm, so the copy is a value of its own
+// to the compiler) and compares bit for bit after it: the first mismatch names the block (site), the field and the lane.
+#if defined(HPT_DEBUG_SHADOW) && defined(HPT_DEBUG_CHECKS)
+#define HPT_SNAP_N 26
+struct LaneSnap { int v[HPT_SNAP_N]; };
+template <class LANE> __device__ __forceinline__ void lane_fields(const LANE &l, int *o) {
+    const f3 L = l.cold.L(), B = l.cold.beta();
+    const float f[HPT_SNAP_N] = {L.x, L.y, L.z, B.x, B.y, B.z, l.Ld.x, l.Ld.y, l.Ld.z, l.C_mis.x, l.C_mis.y, l.C_mis.z, l.beta_next.x, l.beta_next.y, l.beta_next.z,
+                                 l.p.x, l.p.y, l.p.z, l.wi_mis.x, l.wi_mis.y, l.wi_mis.z, l.wi_next.x, l.wi_next.y, l.wi_next.z, l.eps, l.time};
+    for (int i = 0; i < HPT_SNAP_N; ++i) o[i] = as_int(f[i]);
+}
+template <class LANE> __device__ __forceinline__ void lane_snap(const LANE &l, LaneSnap &s) {
+    lane_fields(l, s.v);
+    for (int i = 0; i < HPT_SNAP_N; ++i) asm volatile("" : "+v"(s.v[i]));
+}
+template <class LANE> __device__ __forceinline__ void lane_cmp(const LANE &l, const LaneSnap &s, int site, bool relevant) {
+    int now[HPT_SNAP_N];
+    lane_fields(l, now);
+    if (relevant) for (int i = 0; i < HPT_SNAP_N; ++i) HPT_CHECK(now[i] == s.v[i], HPT_CK_STATE, 1000 + site * 100 + i, (int)(threadIdx.x & 63u), now[i], s.v[i]);
+}
+#define HPT_SNAP(name) LaneSnap name; lane_snap(lane, name)
+#define HPT_SNAP_CMP(name, site, relevant) lane_cmp(lane, name, site, relevant)
+#else
+#define HPT_SNAP(name)
+#define HPT_SNAP_CMP(name, site, relevant)
+#endif
+
 // WAVES: waves per SIMD the register allocator must allow; EE: early-exit threshold of the traversal phase
 // (0 = each lane walks its ray to completion).  Which (WAVES, EE) wins depends on the scene — cache-resident
 // scenes with short rays prefer fewer, fatter waves; scenes whose BVH lives in HBM prefer more waves and early
@@ -414,7 +445,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // matte / plastic kernels gain < 1 % and a deep tree — the 1 M-triangle soup — would lose a resident workgroup to the ten rows)
     constexpr bool PARK = HPT_PARK_MATS(MATS) && !DL;   // (direct lighting keeps registers: its six stealing rows + a depth-24 tree + ten cold rows would not fit the 40 LDS rows)
     const int top = a.stack_entries - (PARK ? HPT_COLD_ROWS : 0);
-    Lane<LdHashSrcT<WIN>, INST, MATS, DL, typename ColdSel<PARK>::type> lane;
+    // Every word of the lane state is DEFINED from the start (round 5).  The state machine only reads a field after it has written it, but the
+    // wave-level code around it passes fields of idle lanes along (the rays and times of lanes without a ray into the walk, shuffles of all 64
+    // lanes' registers), and an uninitialised automatic is `undef` to LLVM: every use may see a different value and a branch on it is undefined
+    // behaviour — the one property the wrong films of rounds 4 / 5 share is that they move with the code generator (profiles/r05_ab.md).
+    Lane<LdHashSrcT<WIN>, INST, MATS, DL, typename ColdSel<PARK>::type> lane = {};
     ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);
     ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
@@ -425,7 +460,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         lane.abuf = a.adapt_buf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x; lane.abuf_stride = (int64_t)gridDim.x * HPT_BLOCK;
     }
     bool exhausted = false;
-    TravState ts;                  // this lane's walk, resumable across iterations (see the traversal phase)
+    TravState ts = {};             // this lane's walk, resumable across iterations (see the traversal phase)
     ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false;
     bool tracing = false;
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
@@ -474,6 +509,10 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         // Lock step + stealing only (configurations 5 / 6 and direct lighting — what production runs): there a waiting lane works as a thief.
         // (The free-running instantiation of the extension set with animated instances faulted under a threshold of 16 — GPU run B2 of round 4,
         //  cause not found; the free-running and plain lock-step kernels keep the per-round flush they have always had.)
+#if defined(HPT_DEBUG_SHADOW) && defined(HPT_DEBUG_CHECKS)
+        const bool keeps_ = lane.stage != ST_IDLE && !lane.fin;
+#endif
+        HPT_SNAP(snap_flush);
         {
 #ifdef HPT_DBG_NO_REGEN
             const int regen_min = 1;
@@ -484,6 +523,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #endif
             const unsigned long long mfin = __ballot(lane.fin);
             HPT_CHECK(!lane.fin || lane.stage != ST_IDLE, HPT_CK_STATE, 1, lane.stage, lane.fin, 0);
+
             if (mfin != 0ull && (__popcll(mfin) >= regen_min || __ballot(lane.stage != ST_IDLE && !lane.fin) == 0ull)) {
                 n_flushed += (unsigned)__popcll(mfin);
                 lane.flush(rp, a.film, COUNT ? &wc : nullptr);
@@ -515,6 +555,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             }
             if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }
+        HPT_SNAP_CMP(snap_flush, 1, keeps_);                         // (flush + refill: the lanes in mid-path)
         const bool active = lane.stage != ST_IDLE && !lane.fin;      // (a finished lane waiting for its flush is idle)
         if (INST && xf_col && active && lane.time != xf_time) {
             xf_time = lane.time;
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         }
         // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for -------------
         bool mine = active, shaded = false;
-        ShadeV sv;
+        ShadeV sv = {};
         sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
             // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
@@ -546,9 +587,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool anyhit = lane.stage == ST_SHADOW;
             const bool has_b = MERGE && tr && anyhit && lane.has_mis;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; if (has_b) wc.closest++; }
-            Hit hitb;
+            Hit hitb = {0.f, 0.f, 0.f, -1, -1};
+            HPT_SNAP(snap_walk);
             traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0, MERGE, TOP>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - STEAL_ROWS_K, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal,
                                                                         MERGE && phase != ST_EXTEND, has_b, &lane.p, &lane.wi_mis, lane.eps, &hitb);
+            HPT_SNAP_CMP(snap_walk, 2, true);                      // (the traversal phase: every lane)
             if (RETRACE && phase == ST_EXTEND) {
                 // Extension rays that escaped end their paths without shading.  If there are enough of them, they take their next camera
                 // ray now (flush at the top of the loop; idle lanes pull new work there too) and the wave walks once more — the lanes that
@@ -571,7 +614,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #ifdef HPT_PRIO_SHADE
             __builtin_amdgcn_s_setprio(HPT_PRIO_SHADE);
 #endif
+            HPT_SNAP(snap_hit);
             if (mine) shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv, MERGE ? &hitb : nullptr);
+            HPT_SNAP_CMP(snap_hit, 3, !mine);                      // (on_hit: the lanes of the other phases)
 #ifdef HPT_PRIO_SHADE
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -581,7 +626,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 if (!DL || lane.stage != ST_SHADE) {
                     bool anyhit = lane.stage == ST_SHADOW;
                     if (COUNT) { if (anyhit) wc.shadow++; else wc.closest++; }
+                    HPT_SNAP(snap_walk0);
                     traverse<COUNT, INST, (MATS & MATS_EXT) != 0>(sc, lane.ray, lane.time, anyhit, &hit, stack, HPT_BLOCK, &tc, xf_col, xf_stride);
+                    HPT_SNAP_CMP(snap_walk0, 4, true);
                 }
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
@@ -614,6 +661,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         }
         HPT_PT(3)
         // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
+        HPT_SNAP(snap_q);
         if (MATS & MATS_MEASURED) {
             if (INST || EE == 0) {
 #ifdef HPT_PRIO_QUERY
@@ -627,8 +675,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             else if (shaded)     // early exit: stragglers' BVH stacks are live in their columns — each owner walks for itself
                 for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
         }
+        HPT_SNAP_CMP(snap_q, 5, true);                             // (the measured-BRDF queries: every lane)
         HPT_PT(4)
+        HPT_SNAP(snap_fin);
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
+        HPT_SNAP_CMP(snap_fin, 6, !shaded);                        // (shade_finish: the lanes that did not shade)
         HPT_PT(5)
         if (PHASED) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
     }

@@ -18,6 +18,7 @@
 // accepts a device list with repeats (several shards on one GPU, e.g. {0, 0}) and moves their tiles with hipMemcpyAsync instead — the
 // single-GPU test path of the sharding, packing and threading; RCCL itself then runs with a communicator of one rank.
 #include <hip/hip_runtime.h>
+#include <cerrno>
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -177,7 +178,9 @@ struct HostBox {                       // one mailbox, mapped by its owner and b
         name = nm; owner = own;
         const size_t want = sizeof(Hdr) + payload_bytes;
         if (fd < 0) {
-            fd = shm_open(nm.c_str(), own ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+            // (the owner creates its mailbox exclusively: a name left over from a crashed run — pid and clock make that unlikely — is removed, not adopted)
+            if (own) { fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600); if (fd < 0 && errno == EEXIST) { shm_unlink(nm.c_str()); fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600); } }
+            else fd = shm_open(nm.c_str(), O_RDWR, 0600);
             if (fd < 0) return false;
         }
         struct stat sb;
@@ -262,6 +265,10 @@ extern "C" void hpt_comm_destroy(hpt_comm *c) {
     (void)hipSetDevice(c->device);
     if (c->packed) (void)hipFree(c->packed);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    // host transport, non-root: the mailbox is unlinked only when rank 0 has taken the last frame published in it — a rank that exchanged once and
+    // left at once used to remove the name before rank 0 had opened it, and rank 0 then span until "no mailbox" 
+    if (c->host && c->rank != 0 && c->frame > 0 && !c->boxes.empty() && c->boxes[0].map)
+        (void)host_wait(c->boxes[0].hdr()->ack, c->frame, comm_timeout_s());
     for (HostBox &b : c->boxes) b.close_box();
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     delete c;
@@ -295,7 +302,13 @@ template <class F> static int host_recv_all(hpt_comm *c, F &&per_peer) {
         if (!b.open_box(nm, false, 0) || b.map_bytes < sizeof(HostBox::Hdr) + bytes) { hpt_set_error("hpt_comm (host transport): mailbox %s is smaller than its payload", nm.c_str()); return HPT_E_HIP; }
         const int rc = per_peer(p, b.payload(), bytes);
         b.hdr()->ack.store(f, std::memory_order_release);
-        if (rc != HPT_OK) return rc;
+        if (rc != HPT_OK) {                                   // the frame is lost, but no peer is left waiting for its acknowledgement until its own timeout
+            for (int q = p + 1; q < c->world; ++q) {
+                HostBox &bq = c->boxes[(size_t)q - 1];
+                if (bq.open_box(c->key + "." + std::to_string(q), false, 0) && host_wait(bq.hdr()->seq, f, comm_timeout_s())) bq.hdr()->ack.store(f, std::memory_order_release);
+            }
+            return rc;
+        }
     }
     return HPT_OK;
 }

@@ -308,11 +308,22 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
     // on_hit() / shade_finish() run ONCE per round through flush() instead of the four places of the state machine that can end a path
     // (each an inlined copy of the film update and the camera-ray set-up: the path kernels are 30-50 k instructions).
     bool fin;
+#if defined(HPT_DEBUG_SHADOW) && defined(HPT_DEBUG_CHECKS) && defined(__HIPCC__)
+    // shadow build: the radiance as it was when the path ended — finish_path must find the same bits (site 7)
+    int finL[3];
+    HPT_MFN void set_fin() { fin = true; const f3 L = cold.L(); finL[0] = as_int(L.x); finL[1] = as_int(L.y); finL[2] = as_int(L.z); for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(finL[i])); }
+    HPT_MFN void check_fin() { const f3 L = cold.L(); const int n[3] = {as_int(L.x), as_int(L.y), as_int(L.z)};
+                               for (int i = 0; i < 3; ++i) HPT_CHECK(n[i] == finL[i], HPT_CK_STATE, 1700 + i, (int)(threadIdx.x & 63u), n[i], finL[i]); }
+#else
+    HPT_MFN void set_fin() { fin = true; }
+    HPT_MFN void check_fin() {}
+#endif
 
     HPT_MFN void init() { stage = ST_IDLE; px = py = 0; si = 0; depth = 0; nsp = 0; dls_cap = 0; dls = nullptr; dls_stride = 0; abuf = nullptr; abuf_stride = 0; fin = false; }
     HPT_MFN void flush(const RenderParams &rp, float *film, WorkCounters *wc) {
         if (fin) {
             fin = false;
+            check_fin();
             if (Smp::windowed && rp.adapt_min > 0) finish_path_adaptive(rp, film, wc);
             else finish_path(rp, film, wc);
         }
@@ -531,7 +542,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
             ray.o = p; ray.d = wi_next; ray.mint = eps; ray.maxt = HPT_INF; // RayDifferential(p, wi, ray, eps) path.cpp:100
             ++bounce;
             stage = ST_EXTEND;
-        } else fin = true;
+        } else set_fin();
     }
     HPT_MFN void after_shadow(const DScene &sc, const RenderParams &rp, float *film, WorkCounters *wc) {
         if (has_mis) {
@@ -603,7 +614,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
                 return;
             }
         }
-        fin = true;
+        set_fin();
     }
 
     // The extension ray escaped: the radiance it sees (samplerrenderer.cpp:240-243, path.cpp:114-116); the path is complete.
@@ -612,7 +623,7 @@ template <class Smp, bool INST, int MATS, bool DL = false, class Cold = ColdRegs
         if (bounce == 0) cold.setL(all_lights_Le(sc, ray.d));                 // samplerrenderer.cpp:240-243
         else if (specular)                                             // path.cpp:114-116
             for (int i = 0; i < sc.n_lights; ++i) cold.setL(cold.L() + smul(cold.beta(), light_Le(sc, sc.lights[i], ray.d)));
-        fin = true;
+        set_fin();
     }
 
     // Called with the result of the traversal phase for this lane's pending ray.  Shadow / MIS results and
