@@ -405,6 +405,16 @@ struct DScene {
 #endif
 };
 
+// What the walk reads of the scene, BY VALUE: the out-of-line walk (steal_walk_ool, hpt_kernels_impl.h) must not take a reference into the kernel-argument
+// block (that forces the whole block into private memory: round 3, run G).  The walks of the extension set evaluate alpha textures and take the DScene itself.
+struct WalkScene {
+    const f4 *nodes4, *tris;
+    const hpt_quadric *quadrics;
+    const hpt_instance *instances;
+    const int32_t *inst_root4;
+    int32_t n_tris, n_quadrics, n_instances, world_root4, top_root4;
+    uint32_t inst_quadric_mask;
+};
 struct Ray { f3 o, d; float mint, maxt; };
 HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
 struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or HPT_PRIM_QUADRIC | quadric; -1 miss; inst: animated instance or -1
@@ -699,8 +709,8 @@ struct TravState {
 // QI (the extension set's walks): animated spheres / disks — an instance whose primitive is ONE quadric (hpt_instance.quadric1, core/api.cpp:1032-1042)
 // is tested here when the walk enters the instance (world = false, inst = its index; `ray` is in the instance's space and the quadric's
 // ObjectToWorld is the identity), and is skipped among the quadrics of the world.
-template <bool QI = false>
-HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world, int inst = -1) {
+template <bool QI = false, class SC = DScene>
+HPT_FN void trav_begin(const SC &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world, int inst = -1) {
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
@@ -846,8 +856,8 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
 
 // trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
 // any-hit ray is done (occluded).
-template <bool COUNT, bool ALPHA>
-HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
+template <bool COUNT, bool ALPHA, class SC>
+HPT_FN bool trav_leaf(const SC &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     HPT_CHECK(first + count <= (uint32_t)sc.n_tris, HPT_CK_TRI, first, count, sc.n_tris, 0);
@@ -857,7 +867,7 @@ HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray,
         if (COUNT) cnt->tris++;
         float t, b1, b2;
         if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
-            if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
+            if constexpr (ALPHA) { if ((as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue; }
             ts.hit.prim = (int32_t)(first + k);
             if (ts.anyhit) return true;
             ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;

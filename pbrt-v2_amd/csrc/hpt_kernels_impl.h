@@ -155,10 +155,11 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // TOP: the walk from the top-level tree; false (scenes of a handful of instances: measured on anim-killeroos-moving, two instances, the serial
 // visit is 5-7 % faster — run D of round 4): the ray's OWNER walks the world tree and then, one after the other, the tree of every instance whose
 // motion bounds the (shrinking) ray still crosses, helpers only ever walk the subtree they were given.
-template <bool COUNT, bool INST, bool ALPHA, bool TWO = false, bool TOP = false>
-__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
-                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
-                                               bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
+template <bool COUNT, bool INST, bool ALPHA, bool TWO, bool TOP, class SC>
+__device__ __forceinline__ void steal_walk(const SC &sc, const Ray &ray, float time, bool anyhit, bool has_ray, int32_t *stack, int aux,
+                                           TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
+                                           bool light, bool has_b, const f3 pbv, const f3 dbv, float epsb) {
+    const f3 *pb = &pbv, *db = &dbv;
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
@@ -359,6 +360,46 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         }
     }
     HPT_WAVE_SYNC();
+#ifdef HPT_PRIO_WALK
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    #undef HPT_AUX
+    #undef HPT_WAVE_SYNC
+}
+// The walk OUT OF LINE (round 5, -DHPT_WALK_OOL): a function of its own — its own register allocation, the caller's lane state parked once
+// around the call (callee-saved registers / scratch) instead of wherever the allocator of one 15 k-instruction function puts it — taking the scene view, the
+// ray(s) and the lane's LDS column BY VALUE and returning nothing: the results are in the owner's LDS rows, where traverse_steal reads them.
+template <bool INST, bool ALPHA, bool TWO, bool TOP, class SC>
+__device__ __noinline__ void steal_walk_ool(const SC sc, const Ray ray, float time, unsigned flags, HPT_LDS int32_t *stack_l, int aux, const float *xf_cache, int64_t xf_stride,
+                                            int leaf_q, int block_q, int cap_normal, const f3 pb, const f3 db, float epsb) {
+    steal_walk<false, INST, ALPHA, TWO, TOP, SC>(sc, ray, time, (flags & 1u) != 0u, (flags & 2u) != 0u, (int32_t *)stack_l, aux, nullptr, xf_cache, xf_stride, leaf_q, block_q, cap_normal,
+                                                (flags & 4u) != 0u, (flags & 8u) != 0u, pb, db, epsb);
+}
+template <bool ALPHA> struct WalkSceneSel {
+    typedef WalkScene type;
+    static __device__ __forceinline__ WalkScene make(const DScene &sc) {
+        WalkScene w; w.nodes4 = sc.nodes4; w.tris = sc.tris; w.quadrics = sc.quadrics; w.instances = sc.instances; w.inst_root4 = sc.inst_root4;
+        w.n_tris = sc.n_tris; w.n_quadrics = sc.n_quadrics; w.n_instances = sc.n_instances; w.world_root4 = sc.world_root4; w.top_root4 = sc.top_root4; w.inst_quadric_mask = sc.inst_quadric_mask;
+        return w;
+    }
+};
+template <> struct WalkSceneSel<true> { typedef DScene type; static __device__ __forceinline__ DScene make(const DScene &sc) { return sc; } };
+template <bool COUNT, bool INST, bool ALPHA, bool TWO = false, bool TOP = false>
+__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
+                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
+                                               bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
+    const int lane = lane_id();
+    int32_t *col0 = stack - lane;
+    #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
+    #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    const f3 zero3 = mk3(0.f, 0.f, 0.f);
+#ifdef HPT_WALK_OOL
+    if constexpr (!COUNT) {
+        steal_walk_ool<INST, ALPHA, TWO, TOP, typename WalkSceneSel<ALPHA>::type>(WalkSceneSel<ALPHA>::make(sc), ray, time, (anyhit ? 1u : 0u) | (has_ray ? 2u : 0u) | (light ? 4u : 0u) | (has_b ? 8u : 0u),
+                                                                                 (HPT_LDS int32_t *)stack, aux, xf_cache, xf_stride, leaf_q, block_q, cap_normal, (TWO && pb) ? *pb : zero3, (TWO && db) ? *db : zero3, epsb);
+    } else
+#endif
+    steal_walk<COUNT, INST, ALPHA, TWO, TOP, DScene>(sc, ray, time, anyhit, has_ray, stack, aux, cnt, xf_cache, xf_stride, leaf_q, block_q, cap_normal, light, has_b, (TWO && pb) ? *pb : zero3, (TWO && db) ? *db : zero3, epsb);
     // ---- every owner collects the nearest hit of its group ----------------------------------------------------------------
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
     if (TWO) { hitb->prim = -1; hitb->t = 0.f; hitb->b1 = 0.f; hitb->b2 = 0.f; hitb->inst = -1; }
