@@ -128,30 +128,13 @@ HPT_FN f3 cross(f3 a, f3 b) { // geometry.h:475-484: evaluated in DOUBLE
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return mk3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
 }
-// The two cross products of the triangle test (the hot ones: trav_leaf is half of a node step's time, and an f64 instruction issues at the
-// 4-clock rate, a float add / mul / fma at the 2-clock rate — profiles/r02j_valu_rate.md).  HPT_CROSS_MODE:
-//   0 (default)  the reference's arithmetic, geometry.h:475-484: both products exact in double, ONE rounding of their difference to double,
-//                one to float — written with fma(a, b, -(c * d)), which is that same single rounding (3 f64 instructions fewer per cross
-//                than mul, mul, sub: bit-identical results);
-//   1            Kahan's difference of products in float (w = c d; e = fma(-c, d, w); f = fma(a, b, -w); f + e): 4 two-clock instructions a
-//                component instead of 7 four-clock ones, no 64-bit temporaries; within 1.5 ulp of the exact value, NOT bit-identical;
-//   2            an error-free float evaluation (two-product, two-sum, one final rounding): the exact value rounded once — agrees with the
-//                double-then-round result except when the exact value sits within 2^-29 relative of a rounding boundary; 13 two-clock
-//                instructions a component (no faster than mode 0 — it exists to measure what the 64-bit registers cost).
-#ifndef HPT_CROSS_MODE
-#define HPT_CROSS_MODE 0
-#endif
+// The two cross products of the triangle test: the reference's arithmetic (geometry.h:475-484: both products exact in double, ONE rounding of their
+// difference to double, one to float) written as fma(a, b, -(c d)) — that same single rounding, one f64 instruction a component fewer than mul, mul, sub,
+// bit-identical results.  Round 5 also measured Kahan's difference of products in FLOAT (4 two-clock instructions a component instead of 7 four-clock
+// ones, no 64-bit temporaries): no faster on any workload (killeroo 1358 against 1364, soup / bunny / anim within 0.3 %), t off the
+// reference's by up to 215 ulps where the products cancel — not taken (profiles/r05_ab.md, run C).
 HPT_FN float diff_of_products(float a, float b, float c, float d) {   // a b - c d
-#if HPT_CROSS_MODE == 1
-    const float w = c * d, e = __builtin_fmaf(-c, d, w), f = __builtin_fmaf(a, b, -w);
-    return f + e;
-#elif HPT_CROSS_MODE == 2
-    const float p1 = a * b, e1 = __builtin_fmaf(a, b, -p1), p2 = c * d, e2 = __builtin_fmaf(c, d, -p2);
-    const float s = p1 - p2, bv = s - p1, av = s - bv, dl = (p1 - av) + (-p2 - bv);   // two-sum: p1 - p2 = s + dl exactly
-    return s + (dl + (e1 - e2));
-#else
     return (float)__builtin_fma((double)a, (double)b, -((double)c * (double)d));
-#endif
 }
 HPT_FN f3 cross_tri(f3 a, f3 b) {
     return mk3(diff_of_products(a.y, b.z, a.z, b.y), diff_of_products(a.z, b.x, a.x, b.z), diff_of_products(a.x, b.y, a.y, b.x));
@@ -405,16 +388,6 @@ struct DScene {
 #endif
 };
 
-// What the walk reads of the scene, BY VALUE: the out-of-line walk (steal_walk_ool, hpt_kernels_impl.h) must not take a reference into the kernel-argument
-// block (that forces the whole block into private memory: round 3, run G).  The walks of the extension set evaluate alpha textures and take the DScene itself.
-struct WalkScene {
-    const f4 *nodes4, *tris;
-    const hpt_quadric *quadrics;
-    const hpt_instance *instances;
-    const int32_t *inst_root4;
-    int32_t n_tris, n_quadrics, n_instances, world_root4, top_root4;
-    uint32_t inst_quadric_mask;
-};
 struct Ray { f3 o, d; float mint, maxt; };
 HPT_FN f3 ray_at(const Ray &r, float t) { return r.o + r.d * t; }
 struct Hit { float t, b1, b2; int32_t prim; int32_t inst; }; // prim: tri slot (BVH order) or HPT_PRIM_QUADRIC | quadric; -1 miss; inst: animated instance or -1
@@ -709,8 +682,8 @@ struct TravState {
 // QI (the extension set's walks): animated spheres / disks — an instance whose primitive is ONE quadric (hpt_instance.quadric1, core/api.cpp:1032-1042)
 // is tested here when the walk enters the instance (world = false, inst = its index; `ray` is in the instance's space and the quadric's
 // ObjectToWorld is the identity), and is skipped among the quadrics of the world.
-template <bool QI = false, class SC = DScene>
-HPT_FN void trav_begin(const SC &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world, int inst = -1) {
+template <bool QI = false>
+HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, int32_t root, bool world, int inst = -1) {
     ts.anyhit = anyhit;
     ts.hit.prim = -1; ts.hit.t = 0.f; ts.hit.b1 = 0.f; ts.hit.b2 = 0.f; ts.hit.inst = -1;
     ts.sp = 0; ts.node = root;
@@ -856,8 +829,8 @@ HPT_FN void trav_node4(const f4 *nodes4, TravState &ts, const Ray &ray, int32_t 
 
 // trav_leaf: the <= 8 pre-gathered 48-byte triangle records of leaf `leaf`; a hit goes to ts.hit and shrinks the ray.  Returns true when an
 // any-hit ray is done (occluded).
-template <bool COUNT, bool ALPHA, class SC>
-HPT_FN bool trav_leaf(const SC &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
+template <bool COUNT, bool ALPHA>
+HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray, int32_t leaf, TravCounters *cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     HPT_CHECK(first + count <= (uint32_t)sc.n_tris, HPT_CK_TRI, first, count, sc.n_tris, 0);
@@ -867,7 +840,7 @@ HPT_FN bool trav_leaf(const SC &sc, const f4 *tris, TravState &ts, Ray &ray, int
         if (COUNT) cnt->tris++;
         float t, b1, b2;
         if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
-            if constexpr (ALPHA) { if ((as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue; }
+            if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
             ts.hit.prim = (int32_t)(first + k);
             if (ts.anyhit) return true;
             ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;

@@ -155,11 +155,10 @@ __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls
 // TOP: the walk from the top-level tree; false (scenes of a handful of instances: measured on anim-killeroos-moving, two instances, the serial
 // visit is 5-7 % faster — run D of round 4): the ray's OWNER walks the world tree and then, one after the other, the tree of every instance whose
 // motion bounds the (shrinking) ray still crosses, helpers only ever walk the subtree they were given.
-template <bool COUNT, bool INST, bool ALPHA, bool TWO, bool TOP, class SC>
-__device__ __forceinline__ void steal_walk(const SC &sc, const Ray &ray, float time, bool anyhit, bool has_ray, int32_t *stack, int aux,
-                                           TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
-                                           bool light, bool has_b, const f3 pbv, const f3 dbv, float epsb) {
-    const f3 *pb = &pbv, *db = &dbv;
+template <bool COUNT, bool INST, bool ALPHA, bool TWO = false, bool TOP = false>
+__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
+                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
+                                               bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t *col0 = stack - lane;                                   // column of lane 0 of this wave
@@ -360,46 +359,6 @@ __device__ __forceinline__ void steal_walk(const SC &sc, const Ray &ray, float t
         }
     }
     HPT_WAVE_SYNC();
-#ifdef HPT_PRIO_WALK
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    #undef HPT_AUX
-    #undef HPT_WAVE_SYNC
-}
-// The walk OUT OF LINE (round 5, -DHPT_WALK_OOL): a function of its own — its own register allocation, the caller's lane state parked once
-// around the call (callee-saved registers / scratch) instead of wherever the allocator of one 15 k-instruction function puts it — taking the scene view, the
-// ray(s) and the lane's LDS column BY VALUE and returning nothing: the results are in the owner's LDS rows, where traverse_steal reads them.
-template <bool INST, bool ALPHA, bool TWO, bool TOP, class SC>
-__device__ __noinline__ void steal_walk_ool(const SC sc, const Ray ray, float time, unsigned flags, HPT_LDS int32_t *stack_l, int aux, const float *xf_cache, int64_t xf_stride,
-                                            int leaf_q, int block_q, int cap_normal, const f3 pb, const f3 db, float epsb) {
-    steal_walk<false, INST, ALPHA, TWO, TOP, SC>(sc, ray, time, (flags & 1u) != 0u, (flags & 2u) != 0u, (int32_t *)stack_l, aux, nullptr, xf_cache, xf_stride, leaf_q, block_q, cap_normal,
-                                                (flags & 4u) != 0u, (flags & 8u) != 0u, pb, db, epsb);
-}
-template <bool ALPHA> struct WalkSceneSel {
-    typedef WalkScene type;
-    static __device__ __forceinline__ WalkScene make(const DScene &sc) {
-        WalkScene w; w.nodes4 = sc.nodes4; w.tris = sc.tris; w.quadrics = sc.quadrics; w.instances = sc.instances; w.inst_root4 = sc.inst_root4;
-        w.n_tris = sc.n_tris; w.n_quadrics = sc.n_quadrics; w.n_instances = sc.n_instances; w.world_root4 = sc.world_root4; w.top_root4 = sc.top_root4; w.inst_quadric_mask = sc.inst_quadric_mask;
-        return w;
-    }
-};
-template <> struct WalkSceneSel<true> { typedef DScene type; static __device__ __forceinline__ DScene make(const DScene &sc) { return sc; } };
-template <bool COUNT, bool INST, bool ALPHA, bool TWO = false, bool TOP = false>
-__device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float time, bool anyhit, bool has_ray, Hit *hit, int32_t *stack, int aux,
-                                               TravCounters *cnt, const float *xf_cache, int64_t xf_stride, int leaf_q, int block_q, int cap_normal,
-                                               bool light = false, bool has_b = false, const f3 *pb = nullptr, const f3 *db = nullptr, float epsb = 0.f, Hit *hitb = nullptr) {
-    const int lane = lane_id();
-    int32_t *col0 = stack - lane;
-    #define HPT_AUX(row, l) col0[(l) + (row) * HPT_BLOCK]
-    #define HPT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-    const f3 zero3 = mk3(0.f, 0.f, 0.f);
-#ifdef HPT_WALK_OOL
-    if constexpr (!COUNT) {
-        steal_walk_ool<INST, ALPHA, TWO, TOP, typename WalkSceneSel<ALPHA>::type>(WalkSceneSel<ALPHA>::make(sc), ray, time, (anyhit ? 1u : 0u) | (has_ray ? 2u : 0u) | (light ? 4u : 0u) | (has_b ? 8u : 0u),
-                                                                                 (HPT_LDS int32_t *)stack, aux, xf_cache, xf_stride, leaf_q, block_q, cap_normal, (TWO && pb) ? *pb : zero3, (TWO && db) ? *db : zero3, epsb);
-    } else
-#endif
-    steal_walk<COUNT, INST, ALPHA, TWO, TOP, DScene>(sc, ray, time, anyhit, has_ray, stack, aux, cnt, xf_cache, xf_stride, leaf_q, block_q, cap_normal, light, has_b, (TWO && pb) ? *pb : zero3, (TWO && db) ? *db : zero3, epsb);
     // ---- every owner collects the nearest hit of its group ----------------------------------------------------------------
     hit->prim = -1; hit->t = 0.f; hit->b1 = 0.f; hit->b2 = 0.f; hit->inst = -1;
     if (TWO) { hitb->prim = -1; hitb->t = 0.f; hitb->b1 = 0.f; hitb->b2 = 0.f; hitb->inst = -1; }
@@ -486,11 +445,17 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // matte / plastic kernels gain < 1 % and a deep tree — the 1 M-triangle soup — would lose a resident workgroup to the ten rows)
     constexpr bool PARK = HPT_PARK_MATS(MATS) && !DL;   // (direct lighting keeps registers: its six stealing rows + a depth-24 tree + ten cold rows would not fit the 40 LDS rows)
     const int top = a.stack_entries - (PARK ? HPT_COLD_ROWS : 0);
-    // Every word of the lane state is DEFINED from the start (round 5).  The state machine only reads a field after it has written it, but the
-    // wave-level code around it passes fields of idle lanes along (the rays and times of lanes without a ray into the walk, shuffles of all 64
-    // lanes' registers), and an uninitialised automatic is `undef` to LLVM: every use may see a different value and a branch on it is undefined
-    // behaviour — the one property the wrong films of rounds 4 / 5 share is that they move with the code generator (profiles/r05_ab.md).
-    Lane<LdHashSrcT<WIN>, INST, MATS, DL, typename ColdSel<PARK>::type> lane = {};
+    // The state machine only reads a field after it has written it; the wave-level code around it passes fields of idle lanes along (the rays and times
+    // of lanes without a ray into the walk, shuffles of all 64 lanes' registers) but never branches on them.  Round 5 tried every word of lane state
+    // DEFINED from the start as a cure for the wrong films that move with the code generator: it is not (profiles/r05_ab.md, run E: the failure moved to
+    // another instantiation) and it costs the measured-BRDF kernel 6 % (run L: bunny 1875 against 1994 Msamples/s — more values for the allocator to
+    // carry from the kernel's head).  The debug / shadow builds, which READ the whole state to compare it, keep the initialisation.
+#ifdef HPT_DEBUG_CHECKS
+#define HPT_ZERO_INIT = {}
+#else
+#define HPT_ZERO_INIT
+#endif
+    Lane<LdHashSrcT<WIN>, INST, MATS, DL, typename ColdSel<PARK>::type> lane HPT_ZERO_INIT;
     ColdSel<PARK>::bind(lane.cold, (HPT_LDS float *)stack + top * HPT_BLOCK, HPT_BLOCK);
     ls.qrow = top - 12;                        // query queue of wave_eval_queries: the 12 rows below the cold rows (free while shading)
     lane.init();
@@ -501,7 +466,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         lane.abuf = a.adapt_buf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x; lane.abuf_stride = (int64_t)gridDim.x * HPT_BLOCK;
     }
     bool exhausted = false;
-    TravState ts = {};             // this lane's walk, resumable across iterations (see the traversal phase)
+    TravState ts HPT_ZERO_INIT;    // this lane's walk, resumable across iterations (see the traversal phase)
     ts.node = HPT_TRAV_EMPTY; ts.sp = 0; ts.anyhit = false;
     bool tracing = false;
     WorkCounters wc = {0, 0, 0, 0, 0, 0};
@@ -613,7 +578,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         }
         // ---- lock step: the next phase (extension -> shadow -> MIS) that any lane is waiting for -------------
         bool mine = active, shaded = false;
-        ShadeV sv = {};
+        ShadeV sv HPT_ZERO_INIT;
         sv.has[0] = sv.has[1] = sv.has[2] = false;
         if (PHASED) {
             // (direct lighting: a lane whose next light sample is due, ST_SHADE, belongs to the extension phase)
@@ -628,7 +593,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             const bool anyhit = lane.stage == ST_SHADOW;
             const bool has_b = MERGE && tr && anyhit && lane.has_mis;
             if (COUNT && tr) { if (anyhit) wc.shadow++; else wc.closest++; if (has_b) wc.closest++; }
-            Hit hitb = {0.f, 0.f, 0.f, -1, -1};
+            Hit hitb HPT_ZERO_INIT;
             HPT_SNAP(snap_walk);
             traverse_steal<COUNT, INST, (MATS & MATS_EXT) != 0, MERGE, TOP>(sc, lane.ray, lane.time, anyhit, tr, &hit, stack, top - STEAL_ROWS_K, &tc, xf_col, xf_stride, a.leaf_q, a.block_q, a.cap_normal,
                                                                         MERGE && phase != ST_EXTEND, has_b, &lane.p, &lane.wi_mis, lane.eps, &hitb);
