@@ -144,3 +144,15 @@ def test_no_cpu_fallback_without_device(cases):
         hpt.DeviceScene(cases["env"])
     with pytest.raises(hpt.HptError):
         hpt.sampler(cases["env"].render, 0, 0)
+
+
+def test_the_extension_units_stay_off_the_greedy_vgpr_allocator():
+    """profiles/r05_ab.md: under clang 22's greedy register allocator every build of the two 0.5-1 MB extension units had one kernel instantiation that was wrong as a
+    whole (one component of a float3 of the lane state overwritten, a memory fault, an illegal instruction); under -vgpr-regalloc=basic none.  The flag lives in the
+    Makefile, where a clean-up would lose it silently: this test is the note on the door (scripts/gpu_matrix.py and the GPU suite are the gate proper)."""
+    mk = open(os.path.join(ROOT, "pbrt-v2_amd", "Makefile")).read()
+    for unit in ("hpt_kernels_ext", "hpt_kernels_ext_i"):
+        m = re.search(r"^FLAGS_%s\s*:=(.*)$" % unit, mk, flags=re.M)
+        assert m and "-vgpr-regalloc=basic" in m.group(1), unit
+    m = re.search(r"^FLAGS_hpt_kernels_lean\s*:=(.*)$", mk, flags=re.M)
+    assert m and "iterative-ilp" not in m.group(1)      # (the scheduler whose output LLVM's machine verifier rejects and on which the allocator segfaults)
