@@ -165,15 +165,16 @@ def test_pbrt_binary_shards_over_gpus_end_to_end(tmp_path):
     assert got.shape == want.shape and film.rmse(got, want) < 1e-4
 
 
-@pytest.mark.parametrize("case,world,wide", [("k8", 2, 0), ("b8", 3, 0), ("k8", 2, 1)])
-def test_hpt_comm_runs_with_two_processes_over_the_host_transport(case, world, wide, tmp_path):
+@pytest.mark.parametrize("case,world,wide,nframes", [("k8", 2, 0, 2), ("b8", 3, 0, 2), ("k8", 2, 1, 2), ("k8", 3, 0, 1)])
+def test_hpt_comm_runs_with_two_processes_over_the_host_transport(case, world, wide, nframes, tmp_path):
     """hpt_comm's multi-rank logic (csrc/hpt_multi.hip: shard bookkeeping, hpt_pack_tiles_kernel, the per-peer offsets of
     the root's receive buffer, hpt_unpack_tiles_kernel; under a wide filter the sum of full-frame films) executed with world > 1 — one process
     per rank, all on device 0, the hop between them through shared memory (HPT_COMM_TRANSPORT=host).  Two frames: the mailboxes are reused.
-    The gathered frame must be the single-rank frame."""
+    ONE frame (round 5): a rank that exchanges once and destroys its communicator at once must leave its mailbox in place until rank 0
+    has taken the frame (hpt_comm_destroy waits for the acknowledgement before it unlinks).  The gathered frame must be the single-rank frame."""
     env = dict(os.environ, HPT_COMM_TRANSPORT="host", HPT_COMM_TIMEOUT_S="60")
     worker = os.path.join(ROOT, "tests", "workers", "comm_rank.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), case, str(wide), "2"], env=env,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(tmp_path), case, str(wide), str(nframes)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
@@ -189,7 +190,7 @@ def test_hpt_comm_runs_with_two_processes_over_the_host_transport(case, world, w
     dev = hpt.DeviceScene(s)
     if wide:
         dev.set_filter(abi.make_filter("gaussian"))
-    for k in range(2):
+    for k in range(nframes):
         rd = hash_rd(s, seed=4 + k)
         single, _ = dev.render(s.camera, rd)
         got = np.load(os.path.join(str(tmp_path), "frame%d.npy" % k))
