@@ -14,8 +14,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", _HERE])
-        L = C.CDLL(os.path.join(_HERE, "libhostemu.so"))
+        name = "libhostemu_san.so" if os.environ.get("HPT_HOSTEMU_SAN") else "libhostemu.so"      # (the sanitizer build: scripts/hostemu_sanitize.sh)
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
+        L = C.CDLL(os.path.join(_HERE, name))
         L.emu_scene_create.restype = C.c_void_p
         L.emu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
         L.emu_scene_destroy.argtypes = [C.c_void_p]

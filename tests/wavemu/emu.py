@@ -1,0 +1,90 @@
+"""ctypes binding of tests/wavemu/libwavemu.so — TEST-ONLY: the product's wave-level path kernel (pbrt-v2_amd/csrc/hpt_kernels_impl.h, the source the
+GPU runs) on a CPU scheduler, 64 fibers per wave (tests/wavemu/wavemu_core.cpp)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+abi = importlib.import_module("pbrt-v2_amd.abi")
+_lib = None
+
+# kernel ids (wavemu_kernels.cpp): the instantiation of hpt_path_kernel a render runs
+K_FREE, K_LOCKSTEP, K_STEAL = 0, 3, 5                 # extension set, instances: configurations 0, 3, 5 / 6
+K_STEAL_TOP, K_STEAL_COUNT = 15, 25                   # ... from the top-level tree; the instrumented build
+K_DL, K_DL_TOP = 6, 16                                # ... direct lighting
+K_WIN, K_DL_WIN = 35, 36                              # ... the window samplers (halton, adaptive, bestcandidate)
+K_EARLY_EXIT = 41                                     # no instances: configuration 1 (early exit at 12 lanes)
+K_MEASURED_FREE, K_MEASURED_STEAL = 50, 55            # the measured set (cold lane state in LDS rows)
+K_BASIC_STEAL = 65
+K_LEAN_STEAL = 75
+K_EXT_STEAL_NOINST = 85
+KNOBS = ("regen_min", "retrace_min", "retrace_max", "leaf_q", "block_q", "bvh4_cap", "heads", "chunk", "shuffle")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        name = "libwavemu_san.so" if os.environ.get("HPT_WAVEMU_SAN") else "libwavemu.so"      # (the sanitizer build: scripts/wavemu_sanitize.sh)
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, name])
+        L = C.CDLL(os.path.join(_HERE, name))
+        L.emu_scene_create.restype = C.c_void_p
+        L.emu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
+        L.emu_scene_destroy.argtypes = [C.c_void_p]
+        L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
+        L.emu_set_filter.restype = None
+        L.emu_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
+        L.emu_set_camera_motion.restype = None
+        L.emu_set_sample_table.argtypes = [C.c_void_p]
+        L.emu_set_sample_table.restype = None
+        L.emu_set_two_pass.argtypes = [C.c_int]
+        L.emu_set_two_pass.restype = None
+        L.wavemu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+class WaveEmuError(RuntimeError):
+    pass
+
+
+class WaveScene:
+    def __init__(self, scene, max_leaf=4):
+        self.h = None
+        self.scene = scene
+        self.h = lib().emu_scene_create(C.byref(scene.desc), max_leaf)
+        if not self.h:
+            raise RuntimeError("emu_scene_create failed")
+
+    def render(self, cam, rd, kernel, grid=2, flt=None, two_pass=False, cam_motion=None, sample_table=None, **knobs):
+        """-> film (y, x, 4), info dict (work counters, rendezvous executed, LDS rows).  Raises WaveEmuError when the scheduler finds a cross-lane
+        operation that part of a wave did not reach, or a check of the debug build fails."""
+        L = lib()
+        L.emu_set_filter(C.byref(flt) if flt is not None else None)
+        L.emu_set_two_pass(1 if two_pass else 0)
+        tbl = np.ascontiguousarray(sample_table, dtype=np.float32) if sample_table is not None else None
+        L.emu_set_sample_table(tbl.ctypes.data if tbl is not None else None)
+        L.emu_set_camera_motion(C.byref(cam_motion) if cam_motion is not None else None)
+        kn = np.full(len(KNOBS), -1, dtype=np.int32)
+        kn[KNOBS.index("shuffle")] = 0
+        for k, v in knobs.items():
+            kn[KNOBS.index(k)] = v
+        film = np.zeros((rd.y_count, rd.x_count, 4), dtype=np.float32)
+        out = np.zeros(9, dtype=np.uint64)
+        err = C.create_string_buffer(600)
+        rc = L.wavemu_render(self.h, C.byref(cam), C.byref(rd), film.ctypes.data, out.ctypes.data, kernel, grid, kn.ctypes.data, err, 600)
+        if rc != 0:
+            raise WaveEmuError(err.value.decode())
+        info = {"samples": int(out[0]), "closest": int(out[1]), "shadow": int(out[2]), "nodes": int(out[3]), "tris": int(out[4]), "bad": int(out[5]),
+                "rendezvous": int(out[6]), "lds_rows": int(out[7]), "cap_normal": int(out[8])}
+        return film, info
+
+    def close(self):
+        if self.h:
+            lib().emu_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

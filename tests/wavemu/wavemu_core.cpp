@@ -1,0 +1,213 @@
+// tests/wavemu/wavemu_core.cpp — TEST-ONLY.  A SIMT scheduler for the product's wave-level kernel source on the CPU.
+//
+// Every lane of a wave64 is a fiber (ucontext) running hpt_path_kernel<...> — the SAME source the GPU runs
+// (pbrt-v2_amd/csrc/hpt_kernels_impl.h, compiled with g++ against tests/wavemu/shim/hip/hip_runtime.h).  A lane runs until it reaches a
+// cross-lane operation (__ballot, __shfl, readfirstlane, a wave barrier) and parks there; when all 64 lanes of the wave are parked the
+// scheduler checks that they are parked at the SAME operation (same kind, same source line — the kernel's protocol is that every such
+// operation is executed by the whole wave), forms the results and lets them go on.  What this gives, without a GPU:
+//   * the wave-level logic (regeneration, the lock-step phases, subtree stealing, the query queue, the queue heads) checked against the
+//     oracle's film — the per-lane emulation of tests/hostemu never executes it;
+//   * the debug build's checks (-DHPT_DEBUG_CHECKS: LDS rows, stack pointers, shuffle sources, indices) and AddressSanitizer /
+//     UndefinedBehaviorSanitizer over that logic (scripts/wavemu_sanitize.sh): LDS is a buffer of exactly the launch's size;
+//   * a proof by execution that no cross-lane operation sits under divergent control flow.
+// What it is not: lock step.  Between two rendezvous the lanes run one after the other, lane 0 first.  Cross-lane LDS traffic that the
+// GPU orders by executing instruction by instruction (a thief reading a donor's column while the donor — in the same instruction stream —
+// has not yet moved on) is ordered here by a rendezvous at the head of the walk's loop (wavemu_kernels.cpp, HPT_TS_SETLIM); lane order
+// inside a round can be shuffled (shuffle_seed) to show that nothing else depends on it.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <vector>
+
+#include "shim/hip/hip_runtime.h"
+#include "wavemu.h"
+
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#define WAVEMU_ASAN 1
+#endif
+
+wavemu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+namespace hpt { uint64_t dyn_lds[40 * 256 / 2 + 64]; }      // `extern __shared__ uint64_t dyn_lds[]` of the running workgroup (40 rows x 256 lanes x 4 B at most)
+
+namespace wavemu {
+
+static const size_t kStack = 1u << 20;
+// The context switch.  swapcontext saves and restores the signal mask — two system calls per switch, a third of the run time — so on x86-64 the
+// switch is the six callee-saved registers and the stack pointer (the fibers touch neither the signal mask nor the floating-point control words).
+#if defined(__x86_64__)
+#define WAVEMU_ASM_SWITCH 1
+extern "C" void wavemu_switch(void **save_sp, void *load_sp);
+asm(".text\n.globl wavemu_switch\n.type wavemu_switch,@function\nwavemu_switch:\n"
+    "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n    movq %rsi, %rsp\n"
+    "    popq %r15\n    popq %r14\n    popq %r13\n    popq %r12\n    popq %rbx\n    popq %rbp\n    ret\n"
+    ".size wavemu_switch, .-wavemu_switch\n");
+struct Ctx { void *sp = nullptr; };
+static inline void ctx_switch(Ctx &from, Ctx &to) { wavemu_switch(&from.sp, to.sp); }
+static void ctx_make(Ctx &c, char *stack, size_t size, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void **p = (void **)top;
+    *--p = nullptr;                 // (the entry never returns)
+    *--p = (void *)entry;           // popped by wavemu_switch's ret: the entry starts with the stack the ABI promises a callee
+    for (int i = 0; i < 6; ++i) *--p = nullptr;
+    c.sp = (void *)p;
+}
+#else
+struct Ctx { ucontext_t uc; };
+static inline void ctx_switch(Ctx &from, Ctx &to) { swapcontext(&from.uc, &to.uc); }
+static void ctx_make(Ctx &c, char *stack, size_t size, void (*entry)()) {
+    getcontext(&c.uc); c.uc.uc_stack.ss_sp = stack; c.uc.uc_stack.ss_size = size; c.uc.uc_link = nullptr; makecontext(&c.uc, entry, 0);
+}
+#endif
+struct LaneCtx {
+    Ctx ctx; char *stack = nullptr; bool done = false, started = false;
+    int kind = 0, site = 0, src = 0; uint32_t val = 0, res32 = 0; unsigned long long res64 = 0;
+    void *fake = nullptr;
+};
+struct WaveCtx { LaneCtx lane[64]; int block = 0, wib = 0; bool done = false; };
+
+static Ctx g_sched;
+static WaveCtx *g_wave = nullptr;
+static int g_lane = 0;
+static KernelFn g_fn = nullptr;
+static const hpt::PathKernelArgs *g_args = nullptr;
+static char g_error[512];
+static bool g_failed = false;
+static unsigned long long g_rendezvous = 0;
+#ifdef WAVEMU_ASAN
+static const void *g_sched_bottom = nullptr; static size_t g_sched_size = 0;
+#endif
+
+const char *error() { return g_error; }
+unsigned long long rendezvous_count() { return g_rendezvous; }
+static void fail(const char *fmt, ...) {
+    if (g_failed) return;
+    g_failed = true;
+    va_list ap; va_start(ap, fmt); vsnprintf(g_error, sizeof(g_error), fmt, ap); va_end(ap);
+}
+
+static void to_sched(LaneCtx &L, bool last) {
+#ifdef WAVEMU_ASAN
+    __sanitizer_start_switch_fiber(last ? nullptr : &L.fake, g_sched_bottom, g_sched_size);
+#endif
+    ctx_switch(L.ctx, g_sched);
+#ifdef WAVEMU_ASAN
+    __sanitizer_finish_switch_fiber(L.fake, nullptr, nullptr);
+#endif
+    (void)last;
+}
+static void fiber_main() {
+    LaneCtx &L = g_wave->lane[g_lane];
+#ifdef WAVEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);
+#endif
+    g_fn(g_args);
+    L.done = true;
+    to_sched(L, true);
+    abort();   // (a finished fiber is never resumed)
+}
+static void park(int kind, int site, uint32_t val, int src) {
+    LaneCtx &L = g_wave->lane[g_lane];
+    L.kind = kind; L.site = site; L.val = val; L.src = src;
+    to_sched(L, false);
+}
+unsigned long long ballot(int pred, int site) { park(OP_BALLOT, site, (uint32_t)pred, 0); return g_wave->lane[g_lane].res64; }
+uint32_t shfl32(uint32_t v, int src, int site) { park(OP_SHFL, site, v, src); return g_wave->lane[g_lane].res32; }
+uint32_t readfirstlane32(uint32_t v, int site) { park(OP_FIRST, site, v, 0); return g_wave->lane[g_lane].res32; }
+void barrier(int kind, int site) { park(kind, site, 0, 0); }
+// HPT_CHECK of the debug build (its message is already on stderr): the frame fails, the lane never runs on
+[[noreturn]] void check_failed() {
+    fail("a check of the debug build failed in workgroup %u, thread %u (the failed condition is on stderr)", blockIdx.x, threadIdx.x);
+    for (;;) park(OP_SYNC, -1, 0, 0);
+}
+
+static void resume(WaveCtx &w, int l) {
+    LaneCtx &L = w.lane[l];
+    g_wave = &w; g_lane = l;
+    threadIdx.x = (unsigned)(w.wib * 64 + l); blockIdx.x = (unsigned)w.block;
+    if (!L.started) {
+        L.started = true;
+        L.stack = (char *)malloc(kStack);
+        ctx_make(L.ctx, L.stack, kStack, fiber_main);
+    }
+#ifdef WAVEMU_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, L.stack, kStack);
+#endif
+    ctx_switch(g_sched, L.ctx);
+#ifdef WAVEMU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+}
+
+// One round of a wave: every live lane up to its next cross-lane operation, then the operation.
+static void step_wave(WaveCtx &w, uint32_t *rng) {
+    int order[64];
+    for (int i = 0; i < 64; ++i) order[i] = i;
+    if (rng) for (int i = 63; i > 0; --i) { *rng = *rng * 1664525u + 1013904223u; const int j = (int)((*rng >> 8) % (uint32_t)(i + 1)); const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < 64; ++i) if (!w.lane[order[i]].done) resume(w, order[i]);
+    int live = 0, first = -1;
+    for (int l = 0; l < 64; ++l) if (!w.lane[l].done) { ++live; if (first < 0) first = l; }
+    if (live == 0) { w.done = true; for (int l = 0; l < 64; ++l) { free(w.lane[l].stack); w.lane[l].stack = nullptr; } return; }
+    if (live != 64) { fail("workgroup %d wave %d: %d lanes left the kernel while %d wait at a cross-lane operation (kind %d, line %d)", w.block, w.wib, 64 - live, live, w.lane[first].kind, w.lane[first].site); return; }
+    ++g_rendezvous;
+    const int kind = w.lane[first].kind, site = w.lane[first].site;
+    for (int l = 0; l < 64; ++l)
+        if (w.lane[l].kind != kind || w.lane[l].site != site) {
+            fail("workgroup %d wave %d: divergent cross-lane operation — lane %d is at kind %d line %d, lane %d at kind %d line %d", w.block, w.wib, first, kind, site, l, w.lane[l].kind, w.lane[l].site);
+            return;
+        }
+    if (kind == OP_BALLOT) {
+        unsigned long long m = 0ull;
+        for (int l = 0; l < 64; ++l) if (w.lane[l].val) m |= 1ull << l;
+        for (int l = 0; l < 64; ++l) w.lane[l].res64 = m;
+    } else if (kind == OP_SHFL) {
+        for (int l = 0; l < 64; ++l) {
+            const int s = w.lane[l].src;
+            if (s < 0 || s > 63) { fail("workgroup %d wave %d lane %d: shuffle from lane %d (line %d)", w.block, w.wib, l, s, site); return; }
+            w.lane[l].res32 = w.lane[s].val;
+        }
+    } else if (kind == OP_FIRST) {
+        for (int l = 0; l < 64; ++l) w.lane[l].res32 = w.lane[0].val;
+    }
+}
+
+int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes, int shuffle_seed) {
+    g_fn = fn; g_args = args; g_failed = false; g_error[0] = 0; g_rendezvous = 0;
+    blockDim.x = 256; blockDim.y = blockDim.z = 1; gridDim.x = (unsigned)grid; gridDim.y = gridDim.z = 1;
+    threadIdx.y = threadIdx.z = blockIdx.y = blockIdx.z = 0;
+    const size_t lds_cap = sizeof(hpt::dyn_lds);
+    if (lds_bytes > lds_cap - 512) { fail("dynamic LDS of %zu bytes exceeds a workgroup's 40 rows", lds_bytes); return -1; }
+    std::vector<WaveCtx *> waves;
+    for (int b = 0; b < grid; ++b) for (int k = 0; k < 4; ++k) { WaveCtx *w = new WaveCtx(); w->block = b; w->wib = k; waves.push_back(w); }
+    std::vector<std::vector<char>> lds((size_t)grid, std::vector<char>(lds_bytes, 0));
+    uint32_t rng = (uint32_t)shuffle_seed * 2654435761u + 12345u;
+#ifdef WAVEMU_ASAN
+    ASAN_POISON_MEMORY_REGION((char *)hpt::dyn_lds + lds_bytes, lds_cap - lds_bytes);
+#endif
+    bool any = true;
+    while (any && !g_failed) {
+        any = false;
+        for (int b = 0; b < grid && !g_failed; ++b) {
+            bool live = false;
+            for (int k = 0; k < 4; ++k) live = live || !waves[(size_t)b * 4 + k]->done;
+            if (!live) continue;
+            any = true;
+            memcpy(hpt::dyn_lds, lds[(size_t)b].data(), lds_bytes);       // this workgroup's LDS in, ...
+            for (int k = 0; k < 4 && !g_failed; ++k) { WaveCtx &w = *waves[(size_t)b * 4 + k]; if (!w.done) step_wave(w, shuffle_seed ? &rng : nullptr); }
+            memcpy(lds[(size_t)b].data(), hpt::dyn_lds, lds_bytes);       // ... and out again
+        }
+    }
+#ifdef WAVEMU_ASAN
+    ASAN_UNPOISON_MEMORY_REGION((char *)hpt::dyn_lds + lds_bytes, lds_cap - lds_bytes);
+#endif
+    for (WaveCtx *w : waves) { for (int l = 0; l < 64; ++l) free(w->lane[l].stack); delete w; }   // (after a failure the parked fibers are simply dropped)
+    return g_failed ? -1 : 0;
+}
+
+} // namespace wavemu
