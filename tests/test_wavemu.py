@@ -110,6 +110,29 @@ def test_scheduling_knobs_do_not_change_the_film(knobs):
         assert info["cap_normal"] == knobs["bvh4_cap"]
 
 
+@pytest.mark.parametrize("name,kernel", [("aquad", w.K_STEAL), ("aquad", w.K_STEAL_TOP), ("anim", w.K_FREE), ("b8", w.K_MEASURED_STEAL), ("cfg1", w.K_EARLY_EXIT), ("abi8dl", w.K_DL), ("hk", w.K_WIN)])
+def test_uninitialised_lane_state_does_not_reach_the_film(name, kernel):
+    """The production kernels do not initialise their lane state (a measured 6 % on the headline kernel, profiles/r05_ab.md run L): the state machine writes a field
+    before it reads it, the wave-level code passes idle lanes' fields along without branching on them.  libwavemu_raw.so is the kernel source WITHOUT the debug
+    build's initialisation, compiled at -O0 — every local lives in its fiber's stack — and the scheduler fills the stacks and the LDS with a byte of our choice
+    before the launch: whatever a never-written local reads as (0, -1 / NaN, 0x55555555, 0x7f7f7f7f = 3.4e38), the film is the same, bit for bit, and the oracle's."""
+    s, o, _ = pair(name)
+    if ("raw", name) not in _scenes:
+        _scenes[("raw", name)] = w.WaveScene(s, raw=True)
+    e = _scenes[("raw", name)]
+    rd = abi.copy_struct(s.render)
+    if abi.sampler_kind(rd.sampler_mode) == abi.HPT_SAMPLER_HALTON_HASH:
+        rd = crop(rd, 32, align=32)
+    else:
+        rd = crop(hash_rd(s, seed=3) if rd.integrator == abi.HPT_INTEGRATOR_PATH else rd, 16)
+    rd.seed = 3
+    fo, so = o.render(s.camera, rd)
+    films = [e.render(s.camera, rd, kernel, fill=fill) for fill in (0x00, 0xff, 0x55, 0x7f)]
+    for f, info in films:
+        assert np.array_equal(f, films[0][0])
+        check(f, fo, info, so)
+
+
 def test_one_sample_work_items_sum_through_atomics_to_the_same_film():
     """large jobs: one sample per work item, every sample adds itself to its pixel (film_atomic_add) — same samples, sums in another order"""
     s, o, e = pair("b8")

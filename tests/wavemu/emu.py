@@ -21,29 +21,50 @@ K_MEASURED_FREE, K_MEASURED_STEAL = 50, 55            # the measured set (cold l
 K_BASIC_STEAL = 65
 K_LEAN_STEAL = 75
 K_EXT_STEAL_NOINST = 85
-KNOBS = ("regen_min", "retrace_min", "retrace_max", "leaf_q", "block_q", "bvh4_cap", "heads", "chunk", "shuffle")
+KNOBS = ("regen_min", "retrace_min", "retrace_max", "leaf_q", "block_q", "bvh4_cap", "heads", "chunk", "shuffle", "fill")
 
 
 def lib():
     global _lib
     if _lib is None:
-        name = "libwavemu_san.so" if os.environ.get("HPT_WAVEMU_SAN") else "libwavemu.so"      # (the sanitizer build: scripts/wavemu_sanitize.sh)
-        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, name])
-        L = C.CDLL(os.path.join(_HERE, name))
-        L.emu_scene_create.restype = C.c_void_p
-        L.emu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
-        L.emu_scene_destroy.argtypes = [C.c_void_p]
-        L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
-        L.emu_set_filter.restype = None
-        L.emu_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
-        L.emu_set_camera_motion.restype = None
-        L.emu_set_sample_table.argtypes = [C.c_void_p]
-        L.emu_set_sample_table.restype = None
-        L.emu_set_two_pass.argtypes = [C.c_int]
-        L.emu_set_two_pass.restype = None
-        L.wavemu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        L = _load("libwavemu_san.so" if os.environ.get("HPT_WAVEMU_SAN") else "libwavemu.so")      # (the sanitizer build: scripts/wavemu_sanitize.sh)
+        _bind(L)
         _lib = L
     return _lib
+
+
+def _bind(L):
+    L.emu_scene_create.restype = C.c_void_p
+    L.emu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
+    L.emu_scene_destroy.argtypes = [C.c_void_p]
+    L.emu_set_filter.argtypes = [C.POINTER(abi.Filter)]
+    L.emu_set_filter.restype = None
+    L.emu_set_camera_motion.argtypes = [C.POINTER(abi.Instance)]
+    L.emu_set_camera_motion.restype = None
+    L.emu_set_sample_table.argtypes = [C.c_void_p]
+    L.emu_set_sample_table.restype = None
+    L.emu_set_two_pass.argtypes = [C.c_int]
+    L.emu_set_two_pass.restype = None
+    L.wavemu_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    return L
+
+
+def _load(name):
+    subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, name])
+    L = C.CDLL(os.path.join(_HERE, name))
+    L.emu_scene_create.restype = C.c_void_p
+    return L
+
+
+_raw = None
+
+
+def raw_lib():
+    """libwavemu_raw.so: the kernels WITHOUT the debug build's initialisation of lane state (as production compiles them), at -O0"""
+    global _raw
+    if _raw is None:
+        _raw = _bind(_load("libwavemu_raw.so"))
+    return _raw
 
 
 class WaveEmuError(RuntimeError):
@@ -51,17 +72,18 @@ class WaveEmuError(RuntimeError):
 
 
 class WaveScene:
-    def __init__(self, scene, max_leaf=4):
+    def __init__(self, scene, max_leaf=4, raw=False):
         self.h = None
         self.scene = scene
-        self.h = lib().emu_scene_create(C.byref(scene.desc), max_leaf)
+        self.L = raw_lib() if raw else lib()
+        self.h = self.L.emu_scene_create(C.byref(scene.desc), max_leaf)
         if not self.h:
             raise RuntimeError("emu_scene_create failed")
 
     def render(self, cam, rd, kernel, grid=2, flt=None, two_pass=False, cam_motion=None, sample_table=None, **knobs):
         """-> film (y, x, 4), info dict (work counters, rendezvous executed, LDS rows).  Raises WaveEmuError when the scheduler finds a cross-lane
         operation that part of a wave did not reach, or a check of the debug build fails."""
-        L = lib()
+        L = self.L
         L.emu_set_filter(C.byref(flt) if flt is not None else None)
         L.emu_set_two_pass(1 if two_pass else 0)
         tbl = np.ascontiguousarray(sample_table, dtype=np.float32) if sample_table is not None else None
@@ -83,7 +105,7 @@ class WaveScene:
 
     def close(self):
         if self.h:
-            lib().emu_scene_destroy(self.h)
+            self.L.emu_scene_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -17,7 +17,7 @@ static KernelInfo find_kernel(int id) {
 }
 
 // knobs (PathKernelArgs fields hpt_api.hip reads from the environment; < 0: its default): 0 regen_min, 1 retrace_min, 2 retrace_max, 3 leaf_q, 4 block_q,
-// 5 rows for ordinary BVH4 entries (HPT_BVH4_CAP), 6 queue heads (1 / 8), 7 samples per work item, 8 lane-order shuffle seed (0: lane 0 first)
+// 5 rows for ordinary BVH4 entries (HPT_BVH4_CAP), 6 queue heads (1 / 8), 7 samples per work item, 8 lane-order shuffle seed (0: lane 0 first), 9 the byte fiber stacks and LDS are filled with before the launch
 // out (uint64): 0-5 the work counters (samples, closest, shadow, nodes, tris, bad), 6 rendezvous executed, 7 LDS rows per lane, 8 rows for ordinary entries
 extern "C" int wavemu_render(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, uint64_t *out, int kernel_id, int grid, const int32_t *knobs,
                              char *err, int err_len) {
@@ -95,7 +95,7 @@ extern "C" int wavemu_render(const emu_scene *s, const hpt_camera *cam, const hp
     if (a.rp.adapt_min > 0) { adapt_buf.assign((size_t)3 * a.rp.adapt_min * lanes, 0.f); a.adapt_buf = adapt_buf.data(); }
     size_t lds_bytes = path_kernel_dyn_lds(a);
     if (const char *t = getenv("WAVEMU_TEST_LDS_SHORT")) lds_bytes -= (size_t)atoi(t) * HPT_BLOCK * 4;      // (scripts/wavemu_sanitize.sh: a launch with fewer LDS rows than the kernel uses — the sanitizer must report it)
-    if (a.rp.n_items > 0 && wavemu::run(k.fn, &a, grid, lds_bytes, knobs[8]) != 0) return bail(wavemu::error());
+    if (a.rp.n_items > 0 && wavemu::run(k.fn, &a, grid, lds_bytes, knobs[8], knobs[9] > 0 ? knobs[9] : 0) != 0) return bail(wavemu::error());
     if (a.rp.sbuf_xyzw) gather_film(a.rp, film);
     if (out) {
         out[0] = wc.samples; out[1] = wc.closest; out[2] = wc.shadow; out[3] = wc.nodes; out[4] = wc.tris; out[5] = wc.bad;

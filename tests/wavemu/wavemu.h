@@ -14,7 +14,7 @@ KernelInfo kernel_part4(int id); KernelInfo kernel_part5(int id);
 // Runs `grid` workgroups of 256 lanes of `fn` to completion: the four waves of every workgroup round-robin, one rendezvous at a time.
 // lds_bytes: the launch's dynamic LDS (accesses beyond it are reported by AddressSanitizer builds).  Returns 0, or -1 with error() set
 // (a cross-lane operation reached by part of a wave, lanes at different operations, a shuffle from a lane that is not there).
-int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes, int shuffle_seed);
+int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes, int shuffle_seed, int stack_fill);   // stack_fill: the byte every fiber's stack is filled with before it starts
 const char *error();
 unsigned long long rendezvous_count();
 }

@@ -36,7 +36,7 @@ namespace hpt { uint64_t dyn_lds[40 * 256 / 2 + 64]; }      // `extern __shared_
 
 namespace wavemu {
 
-static const size_t kStack = 1u << 20;
+static const size_t kStack = 128u << 10;     // (the kernels go 6 KB deep at -O0, WAVEMU_STACK_REPORT=1; an overflow is a heap-buffer-overflow in the sanitizer build)
 // The context switch.  swapcontext saves and restores the signal mask — two system calls per switch, a third of the run time — so on x86-64 the
 // switch is the six callee-saved registers and the stack pointer (the fibers touch neither the signal mask nor the floating-point control words).
 #if defined(__x86_64__)
@@ -79,6 +79,8 @@ static const hpt::PathKernelArgs *g_args = nullptr;
 static char g_error[512];
 static bool g_failed = false;
 static unsigned long long g_rendezvous = 0;
+static int g_fill = 0;
+static size_t g_deepest = 0;
 #ifdef WAVEMU_ASAN
 static const void *g_sched_bottom = nullptr; static size_t g_sched_size = 0;
 #endif
@@ -133,6 +135,7 @@ static void resume(WaveCtx &w, int l) {
     if (!L.started) {
         L.started = true;
         L.stack = (char *)malloc(kStack);
+        memset(L.stack, g_fill, kStack);      // what a local that is never written reads as (libwavemu_raw.so: -O0, every local in memory)
         ctx_make(L.ctx, L.stack, kStack, fiber_main);
     }
 #ifdef WAVEMU_ASAN
@@ -153,7 +156,17 @@ static void step_wave(WaveCtx &w, uint32_t *rng) {
     for (int i = 0; i < 64; ++i) if (!w.lane[order[i]].done) resume(w, order[i]);
     int live = 0, first = -1;
     for (int l = 0; l < 64; ++l) if (!w.lane[l].done) { ++live; if (first < 0) first = l; }
-    if (live == 0) { w.done = true; for (int l = 0; l < 64; ++l) { free(w.lane[l].stack); w.lane[l].stack = nullptr; } return; }
+    if (live == 0) {
+        w.done = true;
+        for (int l = 0; l < 64; ++l) {
+            if (getenv("WAVEMU_STACK_REPORT") && w.lane[l].stack) {      // (how deep did the fiber go: the first byte from the bottom that is not the fill)
+                size_t i = 0; while (i < kStack && (unsigned char)w.lane[l].stack[i] == (unsigned char)g_fill) ++i;
+                if (kStack - i > g_deepest) g_deepest = kStack - i;
+            }
+            free(w.lane[l].stack); w.lane[l].stack = nullptr;
+        }
+        return;
+    }
     if (live != 64) { fail("workgroup %d wave %d: %d lanes left the kernel while %d wait at a cross-lane operation (kind %d, line %d)", w.block, w.wib, 64 - live, live, w.lane[first].kind, w.lane[first].site); return; }
     ++g_rendezvous;
     const int kind = w.lane[first].kind, site = w.lane[first].site;
@@ -177,7 +190,8 @@ static void step_wave(WaveCtx &w, uint32_t *rng) {
     }
 }
 
-int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes, int shuffle_seed) {
+int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes, int shuffle_seed, int stack_fill) {
+    g_fill = stack_fill & 255;
     g_fn = fn; g_args = args; g_failed = false; g_error[0] = 0; g_rendezvous = 0;
     blockDim.x = 256; blockDim.y = blockDim.z = 1; gridDim.x = (unsigned)grid; gridDim.y = gridDim.z = 1;
     threadIdx.y = threadIdx.z = blockIdx.y = blockIdx.z = 0;
@@ -185,7 +199,7 @@ int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes
     if (lds_bytes > lds_cap - 512) { fail("dynamic LDS of %zu bytes exceeds a workgroup's 40 rows", lds_bytes); return -1; }
     std::vector<WaveCtx *> waves;
     for (int b = 0; b < grid; ++b) for (int k = 0; k < 4; ++k) { WaveCtx *w = new WaveCtx(); w->block = b; w->wib = k; waves.push_back(w); }
-    std::vector<std::vector<char>> lds((size_t)grid, std::vector<char>(lds_bytes, 0));
+    std::vector<std::vector<char>> lds((size_t)grid, std::vector<char>(lds_bytes, (char)g_fill));   // (LDS is not initialised on the GPU either)
     uint32_t rng = (uint32_t)shuffle_seed * 2654435761u + 12345u;
 #ifdef WAVEMU_ASAN
     ASAN_POISON_MEMORY_REGION((char *)hpt::dyn_lds + lds_bytes, lds_cap - lds_bytes);
@@ -207,6 +221,7 @@ int run(KernelFn fn, const hpt::PathKernelArgs *args, int grid, size_t lds_bytes
     ASAN_UNPOISON_MEMORY_REGION((char *)hpt::dyn_lds + lds_bytes, lds_cap - lds_bytes);
 #endif
     for (WaveCtx *w : waves) { for (int l = 0; l < 64; ++l) free(w->lane[l].stack); delete w; }   // (after a failure the parked fibers are simply dropped)
+    if (getenv("WAVEMU_STACK_REPORT")) fprintf(stderr, "wavemu: deepest fiber stack %zu bytes of %zu\n", g_deepest, kStack);
     return g_failed ? -1 : 0;
 }
 

@@ -1,6 +1,7 @@
 // tests/wavemu/wavemu_kernels.cpp — TEST-ONLY.  The product's path kernel template (pbrt-v2_amd/csrc/hpt_kernels_impl.h, unmodified) instantiated
 // for the CPU scheduler of wavemu_core.cpp.  Compiled once per part (-DWAVEMU_PART=n: a handful of instantiations each, so that the parts build in
-// parallel), always with -DHPT_DEBUG_CHECKS: every check of the GPU's `make debug` build is armed here too.
+// parallel), with -DHPT_DEBUG_CHECKS: every check of the GPU's `make debug` build is armed here too (libwavemu_raw.so: without — the lane state NOT
+// initialised, as in production — and at -O0, so that every local lives in the fiber's stack, which the scheduler pre-fills with a chosen byte).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -13,7 +14,7 @@ namespace wavemu { [[noreturn]] void check_failed(); }
 #include "../../pbrt-v2_amd/csrc/hpt_kernels.h"
 #undef abort
 
-namespace hpt { static unsigned *hpt_dbg_ptr; static int hpt_dbg_n_nodes4; }       // (the kernel's entry stores PathKernelArgs::dbg / DScene::n_nodes4 here in a debug build)
+namespace hpt { static unsigned *hpt_dbg_ptr __attribute__((unused)); static int hpt_dbg_n_nodes4 __attribute__((unused)); }       // (the kernel's entry stores PathKernelArgs::dbg / DScene::n_nodes4 here in a debug build)
 
 // Every lane of the wave must be at a wave-level operation: on the GPU the debug build asks __ballot(true); here the scheduler checks that all 64
 // lanes are parked at the same line anyway — the ballot is kept so that the sites are rendezvous of their own.
@@ -23,7 +24,11 @@ namespace hpt { static unsigned *hpt_dbg_ptr; static int hpt_dbg_n_nodes4; }    
 // where it may pop the marker under which its saved world ray lies — while a thief of this iteration still reads that ray out of its column.
 // The GPU orders the two by executing the wave's instructions one at a time.
 #undef HPT_TS_SETLIM
+#ifdef HPT_DEBUG_CHECKS
 #define HPT_TS_SETLIM(ts, n) ((ts).lim = (n), wavemu::barrier(wavemu::OP_SYNC, __LINE__))
+#else
+#define HPT_TS_SETLIM(ts, n) wavemu::barrier(wavemu::OP_SYNC, __LINE__)
+#endif
 
 #include "../../pbrt-v2_amd/csrc/hpt_kernels_impl.h"
 
