@@ -33,6 +33,21 @@ SCALAR_DEST_VALU = ("v_readlane_b32", "v_readfirstlane_b32", "v_cmp", "v_writela
 STOP = ("s_cbranch", "s_branch", "s_setpc", "s_swappc", "s_endpgm", "s_barrier")
 
 
+# The one site of this shape in the build that ships (profiles/r05_isaemu_root_cause.md §4: executed in the interpreter on the environment-map fixtures, never with a
+# lane left to come back; moving it below the restore changes no film).  Listed so that every OTHER site fails the gate; a rebuild of the unit should make it go away.
+KNOWN_SITES = {("hpt_kernels_basic.o", "_ZN3hpt15hpt_path_kernelILb0ELb0ELi1ELi4ELi0ELb0ELb0ELb0ELb0ELb0EEEvNS_14PathKernelArgsE", "v_mov_b64_e32 v[118:119], v[110:111]")}
+
+
+def new_sites(paths=None):
+    """the definitions above an EXEC restore in the build's kernel units that are not in KNOWN_SITES -> set of (unit, kernel, instruction)"""
+    paths = paths or sorted(glob.glob(os.path.join(ROOT, "pbrt-v2_amd", "build", "hpt_kernels*.o")))
+    sites = set()
+    for p in paths:
+        nf, ni, found = scan(disassembly_of(p))
+        sites |= {(os.path.basename(p), f[0], f[3]) for f in found if f[-1].startswith("DEFINES")}
+    return sites - KNOWN_SITES
+
+
 def disassembly_of(path, tmp="/tmp/check_exec_restore"):
     if path.endswith(".s"):
         return open(path)
