@@ -430,6 +430,7 @@ template <class LANE> __device__ __forceinline__ void lane_cmp(const LANE &l, co
 // of their own so that the default sampler's kernels stay instruction for instruction what they were (LdHashSrcT, hpt_path.h)
 // TOP (lock step + stealing with animated instances): the walk starts at the top-level tree (traverse_steal; PathKernelArgs::top: scenes of more than
 // HPT_TOP_MIN_INSTANCES instances)
+#define HPT_CODEGEN_NUDGE(COUNT, INST, MATS, WAVES, EE, PHASED, DL, STEAL, WIN, TOP) (!(COUNT) && !(INST) && (MATS) == MATS_PLASTIC && (WAVES) == 4 && (EE) == 0 && !(PHASED) && !(DL))
 template <bool COUNT, bool INST, int MATS, int WAVES, int EE, bool PHASED, bool DL, bool STEAL = false, bool WIN = false, bool TOP = false>
 __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKernelArgs a) {
     extern __shared__ uint64_t dyn_lds[];      // traversal stacks — sized per scene (path_kernel_dyn_lds)
@@ -507,6 +508,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     unsigned n_flushed = 0u;
     for (;;) {
         HPT_CHECK_FULL_EXEC(4);
+        // Round 5, profiles/r05_isaemu_root_cause.md: in ONE instantiation of the shipped build — the free-running configuration 0 of the basic set — clang 22's greedy allocator
+        // placed a live-range copy above the EXEC restore of a reconvergence block (scripts/check_exec_restore.py; the shape of the miscompile behind round 5's wrong films).  An
+        // empty barrier here, compiled into that instantiation only, moves its allocation off the shape; every other kernel of every unit is instruction for instruction what it
+        // was (compared function by function against the validated build), and the new binary of this one renders the oracle's films in tests/isaemu.
+        if constexpr (HPT_CODEGEN_NUDGE(COUNT, INST, MATS, WAVES, EE, PHASED, DL, STEAL, WIN, TOP)) asm volatile("" ::: "memory");
         // ---- camera samples completed in the last round: to the film, next sample (the one place finish_path is compiled in) ----
         // Batched (round 4, regen_min): finish_path + the refill + the first camera ray are ~1.5 k instructions that used to run in every round
         // with the handful of lanes that had just ended a path (and, with animated instances, two AnimatedTransform interpolations behind

@@ -33,9 +33,9 @@ SCALAR_DEST_VALU = ("v_readlane_b32", "v_readfirstlane_b32", "v_cmp", "v_writela
 STOP = ("s_cbranch", "s_branch", "s_setpc", "s_swappc", "s_endpgm", "s_barrier")
 
 
-# The one site of this shape in the build that ships (profiles/r05_isaemu_root_cause.md §4: executed in the interpreter on the environment-map fixtures, never with a
-# lane left to come back; moving it below the restore changes no film).  Listed so that every OTHER site fails the gate; a rebuild of the unit should make it go away.
-KNOWN_SITES = {("hpt_kernels_basic.o", "_ZN3hpt15hpt_path_kernelILb0ELb0ELi1ELi4ELi0ELb0ELb0ELb0ELb0ELb0EEEvNS_14PathKernelArgsE", "v_mov_b64_e32 v[118:119], v[110:111]")}
+# Sites of this shape the build is known to ship with: none.  (Round 5 found one — `v_mov_b64 v[118:119], v[110:111]` in the free-running configuration 0 of the basic set — and
+# removed it with a barrier compiled into that instantiation only, hpt_kernels_impl.h HPT_CODEGEN_NUDGE: profiles/r05_isaemu_root_cause.md §4.)
+KNOWN_SITES = set()
 
 
 def new_sites(paths=None):

@@ -96,6 +96,7 @@ def test_interpreter_agrees_with_the_host_on_a_battery_of_device_functions(tmp_p
 @needs_build
 @pytest.mark.parametrize("unit,symbol,kid,case,n", [
     ("basic", R.kernel_symbol(False, False, 1, 4, 0, True, False, True), w.K_BASIC_STEAL, "cfg1", 8),       # killeroo's kernel (configuration 5)
+    ("basic", R.kernel_symbol(False, False, 1, 4, 0, False, False, False), w.K_FREE, "envmap", 12),        # the one kernel round 5 rebuilt (configuration 0), on the code the site was in
     ("ext_i", CFG6_INST_EXT, w.K_STEAL, "aquad", 8),                                                        # the instantiation that was wrong in round 5's builds
 ])
 def test_shipped_kernel_binaries_render_the_oracles_film_in_the_interpreter(unit, symbol, kid, case, n):
@@ -140,7 +141,8 @@ def test_the_gate_finds_the_misplaced_copy_in_the_failing_build():
     assert [(f[2], f[3]) for f in defects] == [(0x92B9D0, "v_mov_b64_e32 v[150:151], v[10:11]")], found
 
 
-# (one site of this shape exists in the build that ships — scripts/check_exec_restore.py, KNOWN_SITES, profiles/r05_isaemu_root_cause.md §4: the gate fails on any OTHER)
+# (the build that round 4's GPU runs validated had ONE site of this shape, in the free-running configuration 0 of the basic set; a barrier compiled into that instantiation only
+#  — hpt_kernels_impl.h, HPT_CODEGEN_NUDGE — removed it, every other kernel of the build stayed instruction for instruction the same: profiles/r05_isaemu_root_cause.md §4)
 @needs_build
 def test_no_shipped_kernel_defines_a_vector_register_above_an_exec_restore():
     objs = sorted(glob.glob(os.path.join(BUILD, "hpt_kernels*.o")))
