@@ -122,6 +122,28 @@ def check_function(name, insns):
                 break                                 # (another region starts, or the saved mask is redefined: not the simple shape)
             if writes_vgpr(t1):
                 pending.append((a1, t1))
+    # The same hazard at an `else`: the block that a skipped `then` lands in begins with the s_or_saveexec_b64 / s_andn2_saveexec_b64 that flips EXEC to the other lanes — a vector
+    # register defined above it is defined for the wrong half of the wave.  (No build of rounds 4 / 5 has one; the shape is checked because it is the same mistake.)
+    targets = set()
+    for addr, text in insns:
+        if text.startswith(("s_cbranch_execz", "s_cbranch_execnz")):
+            off = int(text.split()[-1])
+            if off < 32768:
+                targets.add(addr + 4 + 4 * off)
+    for label in sorted(targets):
+        j = pos.get(label)
+        if j is None:
+            continue
+        pending = []
+        for a1, t1 in insns[j:j + 12]:
+            op = t1.split(None, 1)[0]
+            if re.match(r"^s_(or|andn2|xor)_saveexec_b64 ", t1):
+                found += [(label, a2, t2, a1, t1, "DEFINES a register above the EXEC flip of an else") for a2, t2 in pending]
+                break
+            if op.startswith(STOP) or EXEC_RESTORE.match(t1):
+                break
+            if re.match(r"^(v_mov_b32_e32 v\d+, v\d+|v_mov_b64_e32 v\[|v_pk_mov_b32 |scratch_load_)", t1):     # (the allocator's products: copies and reloads — ordinary arithmetic is scheduled there legitimately)
+                pending.append((a1, t1))
     return found
 
 

@@ -69,6 +69,11 @@ def parse_operand(t):
         if t.startswith("|") and t.endswith("|"):
             ab, t = True, t[1:-1]
         m = re.match(r"^(neg|abs|sext)\((.*)\)$", t)
+    m = re.match(r"^gpr_idx\((.*)\)$", t)
+    if m:                                          # s_set_gpr_idx_on: which operands of the following VALU instructions are indexed
+        o = Op("gpridx")
+        o.fval = set(x.strip() for x in m.group(1).split(",") if x.strip())
+        return o
     m = re.match(r"^([vsa])(\d+)$", t)
     if m:
         o = Op(m.group(1), int(m.group(2)), 1)
@@ -108,7 +113,7 @@ def parse_insn(addr, size, text):
     ins.op = parts[0]
     rest = " " + parts[1] if len(parts) > 1 else ""
     if ins.op in ("s_waitcnt", "s_nop", "s_sleep", "s_setprio", "s_endpgm", "s_barrier", "s_waitcnt_depctr", "s_sethalt", "s_trap", "s_setreg_imm32_b32", "s_setreg_b32", "s_icache_inv", "s_dcache_wb",
-                  "buffer_wbl2", "buffer_inv", "s_ttracedata", "s_code_end", "s_waitcnt_vscnt"):
+                  "buffer_wbl2", "buffer_inv", "s_ttracedata", "s_code_end", "s_waitcnt_vscnt", "s_set_gpr_idx_off"):
         ins.ops = []
         return ins
 
@@ -292,6 +297,7 @@ class Wave:
         self.done = False
         self.count = 0
         self.trace = trace
+        self.gpr_idx_on, self.gpr_idx, self.gpr_idx_mode = False, 0, set()     # s_set_gpr_idx_on: relative VGPR indexing of the VALU instructions that follow
         self.pre = None          # (debugging: called with (wave, instruction) BEFORE the instruction executes)
         # initial state (AMDHSA, gfx9 family with architected flat scratch): user SGPRs in descriptor order, then the workgroup ids; v0 = packed work-item id
         i = 0
@@ -453,7 +459,10 @@ class Wave:
                 if self.pre is not None:
                     self.pre(self, ins)
                 try:
-                    ins.fn(self, ins)
+                    if self.gpr_idx_on and ins.op.startswith("v_"):
+                        self.exec_indexed(ins)
+                    else:
+                        ins.fn(self, ins)
                 except EmuError as e:
                     raise EmuError("%s\n  at 0x%x: %s" % (e, ins.addr, ins.text)) from None
                 except Exception as e:
@@ -465,6 +474,20 @@ class Wave:
                     break
         self.count += n
         return n
+
+    def exec_indexed(self, ins):
+        """a VALU instruction under s_set_gpr_idx_on: the compiler only ever brackets v_mov_b32 (dynamic indexing of an array kept in registers)"""
+        if ins.op != "v_mov_b32_e32" or ins.ops[0].kind != "v":
+            raise EmuError("VGPR index mode around something else than v_mov_b32")
+        d = ins.ops[0].idx + (self.gpr_idx if "DST" in self.gpr_idx_mode else 0)
+        o = ins.ops[1]
+        if o.kind == "v":
+            src = self.V[o.idx + (self.gpr_idx if "SRC0" in self.gpr_idx_mode else 0)]
+        else:
+            src = U32(self.s32(o))
+        if not 0 <= d < 512:
+            raise EmuError("indexed VGPR write outside the register file")
+        np.copyto(self.V[d], src, where=self.em)
 
     def jump(self, addr):
         i = self.index.get(addr)
@@ -640,6 +663,14 @@ def bind_scalar(ins):
     if op in ("s_bitcmp0_b32", "s_bitcmp1_b32"):
         want = 1 if op == "s_bitcmp1_b32" else 0
         return lambda w, i: setattr(w, "scc", int(((w.s32(ops[0]) >> (w.s32(ops[1]) & 31)) & 1) == want))
+    if op == "s_set_gpr_idx_on":
+        def fon(w, i):
+            w.gpr_idx_on, w.gpr_idx, w.gpr_idx_mode = True, w.s32(ops[0]) & 0xff, ops[1].fval
+        return fon
+    if op == "s_set_gpr_idx_off":
+        return lambda w, i: setattr(w, "gpr_idx_on", False)
+    if op == "s_set_gpr_idx_idx":
+        return lambda w, i: setattr(w, "gpr_idx", w.s32(ops[0]) & 0xff)
     if op == "s_getpc_b64":
         return lambda w, i: w.ws64(ops[0], i.addr + 4)
     if op == "s_setpc_b64":
