@@ -98,6 +98,9 @@ def test_interpreter_agrees_with_the_host_on_a_battery_of_device_functions(tmp_p
     ("basic", R.kernel_symbol(False, False, 1, 4, 0, True, False, True), w.K_BASIC_STEAL, "cfg1", 8),       # killeroo's kernel (configuration 5)
     ("basic", R.kernel_symbol(False, False, 1, 4, 0, False, False, False), w.K_FREE, "envmap", 12),        # the one kernel round 5 rebuilt (configuration 0), on the code the site was in
     ("ext_i", CFG6_INST_EXT, w.K_STEAL, "aquad", 8),                                                        # the instantiation that was wrong in round 5's builds
+    ("measured", R.kernel_symbol(False, False, 3, 4, 0, True, False, True), w.K_MEASURED_STEAL, "b8", 8),   # bunny's kernel — the headline (with its out-of-line kd-tree walk)
+    ("lean", R.kernel_symbol(False, False, 61, 4, 0, True, False, True), w.K_LEAN_STEAL, "metal", 8),       # metal.pbrt's kernel
+    ("basic", R.kernel_symbol(False, False, 1, 3, 0, True, False, True), w.K_BASIC_STEAL, "env", 8),        # the soup's kernel (configuration 6)
 ])
 def test_shipped_kernel_binaries_render_the_oracles_film_in_the_interpreter(unit, symbol, kid, case, n):
     s = load_case(case)
