@@ -979,6 +979,8 @@ def bind_vector(ins):
         return lambda w, i: w.w64(ops[0], (w.rd(ops[1]) * w.rd(ops[2]) + bcast(w.r64(ops[0])).view(F64)).view(U64))
     if base == "v_bitop3_b32":
         return lambda w, i: w.w32(ops[0], _bitop3(w.r32(ops[1]), w.r32(ops[2]), w.r32(ops[3]), mods["bitop3"]))
+    if base == "v_bitop3_b16":
+        return lambda w, i: w.w32(ops[0], (_bitop3(w.r32(ops[1]), w.r32(ops[2]), w.r32(ops[3]), mods["bitop3"]) & U32(0xffff)) | (w.V[ops[0].idx] & U32(0xffff0000)))
     # ---- division support ----
     if base == "v_div_scale_f32":
         def fds(w, i):

@@ -92,6 +92,47 @@ def test_interpreter_agrees_with_the_host_on_a_battery_of_device_functions(tmp_p
     assert np.array_equal(uo, ruo)
 
 
+@needs_hipcc
+def test_interpreter_does_64_bit_integers_and_strided_global_memory(tmp_path):
+    """64-bit multiplies / shifts / divisions (v_mad_u64_u32, v_lshl_add_u64, v_mul_hi, the carry chains), and columns of a strided buffer written and read back across lanes —
+    the addressing of the per-lane transform cache"""
+    here = os.path.join(ROOT, "tests", "isaemu", "battery")
+    obj = str(tmp_path / "int64.o")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-c", os.path.join(here, "int64.hip"), "-o", obj])
+    co = R.code_object(obj, str(tmp_path))
+    insns, index, starts = g.disassemble(co, ["k2"])
+    assert g.unimplemented(insns) == {}
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(64).astype(np.float32) * 100
+    u = rng.integers(0, 2 ** 32, 64, dtype=np.uint64).astype(np.uint32)
+    u[0] = 0; u[1] = 0xffffffff; u[2] = 0x80000000
+    stride, K = 512, 7
+    out, qo, buf = np.zeros(128, np.float32), np.zeros((64, 16), np.uint64), np.zeros(stride * 16, np.float32)
+
+    class Args(C.Structure):
+        _fields_ = [("a", C.c_void_p), ("out", C.c_void_p), ("u", C.c_void_p), ("qo", C.c_void_p), ("buf", C.c_void_p), ("stride", C.c_int64), ("n", C.c_int), ("k", C.c_int)]
+    args = Args(a.ctypes.data, out.ctypes.data, u.ctypes.data, qo.ctypes.data, buf.ctypes.data, stride, 64, K)
+    g.Wave((insns, index), g.HostMemory(), np.zeros(16384, np.uint32), g.kernel_descriptor(co, "k2"), C.addressof(args), 0, 0).run()
+    M = (1 << 64) - 1
+    for i in range(64):
+        uu, s = int(u[i]), stride
+        si = uu - (1 << 32) if uu & 0x80000000 else uu
+        cdiv = (abs(si) // 3) * (1 if si >= 0 else -1)
+        q0, q1 = (uu * s) & M, (si * s) & M
+        exp = [q0, q1, (si >> (i & 31)) & M, (uu << (i & 63)) & M, ((si * 12 + 7) * s + i) & M, cdiv & M, (uu * uu + uu) & M, (((uu << 32) | uu) >> (i & 63)) & M,
+               int(np.float32(a[i] * np.float32(1000.0))) & M, (s % (i + 1)) & M, uu // (i + 1), (-si) & M, (abs(si) + (s << 3)) & M, bin(q0).count("1"), (q0 - q1) if q0 > q1 else (q1 - q0),
+               (uu * 0x100000001b3) & M]
+        assert [int(x) for x in qo[i]] == exp, i
+    col = np.zeros((16, 64), np.float32)
+    for j in range(K):
+        col[j] = a * np.float32(j + 1)
+    acc = np.zeros(64, np.float32)
+    for i in range(64):
+        for j in range(K):
+            acc[i] = np.float32(acc[i] + np.float32(col[K - 1 - j][(i * 5 + 1) & 63] * np.float32(j & 3)))
+    assert np.array_equal(acc, out[:64])
+
+
 # ---- the binaries the build ships, on the CPU ----------------------------------------------------------------------------------------------
 @needs_build
 @pytest.mark.parametrize("unit,symbol,kid,case,n", [
