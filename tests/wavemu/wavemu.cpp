@@ -33,8 +33,15 @@ struct Prepared {       // one frame's launch: the kernel's arguments and everyt
 static int prepare(const emu_scene *s, const hpt_camera *cam, const hpt_render_desc *rd, float *film, int kernel_id, int grid, const int32_t *knobs, Prepared &P, char *err, int err_len) {
     using namespace hpt;
     auto bail = [&](const char *m) { if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", m); return -1; };
-    const wavemu::KernelInfo k = wavemu::find_kernel(kernel_id);
-    if (!k.fn) return bail("no such kernel id");
+    wavemu::KernelInfo k;
+    if (kernel_id < 0) {       // tests/isaemu: a launch for a kernel this library has no instantiation of — the template arguments that decide the launch, packed in -kernel_id
+        const int f = -kernel_id;           // 1 STEAL, 2 DL, 4 TOP, 8 WIN, 16 PARK (the measured set: cold lane state in LDS rows), 32 INST, 64 COUNT, 128 the extension set's rare features
+        k.fn = nullptr; k.steal = f & 1; k.dl = f & 2; k.top = f & 4; k.win = f & 8; k.inst = f & 32; k.count = f & 64; k.phased = true; k.ee = 0;
+        k.mats = (f & 16) ? (hpt::MATS_PLASTIC | hpt::MATS_MEASURED) : (f & 128) ? hpt::MATS_FULL : hpt::MATS_PLASTIC;
+    } else {
+        k = wavemu::find_kernel(kernel_id);
+        if (!k.fn) return bail("no such kernel id");
+    }
     P.k = k;
     const bool dl = rd->integrator != HPT_INTEGRATOR_PATH;
     if (dl != k.dl) return bail("integrator and kernel do not match");
