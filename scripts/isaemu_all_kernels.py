@@ -82,6 +82,9 @@ def main():
             try:
                 f, info = R.BinaryRender(s, co, sym, -flags).render(s.camera, rd)
             except g.EmuError as e:
+                if "tree too deep" in str(e) or "no LDS rows" in str(e):      # (kernel_residency's refusal: the device falls back to another configuration on such a scene)
+                    total -= 1
+                    print("%-10s %s %-7s not launched: %s" % (unit, label, name, str(e)[:200])); sys.stdout.flush(); continue
                 bad += 1
                 print("%-10s %s %-7s ERROR %s" % (unit, label, name, str(e)[:240])); sys.stdout.flush(); continue
             a, b = film.xyzw_to_rgb(f), film.xyzw_to_rgb(fo)
