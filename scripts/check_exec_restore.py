@@ -40,12 +40,19 @@ KNOWN_SITES = set()
 
 def new_sites(paths=None):
     """the definitions above an EXEC restore in the build's kernel units that are not in KNOWN_SITES -> set of (unit, kernel, instruction)"""
+    import concurrent.futures
     paths = paths or sorted(glob.glob(os.path.join(ROOT, "pbrt-v2_amd", "build", "hpt_kernels*.o")))
     sites = set()
-    for p in paths:
-        nf, ni, found = scan(disassembly_of(p))
-        sites |= {(os.path.basename(p), f[0], f[3]) for f in found if f[-1].startswith("DEFINES")}
+    with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, len(paths))) as pool:       # (a unit is a few hundred thousand to 1.7 M instructions of text: one process each)
+        for p, (nf, ni, found) in zip(paths, pool.map(_scan_path, paths)):
+            if nf == 0 or ni < 1000:
+                raise RuntimeError("no code found in " + p)
+            sites |= {(os.path.basename(p), f[0], f[3]) for f in found if f[-1].startswith("DEFINES")}
     return sites - KNOWN_SITES
+
+
+def _scan_path(p):
+    return scan(disassembly_of(p))
 
 
 def disassembly_of(path, tmp="/tmp/check_exec_restore"):
