@@ -41,7 +41,7 @@ KNOWN_SITES = set()
 def new_sites(paths=None):
     """the definitions above an EXEC restore in the build's kernel units that are not in KNOWN_SITES -> set of (unit, kernel, instruction)"""
     import concurrent.futures
-    paths = paths or sorted(glob.glob(os.path.join(ROOT, "pbrt-v2_amd", "build", "hpt_kernels*.o")))
+    paths = paths or device_objects()
     sites = set()
     with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, len(paths))) as pool:       # (a unit is a few hundred thousand to 1.7 M instructions of text: one process each)
         for p, (nf, ni, found) in zip(paths, pool.map(_scan_path, paths)):
@@ -49,6 +49,12 @@ def new_sites(paths=None):
                 raise RuntimeError("no code found in " + p)
             sites |= {(os.path.basename(p), f[0], f[3]) for f in found if f[-1].startswith("DEFINES")}
     return sites - KNOWN_SITES
+
+
+def device_objects():
+    """every object of the build that carries gfx950 code: the kernel units, the wavefront pipeline, the device BVH builder, the calibration and exchange kernels"""
+    build = os.path.join(ROOT, "pbrt-v2_amd", "build")
+    return sorted(glob.glob(os.path.join(build, "hpt_kernels*.o"))) + [p for p in (os.path.join(build, n) for n in ("hpt_wavefront.o", "hpt_bvh_gpu.o", "hpt_calib.o", "hpt_multi.o")) if os.path.exists(p)]
 
 
 def _scan_path(p):
@@ -177,7 +183,7 @@ def scan(stream):
 
 
 def main():
-    paths = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "pbrt-v2_amd", "build", "hpt_kernels*.o")))
+    paths = sys.argv[1:] or device_objects()
     bad = 0
     for p in paths:
         nf, ni, found = scan(disassembly_of(p))
