@@ -45,7 +45,7 @@ def new_sites(paths=None):
     sites = set()
     with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, len(paths))) as pool:       # (a unit is a few hundred thousand to 1.7 M instructions of text: one process each)
         for p, (nf, ni, found) in zip(paths, pool.map(_scan_path, paths)):
-            if nf == 0 or ni < 1000:
+            if nf == 0 or ni == 0:
                 raise RuntimeError("no code found in " + p)
             sites |= {(os.path.basename(p), f[0], f[3]) for f in found if f[-1].startswith("DEFINES")}
     return sites - KNOWN_SITES
