@@ -151,7 +151,8 @@ def check_function(name, insns):
         for a1, t1 in insns[j:j + 12]:
             op = t1.split(None, 1)[0]
             if re.match(r"^s_(or|andn2|xor)_saveexec_b64 ", t1):
-                found += [(label, a2, t2, a1, t1, "DEFINES a register above the EXEC flip of an else") for a2, t2 in pending]
+                if not t1.rstrip().endswith(", -1"):         # (s_or_saveexec_b64 s[a:b], -1 opens a whole-wave section — the save / restore of an SGPR-spill register — not an else)
+                    found += [(label, a2, t2, a1, t1, "DEFINES a register above the EXEC flip of an else") for a2, t2 in pending]
                 break
             if op.startswith(STOP) or EXEC_RESTORE.match(t1):
                 break
