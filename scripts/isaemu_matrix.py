@@ -45,7 +45,7 @@ def main():
             t = time.time()
             total += 1
             try:
-                f, info = R.BinaryRender(s, R.code_object(unit), sym, kid).render(s.camera, rd)
+                f, info = R.BinaryRender(s, R.code_object(os.environ.get("ISAEMU_UNIT_" + unit.upper(), unit)), sym, kid).render(s.camera, rd)      # (ISAEMU_UNIT_EXT_I=<object>: another build of the unit)
             except g.EmuError as e:
                 bad += 1
                 print("%-8s %-10s ERROR %s" % (name, label, str(e)[:300])); sys.stdout.flush(); continue
