@@ -4,15 +4,12 @@ crop of the workload's parity fixture — how much of the stream is arithmetic, 
 v_readlane spills of SGPRs), the VALU lane utilisation (active lanes per vector instruction / 64: the GPU's SQ_ACTIVE_INST_VALU x lanes counter measures the same thing).
 
     python scripts/isaemu_profile.py <crop> [workload ...]        -> profiles/r05_isaemu_instruction_mix.md"""
-import importlib
 import os
 import sys
 
-import numpy as np
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import hash_rd, load_case   # noqa: E402
-from tests.isaemu import gfx950 as g, run as R   # noqa: E402
+from tests.isaemu import run as R   # noqa: E402
 from tests.wavemu import emu as w   # noqa: E402
 K = R.kernel_symbol
 WORKLOADS = {"bunny": ("b8", "measured", K(False, False, 3, 4, 0, True, False, True), w.K_MEASURED_STEAL), "killeroo": ("cfg1", "basic", K(False, False, 1, 4, 0, True, False, True), w.K_BASIC_STEAL),

@@ -8,7 +8,6 @@ the block in which the lanes of an `if` rejoin, ABOVE the `s_or_b64 exec, exec, 
 the copy and read a stale register as the diffuse colour's first component.  Executing that one instruction after the restore makes the binary render the oracle's
 film.  scripts/check_exec_restore.py finds the shape in any build without running anything: the gate below."""
 import ctypes as C
-import glob
 import importlib
 import os
 import subprocess

@@ -11,7 +11,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.util import ADAPTIVE_CASES, BESTCANDIDATE_CASES, HALTON_CASES, abi, hash_rd, load_case, sample_table, with_instance_copies
+from tests.util import abi, hash_rd, load_case, sample_table, with_instance_copies
 
 film = importlib.import_module("pbrt-v2_amd.film")
 from oracle import orc          # noqa: E402  (the checker)
