@@ -523,6 +523,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         dt = float(t.item())
     total_samples = rd.x_count * rd.y_count * rd.spp * steps
     value = total_samples / dt / 1e6
+    exch = None
+    if comm is not None:
+        exch = comm.info()                      # the LAST timed frame's exchange as the library saw it: ncclCommCount, peers rank 0 received from, duration on the stream
     if rank != 0:
         return None, scene, flt
     full_h = full.cpu().numpy()
@@ -555,6 +558,11 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
         "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
         "film_mean_Y": round(float(full_h[..., 1].astype(np.float64).sum() / max(float(full_h[..., 3].astype(np.float64).sum()), 1.0)), 5),
     }
+    if world > 1:
+        # what moved the film (a driver must be able to tell an N-rank RCCL gather from anything else)
+        out["film_exchange"] = ({"transport": exch["transport"], "rccl_ranks": exch["ranks"] if exch["transport"] == "rccl" else 0, "ranks": exch["ranks"],
+                                 "peers_received": exch["peers"], "exchange_ms": None if exch["exchange_ms"] is None else round(exch["exchange_ms"], 3)}
+                                if exch is not None else {"transport": "torch.distributed fallback (pbrt-v2_amd/dist.py)", "rccl_ranks": 0, "why": _EXCHANGE.get("fallback")})
     if not args.no_verify:
         out["verify"] = verify_film(scene, rd, full_h, flt)
         out["rmse_vs_oracle"] = out["verify"]["rmse_vs_oracle"]
@@ -638,6 +646,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                                 "frac": round(ach / VALU_PEAK_GINST, 4), "frac_at_4_clocks": round(2.0 * ach / VALU_PEAK_GINST, 4),
                                 "lane_utilisation": prof.get("valu_lane_utilisation"),
                                 "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"), "source": prof.get("source")}
+        if out.get("roofline"):      # the bound that binds the cache-resident scenes, inside `roofline` too: VALU issue slots used, and the lanes busy in them
+            out["roofline"]["valu_frac"] = out["roofline_valu"]["frac_at_4_clocks"]
+            out["roofline"]["valu_frac_note"] = "VALU wave-instructions / s over one per SIMD every 4 clocks (f64, min/max, compares; 2-clock ops bracket it at half): the issue-slot occupancy; x lane_util = useful lane-slots"
     return out, scene, flt
 
 # ---- the line the driver parses ----------------------------------------------------------------------------------------------------
@@ -658,7 +669,7 @@ def _num(v, nd=4):
 def _roofline_compact(r):
     if not r:
         return None
-    out = {k: _num(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_sample", "achieved_peak", "achieved_peak_copy", "frac_of_achieved_peak", "hbm_real_frac", "lane_util") if k in r}
+    out = {k: _num(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_sample", "achieved_peak", "achieved_peak_copy", "frac_of_achieved_peak", "hbm_real_frac", "valu_frac", "lane_util") if k in r}
     if r.get("traffic") and r.get("algorithmic_bytes") :
         out["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
     if r.get("traffic_write_bytes") is not None:
@@ -707,6 +718,8 @@ def compact_line(out, full_path=None):
                "rmse": _num(w.get("rmse_vs_oracle"), 3) if w.get("rmse_vs_oracle") is not None else None}
         if w.get("scaling"):
             row["scaling"] = w["scaling"]
+        if isinstance(w.get("film_exchange"), dict):
+            row["exchange_ms"], row["rccl_ranks"] = w["film_exchange"].get("exchange_ms"), w["film_exchange"].get("rccl_ranks")
         if w.get("cpu_baseline"):
             row["cpu"] = w["cpu_baseline"].get("value")
             row["cpu_kind"] = w["cpu_baseline"].get("kind")
@@ -714,7 +727,12 @@ def compact_line(out, full_path=None):
     if rows:
         c["workloads"] = rows
     if out.get("film_exchange"):
-        c["film_exchange"] = _short(out["film_exchange"], 120)
+        fe = out["film_exchange"]
+        c["film_exchange"] = {k: (_short(v, 80) if isinstance(v, str) else v) for k, v in fe.items()} if isinstance(fe, dict) else _short(fe, 120)
+        if isinstance(fe, dict):
+            c["rccl_ranks"], c["exchange_ms"] = fe.get("rccl_ranks"), fe.get("exchange_ms")
+    if out.get("north_star_scaling"):
+        c["north_star_scaling"] = out["north_star_scaling"]
     if full_path:
         c["full_record"] = full_path
     line = json.dumps(c, separators=(",", ":"))
@@ -866,11 +884,21 @@ def main():
             for w, st in (("soup", 2), ("killeroo", 5), ("anim", 3)):
                 o, _, _ = measure(args, w, 0, min(st, args.steps), min(1, args.warmup), world, rank, local, dist, torch, comm, strong=True)
                 if rank == 0:
-                    extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle", "roofline") if k in o})
+                    extras.append({k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "scaling", "config", "kernel", "rmse_vs_oracle", "roofline", "film_exchange") if k in o})
                     extras[-1]["workload"] = "%s (strong scaling: the fixed %d-spp frame split over %d GPUs)" % (w, DEFAULT_SPP[w], world)
     if rank == 0:
         if extras:
             out["workloads"] = extras
+            # north_star's own scaling statement — "Msamples/sec on a synthetic ~1M-triangle scene at 1920x1080 at 1/2/4/8 GPUs", ">= 6x at 8 GPUs": a FIXED frame
+            # (configs[2]: 256 spp) split N ways — under ONE key at every N, so that the driver's N = 1, 2, 4, 8 lines hold the curve: value_N / value_1 is the
+            # speed-up.  (`value` itself stays configs[1] with fixed per-GPU work at every N — the contract's metric, and what the driver's own efficiency
+            # figure needs: one workload across N.)
+            soup = next((e for e in extras if str(e.get("workload", "")).startswith("soup") and "4m" not in str(e.get("workload", ""))), None)
+            if soup:
+                fe = soup.get("film_exchange") if isinstance(soup.get("film_exchange"), dict) else {}
+                out["north_star_scaling"] = {"workload": "synthetic 1M triangles + env light, 1920x1080, 256 spp, maxdepth 8: the fixed frame over %d GPU(s)" % world,
+                                             "value": soup.get("value"), "unit": "Msamples/s", "ms_per_step": soup.get("ms_per_step"), "n_gpus": world, "scaling": "strong",
+                                             "exchange_ms": fe.get("exchange_ms"), "rccl_ranks": fe.get("rccl_ranks") if world > 1 else None}
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline_port(scene, flt=flt)
             ref = cpu_baseline_reference(workload, scene) if (flt is None and args.sampler == "lowdiscrepancy") else None

@@ -445,6 +445,11 @@ int hpt_comm_unique_id(void *out_128_bytes);
 hpt_comm *hpt_comm_create(const void *id_128_bytes, int rank, int world, int device);
 void hpt_comm_destroy(hpt_comm *c);
 int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film_xyzw, void *stream, int wide_filter);
+/* What the communicator is and what its last exchange did (round 6; any pointer may be NULL).  *ranks: ncclCommCount of the RCCL communicator (host-staged
+ * transport: the world size); *transport: 0 RCCL, 1 host-staged (the one-device dry run); *peers: ranks whose tile records (wide filter: films) rank 0
+ * received in the last exchange, 0 on the other ranks; *exchange_ms: the last exchange's duration on its stream (pack, transfer, unpack; the call waits
+ * for it; < 0: none yet). */
+int hpt_comm_info(hpt_comm *c, int *ranks, int *transport, int *peers, float *exchange_ms);
 
 /* ---- scene blob (serialised hpt_scene_desc + camera + render defaults); host only ------ */
 typedef struct hpt_blob hpt_blob;

@@ -785,7 +785,8 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     const bool inst = s->d.n_instances > 0 || s->cam_animated;     // (a moving camera runs the kernels that carry a time sample)
     float t[HPT_N_TUNE_CFG];
     bool in_race[HPT_N_TUNE_CFG];
-    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1); }  // early exit is not compiled for instanced scenes
+    // (only configurations this library carries as kernels of their own race: the shipped build 3, 5, 6 — an alias would be the same kernel timed twice)
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1) && path_kernel_effective_cfg(s->mats, cfg) == cfg; }  // early exit is not compiled for instanced scenes
     int best_cfg = 0;
     // round 0: every configuration at <= 16 spp; round 1: the ones within 10 % of the best again at <= 64 spp
     for (int round = 0; round < 2 && e == hipSuccess; ++round) {
@@ -887,8 +888,8 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
     if (e == hipSuccess && kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) {
         if (rd->count_work && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the instrumented kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
         if (windowed && !dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the window samplers' kernel (lock step + subtree stealing)", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
-        if (path_kernel_effective_cfg(s->mats, cfg) >= 5 && !dl) {      // tree too deep for the stealing rows: the plain lock-step walk (extension set: free-running)
-            cfg = (s->mats & MATS_EXT) ? 0 : cfg - 2;
+        if (path_kernel_effective_cfg(s->mats, cfg) >= 5 && !dl) {      // tree too deep for the stealing rows: the plain lock-step walk (configuration 3; an HPT_ALL_CONFIGS build: 3 / 4, its extension units free-running)
+            cfg = path_kernel_effective_cfg(s->mats, cfg - 2) >= 5 ? 0 : cfg - 2;
             if (kernel_residency(s, cfg, &a, &bpc, &vgprs) != 0) e = hipErrorUnknown;
         }
         else if (dl) { hpt_set_error("BVH depth %d leaves no LDS rows for the direct-lighting kernel's subtree stealing", s->info.bvh_max_depth); return HPT_E_UNSUPPORTED; }
@@ -975,7 +976,8 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
     if (ra.mt) (void)hipFree(ra.mt);
     if (ra.buf) (void)hipFree(ra.buf);
     if (e != hipSuccess) { hpt_set_error("render failed: %s", hipGetErrorString(e)); return HPT_E_HIP; }
-    if (h_scr.dbg[0] != 0u) {         // a `make debug` build: the first check that failed in this frame's kernels (codes: hpt_device.h, HPT_CK_*)
+    const int timers = path_kernel_phase_timers();     // (compile-time property of the kernel units, not an environment variable: ADVICE r05)
+    if (!timers && h_scr.dbg[0] != 0u) {         // a `make debug` build: the first check that failed in this frame's kernels (codes: hpt_device.h, HPT_CK_*)
         static const char *const names[] = {"?", "STACK_ROW", "STACK_NEG", "EXEC", "SHFL_SRC", "NODE", "TRI", "PRIM", "QUEUE", "INST", "ITEM", "PIXEL", "STATE", "MATERIAL", "XF"};
         const unsigned c = h_scr.dbg[0];
         hpt_set_error("debug check %u (%s) failed in the path kernel: values %d %d %d %d, workgroup %u thread %u; %u failures in all (configuration %d, mats %d, instances %d, top %d, integrator %d, sampler kind %d)",
@@ -995,34 +997,42 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
             px += (uint64_t)w * (uint64_t)h;
         }
         job_samples = px * (uint64_t)rd->spp;
-        if (const char *t = getenv("HPT_TEST_CONSERVATION_DELTA")) job_samples += (uint64_t)atoll(t);   // (tests: a job size the kernels cannot meet — the check must fire)
+        // (tests: a job size the kernels cannot meet — the check must fire.  Honoured only together with HPT_TEST_HOOKS=1, so that one stray variable cannot fail every render: ADVICE r05)
+        if (const char *t = getenv("HPT_TEST_CONSERVATION_DELTA")) if (const char *hk = getenv("HPT_TEST_HOOKS")) if (atoi(hk) == 1) job_samples += (uint64_t)atoll(t);
     }
     // Sample conservation (renderers/samplerrenderer.cpp:60-164: every camera sample of the job is traced and reaches film->AddSample exactly
     // once).  Every path kernel counts the camera samples it completes (hpt_kernels_impl.h, n_flushed); for the samplers whose samples belong
     // to pixels the total is known before the launch.  (The window samplers reject points outside the extent and the adaptive sampler renders
     // some pixels twice: their count is reported, not checked.  A -DHPT_PHASE_TIMERS build keeps wave clocks in these words.)
-    if (!replay && !windowed && !getenv("HPT_PHASE_TIMERS") && h_scr.wc.samples != job_samples) {
+    if (!replay && !windowed && !timers && h_scr.wc.samples != job_samples) {
         hpt_set_error("sample conservation violated: the kernels completed %llu camera samples, the job has %llu (configuration %d, %d x %d pixels from (%d, %d), %d spp, shard %d of %d, "
                       "material set %d, %d instances, top-level walk %d, integrator %d, sampler kind %d, work items of %d samples, regeneration threshold %d)",
                       (unsigned long long)h_scr.wc.samples, (unsigned long long)job_samples, cfg, a.rp.sx_count, a.rp.sy_count, a.rp.sx_start, a.rp.sy_start, rd->spp, a.rp.shard_rank, a.rp.shard_count,
                       s->mats, s->d.n_instances, a.top, rd->integrator, a.rp.sampler_kind, a.rp.chunk, a.regen_min);
         return HPT_E_INTERNAL;
     }
-    if (getenv("HPT_PHASE_TIMERS"))   // a -DHPT_PHASE_TIMERS kernel build leaves wave clocks per loop section in the work counters
+    if (timers && getenv("HPT_PHASE_TIMERS")) {   // a -DHPT_PHASE_TIMERS kernel build leaves wave clocks per loop section in the work counters
         fprintf(stderr, "hpt phase clocks (refill, extension walk, shadow+MIS walk, on_hit, BRDF queries, shade_finish): %llu %llu %llu %llu %llu %llu  kernel %.3f ms cfg %d\n",
                 (unsigned long long)h_scr.wc.samples, (unsigned long long)h_scr.wc.closest, (unsigned long long)h_scr.wc.shadow, (unsigned long long)h_scr.wc.nodes,
                 (unsigned long long)h_scr.wc.tris, (unsigned long long)h_scr.wc.bad, ms, cfg);
+        // round 6: the same clocks weighted with the lanes each section worked for (x lanes), and the stealing walk's own counts per kind of phase
+        // (iterations, lanes in the node half, leaf phases, lanes in them, busy lanes) — the failure record of the debug build is free in a timers build
+        const unsigned long long *d64 = (const unsigned long long *)h_scr.dbg;
+        fprintf(stderr, "hpt phase lane-clocks: %llu %llu %llu %llu %llu %llu\n", d64[0], d64[1], d64[2], d64[3], d64[4], d64[5]);
+        fprintf(stderr, "hpt walk counts (extension | light: iterations, node lanes, leaf phases, leaf lanes, busy lanes): %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu\n",
+                d64[6], d64[7], d64[8], d64[9], d64[10], d64[11], d64[12], d64[13], d64[14], d64[15]);
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
         // samples of this shard (checked above against the kernels' own count; the window samplers report what the kernels counted)
-        stats->camera_samples = (windowed && !getenv("HPT_PHASE_TIMERS")) ? h_scr.wc.samples : job_samples;
+        stats->camera_samples = (windowed && !timers) ? h_scr.wc.samples : job_samples;
         if (rd->count_work || replay) {
             stats->camera_samples = h_scr.wc.samples;
             stats->closest_rays = h_scr.wc.closest; stats->shadow_rays = h_scr.wc.shadow;
             stats->nodes_visited = h_scr.wc.nodes; stats->tris_tested = h_scr.wc.tris;
         }
-        if (!getenv("HPT_PHASE_TIMERS")) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:118-131: the host plugin reports them)
+        if (!timers) stats->bad_samples = h_scr.wc.bad;   // always counted (samplerrenderer.cpp:118-131: the host plugin reports them)
         stats->grid_blocks = (uint32_t)grid; stats->block_threads = HPT_BLOCK;
         stats->resident_waves = (uint32_t)(bpc * (HPT_BLOCK / 64)); stats->vgprs = (uint32_t)vgprs & 1023u; stats->scratch_bytes = (uint32_t)vgprs >> 10;
         stats->tune_cfg = replay ? 0u : (uint32_t)cfg;

@@ -60,7 +60,7 @@ namespace hpt {
 // not trap (a trapped wave tells nothing): the FIRST failure's code and four values go into a 16-word record of the frame's scratch block
 // (PathKernelArgs::dbg -> RenderScratch::dbg), word 15 counts all failures, the offending index is clamped by the caller where it can be, the
 // kernel runs on, and hpt_render_device returns HPT_E_INTERNAL with the record in the message.  Production builds compile the checks away.
-#define HPT_DBG_WORDS 16
+#define HPT_DBG_WORDS 32
 enum {  // check codes (hpt_render_device prints the name)
     HPT_CK_STACK_ROW = 1,      // a walk-stack write / read outside the rows the lane owns          v: sp, limit, sb, node
     HPT_CK_STACK_NEG = 2,      // a negative stack pointer                                          v: sp, sb, fl, node
@@ -635,6 +635,8 @@ HPT_FN Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse
 // wave hit 64 different banks).
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
 struct TravCounters { uint32_t nodes, tris; unsigned long long leaf_clocks = 0, step_clocks = 0; uint32_t leaf_lanes = 0, steps = 0; };
+#elif defined(HPT_PHASE_TIMERS)   /* the pilot of round 6: wave-uniform counts of the stealing walk — iterations, lanes in the node half, leaf phases, lanes in them, busy lanes — per kind of phase (0 extension, 1 light) */
+struct TravCounters { uint32_t nodes, tris; unsigned long long wk[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; };
 #else
 struct TravCounters { uint32_t nodes, tris; };
 #endif
@@ -1192,8 +1194,22 @@ HPT_FN void kd_begin(const float *fpool, const hpt_material *m, f3 mpt, KdWalk *
     irreg_proc_reset(&w->pr, w->level > 0 ? r * .5f : 0.f);
     kd_set_box(w);
 }
-// returns true when the query is finished: *out = IrregIsotropicBRDF::f
-HPT_FN bool kd_step(KdWalk *w, f3 *out) {
+// The weight of a sample inside the radius (IrregIsoProc::operator(), reflection.cpp:49): expf(-100 d2).  On the device the hardware exponential
+// (v_exp_f32 of x log2 e: three instructions where the library's expf is ~15): the weights that matter have -100 d2 > -10, where the rounding of the
+// product moves the weight by < 1e-6 relative — the value of a query is a ratio of sums of a handful of them (BSDF hook tolerance 1e-5; round 6).
+HPT_FN float kd_weight(float d2) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HPT_KD_LIBM_EXP)
+    return __expf(-100.f * d2);
+#else
+    return expf(-100.f * d2);
+#endif
+}
+// One step of the walk.  Returns true when the query is finished: *res = {sum of weight x value, sum of weights} of the samples inside the final
+// radius — IrregIsotropicBRDF::f is kd_result(*res), the division the caller does (the wave-cooperative evaluator: for all of a wave's queries at once).
+// Round 6 (profiles/r06_lineprofile_bunny.md: this function was a quarter of the headline kernel's vector instructions at 8 % of the lanes — every step
+// ran four blocks one after the other, each with the few lanes that needed it): the sample test no longer branches on "inside the radius" — every lane
+// with a sample accumulates, a sample outside adds zeros and offers +inf to the three-smallest network — and the pass's end hands back sums, not quotients.
+HPT_FN bool kd_step(KdWalk *w, f4 *res) {
     if (w->j >= w->jend) {                               // this row's range is used up: on to the next row of the box
         // (skipping EMPTY rows inside the step — about one row in seven — was measured: bunny 1941 against 1974 Msamples/s, run AA of round 4: the loop costs more than the steps it saves)
         ++w->iy;
@@ -1208,39 +1224,47 @@ HPT_FN bool kd_step(KdWalk *w, f3 *out) {
         const f4 n0 = w->samples[2 * (int64_t)w->j], n1 = w->samples[2 * (int64_t)w->j + 1];
         ++w->j;
         const float d2 = dist2(mk3(n0.x, n0.y, n0.z), w->q);
-        if (d2 < w->r) { // IrregIsoProc::operator() (reflection.cpp:46-51)
-            float weight = expf(-100.f * d2);
-            f3 wv = mk3(n0.w, n1.x, n1.y) * weight;
-            proc->v = proc->v + wv;
-            proc->sumWeights += weight;
-            const bool in2 = d2 < proc->r2;              // (adding +0 leaves a sum unchanged: no branch needed)
-            proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
-            proc->sumWeights2 += in2 ? weight : 0.f;
-            // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion
-            const float t1 = maxf(proc->m1, d2); proc->m1 = minf(proc->m1, d2);
-            const float t2 = maxf(proc->m2, t1); proc->m2 = minf(proc->m2, t1);
-            proc->m3 = minf(proc->m3, t2);
-        }
+        const bool in = d2 < w->r, in2 = d2 < proc->r2;  // IrregIsoProc::operator() (reflection.cpp:46-51); r2 <= r: in2 implies in
+        const float wt = kd_weight(d2);
+        const float weight = in ? wt : 0.f;              // (adding +0 leaves a sum unchanged: no branch needed)
+        const f3 wv = mk3(in ? n0.w * wt : 0.f, in ? n1.x * wt : 0.f, in ? n1.y * wt : 0.f);
+        proc->v = proc->v + wv;
+        proc->sumWeights += weight;
+        proc->v2 = proc->v2 + mk3(in2 ? wv.x : 0.f, in2 ? wv.y : 0.f, in2 ? wv.z : 0.f);
+        proc->sumWeights2 += in2 ? weight : 0.f;
+        // keep the three smallest distances, m1 <= m2 <= m3: a three-stage min / max insertion (+inf passes through)
+        const float dm = in ? d2 : HPT_INF;
+        const float t1 = fmaxf(proc->m1, dm); proc->m1 = fminf(proc->m1, dm);
+        const float t2 = fmaxf(proc->m2, t1); proc->m2 = fminf(proc->m2, t1);
+        proc->m3 = fminf(proc->m3, t2);
         return false;
     }
     if (w->iz <= w->z1) return false;                    // (an empty row: keep going)
     // ---- the pass is over ------------------------------------------------------------------------------------------
-    if (w->last) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
-    if (proc->m3 < w->r) {                               // more than two samples inside r: the reference stopped at k <= level
-        int k = w->level; float rk = w->r;
-        while (k > 0 && proc->m3 < rk * .5f) { --k; rk *= .5f; }
-        if (k == w->level) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
-        if (k == w->level - 1) { *out = sdivf(sclamp0(proc->v2), proc->sumWeights2); return true; }
-        w->r = rk; w->last = true;                       // guessed too high by two or more levels: one pass at the exact radius
-        irreg_proc_reset(proc, 0.f);
-    } else {
-        if (w->r > 1.5f) { *out = sdivf(sclamp0(proc->v), proc->sumWeights); return true; }
-        w->r *= 2.f; ++w->level;
-        irreg_proc_reset(proc, w->r * .5f);
+    bool second = false;                                 // the sums for r / 2 are the answer
+    if (!w->last) {
+        if (proc->m3 < w->r) {                           // more than two samples inside r: the reference stopped at k <= level
+            int k = w->level; float rk = w->r;
+            while (k > 0 && proc->m3 < rk * .5f) { --k; rk *= .5f; }
+            if (k == w->level - 1) second = true;
+            else if (k != w->level) {                    // guessed too high by two or more levels: one pass at the exact radius
+                w->r = rk; w->last = true;
+                irreg_proc_reset(proc, 0.f);
+                kd_set_box(w);
+                return false;
+            }
+        } else if (!(w->r > 1.5f)) {
+            w->r *= 2.f; ++w->level;
+            irreg_proc_reset(proc, w->r * .5f);
+            kd_set_box(w);
+            return false;
+        }
     }
-    kd_set_box(w);
-    return false;
+    res->x = second ? proc->v2.x : proc->v.x; res->y = second ? proc->v2.y : proc->v.y; res->z = second ? proc->v2.z : proc->v.z;
+    res->w = second ? proc->sumWeights2 : proc->sumWeights;
+    return true;
 }
+HPT_FN f3 kd_result(f4 r) { return sdivf(sclamp0(mk3(r.x, r.y, r.z)), r.w); }     // reflection.cpp:270: v.Clamp() / sumWeights
 // The query point of IrregIsotropicBRDF::f (reflection.cpp:248-260, BRDFRemap)
 HPT_FN f3 irreg_point(f3 wo, f3 wi) {
     float cosi = wi.z, coso = wo.z;
@@ -1258,9 +1282,9 @@ HPT_FN f3 irreg_point(f3 wo, f3 wi) {
 HPT_FN_NOINLINE f3 irreg_eval(const float *fpool, const hpt_material *m, f3 mpt) {
     KdWalk w;
     kd_begin(fpool, m, mpt, &w);
-    f3 out = S(0.f);
-    while (!kd_step(&w, &out)) {}
-    return out;
+    f4 res; res.x = res.y = res.z = res.w = 0.f;
+    while (!kd_step(&w, &res)) {}
+    return kd_result(res);
 }
 HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {
     return irreg_eval(sc.fpool, m, irreg_point(wo, wi));

@@ -26,10 +26,23 @@ namespace hpt {
 #error "HPT_NO_BVH4 is gone: the stealing walk (traverse_steal) only exists on the four-wide trees"
 #endif
 bool path_kernel_wide_bvh() { return true; }
+// a -DHPT_PHASE_TIMERS build keeps wave clocks in the work-counter words (hpt_render_device must not read them as sample counts); 0: a production build
+int path_kernel_phase_timers() {
+#ifdef HPT_PHASE_TIMERS
+    return HPT_PHASE_TIMERS + 0 > 0 ? HPT_PHASE_TIMERS + 0 : 1;
+#else
+    return 0;
+#endif
+}
 int path_kernel_steal_rows(bool dl) { (void)dl; return HPT_STEAL_ROWS; }
-int path_kernel_effective_cfg(int mats, int cfg) {
+int path_kernel_effective_cfg(int mats, int cfg) {   // HPT_CFG_ALIAS (hpt_kernels_impl.h)
+#ifdef HPT_ALL_CONFIGS
     if (!(mats & MATS_EXT)) return cfg;
-    return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // HPT_CFG_ALIAS under HPT_LEAN_SET (hpt_kernels_impl.h)
+    return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // under HPT_LEAN_SET
+#else
+    (void)mats;
+    return cfg >= 5 ? cfg : 3;                                     // the shipped matrix: 3, 5, 6
+#endif
 }
 int path_kernel_cold_rows(int mats, bool dl) {       // must mirror launch_path_kernel's choice of instantiation (below)
     const int set = (mats & MATS_NORARE) ? MATS_LEAN : (mats & MATS_EXT) ? MATS_FULL : (mats & ~MATS_PLASTIC) == 0 ? MATS_PLASTIC : (mats & ~(MATS_PLASTIC | MATS_MEASURED)) == 0 ? (MATS_PLASTIC | MATS_MEASURED) : MATS_ALL;

@@ -42,6 +42,21 @@ __device__ __forceinline__ int64_t wave_fetch(unsigned long long *counter, bool 
     int rank = __popcll(mask & ((1ull << lane_id()) - 1ull));
     return need ? (int64_t)(base + (unsigned long long)rank) : -1;
 }
+// the same, handing out the wave's base (uniform) and the lane's rank apart: the refill derives (pass, item) from the BASE once and from the rank by an add
+__device__ __forceinline__ bool wave_fetch_base(unsigned long long *counter, bool need, int64_t *base_out, int *rank_out) {
+    HPT_CHECK_FULL_EXEC(3);
+    unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return false;
+    int n = __popcll(mask);
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)n);
+    unsigned lo = __shfl((unsigned)(base & 0xffffffffull), leader);
+    unsigned hi = __shfl((unsigned)(base >> 32), leader);
+    *base_out = (int64_t)(((unsigned long long)hi << 32) | lo);
+    *rank_out = __popcll(mask & ((1ull << lane_id()) - 1ull));
+    return true;
+}
 
 // The measured-BRDF values a wave's lanes still owe their path vertices (ShadeV::has[], up to three kd-tree
 // queries per lane) — evaluated by ALL 64 lanes.  After the first bounce only a fraction of a wave's lanes sits
@@ -71,11 +86,11 @@ __device__ __noinline__ void wave_kd_run(const float *fpool, const hpt_material 
     for (;;) {
         if (__ballot(slot >= 0) == 0ull) break;
         if (slot >= 0) {                                 // a burst of steps between two looks at the queue
-            f3 f;
+            f4 f;
             bool done = false;
             _Pragma("unroll 1") for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step(&w, &f);
-            if (done) {
-                HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z);
+            if (done) {                                  // the query's sums (its material index is no longer needed): divided below, all entries at once
+                HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z); HPT_QSLOT(slot, 3) = as_int(f.w);
                 slot = -1;
             }
         }
@@ -90,6 +105,16 @@ __device__ __noinline__ void wave_kd_run(const float *fpool, const hpt_material 
                 }
             }
         }
+    }
+    // IrregIsotropicBRDF::f = v.Clamp() / sumWeights (reflection.cpp:270) of every entry, 64 at a time: three true divisions that used to run at the end of
+    // each walk with the one or two lanes that had just finished (profiles/r06_lineprofile_bunny.md: 5 % of the kernel's vector instructions at 6 % of the lanes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < total; e += 64) {
+        f4 r; r.x = as_float(HPT_QSLOT(e, 0)); r.y = as_float(HPT_QSLOT(e, 1)); r.z = as_float(HPT_QSLOT(e, 2)); r.w = as_float(HPT_QSLOT(e, 3));
+        const f3 f = kd_result(r);
+        HPT_QSLOT(e, 0) = as_int(f.x); HPT_QSLOT(e, 1) = as_int(f.y); HPT_QSLOT(e, 2) = as_int(f.z);
     }
 }
 __device__ __forceinline__ void wave_eval_queries(const DScene &sc, LaneStack ls, ShadeV &sv, bool shaded) {
@@ -224,32 +249,99 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         const unsigned long long w0_ = __builtin_readcyclecounter();
         cnt->steps++;
 #endif
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS != 3
+        { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; wk_[0] += 1ull; wk_[1] += (unsigned long long)__popcll(__ballot(ts.node >= 0)); wk_[4] += (unsigned long long)__popcll(mbusy); }
+#endif
         if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
         if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && TOP && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
         const unsigned long long w1_ = __builtin_readcyclecounter();
         cnt->step_clocks += w1_ - w0_;
 #endif
+        bool coop_found = false;                                        // (uniform) a cooperative leaf phase of this iteration published a hit
         {
             const bool has = pend != HPT_TRAV_EMPTY;
             const unsigned long long mh = __ballot(has);
             if (mh != 0ull) {
                 const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
                 if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
+#ifdef HPT_NO_COOP_LEAF   /* A/B control: every lane that holds a leaf loops over its own triangles (rounds 2-5) */
                     if (has) {
                         if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
                         pend = HPT_TRAV_EMPTY;
                     }
+#else
+                    // ---- COOPERATIVE LEAVES (round 6): the parked leaves' triangles as (ray, triangle) PAIRS dealt out over all 64 lanes --------------
+                    // A leaf holds 1-8 triangles and a leaf phase runs with a third of the wave at best: the loop over a lane's own triangles took as long as
+                    // the fullest leaf and issued the double-precision triangle test with 17-22 % of the lanes (profiles/r06_lineprofile_*_before.md: 10-18 % of a
+                    // kernel's vector instructions).  Here every lane tests ONE triangle against ONE ray: the holders' counts are prefix-summed with three
+                    // ballots, each holder writes (its lane, its ray's owner, the triangle's number in the leaf) into its slots of the donor-table row, lane j takes
+                    // pair j — the holder's ray through cross-lane shuffles — and a hit goes straight to the ray's OWNER's result rows, the way helpers publish
+                    // (atomic min on the distance's bits, the lane that holds the minimum writes barycentrics / primitive / instance; an any-hit ray: the flag).
+                    // The publish block below then hands the shrunk distance (or "occluded") back to every lane of the group, the holder included — which is
+                    // also how a holder's own hit reaches its maxt now.  More than 64 pairs: rounds.  Equal distances (shared edges) resolve by publishing
+                    // order, as between helpers; the nearest hit is otherwise the serial loop's.
+                    {
+                        const int c1 = has ? (int)((uint32_t)~pend >> 28) : 0;      // triangles in this lane's leaf - 1
+                        const unsigned long long q0 = __ballot(has && (c1 & 1) != 0), q1 = __ballot(has && (c1 & 2) != 0), q2 = __ballot(has && (c1 & 4) != 0);
+                        const int pbase = __popcll(mh & lt) + __popcll(q0 & lt) + 2 * __popcll(q1 & lt) + 4 * __popcll(q2 & lt);
+                        const int total = nh + __popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2);
+                        const int word = lane | (owner << 6) | (ts.anyhit ? 1 << 12 : 0);
+                        for (int base = 0; base < total; base += 64) {
+                            if (has) for (int k = 0; k <= c1; ++k) { const int j = pbase + k - base; if (j >= 0 && j < 64) HPT_AUX(aux, j) = word | (k << 13); }
+                            HPT_WAVE_SYNC();
+                            const bool work = base + lane < total;
+                            const int w = work ? HPT_AUX(aux, lane) : lane;
+                            const int ws = w & 63;
+                            HPT_CHECK(!work || ((mh >> ws) & 1ull), HPT_CK_SHFL_SRC, ws, base, total, w);
+                            Ray rr;
+                            rr.o = mk3(__shfl(r.o.x, ws), __shfl(r.o.y, ws), __shfl(r.o.z, ws));
+                            rr.d = mk3(__shfl(r.d.x, ws), __shfl(r.d.y, ws), __shfl(r.d.z, ws));
+                            rr.mint = __shfl(r.mint, ws); rr.maxt = __shfl(r.maxt, ws);
+                            const int leaf_w = __shfl(pend, ws);
+                            const int inst_w = INST ? __shfl(cur_inst, ws) : -1;
+                            const int wown = (w >> 6) & 63;
+                            const bool wany = ((w >> 12) & 1) != 0;
+                            bool wf = false; float wt = 0.f, wb1 = 0.f, wb2 = 0.f; int32_t wprim = -1;
+                            if (work) {
+                                const uint32_t ti = ((uint32_t)~leaf_w & 0x0fffffffu) + (uint32_t)(w >> 13);
+                                HPT_CHECK(ti < (uint32_t)sc.n_tris, HPT_CK_TRI, ti, w, sc.n_tris, leaf_w);
+                                const HPT_GLOBAL f4 *tp = (const HPT_GLOBAL f4 *)tris + 3 * (int64_t)ti;
+                                const f4 ta = tp[0], tb = tp[1], tcx = tp[2];
+                                if (COUNT) cnt->tris++;
+                                if (tri_test(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tcx.x, tcx.y, tcx.z), rr, &wt, &wb1, &wb2)
+                                    && !(ALPHA && (as_int(ta.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(ta.w), as_int(tb.w), wb1, wb2))) { wf = true; wprim = (int32_t)ti; }
+                            }
+                            if (__ballot(wf) != 0ull) {
+                                coop_found = true;
+                                if (wf) {
+                                    if (wany) HPT_AUX(aux + 2, wown) = 0;
+                                    else atomicMin((unsigned *)&HPT_AUX(aux + 1, wown), (unsigned)as_int(wt));
+                                }
+                                HPT_WAVE_SYNC();
+                                if (wf && !wany && as_int(wt) == HPT_AUX(aux + 1, wown)) {     // this lane holds the group's nearest hit so far
+                                    if (!light) { HPT_AUX(aux + 2, wown) = as_int(wb1); HPT_AUX(aux + 3, wown) = as_int(wb2); }
+                                    HPT_AUX(aux + 4, wown) = wprim;
+                                    if (INST) HPT_AUX(aux + 5, wown) = inst_w;
+                                }
+                            }
+                            HPT_WAVE_SYNC();
+                        }
+                        pend = HPT_TRAV_EMPTY;
+                    }
+#endif
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
                     cnt->leaf_clocks += __builtin_readcyclecounter() - w1_; cnt->leaf_lanes += (unsigned)nh; cnt->tris++;
+#elif defined(HPT_PHASE_TIMERS)
+                    { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; wk_[2] += 1ull; wk_[3] += (unsigned long long)nh; }
 #endif
                 }
             }
         }
         // (after every step — measured: every 16 / 8 / 4 / 2 / 1 steps = 612 / 660 / 708 / 775 / 800 Msamples/s on killeroo —
         //  but only the parts that have something to do: a publish when some lane found a hit, a steal when some lane idles)
-        const bool found = ts.hit.prim >= 0;
-        const bool any_found = __ballot(found) != 0ull;
+        const bool found = ts.hit.prim >= 0;                            // (a quadric of trav_begin / of an instance; HPT_NO_COOP_LEAF: the lane's own leaf too)
+        const bool any_found = __ballot(found) != 0ull || coop_found;
         if (any_found || !any_busy) {
             // ---- publish finds, share the hit distance inside every group (owner + helpers) ------------------------------
             if (found) {
@@ -482,11 +574,14 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     float *xf_col = (INST && a.inst_xf) ? a.inst_xf + (int64_t)blockIdx.x * HPT_BLOCK + threadIdx.x : nullptr;
     float xf_time = -HPT_INF;
 #ifdef HPT_PHASE_TIMERS   /* debug build (make variants VARIANTS="pt=-DHPT_PHASE_TIMERS"): wave clocks per loop section, into the work counters */
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter();
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, ptl[6] = {0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter();
     for (int i = 0; i < 8; ++i) lane.spt[i] = 0;
 #define HPT_PT(i) { const unsigned long long pt_n = __builtin_readcyclecounter(); pt[i] += pt_n - pt_t; pt_t = pt_n; }
+    // (round 6 pilot: the same clocks weighted with the lanes the section worked for — wave clocks x lanes; / 64 / the plain clocks = the section's lane fraction)
+#define HPT_PTL(i, lanes_mask) { const unsigned long long pt_n = __builtin_readcyclecounter(); pt[i] += pt_n - pt_t; ptl[i] += (pt_n - pt_t) * (unsigned long long)__popcll(lanes_mask); pt_t = pt_n; }
 #else
 #define HPT_PT(i)
+#define HPT_PTL(i, lanes_mask)
 #endif
     // lock step + stealing (path integrator): an extension hit waiting for its shading while the wave walks again for the lanes whose
     // rays escaped (PathKernelArgs::retrace_min)
@@ -506,6 +601,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     // counts the camera samples it completes — a popcount of the flush's ballot in a scalar register, ONE atomic per wave at the end of the
     // kernel — and hpt_render_device compares the frame's total with the job's size (HPT_E_INTERNAL when they differ).
     unsigned n_flushed = 0u;
+    // the work queue's constants (uniform; the refill below used to divide for them in every round)
+    const int64_t q_tiles = rp.items_per_pass >> 10, q_passes = rp.items_per_pass > 0 ? rp.n_items / rp.items_per_pass : 0;
+    const float q_inv_nstx = 1.f / (float)rp.n_stx;
     for (;;) {
         HPT_CHECK_FULL_EXEC(4);
         // Round 5, profiles/r05_isaemu_root_cause.md: in ONE instantiation of the shipped build — the free-running configuration 0 of the basic set — clang 22's greedy allocator
@@ -525,6 +623,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         const bool keeps_ = lane.stage != ST_IDLE && !lane.fin;
 #endif
         HPT_SNAP(snap_flush);
+#ifdef HPT_PHASE_TIMERS
+        const int pt_st0 = lane.stage; const bool pt_fin0 = lane.fin;
+#endif
         {
 #ifdef HPT_DBG_NO_REGEN
             const int regen_min = 1;
@@ -551,19 +652,24 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (__ballot(need) == 0ull) break;
             if (dead_heads == 0xff) { if (need) exhausted = true; break; }
             while ((dead_heads >> src) & 1) src = (src + 1) & 7;
-            const int64_t tiles = rp.items_per_pass >> 10, passes = rp.n_items / rp.items_per_pass;
-            const int64_t t0 = tiles * src / rp.n_heads, per = ((tiles * (src + 1) / rp.n_heads) - t0) << 10, lim = per * passes;
-            int64_t v = wave_fetch(a.next_item + src, need);
-            const bool over = need && v >= lim;
+            // (round 6: no per-lane 64-bit division — the wave's base is divided once, with a float reciprocal and a correction, and a lane's item follows from its rank)
+            const int64_t t0 = rp.n_heads == 8 ? (q_tiles * src) >> 3 : q_tiles * src, per = ((rp.n_heads == 8 ? (q_tiles * (src + 1)) >> 3 : q_tiles * (src + 1)) - t0) << 10, lim = per * q_passes;
+            int64_t vbase = 0; int vrank = 0;
+            (void)wave_fetch_base(a.next_item + src, need, &vbase, &vrank);
+            const bool over = need && vbase + vrank >= lim;
             if (need && !over) {
-                const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
+                int64_t rem_b;
+                const int64_t pass_b = div_floor_by(vbase, per, 1.f / (float)per, &rem_b);      // (uniform: the same for every lane of the wave)
+                int64_t rem = rem_b + vrank; int pass = (int)pass_b;
+                if (rem >= per) { rem -= per; ++pass; }                                            // (a wave's 64 items straddle at most one pass boundary: per >= 1024)
+                const int idx = (int)((t0 << 10) + rem);
                 int x, y; uint32_t s0;
                 if (WIN && rp.bc_table) {            // Sampler "bestcandidate" (scalar branch): the item is an entry of the sample table in a table tile
                     uint32_t tile;
-                    if (item_to_bc(rp, item, &tile, &s0)) (void)lane.begin_bc(rp, tile, s0);
+                    if (item_to_bc(rp, (int64_t)pass * rp.items_per_pass + idx, &tile, &s0)) (void)lane.begin_bc(rp, tile, s0);
                 } else if (WIN && rp.sampler_kind == 3) {   // Sampler "halton": the item is a sample number of a super-tile's window
-                    if (item_to_halton(rp, item, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
-                } else if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
+                    if (item_to_halton(rp, (int64_t)pass * rp.items_per_pass + idx, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
+                } else if (pass_item_to_pixel(rp, pass, idx, q_inv_nstx, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
             if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }
@@ -592,7 +698,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             while (__ballot(my_phase == phase) == 0ull) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
             mine = my_phase == phase;
         }
-        HPT_PT(0)
+#ifdef HPT_PHASE_TIMERS
+        HPT_PTL(0, __ballot((pt_fin0 && !lane.fin) || (pt_st0 == ST_IDLE && lane.stage != ST_IDLE)))   // lanes that were flushed or refilled this round
+#endif
         if (STEAL && PHASED) {
             // ---- one traversal phase of the wave, idle lanes stealing subtrees from the lanes with long rays ----------
             const bool tr = mine && (!DL || lane.stage != ST_SHADE) && !(RETRACE && has_pend);
@@ -614,14 +722,14 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                     if (miss) lane.extend_miss(sc, rp, a.film, COUNT ? &wc : nullptr);
                     else if (tr) { pend = hit; has_pend = true; }
                     ++retraced;
-                    HPT_PT(1)
+                    HPT_PTL(1, __ballot(tr))
                     continue;                                  // (the phase stays ST_EXTEND)
                 }
                 if (has_pend) { hit = pend; has_pend = false; }
                 retraced = 0;
             }
 #ifdef HPT_PHASE_TIMERS
-            if (phase == ST_EXTEND) HPT_PT(1) else HPT_PT(2)
+            if (phase == ST_EXTEND) HPT_PTL(1, __ballot(tr)) else HPT_PTL(2, __ballot(tr))     // lanes that own a ray of this phase (the thieves' work is in the walk counters)
 #endif
 #ifdef HPT_PRIO_SHADE
             __builtin_amdgcn_s_setprio(HPT_PRIO_SHADE);
@@ -671,7 +779,9 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 shaded = lane.on_hit(sc, rp, hit, a.film, COUNT ? &wc : nullptr, ls, &sv);
             }
         }
-        HPT_PT(3)
+#ifdef HPT_PHASE_TIMERS
+        if (!(STEAL && PHASED) || phase == ST_EXTEND) HPT_PTL(3, __ballot(shaded)) else HPT_PTL(5, __ballot(mine))   // on_hit behind an extension walk: the lanes that shade; behind a light walk (cheap): with shade_finish
+#endif
         // ---- the vertex's BSDF values that are kd-tree queries, by the whole wave; then its estimators ----------
         HPT_SNAP(snap_q);
         if (MATS & MATS_MEASURED) {
@@ -688,11 +798,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                 for (int k = 0; k < 3; ++k) if (sv.has[k]) sv.fq[k] = irreg_eval(sc.fpool, &sc.materials[sv.mat], sv.fq[k]);
         }
         HPT_SNAP_CMP(snap_q, 5, true);                             // (the measured-BRDF queries: every lane)
-        HPT_PT(4)
+        HPT_PTL(4, __ballot(shaded && (sv.has[0] || sv.has[1] || sv.has[2])))
         HPT_SNAP(snap_fin);
         if (shaded) lane.shade_finish(sc, rp, a.film, COUNT ? &wc : nullptr, sv);
         HPT_SNAP_CMP(snap_fin, 6, !shaded);                        // (shade_finish: the lanes that did not shade)
-        HPT_PT(5)
+        HPT_PTL(5, __ballot(shaded))
         if (PHASED) phase = phase == LAST_PHASE ? ST_EXTEND : phase + 1;
     }
 #ifdef HPT_PHASE_TIMERS
@@ -708,6 +818,11 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
         atomicAdd((unsigned long long *)&a.counters->samples, pt[0]); atomicAdd((unsigned long long *)&a.counters->closest, pt[1]);
         atomicAdd((unsigned long long *)&a.counters->shadow, pt[2]); atomicAdd((unsigned long long *)&a.counters->nodes, pt[3]);
         atomicAdd((unsigned long long *)&a.counters->tris, pt[4]); atomicAdd((unsigned long long *)&a.counters->bad, pt[5]);
+#if HPT_PHASE_TIMERS != 3 && HPT_PHASE_TIMERS != 2
+        unsigned long long *d64 = (unsigned long long *)a.dbg;      // (the debug build's failure record is free in a timers build: 16 x 64 bits)
+        for (int i = 0; i < 6; ++i) atomicAdd(d64 + i, ptl[i]);
+        for (int i = 0; i < 5; ++i) { atomicAdd(d64 + 6 + i, tc.wk[0][i]); atomicAdd(d64 + 11 + i, tc.wk[1][i]); }
+#endif
     }
 #endif
 #ifndef HPT_PHASE_TIMERS
@@ -738,13 +853,20 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_CFG_EE(c) ((c) == 1 ? 12 : 0)
 #define HPT_CFG_PHASED(c) ((c) >= 3)
 #define HPT_CFG_STEAL(c) ((c) >= 5)
-// HPT_LEAN_SET (defined by a translation unit before this header): build configurations 0, 5 and 6 only — 1 and 2 run as 0, 3 as 5, 4 as 6.
-// The extension set's kernels are several times the size of the others (texture filtering, bump mapping, shape-set lights); the free-running
-// and plain lock-step schedules have not won a scene since subtree stealing (profiles/r01_ab.md) and are not worth their compile time there.
+// Which configurations a library carries (round 6).  The SHIPPED build compiles three per material set: 5 and 6 (lock step + subtree stealing at four / three waves
+// per SIMD: what the autotuner has picked on every fixture and workload since round 2) and 3 (plain lock step: where a tree is too deep for the stealing walk's LDS
+// rows); 0, 1, 2 and 4 run as 3.  The free-running and early-exit schedules have not won a scene since round 1 — and every kernel nobody runs is surface for the
+// compiler defect of round 5 (profiles/r05_isaemu_root_cause.md: the one site the validated build had WAS in configuration 0, and round 6's first edit of the refill
+// put three more into configurations 0, 1 and 4; scripts/check_exec_restore.py).  -DHPT_ALL_CONFIGS (make variant TAG=allcfg VFLAGS=-DHPT_ALL_CONFIGS) builds all
+// seven as rounds 1-5 shipped them — there the extension units (HPT_LEAN_SET, defined by the translation unit) build 0, 5 and 6: 1 and 2 run as 0, 3 as 5, 4 as 6.
+#ifdef HPT_ALL_CONFIGS
 #ifdef HPT_LEAN_SET
 #define HPT_CFG_ALIAS(c) ((c) == 3 ? 5 : (c) == 4 ? 6 : (c) <= 2 ? 0 : (c))
 #else
 #define HPT_CFG_ALIAS(c) (c)
+#endif
+#else
+#define HPT_CFG_ALIAS(c) ((c) >= 5 ? (c) : 3)
 #endif
 #define HPT_CFG_KERNEL_(MATS, INST, C) hpt_path_kernel<false, INST, MATS, HPT_CFG_WAVES(C), (INST) ? 0 : HPT_CFG_EE(C), HPT_CFG_PHASED(C), false, HPT_CFG_STEAL(C)>
 #define HPT_CFG_KERNEL(MATS, INST, C) HPT_CFG_KERNEL_(MATS, INST, HPT_CFG_ALIAS(C))

@@ -38,27 +38,29 @@
 
 #include "hpt_internal.h"
 #include "hpt_kernels.h"
+#include "hpt_rccl_abi.h"
 
 namespace {
 
-// ---- the few RCCL entry points this file needs (rccl.h declarations, resolved at run time) --------------------------------------------
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclFloat32 = 7 };   // ncclDataType_t
-enum { ncclSum = 0 };       // ncclRedOp_t
+// ---- the few RCCL entry points this file needs (hpt_rccl_abi.h: hand-written declarations resolved at run time, checked at build time against
+// <rccl/rccl.h> by hpt_rccl_check.cpp) --------------------------------------------------------------------------------------------------------------
+typedef hpt_nccl_comm_t ncclComm_t;
+typedef hpt_nccl_unique_id ncclUniqueId;
+enum { ncclSuccess = HPT_NCCL_SUCCESS };
+enum { ncclFloat32 = HPT_NCCL_FLOAT32 };   // ncclDataType_t
+enum { ncclSum = HPT_NCCL_SUM };           // ncclRedOp_t
 struct Rccl {
     void *lib = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    hpt_nccl_get_unique_id_fn GetUniqueId = nullptr;
+    hpt_nccl_comm_init_rank_fn CommInitRank = nullptr;
+    hpt_nccl_comm_init_all_fn CommInitAll = nullptr;
+    hpt_nccl_comm_destroy_fn CommDestroy = nullptr;
+    hpt_nccl_comm_count_fn CommCount = nullptr;
+    hpt_nccl_group_fn GroupStart = nullptr, GroupEnd = nullptr;
+    hpt_nccl_send_fn Send = nullptr;
+    hpt_nccl_recv_fn Recv = nullptr;
+    hpt_nccl_reduce_fn Reduce = nullptr;
+    hpt_nccl_get_error_string_fn GetErrorString = nullptr;
 };
 Rccl *rccl() {
     static Rccl r;
@@ -70,7 +72,7 @@ Rccl *rccl() {
         if (r.lib) {
 #define SYM(field, name) *(void **)(&r.field) = dlsym(r.lib, name)
             SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
-            SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+            SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
             SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(Reduce, "ncclReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.Reduce) r.lib = nullptr;
@@ -214,6 +216,9 @@ struct hpt_comm {
     float4 *packed = nullptr; size_t packed_tiles = 0;      // send buffer (peers) / receive buffer for all peers' tiles (root)
     // host-staged transport
     bool host = false; std::string key; uint64_t frame = 0;
+    uint64_t published = 0;                                  // host transport, non-root: the last frame whose bytes were actually published (hpt_comm_destroy waits for ITS acknowledgement)
+    // what the last exchange was (hpt_comm_info): its duration on the stream between two events, and the peers rank 0 took records from
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timed = false; int peers_last = 0;
     std::vector<HostBox> boxes;                              // non-root: [0] = its own mailbox; root: one per peer (index peer - 1)
     void *d_stage = nullptr; size_t d_stage_bytes = 0;       // root, wide filter: a peer's film on the device while it is added
 };
@@ -267,8 +272,11 @@ extern "C" void hpt_comm_destroy(hpt_comm *c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     // host transport, non-root: the mailbox is unlinked only when rank 0 has taken the last frame published in it — a rank that exchanged once and
     // left at once used to remove the name before rank 0 had opened it, and rank 0 then span until "no mailbox" 
-    if (c->host && c->rank != 0 && c->frame > 0 && !c->boxes.empty() && c->boxes[0].map)
-        (void)host_wait(c->boxes[0].hdr()->ack, c->frame, comm_timeout_s());
+    // (the wait is for the last frame PUBLISHED — a host_send that failed before publishing used to cost a second full timeout here)
+    if (c->host && c->rank != 0 && c->published > 0 && !c->boxes.empty() && c->boxes[0].map)
+        (void)host_wait(c->boxes[0].hdr()->ack, c->published, comm_timeout_s());
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (HostBox &b : c->boxes) b.close_box();
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     delete c;
@@ -285,6 +293,7 @@ static int host_send(hpt_comm *c, const void *d_src, size_t bytes, hipStream_t s
     if (bytes) HIP_OK(hipMemcpy(b.payload(), d_src, bytes, hipMemcpyDeviceToHost));
     b.hdr()->bytes.store(bytes, std::memory_order_relaxed);
     b.hdr()->seq.store(f, std::memory_order_release);
+    c->published = f;
     return HPT_OK;
 }
 template <class F> static int host_recv_all(hpt_comm *c, F &&per_peer) {
@@ -315,9 +324,40 @@ template <class F> static int host_recv_all(hpt_comm *c, F &&per_peer) {
 
 // The end-of-frame film exchange on `stream` (the stream the shard was rendered on; asynchronous, like an RCCL call).
 // d_film: this rank's x_count * y_count * 4 floats; on rank 0 it holds the whole frame afterwards.
+static int comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film, void *stream_v, int wide_filter);
 extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film, void *stream_v, int wide_filter) {
     if (!c || !rd || !d_film) { hpt_set_error("null argument"); return HPT_E_INVALID; }
     if (c->world == 1) return HPT_OK;
+    // the exchange between two events on its stream: hpt_comm_info reports the last one's duration (pack + transfer + unpack as the device saw them)
+    HIP_OK(hipSetDevice(c->device));
+    if (!c->ev0) { HIP_OK(hipEventCreate(&c->ev0)); HIP_OK(hipEventCreate(&c->ev1)); }
+    c->timed = false; c->peers_last = 0;
+    HIP_OK(hipEventRecord(c->ev0, (hipStream_t)stream_v));
+    const int rc = comm_exchange_film(c, rd, d_film, stream_v, wide_filter);
+    if (rc != HPT_OK) return rc;
+    HIP_OK(hipEventRecord(c->ev1, (hipStream_t)stream_v));
+    c->timed = true;
+    return HPT_OK;
+}
+// What the communicator is and what its last exchange did (bench.py's `rccl_ranks` / `exchange_ms`: a driver must be able to tell an 8-rank RCCL gather
+// from anything else).  *ranks: ncclCommCount of the RCCL communicator (host transport: the world size the id was created for); *transport: 0 RCCL, 1 the
+// host-staged one-device dry run; *peers: ranks whose records rank 0 received in the last exchange (world - 1 when every shard owns a tile; 0 on other
+// ranks); *exchange_ms: duration of the last exchange on its stream (waits for it; < 0: none yet).  Any pointer may be NULL.
+extern "C" int hpt_comm_info(hpt_comm *c, int *ranks, int *transport, int *peers, float *exchange_ms) {
+    if (!c) { hpt_set_error("null argument"); return HPT_E_INVALID; }
+    if (ranks) {
+        *ranks = c->world;
+        if (!c->host && c->comm) { Rccl *r = rccl(); int n = 0; if (!r || !r->CommCount) { hpt_set_error("ncclCommCount is not available"); return HPT_E_NODEVICE; } NCCL_OK(r->CommCount(c->comm, &n)); *ranks = n; }
+    }
+    if (transport) *transport = c->host ? 1 : 0;
+    if (peers) *peers = c->peers_last;
+    if (exchange_ms) {
+        *exchange_ms = -1.f;
+        if (c->timed) { HIP_OK(hipSetDevice(c->device)); HIP_OK(hipEventSynchronize(c->ev1)); HIP_OK(hipEventElapsedTime(exchange_ms, c->ev0, c->ev1)); }
+    }
+    return HPT_OK;
+}
+static int comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, void *d_film, void *stream_v, int wide_filter) {
     Rccl *r = c->host ? nullptr : rccl();
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_OK(hipSetDevice(c->device));
@@ -334,6 +374,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
             c->d_stage_bytes = n_floats * sizeof(float);
         }
         return host_recv_all(c, [&](int, const char *payload, size_t bytes) -> int {
+            ++c->peers_last;
             if (bytes != n_floats * sizeof(float)) { hpt_set_error("hpt_comm (host transport): a peer's film has %zu bytes, expected %zu", bytes, n_floats * sizeof(float)); return HPT_E_INVALID; }
             HIP_OK(hipMemcpyAsync(c->d_stage, payload, bytes, hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(hpt_film_add_kernel, dim3(1024), dim3(256), 0, stream, (float4 *)d_film, (const float4 *)c->d_stage, n_floats / 4);
@@ -343,6 +384,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
     }
     if (wide_filter) {                                   // partial sums over the whole frame: one sum-reduce to rank 0
         NCCL_OK(r->Reduce(d_film, d_film, n_floats, ncclFloat32, ncclSum, 0, c->comm, stream));
+        if (c->rank == 0) c->peers_last = c->world - 1;
         return HPT_OK;
     }
     const int n_stx = (rd->x_count + 31) / 32, n_sty = (rd->y_count + 31) / 32, n_tiles = n_stx * n_sty;
@@ -369,6 +411,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
             const int n = local_tiles(n_tiles, p, c->world);
             if (bytes != (size_t)n * HPT_TILE_PX * sizeof(float4)) { hpt_set_error("hpt_comm (host transport): rank %d sent %zu bytes for %d tiles", p, bytes, n); return HPT_E_INVALID; }
             if (n > 0) HIP_OK(hipMemcpy(c->packed + off * HPT_TILE_PX, payload, bytes, hipMemcpyHostToDevice));
+            if (n > 0) ++c->peers_last;
             off += (size_t)n;
             return HPT_OK;
         });
@@ -377,7 +420,7 @@ extern "C" int hpt_comm_exchange_film(hpt_comm *c, const hpt_render_desc *rd, vo
         NCCL_OK(r->GroupStart());
         for (int p = 1; p < c->world; ++p) {
             const int n = local_tiles(n_tiles, p, c->world);
-            if (n > 0) NCCL_OK(r->Recv(c->packed + off * HPT_TILE_PX, (size_t)n * HPT_TILE_PX * 4, ncclFloat32, p, c->comm, stream));
+            if (n > 0) { NCCL_OK(r->Recv(c->packed + off * HPT_TILE_PX, (size_t)n * HPT_TILE_PX * 4, ncclFloat32, p, c->comm, stream)); ++c->peers_last; }
             off += (size_t)n;
         }
         NCCL_OK(r->GroupEnd());

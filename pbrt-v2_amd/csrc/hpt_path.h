@@ -73,7 +73,11 @@ struct WorkCounters { uint64_t samples, closest, shadow, nodes, tris, bad; };
 
 // ---- film -------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
+#ifdef HPT_DBG_NO_FILM_ATOMIC   /* timing-only build (wrong films): what the frame costs without the film's atomics — the sums stay live behind a compare that never holds */
+HPT_FN void film_atomic_add(float *p, float v) { if (v == 123.456f) *p = v; }
+#else
 HPT_FN void film_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+#endif
 HPT_FN void count_bad_sample(unsigned long long *p) { atomicAdd(p, 1ull); }
 #else
 HPT_FN void count_bad_sample(unsigned long long *p) {
@@ -166,6 +170,34 @@ HPT_FN bool item_to_pixel(const RenderParams &rp, int64_t item, int *px, int *py
     if (x >= rp.sx_count || y >= rp.sy_count) return false;
     *px = rp.sx_start + x; *py = rp.sy_start + y;
     return true;
+}
+
+// The same mapping from (pass, item inside the pass) without 64-bit divisions (round 6: the refill's four emulated int64 divisions — ~500 instructions with the
+// handful of lanes being refilled — were 2.8 % of killeroo's vector instructions, profiles/r06_lineprofile_killeroo.md).  inv_nstx = 1.f / n_stx; tile numbers
+// are < 2^24, so the float quotient is off by at most one and one correction step makes it exact.
+HPT_FN bool pass_item_to_pixel(const RenderParams &rp, int pass, int item, float inv_nstx, int *px, int *py, uint32_t *s0) {
+    *s0 = (uint32_t)pass * (uint32_t)rp.chunk;
+    const int k = item >> 10, r = item & 1023;
+    const int st = k * rp.shard_count + rp.shard_rank;
+    if (st >= rp.n_stx * rp.n_sty) return false;
+    int ty = (int)((float)st * inv_nstx), tx = st - ty * rp.n_stx;
+    if (tx < 0) { --ty; tx += rp.n_stx; } else if (tx >= rp.n_stx) { ++ty; tx -= rp.n_stx; }
+    const int micro = r >> 6, p = r & 63;
+    const int x = tx * 32 + (micro & 3) * 8 + (p & 7);
+    const int y = ty * 32 + (micro >> 2) * 8 + (p >> 3);
+    if (x >= rp.sx_count || y >= rp.sy_count) return false;
+    *px = rp.sx_start + x; *py = rp.sy_start + y;
+    return true;
+}
+// floor(a / b) for 0 <= a, 0 < b, with the reciprocal of b as a float handed in (no double-precision division in the kernels: three rounding errors of 2^-24 put the
+// estimate within quotient x 2^-22 of the truth — the quotients here are pass numbers, samples per pixel / chunk —, the loops make it exact whatever it is)
+HPT_FN int64_t div_floor_by(int64_t a, int64_t b, float inv_b, int64_t *rem) {
+    int64_t q = (int64_t)((float)a * inv_b);
+    int64_t r = a - q * b;
+    while (r < 0) { --q; r += b; }
+    while (r >= b) { ++q; r -= b; }
+    *rem = r;
+    return q;
 }
 
 // Sampler "halton" (HPT_SAMPLER_HALTON_HASH): samples belong to a WINDOW — here a cell of the global 32x32 raster grid —, not to a pixel.

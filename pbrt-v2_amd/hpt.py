@@ -22,7 +22,7 @@ EXPORTS = [
     "hpt_blob_scene", "hpt_blob_camera", "hpt_blob_render", "hpt_blob_free",
     "hpt_test_intersect", "hpt_test_bsdf", "hpt_test_sampler",
     "hpt_multi_create", "hpt_multi_destroy", "hpt_multi_set_filter", "hpt_multi_scene", "hpt_multi_render",
-    "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film",
+    "hpt_comm_unique_id", "hpt_comm_create", "hpt_comm_destroy", "hpt_comm_exchange_film", "hpt_comm_info",
     "hpt_calib_hbm_triad", "hpt_calib_hbm_copy", "hpt_calib_hbm_read", "hpt_kernel_node_bytes", "hpt_scene_set_camera_motion", "hpt_multi_set_camera_motion", "hpt_warmup",
     "hpt_scene_set_sample_table", "hpt_multi_set_sample_table", "hpt_multi_chunks_taken", "hpt_abi_sizes",
 ]
@@ -80,6 +80,7 @@ def lib():
         L.hpt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.hpt_comm_destroy.argtypes = [C.c_void_p]
         L.hpt_comm_exchange_film.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.c_void_p, C.c_int]
+        L.hpt_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
         for f in (L.hpt_calib_hbm_triad, L.hpt_calib_hbm_copy, L.hpt_calib_hbm_read):
             f.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.hpt_abi_sizes.argtypes = [C.c_void_p]
@@ -263,6 +264,13 @@ class Comm:
 
     def exchange_film(self, rd, d_film_ptr, stream=None, wide_filter=False):
         _check(lib().hpt_comm_exchange_film(self.h, C.byref(rd), C.c_void_p(d_film_ptr), C.c_void_p(stream or 0), 1 if wide_filter else 0))
+
+    def info(self):
+        """hpt_comm_info: {"ranks": ncclCommCount (host transport: the world size), "transport": "rccl" | "host", "peers": ranks whose records rank 0
+        received in the last exchange, "exchange_ms": its duration on the stream (waits for it; None: no exchange yet)}"""
+        r, t, p, ms = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(-1.0)
+        _check(lib().hpt_comm_info(self.h, C.byref(r), C.byref(t), C.byref(p), C.byref(ms)))
+        return {"ranks": int(r.value), "transport": "host" if t.value else "rccl", "peers": int(p.value), "exchange_ms": None if ms.value < 0 else float(ms.value)}
 
     def close(self):
         if getattr(self, "h", None):

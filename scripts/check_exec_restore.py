@@ -58,7 +58,8 @@ def device_objects():
 
 
 def _scan_path(p):
-    return scan(disassembly_of(p))
+    d = disassembly_of(p)
+    return scan(d) if d is not None else (0, 0, [])
 
 
 def disassembly_of(path, tmp="/tmp/check_exec_restore"):
@@ -67,9 +68,17 @@ def disassembly_of(path, tmp="/tmp/check_exec_restore"):
     os.makedirs(tmp, exist_ok=True)
     co = path
     if path.endswith(".o") or path.endswith(".so"):
-        fat, co = os.path.join(tmp, os.path.basename(path) + ".fat"), os.path.join(tmp, os.path.basename(path) + ".co")
+        import hashlib
+        tag = hashlib.sha1(os.path.abspath(path).encode()).hexdigest()[:10] + "_" + os.path.basename(path)      # (the Makefile gates objects of several builds in parallel)
+        fat, co = os.path.join(tmp, tag + ".fat"), os.path.join(tmp, tag + ".co")
         subprocess.check_call([OBJCOPY, "-O", "binary", "--only-section=.hip_fatbin", path, fat])
-        subprocess.check_call([BUNDLER, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
+        if os.path.getsize(fat) == 0:
+            return None                                      # an object without device code (host-only translation unit)
+        r = subprocess.run([BUNDLER, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"], capture_output=True, text=True)
+        if r.returncode != 0:
+            if "Can't find bundles" in r.stderr:
+                return None                                  # a fat binary without a gfx950 code object: nothing to scan
+            raise RuntimeError(r.stderr)
     return subprocess.Popen([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True).stdout
 
 
@@ -187,7 +196,11 @@ def main():
     paths = sys.argv[1:] or device_objects()
     bad = 0
     for p in paths:
-        nf, ni, found = scan(disassembly_of(p))
+        d = disassembly_of(p)
+        if d is None:
+            print("%-40s no gfx950 code" % os.path.basename(p))
+            continue
+        nf, ni, found = scan(d)
         defects = [f for f in found if f[-1].startswith("DEFINES")]
         print("%-40s %4d functions, %8d instructions: %d vector-register writes above an EXEC restore, %d of them definitions the skipped lanes miss" % (os.path.basename(p), nf, ni, len(found), len(defects)))
         for name, label, a, t, ra, rt, verdict in found:

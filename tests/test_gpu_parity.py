@@ -76,11 +76,13 @@ def test_every_render_checks_sample_conservation(cases, dev, monkeypatch):
             _, st = dev[name].render(s.camera, rd)
             assert st.camera_samples == n and st.tune_cfg == cfg
     monkeypatch.setenv("HPT_TUNE", "5")
+    monkeypatch.setenv("HPT_TEST_HOOKS", "1")
     monkeypatch.setenv("HPT_TEST_CONSERVATION_DELTA", "1")
     with pytest.raises(hpt.HptError) as e:
         dev["env"].render(cases["env"].camera, hash_rd(cases["env"], seed=3))
     assert "sample conservation" in str(e.value) and "configuration 5" in str(e.value) and str(hpt.E_INTERNAL) in str(e.value)
     monkeypatch.delenv("HPT_TEST_CONSERVATION_DELTA")
+    monkeypatch.delenv("HPT_TEST_HOOKS")
     _, st = dev["env"].render(cases["env"].camera, hash_rd(cases["env"], seed=3))
     assert st.bad_samples == 0
 

@@ -136,7 +136,7 @@ def test_interpreter_does_64_bit_integers_and_strided_global_memory(tmp_path):
 @needs_build
 @pytest.mark.parametrize("unit,symbol,kid,case,n", [
     ("basic", R.kernel_symbol(False, False, 1, 4, 0, True, False, True), w.K_BASIC_STEAL, "cfg1", 8),       # killeroo's kernel (configuration 5)
-    ("basic", R.kernel_symbol(False, False, 1, 4, 0, False, False, False), w.K_FREE, "envmap", 12),        # the one kernel round 5 rebuilt (configuration 0), on the code the site was in
+    ("basic", R.kernel_symbol(False, False, 1, 4, 0, True, False, False), w.K_LOCKSTEP, "envmap", 12),     # configuration 3: the one kernel without stealing the library still ships (trees too deep for the stealing rows)
     ("ext_i", CFG6_INST_EXT, w.K_STEAL, "aquad", 8),                                                        # the instantiation that was wrong in round 5's builds
     ("measured", R.kernel_symbol(False, False, 3, 4, 0, True, False, True), w.K_MEASURED_STEAL, "b8", 8),   # bunny's kernel — the headline (with its out-of-line kd-tree walk)
     ("lean", R.kernel_symbol(False, False, 61, 4, 0, True, False, True), w.K_LEAN_STEAL, "metal", 8),       # metal.pbrt's kernel
