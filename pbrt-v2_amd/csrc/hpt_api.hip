@@ -1019,8 +1019,11 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
         // (iterations, lanes in the node half, leaf phases, lanes in them, busy lanes) — the failure record of the debug build is free in a timers build
         const unsigned long long *d64 = (const unsigned long long *)h_scr.dbg;
         fprintf(stderr, "hpt phase lane-clocks: %llu %llu %llu %llu %llu %llu\n", d64[0], d64[1], d64[2], d64[3], d64[4], d64[5]);
-        fprintf(stderr, "hpt walk counts (extension | light: iterations, node lanes, leaf phases, leaf lanes, busy lanes): %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu\n",
-                d64[6], d64[7], d64[8], d64[9], d64[10], d64[11], d64[12], d64[13], d64[14], d64[15]);
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long *w = d64 + 6 + 13 * k;
+            fprintf(stderr, "hpt walk counts %s: iterations %llu, node lanes %llu, leaf phases %llu, leaf lanes %llu, busy lanes %llu, idle lanes %llu, steals %llu, spare entries %llu, walks %llu, iterations with <= 8 / 16 / 32 busy lanes %llu %llu %llu, pairs %llu\n",
+                    k ? "light" : "extension", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]);
+        }
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -60,7 +60,7 @@ namespace hpt {
 // not trap (a trapped wave tells nothing): the FIRST failure's code and four values go into a 16-word record of the frame's scratch block
 // (PathKernelArgs::dbg -> RenderScratch::dbg), word 15 counts all failures, the offending index is clamped by the caller where it can be, the
 // kernel runs on, and hpt_render_device returns HPT_E_INTERNAL with the record in the message.  Production builds compile the checks away.
-#define HPT_DBG_WORDS 32
+#define HPT_DBG_WORDS 64
 enum {  // check codes (hpt_render_device prints the name)
     HPT_CK_STACK_ROW = 1,      // a walk-stack write / read outside the rows the lane owns          v: sp, limit, sb, node
     HPT_CK_STACK_NEG = 2,      // a negative stack pointer                                          v: sp, sb, fl, node
@@ -636,7 +636,7 @@ HPT_FN Xf anim_interpolate(const hpt_instance &in, float time, bool want_inverse
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
 struct TravCounters { uint32_t nodes, tris; unsigned long long leaf_clocks = 0, step_clocks = 0; uint32_t leaf_lanes = 0, steps = 0; };
 #elif defined(HPT_PHASE_TIMERS)   /* the pilot of round 6: wave-uniform counts of the stealing walk — iterations, lanes in the node half, leaf phases, lanes in them, busy lanes — per kind of phase (0 extension, 1 light) */
-struct TravCounters { uint32_t nodes, tris; unsigned long long wk[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; };
+struct TravCounters { uint32_t nodes, tris; unsigned long long wk[2][13] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}; };   // + idle lanes, steals, spare stack entries on offer, walks, iterations with <= 8 / 16 / 32 busy lanes, (ray, triangle) pairs, pair rounds
 #else
 struct TravCounters { uint32_t nodes, tris; };
 #endif
@@ -656,6 +656,10 @@ HPT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
     *tentry = tnear;
     return fmaxf(tnear, ray.mint) <= fminf(tfar, ray.maxt);
 }
+
+// (Round 6 tried the four-wide nodes as (lo, hi) PAIRS per axis, the slab test's subtractions and multiplications as v_pk_add_f32 / v_pk_mul_f32 — 24 fewer vector
+//  instructions a node step.  No gain: a packed f32 instruction takes 4 clocks, the two scalar ones it replaces 2 each (profiles/r02j_valu_rate.md), and the 64-bit register
+//  pairs cost the allocator: same-box bunny -5 %, anim -5 % (scratch 168 -> 536 B), killeroo and the soup unchanged — profiles/r06_ab.md, run C.)
 
 #define HPT_TRAV_EMPTY ((int32_t)0x80000000)
 

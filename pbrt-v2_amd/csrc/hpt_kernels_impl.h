@@ -232,6 +232,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
     // (their next node is a leaf too, or their walk is over), or nobody can walk.  Testing a leaf later only delays the shrinking of
     // the ray (a few more nodes visited); the nearest hit is the same up to exact ties.
     int32_t pend = HPT_TRAV_EMPTY;
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS != 3
+    cnt->wk[light ? 1 : 0][8] += 1ull;
+#endif
     for (;;) {
         HPT_TS_SETLIM(ts, aux - sb);
         // ---- a leaf of the top-level tree: enter the instance / return to the world (hpt_device.h, top_special_leaf) — once no ordinary leaf
@@ -250,7 +253,8 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         cnt->steps++;
 #endif
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS != 3
-        { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; wk_[0] += 1ull; wk_[1] += (unsigned long long)__popcll(__ballot(ts.node >= 0)); wk_[4] += (unsigned long long)__popcll(mbusy); }
+        { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; const int nb_ = __popcll(mbusy); wk_[0] += 1ull; wk_[1] += (unsigned long long)__popcll(__ballot(ts.node >= 0)); wk_[4] += (unsigned long long)nb_;
+          wk_[9] += nb_ <= 8 ? 1ull : 0ull; wk_[10] += nb_ <= 16 ? 1ull : 0ull; wk_[11] += nb_ <= 32 ? 1ull : 0ull; }
 #endif
         if (ts.node >= 0) trav_node4<COUNT>(nodes, ts, r, stack + sb * HPT_BLOCK, HPT_BLOCK, cnt, cap_normal - sb);
         if (pend == HPT_TRAV_EMPTY && trav_is_leaf(ts.node) && !(INST && TOP && leaf_is_special(ts.node))) { pend = ts.node; trav_pop(ts, stack + sb * HPT_BLOCK, HPT_BLOCK); }
@@ -287,6 +291,9 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                         const int pbase = __popcll(mh & lt) + __popcll(q0 & lt) + 2 * __popcll(q1 & lt) + 4 * __popcll(q2 & lt);
                         const int total = nh + __popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2);
                         const int word = lane | (owner << 6) | (ts.anyhit ? 1 << 12 : 0);
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS != 3
+                        { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; wk_[12] += (unsigned long long)total; }
+#endif
                         for (int base = 0; base < total; base += 64) {
                             if (has) for (int k = 0; k <= c1; ++k) { const int j = pbase + k - base; if (j >= 0 && j < 64) HPT_AUX(aux, j) = word | (k << 13); }
                             HPT_WAVE_SYNC();
@@ -409,6 +416,17 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
         const unsigned long long mi = __ballot(idle), md = __ballot(donor);
         int n = __popcll(mi);
         const int nd = __popcll(md);
+#if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS != 3
+        { unsigned long long *wk_ = cnt->wk[light ? 1 : 0]; wk_[5] += (unsigned long long)n; wk_[6] += (unsigned long long)(nd < n ? nd : n);
+          unsigned long long spare_ = 0ull; for (int b_ = 0; b_ < 6; ++b_) spare_ += (unsigned long long)__popcll(__ballot(donor && ((ts.sp >> b_) & 1) != 0)) << b_; wk_[7] += spare_; }
+#endif
+        // What round 6 tried in this walk and did not keep (same-box A/B, profiles/r06_ab.md; the code: profiles/r06_one_walk_and_adoption_attempt.patch):
+        //  * SEVERAL entries a donor and step (up to ceil(idle / donors) <= 7 from the bottom of its stack; the tails have 36 idle lanes a step, 21 stacked entries on offer, 3.9
+        //    taken): killeroo -4.4 %, bunny -2.1 %, soup -1.9 % — subtrees the owner's nearer hit would have culled are walked speculatively, every thief costs a publish;
+        //  * the CONTINUATION ray of a vertex walked in the same phase as its shadow and MIS rays (one walk a vertex): 8.6 % fewer steps (a lane walks its rays one after the
+        //    other: the merged walk lasts about as long as the two it replaces), 464 instead of 228 B of scratch: killeroo -13 %, bunny -18 %;
+        //  * idle lanes ADOPTING the MIS ray a lane still busy with its shadow ray has not begun: +2.8 % on killeroo over the same walk without it — and that walk, re-written
+        //    to carry a kind per ray, was 3-6 % slower than this one (register allocation).
         if (nd < n) n = nd;
         if (n == 0) continue;
         const int ri = __popcll(mi & lt), rd = __popcll(md & lt);
@@ -821,7 +839,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #if HPT_PHASE_TIMERS != 3 && HPT_PHASE_TIMERS != 2
         unsigned long long *d64 = (unsigned long long *)a.dbg;      // (the debug build's failure record is free in a timers build: 16 x 64 bits)
         for (int i = 0; i < 6; ++i) atomicAdd(d64 + i, ptl[i]);
-        for (int i = 0; i < 5; ++i) { atomicAdd(d64 + 6 + i, tc.wk[0][i]); atomicAdd(d64 + 11 + i, tc.wk[1][i]); }
+        for (int i = 0; i < 13; ++i) { atomicAdd(d64 + 6 + i, tc.wk[0][i]); atomicAdd(d64 + 19 + i, tc.wk[1][i]); }
 #endif
     }
 #endif

@@ -81,7 +81,7 @@ def main():
     addrs = sorted(stat)
     symb = symbolize(co, addrs)
     total = sum(e[0] for e in stat.values()); tv = sum(e[1] for e in stat.values()); tl = sum(e[2] for e in stat.values())
-    by_sec, by_fn, by_line, by_src = {}, {}, {}, {}
+    by_sec, by_fn, by_line, by_src, by_walk = {}, {}, {}, {}, {}
     for a in addrs:
         names, lines = symb.get(a, (["?"], ["?"]))
         # the section: the frame directly under the kernel (outermost is the kernel itself); code of the kernel body proper: "(loop)"
@@ -95,6 +95,12 @@ def main():
         e = stat[a]
         src = re.sub(r"^.*/", "", lines[0]) if lines else "?"
         src = re.sub(r":\d+$", "", src)                        # file:line (the column dropped)
+        # the line of the WALK this instruction belongs to: the frame of traverse_steal (inlined callees count at their call site)
+        if "traverse_steal" in chain:
+            wl = re.sub(r"^.*/", "", lines[chain.index("traverse_steal")]) if len(lines) > chain.index("traverse_steal") else "?"
+            wl = re.sub(r":\d+$", "", wl)
+            r = by_walk.setdefault(wl, [0, 0, 0])
+            r[0] += e[0]; r[1] += e[1]; r[2] += e[2]
         for d, k in ((by_sec, sec), (by_fn, chain[0] if chain else "?"), (by_line, (sec, sub)), (by_src, (src, chain[0] if chain else "?"))):
             r = d.setdefault(k, [0, 0, 0])
             r[0] += e[0]; r[1] += e[1]; r[2] += e[2]
@@ -115,6 +121,14 @@ def main():
     out += ["", "## by source line (innermost frame; the 40 heaviest)", "", "| file:line (function) | VALU share | lanes | lost |", "|---|---:|---:|---:|"]
     for k, r in sorted(by_src.items(), key=lambda kv: -kv[1][1])[:40]:
         out.append("| `%s` (`%s`) | %.2f %% | %.0f %% | %.2f %% |" % (k[0], k[1], 100.0 * r[1] / tv, 100.0 * r[2] / (64.0 * max(r[1], 1)), 100.0 * (r[1] - r[2] / 64.0) / tv))
+    out += ["", "## the walk (`traverse_steal`) by its own source line — inlined callees (`trav_node4`, `tri_test`, `trav_begin` ...) counted at their call site; `all` = share of ALL issued instructions", "",
+            "| line of hpt_kernels_impl.h | all instr. | VALU share | lanes |", "|---|---:|---:|---:|"]
+    def lno(k):
+        m = re.search(r":(\d+)$", k)
+        return int(m.group(1)) if m else 0
+    for k, r in sorted(by_walk.items(), key=lambda kv: lno(kv[0])):
+        if r[0] * 500 < total: continue
+        out.append("| `%s` | %.2f %% | %.2f %% | %.0f %% |" % (k, 100.0 * r[0] / total, 100.0 * r[1] / tv, 100.0 * r[2] / (64.0 * max(r[1], 1))))
     p = os.path.join(ROOT, "profiles", "r06_lineprofile_%s.md" % name)
     open(p, "w").write("\n".join(out) + "\n")
     print("\n".join(out))

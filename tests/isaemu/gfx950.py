@@ -579,6 +579,7 @@ SOP1 = {
     "s_brev_b32": (32, lambda w, a: (_brev32(a), None)), "s_bcnt1_i32_b32": (32, lambda w, a: (bin(a).count("1"), int(a != 0))), "s_bcnt1_i32_b64": (6400, lambda w, a: (bin(a).count("1"), int(a != 0))),
     "s_bcnt0_i32_b64": (6400, lambda w, a: (64 - bin(a).count("1"), int(a != M64))),
     "s_ff1_i32_b32": (32, lambda w, a: (_ff1(a) & M32, None)), "s_ff1_i32_b64": (6400, lambda w, a: (_ff1(a) & M32, None)),
+    "s_flbit_i32": (32, lambda w, a: (_ffbh((a ^ M32) if a & 0x80000000 else a, 32) & M32, None)),      # first bit that differs from the sign bit, from the MSB (-1: none)
     "s_flbit_i32_b32": (32, lambda w, a: (_ffbh(a, 32) & M32, None)), "s_flbit_i32_b64": (6400, lambda w, a: (_ffbh(a, 64) & M32, None)),
     "s_sext_i32_i8": (32, lambda w, a: (((a & 0xff) ^ 0x80) - 0x80 & M32, None)), "s_sext_i32_i16": (32, lambda w, a: (((a & 0xffff) ^ 0x8000) - 0x8000 & M32, None)),
     "s_abs_i32": (32, lambda w, a: (abs(_sx32(a)) & M32, int(a != 0))),
@@ -828,7 +829,7 @@ VOP = {
     "v_alignbit_b32": lambda a, b, c: (((_u64(a) << U64(32)) | _u64(b)) >> (_u64(c) & U64(31))).astype(U32),
     "v_alignbyte_b32": lambda a, b, c: (((_u64(a) << U64(32)) | _u64(b)) >> (U64(8) * (_u64(c) & U64(3)))).astype(U32),
     "v_perm_b32": None,
-    "v_ffbh_u32": lambda a: _ffbh_u32(a), "v_ffbl_b32": lambda a: _ffbl_b32(a), "v_bfrev_b32": lambda a: _bfrev(a), "v_bcnt_u32_b32": lambda a, b: _popc(a) + _arr(b),
+    "v_ffbh_u32": lambda a: _ffbh_u32(a), "v_ffbh_i32": lambda a: _ffbh_u32(np.where((_arr(a) & U32(0x80000000)) != 0, ~_arr(a), _arr(a))), "v_ffbl_b32": lambda a: _ffbl_b32(a), "v_bfrev_b32": lambda a: _bfrev(a), "v_bcnt_u32_b32": lambda a, b: _popc(a) + _arr(b),
     "v_mbcnt_lo_u32_b32": lambda a, b: _popc(_arr(a) & ((U64(1) << np.minimum(LANES, U64(32))) - U64(1)).astype(U32)) + _arr(b),
     "v_mbcnt_hi_u32_b32": lambda a, b: _popc(_arr(a) & ((U64(1) << (np.maximum(LANES, U64(32)) - U64(32))) - U64(1)).astype(U32)) + _arr(b),
     "v_sad_u32": lambda a, b, c: np.where(_arr(a) > _arr(b), _arr(a) - _arr(b), _arr(b) - _arr(a)) + _arr(c),
