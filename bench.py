@@ -379,8 +379,9 @@ def pmc_live(workload, spp, timeout_s=240):
     """HBM-side bytes and VALU figures of the path kernel, collected NOW: one rocprofv3 --kernel-trace --pmc pass per counter group
     (separate passes, kernel trace only — MI355X_MICROARCH.md's HBM recipe) around a child `bench.py --workload W --steps 1` of the same
     frame.  FETCH_SIZE / WRITE_SIZE are KiB; corrections as profiles/r02_fetch_calibration.md measured them for this kernel's access
-    patterns (lane-scattered 64-B node fetches x1.0, coalesced scratch reloads counted at half, writes x1.0, all of them scratch):
-    read bytes = FETCH_SIZE + WRITE_SIZE / 2.  Returns {} with "error" when rocprofv3 is unavailable or a pass fails."""
+    patterns (lane-scattered 64-B node fetches x1.0, coalesced scratch reloads counted at half, writes x1.0): read bytes = FETCH_SIZE + WRITE_SIZE / 2.
+    The writes are NOT all scratch (what rounds 2-5 said): every film atomic is a memory-side atomic that WRITE_SIZE counts with >= 32 B
+    (scripts/calib/calib_atomic.hip, profiles/r06_ab.md run A) — measure() splits them.  Returns {} with "error" when rocprofv3 is unavailable or a pass fails."""
     import csv
     import glob
     import shutil
@@ -625,6 +626,17 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                            "scene_bytes_in_hbm": int(info.total_device_bytes),
                            "numerator": "reference algorithm on the reference's tree, counted by the oracle in this run (work.reference)"}
         out["roofline"]["achieved_peak_by"] = {k: _CALIB.get(k) for k in ("copy", "triad", "read")}
+        if out["roofline"].get("traffic_write_bytes"):
+            # Who writes (profiles/r06_ab.md run A): a work item adds itself to its film pixel with four float atomics — a frame of >= 32 M camera samples
+            # runs one-sample items (hpt_api.hip) — and every one is a memory-side atomic that WRITE_SIZE counts with 32 B when scattered (calibrated); the rest is the
+            # kernel's scratch (register spills).  The A/B at HPT_CHUNK=64 (8 M atomics instead of 531 M) puts the film's share higher still: 55 % (bunny) / 72 % (killeroo).
+            chunk = 1 if per_launch_samples >= (32 << 20) else min(int(rd.spp), 64)
+            if os.environ.get("HPT_CHUNK", "").isdigit() and int(os.environ["HPT_CHUNK"]) > 0:
+                chunk = int(os.environ["HPT_CHUNK"])
+            n_atomics = 4.0 * per_launch_samples / chunk
+            film = min(32.0 * n_atomics, out["roofline"]["traffic_write_bytes"])
+            out["roofline"]["traffic_write_split"] = {"film": round(film), "scratch": round(out["roofline"]["traffic_write_bytes"] - film), "film_atomics": round(n_atomics),
+                                                      "basis": "film = 4 float atomics per work item (%d sample(s) an item) x 32 B of WRITE_SIZE per scattered memory-side atomic (scripts/calib/calib_atomic.hip); scratch = the rest" % chunk}
         if out["roofline"]["traffic"]:
             # what the hardware actually moved: counter bytes (L2 <-> fabric, incl. register spills) / kernel time / 8 TB/s — the honest HBM figure beside the algorithmic index
             out["roofline"]["hbm_real_GBs"] = round(out["roofline"]["traffic"] / (k_ms * 1e-3) / 1e9, 1)
@@ -674,6 +686,8 @@ def _roofline_compact(r):
         out["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
     if r.get("traffic_write_bytes") is not None:
         out["traffic_write_bytes"] = _num(r["traffic_write_bytes"])
+    if r.get("traffic_write_split"):
+        out["traffic_write_bytes_film"], out["traffic_write_bytes_scratch"] = r["traffic_write_split"]["film"], r["traffic_write_split"]["scratch"]
     out["traffic_source"] = _short(r.get("traffic_source"), 60) if r.get("traffic_source") else None
     return out
 

@@ -4,5 +4,8 @@
 #define HPT_LEAN_SET 1
 #include "hpt_kernels_impl.h"
 namespace hpt {
+// (the kernels of the other parts of this unit: hpt_kernels_ext_p*.hip)
+HPT_PART2_KERNELS(extern, MATS_FULL, false)
+HPT_PART3_KERNELS(extern, MATS_FULL, false)
 HPT_DEFINE_PATH_LAUNCHER(ext, MATS_FULL, false)
 }

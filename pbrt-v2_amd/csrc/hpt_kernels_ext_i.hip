@@ -4,5 +4,9 @@
 #define HPT_LEAN_SET 1
 #include "hpt_kernels_impl.h"
 namespace hpt {
+// (the kernels of the other parts of this unit: hpt_kernels_ext_i_p*.hip)
+HPT_PART1_KERNELS(extern, MATS_FULL)
+HPT_PART2_KERNELS(extern, MATS_FULL, true)
+HPT_PART3_KERNELS(extern, MATS_FULL, true)
 HPT_DEFINE_PATH_LAUNCHER(ext_i, MATS_FULL, true)
 }

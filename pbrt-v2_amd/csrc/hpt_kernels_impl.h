@@ -895,6 +895,26 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
 #define HPT_DL_KERNEL(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true>
 #define HPT_DL_KERNEL_W(MATS, INST, COUNT) hpt_path_kernel<COUNT, INST, MATS, HPT_DL_WAVES, 0, true, true, true, true>
 
+// A material set's kernels in SEVERAL translation units (round 6: build time — the instanced extension unit alone compiled for 5-8 minutes, longer than the other fifteen units
+// together on eight cores).  The unit that defines the launcher (hpt_kernels_<set>.hip) declares the kernels of its other parts `extern template`, so it references their
+// handles without compiling them; hpt_kernels_<set>_p1.hip / _p2.hip instantiate them explicitly (same template, same per-unit compiler flags).  Part 1: the kernels that walk
+// from the top-level tree (instanced units only); parts 2 and 3: the window samplers' kernels and the direct-lighting integrator's (the units that are not split further compile both lists in their part 2).  X = `extern` (launcher unit) or nothing (the part).
+#define HPT_K_(X, ...) X template __global__ void hpt_path_kernel<__VA_ARGS__>(const PathKernelArgs);
+#define HPT_PART1_KERNELS(X, MATS)                                                                  \
+    HPT_K_(X, true, true, MATS, HPT_COUNT_WAVES, 0, true, false, true, false, true)                 \
+    HPT_K_(X, false, true, MATS, 4, 0, true, false, true, false, true)                              \
+    HPT_K_(X, false, true, MATS, HPT_W34, 0, true, false, true, false, true)                        \
+    HPT_K_(X, true, true, MATS, HPT_DL_WAVES, 0, true, true, true, false, true)                     \
+    HPT_K_(X, false, true, MATS, HPT_DL_WAVES, 0, true, true, true, false, true)
+#define HPT_PART2_KERNELS(X, MATS, INSTV)                                                           \
+    HPT_K_(X, true, INSTV, MATS, HPT_COUNT_WAVES, 0, true, false, true, true)                       \
+    HPT_K_(X, false, INSTV, MATS, 4, 0, true, false, true, true)                                    \
+    HPT_K_(X, true, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true)
+#define HPT_PART3_KERNELS(X, MATS, INSTV)   /* (the extension units only: their part 2 alone compiled for five minutes) */ \
+    HPT_K_(X, true, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, true)                           \
+    HPT_K_(X, false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, true)                          \
+    HPT_K_(X, false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true)
+
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS and for scenes with (INSTV = true) or without animated
 // instances — one translation unit each (hpt_kernels_<set>.hip, hpt_kernels_<set>_i.hip): the two halves want different compiler
 // settings (the Makefile schedules the instance-free kernels with -amdgpu-sched-strategy=max-ilp: bunny +2.6 %, soup +2.5 %, killeroo

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scripts/gpu_matrix.py on the CPU, on the BINARIES: the instantiations of the path kernel an instanced scene can run — configuration 0 / 5 / 6, serial visit / top-level walk,
+"""scripts/gpu_matrix.py on the CPU, on the BINARIES: the instantiations of the path kernel an instanced scene can run — configuration 3 / 5 / 6 (what the library ships since round 6), serial visit / top-level walk,
 production / instrumented, direct lighting — taken out of the code objects the build ships (pbrt-v2_amd/build/hpt_kernels_*.o), executed by the gfx950 interpreter of tests/isaemu
 over a crop of each fixture, against the oracle.  profiles/r05_isaemu_matrix.txt.
 
@@ -21,7 +21,7 @@ abi = importlib.import_module("pbrt-v2_amd.abi")
 
 K = R.kernel_symbol
 # (label, unit, symbol, the tests/wavemu kernel id that prepares the same launch)
-PATH_KERNELS = [("cfg 0", "ext_i", K(False, True, 31, 4, 0, False, False, False), w.K_FREE), ("cfg 5", "ext_i", K(False, True, 31, 4, 0, True, False, True), w.K_STEAL),
+PATH_KERNELS = [("cfg 3", "ext_i", K(False, True, 31, 4, 0, True, False, False), w.K_LOCKSTEP), ("cfg 5", "ext_i", K(False, True, 31, 4, 0, True, False, True), w.K_STEAL),
                 ("cfg 6", "ext_i", K(False, True, 31, 3, 0, True, False, True), w.K_STEAL), ("count", "ext_i", K(True, True, 31, 4, 0, True, False, True), w.K_STEAL_COUNT)]
 TOP_KERNELS = [("cfg 5 top", "ext_i", K(False, True, 31, 4, 0, True, False, True, False, True), w.K_STEAL_TOP), ("cfg 6 top", "ext_i", K(False, True, 31, 3, 0, True, False, True, False, True), w.K_STEAL_TOP)]
 DL_KERNELS = [("dl", "ext_i", K(False, True, 31, 3, 0, True, True, True), w.K_DL)]
@@ -45,7 +45,7 @@ def main():
             t = time.time()
             total += 1
             try:
-                f, info = R.BinaryRender(s, R.code_object(os.environ.get("ISAEMU_UNIT_" + unit.upper(), unit)), sym, kid).render(s.camera, rd)      # (ISAEMU_UNIT_EXT_I=<object>: another build of the unit)
+                f, info = R.BinaryRender(s, R.code_object_for(os.environ.get("ISAEMU_UNIT_" + unit.upper(), unit), sym), sym, kid).render(s.camera, rd)      # (ISAEMU_UNIT_EXT_I=<object>: another build of the unit)
             except g.EmuError as e:
                 bad += 1
                 print("%-8s %-10s ERROR %s" % (name, label, str(e)[:300])); sys.stdout.flush(); continue

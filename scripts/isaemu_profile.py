@@ -61,7 +61,7 @@ def main():
             counts[k] = counts.get(k, 0) + 1
             if ins.op.startswith("v_") and not ins.op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
                 lanes[0] += 1; lanes[1] += bin(wv.exec).count("1")
-        f, info = R.BinaryRender(s, R.code_object(unit), sym, kid).render(s.camera, rd, trace=tr)
+        f, info = R.BinaryRender(s, R.code_object_for(unit, sym), sym, kid).render(s.camera, rd, trace=tr)
         total = sum(counts.values())
         rows[name] = (counts, total, lanes[1] / (64.0 * max(lanes[0], 1)), info["samples"])
         for k in counts:

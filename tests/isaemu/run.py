@@ -5,6 +5,7 @@ production-layout flavor (libwavemu_raw.so: hpt_render_device's set-up, the scen
 (pbrt-v2_amd/build/hpt_kernels_<unit>.o) or any other library's."""
 import ctypes as C
 import os
+import re
 import subprocess
 import time
 
@@ -28,6 +29,26 @@ def code_object(unit, out_dir="/tmp/isaemu"):
         subprocess.check_call([OBJCOPY, "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
         subprocess.check_call([BUNDLER, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
     return co
+
+
+def unit_objects(unit):
+    """the objects a kernel unit is compiled into: hpt_kernels_<unit>.o and its parts _p1 / _p2 (round 6: the big units are split for build time)"""
+    if os.path.isabs(unit):
+        stem = unit[:-2] if unit.endswith(".o") else unit
+        cand = [unit] + [stem + s + ".o" for s in ("_p1", "_p2", "_p3")]
+    else:
+        cand = [os.path.join(ROOT, "pbrt-v2_amd", "build", "hpt_kernels_%s%s.o" % (unit, s)) for s in ("", "_p1", "_p2", "_p3")]
+    return [c for c in cand if os.path.exists(c)]
+
+
+def code_object_for(unit, symbol, out_dir="/tmp/isaemu"):
+    """the code object of the unit (or of one of its parts) that DEFINES the kernel `symbol`"""
+    for obj in unit_objects(unit):
+        co = code_object(obj, out_dir)
+        syms = subprocess.run([g.READELF, "-sW", co], check=True, capture_output=True, text=True).stdout
+        if re.search(r" FUNC .* %s\n" % re.escape(symbol), syms):
+            return co
+    raise g.EmuError("kernel %s is in none of %s" % (symbol, unit_objects(unit)))
 
 
 def kernel_symbol(count, inst, mats, waves, ee, phased, dl, steal, win=False, top=False):

@@ -146,7 +146,7 @@ def test_shipped_kernel_binaries_render_the_oracles_film_in_the_interpreter(unit
     s = load_case(case)
     rd = crop(s, n)
     fo, so = orc.OracleScene(s).render(s.camera, rd)
-    f, info = R.BinaryRender(s, R.code_object(unit), symbol, kid).render(s.camera, rd)
+    f, info = R.BinaryRender(s, R.code_object_for(unit, symbol), symbol, kid).render(s.camera, rd)
     rmse, off = compare(f, fo)
     assert info["samples"] == int(so[0]) and info["bad"] == 0 and np.array_equal(f[..., 3], fo[..., 3])
     assert rmse < 1e-5 and off == 0, (rmse, off)
