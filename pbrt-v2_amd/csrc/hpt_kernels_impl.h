@@ -209,6 +209,14 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
 #endif
     HPT_CHECK_FULL_EXEC(1);
     HPT_CHECK(aux >= 8 && cap_normal >= 0, HPT_CK_STACK_ROW, aux, cap_normal, 0, 0);
+    // cooperative leaf phases (below): the kernels without animated instances (-DHPT_NO_COOP_LEAF: none, -DHPT_COOP_LEAF_ALL: all — the A/B controls)
+#if defined(HPT_NO_COOP_LEAF)
+    constexpr bool COOP_LEAF = false;
+#elif defined(HPT_COOP_LEAF_ALL)
+    constexpr bool COOP_LEAF = true;
+#else
+    constexpr bool COOP_LEAF = !INST;
+#endif
     TravState ts;
     Ray r = ray;
     int owner = lane, sb = 0;                                       // whose ray this lane is walking; rows given away from the bottom
@@ -269,12 +277,14 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
             if (mh != 0ull) {
                 const int nb = __popcll(mbusy), nh = __popcll(mh), nblk = __popcll(__ballot(has && ts.node < 0));
                 if (nh * 8 >= nb * leaf_q || nblk * 8 >= nb * block_q || __ballot(ts.node >= 0) == 0ull) {
-#ifdef HPT_NO_COOP_LEAF   /* A/B control: every lane that holds a leaf loops over its own triangles (rounds 2-5) */
+                    // Every lane that holds a leaf loops over its own triangles (rounds 2-5): what the kernels for animated instances still do — there the cooperative
+                    // phase below LOSES (same box, anim: 869 with it against 937 Msamples/s without; 304 against 276 B of scratch — profiles/r06_ab.md, run H).
+                    if constexpr (!COOP_LEAF) {
                     if (has) {
                         if (trav_leaf<COUNT, ALPHA>(sc, tris, ts, r, pend, cnt)) ts.node = HPT_TRAV_EMPTY;      // any-hit ray: occluded
                         pend = HPT_TRAV_EMPTY;
                     }
-#else
+                    } else
                     // ---- COOPERATIVE LEAVES (round 6): the parked leaves' triangles as (ray, triangle) PAIRS dealt out over all 64 lanes --------------
                     // A leaf holds 1-8 triangles and a leaf phase runs with a third of the wave at best: the loop over a lane's own triangles took as long as
                     // the fullest leaf and issued the double-precision triangle test with 17-22 % of the lanes (profiles/r06_lineprofile_*_before.md: 10-18 % of a
@@ -336,7 +346,6 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                         }
                         pend = HPT_TRAV_EMPTY;
                     }
-#endif
 #if defined(HPT_PHASE_TIMERS) && HPT_PHASE_TIMERS == 3
                     cnt->leaf_clocks += __builtin_readcyclecounter() - w1_; cnt->leaf_lanes += (unsigned)nh; cnt->tris++;
 #elif defined(HPT_PHASE_TIMERS)

@@ -5,14 +5,14 @@ set -e
 cd "$(dirname "$0")/../pbrt-v2_amd"
 TAG=$1; shift
 OLD=/tmp/oldsrc_$TAG; rm -rf $OLD; mkdir -p $OLD build/variants
-git -C .. archive HEAD pbrt-v2_amd/csrc include | tar -x -C $OLD
+git -C .. archive ${REV:-HEAD} pbrt-v2_amd/csrc include | tar -x -C $OLD
 OBJS=""
 for u in "$@"; do
   cmd=$(make -n -B build/$u.o | grep hipcc | head -1 | sed "s@csrc/$u.hip@$OLD/pbrt-v2_amd/csrc/$u.hip@; s@-o build/$u.o@-o build/variants/${u}_$TAG.o@")
   echo "$cmd"; eval "$cmd" &
 done
 wait
-ALL="hpt_kernels hpt_kernels_basic hpt_kernels_basic_i hpt_kernels_measured hpt_kernels_measured_i hpt_kernels_all hpt_kernels_all_i hpt_kernels_ext hpt_kernels_ext_i hpt_kernels_lean hpt_wavefront hpt_api hpt_multi hpt_bvh_gpu hpt_calib hpt_blob hpt_bvh hpt_flatten"
+ALL="$(cd build && ls hpt_*.o | sed s/.o$//)"
 for k in $ALL; do
   if [[ " $* " == *" $k "* ]]; then OBJS="$OBJS build/variants/${k}_$TAG.o"; else OBJS="$OBJS build/$k.o"; fi
 done

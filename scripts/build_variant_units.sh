@@ -11,7 +11,7 @@ for u in "$@"; do
   echo "$cmd"; eval "$cmd" &
 done
 wait
-ALL="hpt_kernels hpt_kernels_basic hpt_kernels_basic_i hpt_kernels_measured hpt_kernels_measured_i hpt_kernels_all hpt_kernels_all_i hpt_kernels_ext hpt_kernels_ext_i hpt_kernels_lean hpt_wavefront hpt_api hpt_multi hpt_bvh_gpu hpt_calib hpt_blob hpt_bvh hpt_flatten hpt_rccl_check"
+ALL="$(cd build && ls hpt_*.o | sed s/.o$//)"
 OBJS=""
 for k in $ALL; do
   if [[ " $* " == *" $k "* ]]; then OBJS="$OBJS build/variants/${k}_$TAG.o"; else OBJS="$OBJS build/$k.o"; fi

@@ -3,7 +3,6 @@
 instantiation that was wrong in round 5's builds — taken out of the objects the build has just produced, executed instruction by instruction in the gfx950 interpreter of
 tests/isaemu over an 8 x 8 (12 x 12) crop of a fixture, against the oracle's film.  No GPU; ~40 s on five cores.  __graft_entry__.build() runs it (HPT_BUILD_SKIP_ISAEMU=1 skips it);
 `python scripts/isaemu_gate.py` prints the table and exits non-zero on a film that differs.  Every OTHER shipped kernel: scripts/isaemu_all_kernels.py (20 minutes)."""
-import multiprocessing
 import os
 import sys
 import time
@@ -48,20 +47,35 @@ def run_one(i):
 
 
 def main(raise_on_failure=False):
+    """one child process per kernel (a crash or a hang of one is ITS failure, with a time limit — not a pool that waits for ever), all at once"""
+    import json
+    import subprocess
     n = len(kernels())
     from tests.isaemu import run as R
-    for _, unit, sym, _, _, _ in kernels():      # (unbundle every code object once, here: the workers only read them)
+    for _, unit, sym, _, _, _ in kernels():      # (unbundle every code object once, here: the children only read them)
         R.code_object_for(unit, sym)
-    with multiprocessing.get_context("spawn").Pool(min(n, max(1, (os.cpu_count() or 2) - 1))) as pool:
-        rows = pool.map(run_one, range(n))
-    bad = [r for r in rows if not r[-1]]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--one", str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n)]
+    rows, t0 = [], time.time()
+    for i, pr in enumerate(procs):
+        try:
+            out, err = pr.communicate(timeout=max(1.0, 600.0 - (time.time() - t0)))
+            rows.append(tuple(json.loads(out.strip().splitlines()[-1])) if pr.returncode == 0 else (kernels()[i][0], kernels()[i][1], float("nan"), -1, 0, 0, 0, time.time() - t0, False, err[-300:]))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rows.append((kernels()[i][0], kernels()[i][1], float("nan"), -1, 0, 0, 0, time.time() - t0, False, "timed out"))
+    bad = [r for r in rows if not r[8]]
     print("# kernel, unit, RGB rmse against the oracle, pixels off by > 1e-2, camera samples completed / in the job, bad samples, seconds")
-    for label, unit, rmse, off, ns, nj, nb, dt, ok in rows:
-        print("%-90s %-10s rmse %.2e, %d px off, samples %d/%d, bad %d, %.0f s%s" % (label, unit, rmse, off, ns, nj, nb, dt, "" if ok else "   <-- DIFFERS"))
+    for r in rows:
+        label, unit, rmse, off, ns, nj, nb, dt, ok = r[:9]
+        print("%-90s %-10s rmse %.2e, %d px off, samples %d/%d, bad %d, %.0f s%s" % (label, unit, rmse, off, ns, nj, nb, dt, "" if ok else "   <-- DIFFERS / FAILED %s" % (r[9] if len(r) > 9 else "")))
     if bad and raise_on_failure:
         raise RuntimeError("shipped kernel binaries render a film that differs from the oracle's in the interpreter (scripts/isaemu_gate.py): %s" % [r[0] for r in bad])
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--one":
+        import json
+        print(json.dumps(run_one(int(sys.argv[2]))))
+        sys.exit(0)
     sys.exit(main())
