@@ -416,7 +416,8 @@ def pmc_live(workload, spp, timeout_s=240):
     out.update(meta)
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["write_bytes"] = v["WRITE_SIZE"] * 1024.0
-        out["read_bytes"] = v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0 / 2.0
+        out["fetch_bytes"] = v["FETCH_SIZE"] * 1024.0
+        out["read_bytes"] = v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0 / 2.0      # (every write taken for scratch; measure() corrects it with the film's share)
         out["bytes_per_launch"] = out["read_bytes"] + out["write_bytes"]
     if "SQ_INSTS_VALU" in v:
         out["valu_wave_instructions_per_launch"] = v["SQ_INSTS_VALU"]
@@ -635,6 +636,9 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                 chunk = int(os.environ["HPT_CHUNK"])
             n_atomics = 4.0 * per_launch_samples / chunk
             film = min(32.0 * n_atomics, out["roofline"]["traffic_write_bytes"])
+            if prof.get("fetch_bytes") and out["roofline"].get("traffic"):
+                # (only the SCRATCH writes come back as half-counted reloads; a memory-side film atomic's read of its line is in FETCH_SIZE already)
+                out["roofline"]["traffic"] = (prof["fetch_bytes"] + 1.5 * (prof["write_bytes"] - film / scale) + film / scale) * scale
             out["roofline"]["traffic_write_split"] = {"film": round(film), "scratch": round(out["roofline"]["traffic_write_bytes"] - film), "film_atomics": round(n_atomics),
                                                       "basis": "film = 4 float atomics per work item (%d sample(s) an item) x 32 B of WRITE_SIZE per scattered memory-side atomic (scripts/calib/calib_atomic.hip); scratch = the rest" % chunk}
         if out["roofline"]["traffic"]:

@@ -1157,12 +1157,18 @@ HPT_FN int bg_cell_z(float v) { int c = (int)((v + 1.f) * (.5f * (float)HPT_BG_Z
 // next row of the box when the current range is used up and tests one sample, and, when the pass ends, decides like the reference's
 // loop (reflection.cpp:262-271) whether another pass is needed.  Serial callers loop until done (irreg_eval); the path kernel's
 // wave-cooperative evaluator (hpt_kernels_impl.h) steps 64 walks side by side and hands a lane the next queued query the moment its walk ends.
+#ifndef HPT_KD_G
+#define HPT_KD_G 2        /* lanes a measured-BRDF query is walked on (1, 2 or 4): the ORDER its sums are formed in — the same on every path that evaluates one.  Same box, bunny:
+                             1: 2065, 2: 2132, 4: 2121 Msamples/s; chosen by the queue's fill (2 up to 96 queries, 4 up to 24) 2149 — but then a value's rounding depends on what the
+                             wave happens to hold, and two renders of a frame differ in 1.5 % of the pixels' last bits (profiles/r06_ab.md, runs J / K) */
+#endif
 struct KdWalk {
     f3 q;                 // query point
     float r; int level;   // radius^2 of this pass = .001 * 2^level
     bool last;            // this pass runs at the exact final radius (after a too-high guess)
     int x0, x1, y0, y1, z1;   // cell box of the pass
     int iy, iz;           // row being read
+    int sub, g;           // this walk reads rows sub, sub + g, sub + 2 g, ... of the pass's box (a query on g lanes: round 6; 0 / 1: all rows)
     uint32_t j, jend;     // samples of that row still to test
     const HPT_GLOBAL f4 *samples;    // 32-byte records {p.xyz, v.r | v.g, v.b, 0, 0} in cell order (hpt_flatten.cpp); explicitly global memory:
     const HPT_GLOBAL uint32_t *cells;    // first sample of every cell, + 1 entry                   (inside the out-of-line walk they would be flat loads)
@@ -1179,9 +1185,10 @@ HPT_FN void kd_set_box(KdWalk *w) {
     w->x0 = bg_cell_x(fmaxf(w->q.x - R, 0.f)); w->x1 = bg_cell_x(w->q.x + R);
     w->y0 = bg_cell_y(fmaxf(w->q.y - R, 0.f)); w->y1 = bg_cell_y(w->q.y + R);
     const int z0 = bg_cell_z(fmaxf(w->q.z - R, -1.f)); w->z1 = bg_cell_z(w->q.z + R);
-    w->iy = w->y0 - 1; w->iz = z0; w->j = w->jend = 0u;
+    w->iy = w->y0 - w->g + w->sub; w->iz = z0; w->j = w->jend = 0u;
 }
-HPT_FN void kd_begin(const float *fpool, const hpt_material *m, f3 mpt, KdWalk *w) {
+HPT_FN void kd_begin(const float *fpool, const hpt_material *m, f3 mpt, KdWalk *w, int sub = 0, int g = 1) {
+    w->sub = sub; w->g = g;
     w->samples = (const HPT_GLOBAL f4 *)(fpool + m->kd_data_off);
     w->cells = (const HPT_GLOBAL uint32_t *)(fpool + m->kd_split_off);
     // starting level from the table (bytes, x fastest; z covers [-1,1]); kd_bits_off holds its fpool offset
@@ -1208,16 +1215,18 @@ HPT_FN float kd_weight(float d2) {
     return expf(-100.f * d2);
 #endif
 }
-// One step of the walk.  Returns true when the query is finished: *res = {sum of weight x value, sum of weights} of the samples inside the final
-// radius — IrregIsotropicBRDF::f is kd_result(*res), the division the caller does (the wave-cooperative evaluator: for all of a wave's queries at once).
-// Round 6 (profiles/r06_lineprofile_bunny.md: this function was a quarter of the headline kernel's vector instructions at 8 % of the lanes — every step
+// One step of the walk: the next row of this walk's share of the box when the current range is used up, and one sample.  Returns true when the walk has read its
+// share of the pass: kd_pass_end() then decides — on the sums of ALL the walks of the query (a query on g lanes: the caller adds them up first) — like the reference's
+// loop (reflection.cpp:262-271) whether another pass is needed.
+// Round 6 (profiles/r06_lineprofile_bunny_before.md: this function was a quarter of the headline kernel's vector instructions at 8 % of the lanes — every step
 // ran four blocks one after the other, each with the few lanes that needed it): the sample test no longer branches on "inside the radius" — every lane
-// with a sample accumulates, a sample outside adds zeros and offers +inf to the three-smallest network — and the pass's end hands back sums, not quotients.
-HPT_FN bool kd_step(KdWalk *w, f4 *res) {
-    if (w->j >= w->jend) {                               // this row's range is used up: on to the next row of the box
+// with a sample accumulates, a sample outside adds zeros and offers +inf to the three-smallest network.
+HPT_FN bool kd_step(KdWalk *w) {
+    if (w->j >= w->jend) {                               // this row's range is used up: on to the walk's next row of the box (rows y0..y1 of plane iz, then the next plane)
         // (skipping EMPTY rows inside the step — about one row in seven — was measured: bunny 1941 against 1974 Msamples/s, run AA of round 4: the loop costs more than the steps it saves)
-        ++w->iy;
-        if (w->iy > w->y1) { w->iy = w->y0; ++w->iz; }
+        w->iy += w->g;
+        const int ny = w->y1 - w->y0 + 1;
+        while (w->iy > w->y1 && w->iz <= w->z1) { w->iy -= ny; ++w->iz; }
         if (w->iz <= w->z1) {
             const HPT_GLOBAL uint32_t *row = w->cells + ((w->iz * HPT_BG_Y + w->iy) * HPT_BG_X);
             w->j = row[w->x0]; w->jend = row[w->x1 + 1];
@@ -1243,8 +1252,13 @@ HPT_FN bool kd_step(KdWalk *w, f4 *res) {
         proc->m3 = fminf(proc->m3, t2);
         return false;
     }
-    if (w->iz <= w->z1) return false;                    // (an empty row: keep going)
-    // ---- the pass is over ------------------------------------------------------------------------------------------
+    return w->iz > w->z1;                                // (an empty row: keep going)
+}
+// The pass is over (w->pr holds the sums over the WHOLE box).  Returns true when the query is finished: *res = {sum of weight x value, sum of weights} of the samples inside
+// the final radius — IrregIsotropicBRDF::f is kd_result(*res), the division the caller does (the wave-cooperative evaluator: for all of a wave's queries at once) —, false when
+// another pass has been set up (w->r, the box, the sums reset).
+HPT_FN bool kd_pass_end(KdWalk *w, f4 *res) {
+    IrregProc *proc = &w->pr;
     bool second = false;                                 // the sums for r / 2 are the answer
     if (!w->last) {
         if (proc->m3 < w->r) {                           // more than two samples inside r: the reference stopped at k <= level
@@ -1268,6 +1282,16 @@ HPT_FN bool kd_step(KdWalk *w, f4 *res) {
     res->w = second ? proc->sumWeights2 : proc->sumWeights;
     return true;
 }
+// the sums of two walks of one query's pass, merged (sums add; the three smallest of the six distances)
+HPT_FN void irreg_proc_merge(IrregProc *a, f3 v, float sw, f3 v2, float sw2, float m1, float m2, float m3) {
+    a->v = a->v + v; a->sumWeights += sw; a->v2 = a->v2 + v2; a->sumWeights2 += sw2;
+    const float in[3] = {m1, m2, m3};
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = fmaxf(a->m1, in[i]); a->m1 = fminf(a->m1, in[i]);
+        const float t2 = fmaxf(a->m2, t1); a->m2 = fminf(a->m2, t1);
+        a->m3 = fminf(a->m3, t2);
+    }
+}
 HPT_FN f3 kd_result(f4 r) { return sdivf(sclamp0(mk3(r.x, r.y, r.z)), r.w); }     // reflection.cpp:270: v.Clamp() / sumWeights
 // The query point of IrregIsotropicBRDF::f (reflection.cpp:248-260, BRDFRemap)
 HPT_FN f3 irreg_point(f3 wo, f3 wi) {
@@ -1284,10 +1308,20 @@ HPT_FN f3 irreg_point(f3 wo, f3 wi) {
 // function takes the pools it reads BY VALUE: a reference to the scene record would force the whole kernel-argument block (where
 // the record lives) into private memory, and every later field read of the caller would become a scratch load.
 HPT_FN_NOINLINE f3 irreg_eval(const float *fpool, const hpt_material *m, f3 mpt) {
-    KdWalk w;
-    kd_begin(fpool, m, mpt, &w);
+    // the sums of a pass in the order the wave-cooperative evaluator forms them (wave_kd_run, hpt_kernels_impl.h: a query on HPT_KD_G lanes): HPT_KD_G walks over
+    // interleaved rows of the box, their partial sums added pairwise — so that a value is the same bits here and there
+    KdWalk w[HPT_KD_G];
+    for (int i = 0; i < HPT_KD_G; ++i) kd_begin(fpool, m, mpt, &w[i], i, HPT_KD_G);
     f4 res; res.x = res.y = res.z = res.w = 0.f;
-    while (!kd_step(&w, &res)) {}
+    for (;;) {
+        for (int i = 0; i < HPT_KD_G; ++i) while (!kd_step(&w[i])) {}
+        for (int x = 1; x < HPT_KD_G; x <<= 1)
+            for (int i = 0; i < HPT_KD_G; i += 2 * x) { const IrregProc &o = w[i + x].pr; irreg_proc_merge(&w[i].pr, o.v, o.sumWeights, o.v2, o.sumWeights2, o.m1, o.m2, o.m3); }
+        for (int i = 1; i < HPT_KD_G; ++i) w[i].pr = w[0].pr;
+        bool done = false;
+        for (int i = HPT_KD_G - 1; i >= 0; --i) done = kd_pass_end(&w[i], &res);      // (every walk takes the same decision: same sums, same radius)
+        if (done) break;
+    }
     return kd_result(res);
 }
 HPT_FN f3 irreg_f(const DScene &sc, const hpt_material *m, f3 wo, f3 wi) {

@@ -77,31 +77,61 @@ __device__ __noinline__ void wave_kd_run(const float *fpool, const hpt_material 
     const int lane = lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     HPT_LDS int32_t *col0 = ls.p - lane;
-    int next = total < 64 ? total : 64;                  // wave-uniform: first queue entry nobody has taken yet
-    int slot = lane < total ? lane : -1;
+    // A QUERY ON HPT_KD_G = 2 LANES (round 6).  A wave owes ~70 queries a vertex round on the headline scene, of 5 to 100+ steps each: with one lane a query the phase lasted as
+    // long as the longest walk plus the stragglers of the second hand-out, at about two fifths of the lanes (a quarter of bunny's frame: profiles/r06_ab.md, run A).  Now
+    // HPT_KD_G neighbouring lanes share a query: lane `sub` of the group reads rows sub, sub + G, ... of the pass's box (kd_step), and when all of them are through the group adds the
+    // partial sums up — pairwise, cross-lane shuffles; every lane of it then holds the same totals, so all take kd_pass_end's decision alike.  The split is
+    // FIXED (not chosen by how full the queue is): a query's value is the same bits whatever the wave is doing, and irreg_eval (hpt_device.h) forms the sums in the same
+    // order — the film stays reproducible run to run and across kernel configurations.  Against the reference's sample order the values agree to rounding (1e-7 relative).
+    constexpr int lg = HPT_KD_G == 4 ? 2 : HPT_KD_G == 2 ? 1 : 0;
+    constexpr int g = 1 << lg, ngrp = 64 >> lg;
+    const int sub = lane & (g - 1), grp = lane >> lg;
+    const unsigned long long gmask = ((1ull << g) - 1ull) << (grp << lg);   // the lanes of this lane's group (g <= 4)
+    int next = total < ngrp ? total : ngrp;              // wave-uniform: first queue entry nobody has taken yet
+    int slot = grp < total ? grp : -1;                   // (the same in every lane of a group)
     KdWalk w;
-    w.j = w.jend = 0u; w.iy = w.iz = 0; w.y0 = w.y1 = w.z1 = -1; w.x0 = w.x1 = 0; w.samples = nullptr; w.cells = nullptr;
+    w.j = w.jend = 0u; w.iy = w.iz = 0; w.y0 = w.y1 = w.z1 = -1; w.x0 = w.x1 = 0; w.samples = nullptr; w.cells = nullptr; w.sub = sub; w.g = g;
+    w.last = false; w.level = 0; w.r = 0.f; w.q = S(0.f);
+    irreg_proc_reset(&w.pr, 0.f);
+    bool part = false;                                   // this lane has read its rows of the pass and waits for the rest of its group
     if (slot >= 0)
-        kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
+        kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w, sub, g);
     for (;;) {
         if (__ballot(slot >= 0) == 0ull) break;
-        if (slot >= 0) {                                 // a burst of steps between two looks at the queue
-            f4 f;
-            bool done = false;
-            _Pragma("unroll 1") for (int k = 0; k < HPT_KD_BURST && !done; ++k) done = kd_step(&w, &f);
-            if (done) {                                  // the query's sums (its material index is no longer needed): divided below, all entries at once
-                HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z); HPT_QSLOT(slot, 3) = as_int(f.w);
-                slot = -1;
+        if (slot >= 0 && !part) {                        // a burst of steps between two looks at the queue
+            _Pragma("unroll 1") for (int k = 0; k < HPT_KD_BURST && !part; ++k) part = kd_step(&w);
+        }
+        // ---- groups whose lanes are all through the pass: add the partial sums up, decide ------------------------------------------------------
+        const unsigned long long mpart = __ballot(slot >= 0 && part);
+        const bool gdone = slot >= 0 && (mpart & gmask) == gmask;
+        if (__ballot(gdone) != 0ull) {
+            IrregProc t = w.pr;
+            for (int x = 1; x < g; x <<= 1) {            // (uniform trip count; the shuffles are executed by all 64 lanes, used by the complete groups)
+                const f3 pv = mk3(__shfl(t.v.x, lane ^ x), __shfl(t.v.y, lane ^ x), __shfl(t.v.z, lane ^ x)), pv2 = mk3(__shfl(t.v2.x, lane ^ x), __shfl(t.v2.y, lane ^ x), __shfl(t.v2.z, lane ^ x));
+                const float psw = __shfl(t.sumWeights, lane ^ x), psw2 = __shfl(t.sumWeights2, lane ^ x);
+                const float pm1 = __shfl(t.m1, lane ^ x), pm2 = __shfl(t.m2, lane ^ x), pm3 = __shfl(t.m3, lane ^ x);
+                irreg_proc_merge(&t, pv, psw, pv2, psw2, pm1, pm2, pm3);
+            }
+            if (gdone) {
+                w.pr = t;
+                part = false;
+                f4 f;
+                if (kd_pass_end(&w, &f)) {               // the query's sums (its material index is no longer needed): divided below, all entries at once
+                    if (sub == 0) { HPT_QSLOT(slot, 0) = as_int(f.x); HPT_QSLOT(slot, 1) = as_int(f.y); HPT_QSLOT(slot, 2) = as_int(f.z); HPT_QSLOT(slot, 3) = as_int(f.w); }
+                    slot = -1;
+                }
             }
         }
-        if (next < total) {                              // uniform: entries left — hand them to the lanes that just finished
-            const unsigned long long mneed = __ballot(slot < 0);
+        if (next < total) {                              // uniform: entries left — hand them to the groups that just finished
+            const unsigned long long mneed = __ballot(slot < 0 && sub == 0);
             if (mneed != 0ull) {
                 const int idx = next + __popcll(mneed & lt);
                 next += __popcll(mneed);
-                if (slot < 0 && idx < total) {
-                    slot = idx;
-                    kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w);
+                const int mine = (slot < 0 && sub == 0 && idx < total) ? idx : -1;
+                const int got = g == 1 ? mine : __shfl(mine, grp << lg);       // the group's first lane drew the entry for all of it
+                if (slot < 0 && got >= 0) {
+                    slot = got;
+                    kd_begin(fpool, &materials[HPT_QSLOT(slot, 3)], mk3(as_float(HPT_QSLOT(slot, 0)), as_float(HPT_QSLOT(slot, 1)), as_float(HPT_QSLOT(slot, 2))), &w, sub, g);
                 }
             }
         }

@@ -22,7 +22,8 @@ def kernels():
             ("anim (instanced, configuration 6)", "basic_i", K(False, True, 1, 3, 0, True, False, True), w.K_STEAL, "anim", 8),
             ("metal.pbrt (lean set, configuration 6)", "lean", K(False, False, 61, 3, 0, True, False, True), w.K_LEAN_STEAL, "metal", 8),
             ("plain lock step (configuration 3: trees too deep for the stealing rows)", "basic", K(False, False, 1, 4, 0, True, False, False), w.K_LOCKSTEP, "envmap", 12),
-            ("the instantiation round 5's builds had wrong (instanced extension set, configuration 6)", "ext_i", K(False, True, 31, 3, 0, True, False, True), w.K_STEAL, "aquad", 8)]
+            ("the instantiation round 5's builds had wrong (instanced extension set, configuration 6)", "ext_i", K(False, True, 31, 3, 0, True, False, True), w.K_STEAL, "aquad", 8),
+            ("the instantiation round 6's greedy build had wrong (instanced extension set, top-level walk, configuration 5)", "ext_i", K(False, True, 31, 4, 0, True, False, True, False, True), w.K_STEAL_TOP, "oinst", 8)]
 
 
 def run_one(i):

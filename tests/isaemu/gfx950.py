@@ -815,6 +815,7 @@ VOP = {
     "v_mad_u32_u24": lambda a, b, c: (_arr(a) & U32(0xffffff)) * (_arr(b) & U32(0xffffff)) + _arr(c),
     "v_mad_i32_i24": lambda a, b, c: (((_i(a) << I32(8)) >> I32(8)) * ((_i(b) << I32(8)) >> I32(8))) + _i(c),
     "v_and_b32": lambda a, b: _arr(a) & _arr(b), "v_or_b32": lambda a, b: _arr(a) | _arr(b), "v_xor_b32": lambda a, b: _arr(a) ^ _arr(b), "v_xnor_b32": lambda a, b: ~(_arr(a) ^ _arr(b)),
+    "v_bfm_b32": lambda a, b: (((U32(1) << (_arr(a) & U32(31))) - U32(1)) << (_arr(b) & U32(31))).astype(U32),      # bitfield mask: ((1 << S0[4:0]) - 1) << S1[4:0]
     "v_lshlrev_b32": lambda a, b: _arr(b) << (_arr(a) & U32(31)), "v_lshrrev_b32": lambda a, b: _arr(b) >> (_arr(a) & U32(31)), "v_ashrrev_i32": lambda a, b: _i(b) >> (_arr(a) & U32(31)).view(I32),
     "v_min_u32": lambda a, b: np.minimum(_arr(a), _arr(b)), "v_max_u32": lambda a, b: np.maximum(_arr(a), _arr(b)), "v_min_i32": lambda a, b: np.minimum(_i(a), _i(b)), "v_max_i32": lambda a, b: np.maximum(_i(a), _i(b)),
     "v_min3_u32": lambda a, b, c: np.minimum(np.minimum(_arr(a), _arr(b)), _arr(c)), "v_max3_u32": lambda a, b, c: np.maximum(np.maximum(_arr(a), _arr(b)), _arr(c)),

@@ -146,18 +146,21 @@ def test_no_cpu_fallback_without_device(cases):
         hpt.sampler(cases["env"].render, 0, 0)
 
 
-def test_every_device_object_is_gated_and_the_extension_units_are_back_on_the_greedy_allocator():
+def test_every_device_object_is_gated_and_the_extension_units_stay_off_the_greedy_allocator():
     """Round 5 (profiles/r05_ab.md, r05_isaemu_root_cause.md): under clang 22's greedy register allocator builds of the two 0.5-1 MB extension units had one kernel
     instantiation that was wrong as a whole — a live-range copy placed above an EXEC restore — and the units shipped on -vgpr-regalloc=basic (10-20 % slower code).
-    Round 6: the defect's shape is scanned for in EVERY device object the Makefile compiles (an object that has it is deleted and the build fails), so the units are back
-    on the greedy allocator.  The rules live in the Makefile, where a clean-up would lose them silently: this test is the note on the door."""
+    Round 6: the defect's shape is scanned for in EVERY device object the Makefile compiles (an object that has it is deleted and the build fails) — and a greedy build of
+    the extension units that PASSED that scan rendered bad samples on the GPU (profiles/r06_ab.md, run I): the scan covers one shape, the units stay on the basic allocator, and
+    build() executes kernels of them in the interpreter.  The rules live in the Makefile, where a clean-up would lose them silently: this test is the note on the door."""
     mk = open(os.path.join(ROOT, "pbrt-v2_amd", "Makefile")).read()
     rules = re.findall(r"^build/[^\n:]*\.o: csrc/%\.hip[^\n]*\n((?:\t[^\n]*\n)+)", mk, flags=re.M)
     assert len(rules) >= 3 and all("$(gate)" in r for r in rules), rules          # libhpt.so's objects, `variant`, `flavor` (debug / shadow)
     assert re.search(r"^GATE \?= python3 \.\./scripts/check_exec_restore\.py$", mk, flags=re.M)
-    for unit in ("hpt_kernels_ext", "hpt_kernels_ext_i"):
+    for unit in ("hpt_kernels_ext", "hpt_kernels_ext_i"):     # (round 6: a greedy build of these units passed the static gate and was wrong on the GPU and in the interpreter — they stay on the basic allocator)
         m = re.search(r"^FLAGS_%s\s*:=(.*)$" % unit, mk, flags=re.M)
-        assert m and "-vgpr-regalloc=basic" not in m.group(1), unit
+        assert m and "-vgpr-regalloc=basic" in m.group(1), unit
+        for part in re.findall(r"hpt_kernels_%s_p\d" % unit[len("hpt_kernels_"):], mk):
+            assert re.search(r"FLAGS_hpt_kernels_\$\(u\)_p\d := \$\$\(FLAGS_hpt_kernels_\$\(u\)\)", mk), part      # the parts inherit the unit's flags
     m = re.search(r"^FLAGS_hpt_kernels_lean\s*:=(.*)$", mk, flags=re.M)
     assert m and "iterative-ilp" not in m.group(1)      # (the scheduler whose output LLVM's machine verifier rejects and on which the allocator segfaults)
     entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()

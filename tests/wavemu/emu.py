@@ -50,7 +50,14 @@ def _bind(L):
 
 
 def _load(name):
-    subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, name])
+    # (several processes may arrive here at once — pytest-xdist workers, the children of scripts/isaemu_gate.py: one make at a time, or they link each other's half-written objects)
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, name])
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     L = C.CDLL(os.path.join(_HERE, name))
     L.emu_scene_create.restype = C.c_void_p
     return L
