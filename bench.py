@@ -59,7 +59,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0 * 1e0      # = 1228.8 G wave-instructions / s
 TUNE_NAMES = ["4 waves/SIMD", "4 waves/SIMD, early-exit traversal", "3 waves/SIMD", "4 waves/SIMD, lock-step phases",
               "3 waves/SIMD, lock-step phases", "4 waves/SIMD, lock-step phases, subtree stealing",
-              "3 waves/SIMD, lock-step phases, subtree stealing"]
+              "3 waves/SIMD, lock-step phases, subtree stealing",
+              "4 waves/SIMD, lock-step phases, subtree stealing: second compilation (allocator class-priority switch)"]
 REF_SCENE_FILE = {"bunny": "bunny.pbrt", "killeroo": "killeroo-simple.pbrt", "anim": "anim-killeroos-moving.pbrt", "metal": "metal.pbrt"}
 _CALIB = {}          # achieved-peak HBM bandwidth of device 0 (hpt_calib_hbm_triad), measured once per process
 
@@ -555,7 +556,7 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
                    "avg_ms": round(k_ms, 3), "grid_blocks": last.grid_blocks,
                    "block_threads": last.block_threads, "vgprs": last.vgprs, "scratch_B": int(last.scratch_bytes), "waves_per_cu": last.resident_waves,
                    "occupancy": round(last.resident_waves / 32.0, 3),
-                   "tune_cfg": "%d (%s)" % (last.tune_cfg, TUNE_NAMES[last.tune_cfg]),
+                   "tune_cfg": "%d (%s)" % (last.tune_cfg, TUNE_NAMES[last.tune_cfg] if last.tune_cfg < len(TUNE_NAMES) else "?"),
                    "samples_per_launch": int(per_launch_samples)},
         "setup_s": {"bvh_build_ms": round(info.build_ms, 1), "bvh_device_kernels_ms": round(info.device_build_ms, 3), "bvh_max_depth": int(info.bvh_max_depth), "scene_create_total_s": round(setup_s, 3), "autotune_s": round(tune_s, 3)},
         "film_mean_Y": round(float(full_h[..., 1].astype(np.float64).sum() / max(float(full_h[..., 3].astype(np.float64).sum()), 1.0)), 5),

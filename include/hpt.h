@@ -333,8 +333,9 @@ typedef struct hpt_stats {
     uint32_t resident_waves, grid_blocks, block_threads, vgprs;
     uint32_t tune_cfg;         /* kernel configuration that ran: 0 = 4 waves/SIMD, 1 = 4 waves + early-exit
                                 * traversal, 2 = 3 waves/SIMD, 3 / 4 = 4 / 3 waves with the wave's lanes in lock
-                                * step (extension, shadow, MIS phases), 5 / 6 = 3 / 4 + idle lanes steal subtrees from the wave's long rays; picked per scene by a probe render,
-                                * HPT_TUNE=<n> pins it.  All configurations compute the same film. */
+                                * step (extension, shadow, MIS phases), 5 / 6 = 3 / 4 + idle lanes steal subtrees from the wave's long rays, 7 = 5 in its second compilation
+                                * (other code-generation flags; matte / plastic scenes without animated instances — elsewhere it runs as 5); picked per scene by a probe render,
+                                * HPT_TUNE=<n> pins it.  The shipped library carries 3, 5, 6 and 7 (0, 1, 2, 4 run as 3).  All configurations compute the same film. */
     uint32_t scratch_bytes;    /* private (scratch) memory per lane of the kernel that ran: its register spills (was padding before round 4) */
 } hpt_stats;
 

@@ -786,7 +786,7 @@ static hipError_t autotune(hpt_scene *s, const hpt_camera *cam, const hpt_render
     float t[HPT_N_TUNE_CFG];
     bool in_race[HPT_N_TUNE_CFG];
     // (only configurations this library carries as kernels of their own race: the shipped build 3, 5, 6 — an alias would be the same kernel timed twice)
-    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1) && path_kernel_effective_cfg(s->mats, cfg) == cfg; }  // early exit is not compiled for instanced scenes
+    for (int cfg = 0; cfg < HPT_N_TUNE_CFG; ++cfg) { t[cfg] = 0.f; in_race[cfg] = !(inst && cfg == 1) && path_kernel_effective_cfg(s->mats, cfg, inst) == cfg; }  // early exit is not compiled for instanced scenes
     int best_cfg = 0;
     // round 0: every configuration at <= 16 spp; round 1: the ones within 10 % of the best again at <= 64 spp
     for (int round = 0; round < 2 && e == hipSuccess; ++round) {

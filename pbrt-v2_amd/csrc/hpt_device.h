@@ -1234,6 +1234,11 @@ HPT_FN bool kd_step(KdWalk *w) {
     }
     IrregProc *proc = &w->pr;
     if (w->j < w->jend) {
+#ifndef HPT_KD_UNROLL
+#define HPT_KD_UNROLL 2   /* samples of the row a step tests (round 6: the step's own bookkeeping — the burst loop, the row test — is a third of its instructions) */
+#endif
+        _Pragma("unroll") for (int u = 0; u < HPT_KD_UNROLL; ++u) {
+        if (u > 0 && !(w->j < w->jend)) break;
         const f4 n0 = w->samples[2 * (int64_t)w->j], n1 = w->samples[2 * (int64_t)w->j + 1];
         ++w->j;
         const float d2 = dist2(mk3(n0.x, n0.y, n0.z), w->q);
@@ -1250,6 +1255,7 @@ HPT_FN bool kd_step(KdWalk *w) {
         const float t1 = fmaxf(proc->m1, dm); proc->m1 = fminf(proc->m1, dm);
         const float t2 = fmaxf(proc->m2, t1); proc->m2 = fminf(proc->m2, t1);
         proc->m3 = fminf(proc->m3, t2);
+        }
         return false;
     }
     return w->iz > w->z1;                                // (an empty row: keep going)

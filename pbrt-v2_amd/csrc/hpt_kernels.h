@@ -60,14 +60,14 @@ struct ReplayArgs {            // HPT_SAMPLER_MT_REPLAY scratch (hpt_replay.h)
 inline int fixed_stack_rows(int bvh_depth) { return bvh_depth + 2 > HPT_STACK_DEPTH ? bvh_depth + 2 : HPT_STACK_DEPTH; }
 inline size_t fixed_stack_bytes(int bvh_depth) { return (size_t)fixed_stack_rows(bvh_depth) * HPT_BLOCK * sizeof(int32_t); }
 #define HPT_MAX_STACK_ROWS 40   /* dynamic LDS stack rows of the path kernel: 40 KiB a workgroup = 4 workgroups per CU */
-#define HPT_N_TUNE_CFG 7   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
+#define HPT_N_TUNE_CFG 8   /* {4 waves/SIMD}, {4 waves, early exit 12}, {3 waves}, {4 waves, lock step}, {3 waves, lock step}
                               {4 waves, lock step, subtree stealing}, {3 waves, lock step, subtree stealing} — hpt_kernels_impl.h (lock step + early exit measured and dropped: profiles/r01_ab.md) */
 #define HPT_TOP_MIN_INSTANCES 4 /* up to this many animated instances are visited serially (measured faster on two: profiles/r04_ab.md run D) */
 #define HPT_STEAL_STACK_ROWS 6  /* LDS rows a wave needs above its traversal stacks for configuration 5 (HPT_STEAL_ROWS) */
 int path_kernel_steal_rows(bool dl);   /* LDS rows the lock-step + stealing kernels of THIS build keep above their traversal stacks (HPT_STEAL_ROWS) */
 int path_kernel_phase_timers(); /* > 0: the kernels of this build were compiled with -DHPT_PHASE_TIMERS (the mode): the work counters hold wave clocks per loop section */
 bool path_kernel_wide_bvh();     /* the stealing walk of this build walks the four-wide trees (compiled with HPT_BVH4) */
-int path_kernel_effective_cfg(int mats, int cfg);   /* the configuration that actually runs: the shipped library builds 3, 5 and 6 (0, 1, 2, 4 run as 3); an HPT_ALL_CONFIGS build all seven, its extension units 0, 5, 6 */
+int path_kernel_effective_cfg(int mats, int cfg, bool inst = true);   /* the configuration that actually runs: the shipped library builds 3, 5 and 6 (0, 1, 2, 4 run as 3); an HPT_ALL_CONFIGS build all seven, its extension units 0, 5, 6 */
 int path_kernel_cold_rows(int mats, bool dl);   /* LDS rows per lane the path kernel wants above its stacks for the lane's cold state (ColdLds, hpt_path.h) */
 int path_kernel_occupancy(int mats, bool inst, int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs, bool top = false, bool win = false);   /* *vgprs = VGPRs | scratch bytes per lane << 10 */
 hipError_t launch_path_kernel(int mats, const PathKernelArgs &a, int grid_blocks, bool count, int cfg, hipStream_t stream);

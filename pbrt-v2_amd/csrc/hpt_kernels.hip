@@ -35,7 +35,10 @@ int path_kernel_phase_timers() {
 #endif
 }
 int path_kernel_steal_rows(bool dl) { (void)dl; return HPT_STEAL_ROWS; }
-int path_kernel_effective_cfg(int mats, int cfg) {   // HPT_CFG_ALIAS (hpt_kernels_impl.h)
+int path_kernel_effective_cfg(int mats, int cfg, bool inst) {   // HPT_CFG_ALIAS (hpt_kernels_impl.h)
+    // configuration 7 (round 6): the basic set's configuration-5 kernel compiled a SECOND time under other code-generation flags (csrc/hpt_kernels_basic_v.hip) — a candidate
+    // of the autotuner for scenes of the basic set without animated instances; everywhere else it is configuration 5
+    if (cfg == 7) { if (!inst && (mats & ~MATS_PLASTIC) == 0) return 7; cfg = 5; }
 #ifdef HPT_ALL_CONFIGS
     if (!(mats & MATS_EXT)) return cfg;
     return cfg == 3 ? 5 : cfg == 4 ? 6 : cfg <= 2 ? 0 : cfg;      // under HPT_LEAN_SET

@@ -709,6 +709,22 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             if (__ballot(need) == 0ull) break;
             if (dead_heads == 0xff) { if (need) exhausted = true; break; }
             while ((dead_heads >> src) & 1) src = (src + 1) & 7;
+#ifdef HPT_REFILL_DIV64   /* the refill of rounds 2-5 (a unit may keep it: FLAGS_<unit> in the Makefile): every lane divides its own item number, emulated 64-bit divisions and all */
+            const int64_t tiles = rp.items_per_pass >> 10, passes = rp.n_items / rp.items_per_pass;
+            const int64_t t0 = tiles * src / rp.n_heads, per = ((tiles * (src + 1) / rp.n_heads) - t0) << 10, lim = per * passes;
+            int64_t v = wave_fetch(a.next_item + src, need);
+            const bool over = need && v >= lim;
+            if (need && !over) {
+                const int64_t pass = v / per, item = pass * rp.items_per_pass + (t0 << 10) + (v - pass * per);
+                int x, y; uint32_t s0;
+                if (WIN && rp.bc_table) {            // Sampler "bestcandidate" (scalar branch): the item is an entry of the sample table in a table tile
+                    uint32_t tile;
+                    if (item_to_bc(rp, item, &tile, &s0)) (void)lane.begin_bc(rp, tile, s0);
+                } else if (WIN && rp.sampler_kind == 3) {   // Sampler "halton": the item is a sample number of a super-tile's window
+                    if (item_to_halton(rp, item, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
+                } else if (item_to_pixel(rp, item, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
+            }
+#else
             // (round 6: no per-lane 64-bit division — the wave's base is divided once, with a float reciprocal and a correction, and a lane's item follows from its rank)
             const int64_t t0 = rp.n_heads == 8 ? (q_tiles * src) >> 3 : q_tiles * src, per = ((rp.n_heads == 8 ? (q_tiles * (src + 1)) >> 3 : q_tiles * (src + 1)) - t0) << 10, lim = per * q_passes;
             int64_t vbase = 0; int vrank = 0;
@@ -728,6 +744,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
                     if (item_to_halton(rp, (int64_t)pass * rp.items_per_pass + idx, &x, &y, &s0)) (void)lane.begin_halton(rp, x, y, s0);   // (a rejected point leaves the lane idle: next round)
                 } else if (pass_item_to_pixel(rp, pass, idx, q_inv_nstx, &x, &y, &s0)) lane.begin_pixel(rp, x, y, s0, (uint32_t)rp.chunk);
             }
+#endif
             if (__ballot(over) != 0ull) dead_heads |= 1u << src;     // (a head only grows: once past its range it stays there)
         }
         HPT_SNAP_CMP(snap_flush, 1, keeps_);                         // (flush + refill: the lanes in mid-path)
@@ -954,6 +971,26 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     HPT_K_(X, false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true, true)                          \
     HPT_K_(X, false, INSTV, MATS, HPT_DL_WAVES, 0, true, true, true)
 
+// Configuration 7 (round 6): a SECOND COMPILATION of the configuration-5 kernel of the basic set without instances — csrc/hpt_kernels_basic_v.hip, under the register
+// allocator's class-priority switch: the same source is 3.4 % faster on killeroo and 2.1 % slower on the 1 M-triangle soup with it (profiles/r06_ab.md, run M), so both
+// binaries ship and the autotuner times them on the scene.  It is the same template with an early-exit argument of 1, which a lock-step + stealing kernel never reads: a
+// symbol of its own, no new template parameter.
+#if defined(__HIPCC__)   /* (host-side launch helpers: not for the CPU builds of this header, tests/wavemu) */
+template <int MATS, bool INSTV> struct HasVariant7 { static constexpr bool value = !INSTV && MATS == MATS_PLASTIC; };
+#define HPT_VARIANT7_KERNEL(MATS) hpt_path_kernel<false, false, MATS, 4, 1, true, false, true>
+template <int MATS, bool INSTV> static hipError_t launch_variant7(const PathKernelArgs &a, int grid, size_t dyn_lds, hipStream_t s, bool *done) {
+    if constexpr (HasVariant7<MATS, INSTV>::value) {
+        hipLaunchKernelGGL((HPT_VARIANT7_KERNEL(MATS)), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);
+        *done = true;
+        return hipGetLastError();
+    } else { *done = false; return hipSuccess; }
+}
+template <int MATS, bool INSTV> static const void *fn_variant7() {
+    if constexpr (HasVariant7<MATS, INSTV>::value) return (const void *)HPT_VARIANT7_KERNEL(MATS);
+    else return nullptr;
+}
+#endif
+
 // Defines launch_path_<NAME>() / occupancy_<NAME>() for the material set MATS and for scenes with (INSTV = true) or without animated
 // instances — one translation unit each (hpt_kernels_<set>.hip, hpt_kernels_<set>_i.hip): the two halves want different compiler
 // settings (the Makefile schedules the instance-free kernels with -amdgpu-sched-strategy=max-ilp: bunny +2.6 %, soup +2.5 %, killeroo
@@ -997,6 +1034,7 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
             hipLaunchKernelGGL((hpt_path_kernel<true, INSTV, MATS, HPT_COUNT_WAVES, 0, true, false, true>), dim3(grid), dim3(HPT_BLOCK), dyn_lds, s, a);   \
             return hipGetLastError();                                                                               \
         }                                                                                                           \
+        if (cfg == 7) { bool done7 = false; const hipError_t e7 = launch_variant7<MATS, INSTV>(a, grid, dyn_lds, s, &done7); if (done7) return e7; cfg = 5; } \
         if (INSTV && cfg == 1) cfg = 0;                                                                             \
         switch (cfg) {                                                                                              \
             case 1: return launch_cfg_##NAME<1>(a, grid, dyn_lds, s);                                                        \
@@ -1011,9 +1049,12 @@ __global__ __launch_bounds__(HPT_BLOCK, WAVES) void hpt_path_kernel(const PathKe
     template <int CFG> static const void *fn_cfg_##NAME() { return (const void *)HPT_CFG_KERNEL(MATS, INSTV, CFG); } \
     /* the function that launch_path_##NAME runs for (cfg, dl, top, win) without the instrumented build: same selection, same order */ \
     int occupancy_##NAME(int cfg, bool dl, size_t dyn_lds, int *blocks_per_cu, int *vgprs, bool top, bool win) {     \
+        const bool v7 = cfg == 7;                                                                                   \
+        if (v7) cfg = 5;                                                                                            \
         if (INSTV && cfg == 1) cfg = 0;                                                                             \
         const void *fn = cfg == 1 ? fn_cfg_##NAME<1>() : cfg == 2 ? fn_cfg_##NAME<2>() : cfg == 3 ? fn_cfg_##NAME<3>() \
                        : cfg == 4 ? fn_cfg_##NAME<4>() : cfg == 5 ? fn_cfg_##NAME<5>() : cfg == 6 ? fn_cfg_##NAME<6>() : fn_cfg_##NAME<0>(); \
+        if (v7) if (const void *f7 = fn_variant7<MATS, INSTV>()) fn = f7;                                           \
         if (dl) fn = (const void *)HPT_DL_KERNEL(MATS, INSTV, false);                                               \
         if (win) fn = dl ? (const void *)HPT_DL_KERNEL_W(MATS, INSTV, false) : (const void *)hpt_path_kernel<false, INSTV, MATS, 4, 0, true, false, true, true>; \
         else if constexpr (INSTV) if (top) {                                                                        \

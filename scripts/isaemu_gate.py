@@ -17,6 +17,7 @@ def kernels():
     from tests.wavemu import emu as w
     K = R.kernel_symbol
     return [("killeroo (configuration 5)", "basic", K(False, False, 1, 4, 0, True, False, True), w.K_BASIC_STEAL, "cfg1", 8),
+            ("killeroo (configuration 7: configuration 5 in its second compilation)", "basic_v", K(False, False, 1, 4, 1, True, False, True), w.K_BASIC_STEAL, "cfg1", 8),
             ("bunny: the headline (configuration 5, out-of-line kd-tree walk)", "measured", K(False, False, 3, 4, 0, True, False, True), w.K_MEASURED_STEAL, "b8", 8),
             ("soup (configuration 6)", "basic", K(False, False, 1, 3, 0, True, False, True), w.K_BASIC_STEAL, "env", 8),
             ("anim (instanced, configuration 6)", "basic_i", K(False, True, 1, 3, 0, True, False, True), w.K_STEAL, "anim", 8),

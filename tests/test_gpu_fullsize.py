@@ -149,9 +149,9 @@ def test_kernel_configuration_is_remembered_on_disk(monkeypatch, tmp_path):
     hpt.DeviceScene(s).tune(s.camera, rd2)
     assert len(list(tmp_path.iterdir())) == 2
     files[0].write_text("99\n")                             # a damaged entry is ignored (and rewritten)
-    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(7) and int(files[0].read_text()) in range(7)
+    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(8) and int(files[0].read_text()) in range(8)
     monkeypatch.setenv("HPT_TUNE_CACHE", "off")
-    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(7)
+    assert hpt.DeviceScene(s).tune(s.camera, rd) in range(8)
 
 
 def test_every_kernel_configuration_renders_the_same_bench_frame(monkeypatch):
@@ -161,7 +161,7 @@ def test_every_kernel_configuration_renders_the_same_bench_frame(monkeypatch):
     rd = abi.copy_struct(s.render)
     dev = hpt.DeviceScene(s)
     ref = None
-    for cfg in range(7):
+    for cfg in range(8):
         monkeypatch.setenv("HPT_TUNE", str(cfg))
         f, st = dev.render(s.camera, rd)
         assert st.tune_cfg == cfg

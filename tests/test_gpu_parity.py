@@ -71,7 +71,7 @@ def test_every_render_checks_sample_conservation(cases, dev, monkeypatch):
         s = cases[name]
         rd = hash_rd(s, seed=3)
         n = rd.x_count * rd.y_count * rd.spp
-        for cfg in range(7):
+        for cfg in range(8):
             monkeypatch.setenv("HPT_TUNE", str(cfg))
             _, st = dev[name].render(s.camera, rd)
             assert st.camera_samples == n and st.tune_cfg == cfg
@@ -252,7 +252,7 @@ def test_kernel_configurations_render_the_same_film(cases, dev, name, monkeypatc
     s = cases[name]
     rd = hash_rd(s, seed=9)
     films = []
-    for cfg in range(7):
+    for cfg in range(8):
         monkeypatch.setenv("HPT_TUNE", str(cfg))
         f, st = dev[name].render(s.camera, rd)
         assert st.tune_cfg == cfg and st.bad_samples == 0
