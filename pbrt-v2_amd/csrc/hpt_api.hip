@@ -857,8 +857,10 @@ int hpt_render_device_into(hpt_scene *s, const hpt_camera *cam, const hpt_render
         hpt_set_error("textures / specular / regular half-angle materials / mesh emitters run on the persistent kernel (the wavefront pipeline covers the round-1 feature set)");
         return HPT_E_UNSUPPORTED;
     }
-    if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH && rd->maxdepth > 16) {
-        hpt_set_error("direct lighting over specular surfaces: maxdepth %d exceeds the 16 levels the recursion's ray stack is sized for", rd->maxdepth);
+    // (the recursion's pending rays live in a per-lane stack in HBM of maxdepth + 2 entries of 24 floats, allocated per job: 1.7 GB for a full grid at 64 levels — up to round 5
+    //  the limit was 16 for no better reason than that nothing deeper had been tested)
+    if (s->has_specular && rd->integrator != HPT_INTEGRATOR_PATH && rd->maxdepth > 64) {
+        hpt_set_error("direct lighting over specular surfaces: maxdepth %d exceeds the 64 levels the recursion's ray stack is sized for", rd->maxdepth);
         return HPT_E_UNSUPPORTED;
     }
     hipError_t e = hipSuccess;

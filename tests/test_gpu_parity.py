@@ -1077,9 +1077,21 @@ def test_scope_limits_of_the_extension_are_refused_loudly():
         d.render(s.camera, rd)
     s = load_case("specdl")
     rd = hash_rd(s, seed=1)
-    rd.maxdepth = 40
-    with pytest.raises(hpt.HptError, match="16 levels"):
+    rd.maxdepth = 100
+    with pytest.raises(hpt.HptError, match="64 levels"):
         hpt.DeviceScene(s).render(s.camera, rd)
+
+
+def test_direct_lighting_recursion_forty_levels_deep_matches_the_oracle():
+    """SpecularReflect / SpecularTransmit (core/integrator.cpp:177-258) at maxdepth 40 — the recursion's per-lane ray stack is sized by the job (up to round 5 anything
+    deeper than 16 was refused): the glass sphere / glass mesh / mirror scene under direct lighting, sample for sample against the oracle's recursion."""
+    s = load_case("specdl")
+    rd = hash_rd(s, seed=2)
+    rd.maxdepth = 40
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    fd, st = hpt.DeviceScene(s).render(s.camera, rd)
+    assert st.bad_samples == 0 and np.array_equal(fo[..., 3], fd[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fd)) < 1e-4
 
 
 def test_shards_partition_the_image(cases, dev):

@@ -94,6 +94,16 @@ def test_direct_lighting_kernel_renders_the_oracles_film(name, kernel, n):
     check(f, fo, info, so)
 
 
+def test_direct_lighting_recursion_thirty_levels_deep():
+    """the specular recursion's ray stack at maxdepth 30 (sized by the job): the wave-level source against the oracle's recursion"""
+    s, o, e = pair("specdl")
+    rd = crop(abi.copy_struct(s.render), 16)
+    rd.seed, rd.maxdepth = 3, 30
+    fo, so = o.render(s.camera, rd)
+    f, info = e.render(s.camera, rd, w.K_DL)
+    check(f, fo, info, so)
+
+
 @pytest.mark.parametrize("knobs", [dict(regen_min=1), dict(regen_min=64), dict(retrace_min=1, retrace_max=8), dict(retrace_min=65), dict(leaf_q=0, block_q=0), dict(leaf_q=8, block_q=8),
                                    dict(bvh4_cap=0), dict(bvh4_cap=3), dict(heads=1), dict(shuffle=1), dict(shuffle=2), dict(shuffle=3)],
                          ids=lambda k: "-".join("%s%d" % kv for kv in k.items()))
