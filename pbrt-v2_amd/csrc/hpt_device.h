@@ -1342,13 +1342,37 @@ HPT_FN float fr_cond1(float cosi, float e, float kk) {
     float Rperp2 = (tmp_f - (2.f * e * cosi) + cosi * cosi) / (tmp_f + (2.f * e * cosi) + cosi * cosi);
     return (Rparl2 + Rperp2) / 2.f;
 }
+// The powers of the microfacet DISTRIBUTIONS' values and of the Schlick / FresnelBlend weights (round 6: the library's powf — ~150 instructions — was 6.8 % of the vector
+// instructions of metal.pbrt's kernel and 2.7 % of killeroo's, profiles/r06_lineprofile_*.md).  pow_dist(x, y), x = |cos theta_h| in [0, 1], y = the exponent > 0: on the
+// device exp2(y log2 x) on the hardware's v_log_f32 / v_exp_f32 (1 ulp each): wherever the value matters (x^y > 1e-6: |y log2 x| < 20) the result is within ~5e-6 relative of
+// powf's — the BSDF hooks' stated tolerance is 5e-4 — and where it does not, both are 0 to that tolerance's absolute floor.  pow5(x) = x^5 by multiplication (2 ulp).  The powers
+// that pick a sampled DIRECTION (Blinn::Sample_f, Anisotropic::sampleFirstQuadrant) keep powf: a direction decides which triangle a ray hits.  Host builds (oracle-side
+// emulations) keep powf throughout.  -DHPT_LIBM_POW: powf everywhere (the A/B control).
+HPT_FN float pow_dist(float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HPT_LIBM_POW)
+    // (v_log_f32, v_mul_f32, v_exp_f32.  v_exp_f32 flushes a DENORMAL result to zero where powf returns it — and a term that is exactly zero is "black": no shadow ray for it,
+    //  1 ray in 150 less than the reference traces on metal.pbrt, images equal, counts not (GPU run T).  So the band below 2^-126 is computed 64 binades up and scaled back.)
+    const float t = y * __builtin_amdgcn_logf(x);
+    return t < -126.f ? __builtin_amdgcn_exp2f(t + 64.f) * 0x1p-64f : __builtin_amdgcn_exp2f(t);
+#else
+    return powf(x, y);
+#endif
+}
+HPT_FN float pow5(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HPT_LIBM_POW)
+    const float x2 = x * x;
+    return x2 * x2 * x;
+#else
+    return powf(x, 5.f);
+#endif
+}
 // Anisotropic microfacet distribution (reflection.h:444-451, reflection.cpp:377-443)
 HPT_FN float aniso_D(float ex, float ey, f3 wh) {
     float costhetah = abs_cos_theta(wh);
     float d = 1.f - costhetah * costhetah;
     if (d == 0.f) return 0.f;
     float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / d;
-    return sqrtf((ex + 2.f) * (ey + 2.f)) * HPT_INV_TWOPI * powf(costhetah, e);
+    return sqrtf((ex + 2.f) * (ey + 2.f)) * HPT_INV_TWOPI * pow_dist(costhetah, e);
 }
 HPT_FN float aniso_pdf_wh(float ex, float ey, f3 wo, f3 wh) {
     float costhetah = abs_cos_theta(wh);
@@ -1356,7 +1380,7 @@ HPT_FN float aniso_pdf_wh(float ex, float ey, f3 wo, f3 wh) {
     float p = 0.f;
     if (ds > 0.f && dot(wo, wh) > 0.f) {
         float e = (ex * wh.x * wh.x + ey * wh.y * wh.y) / ds;
-        float d = sqrtf((ex + 1.f) * (ey + 1.f)) * HPT_INV_TWOPI * powf(costhetah, e);
+        float d = sqrtf((ex + 1.f) * (ey + 1.f)) * HPT_INV_TWOPI * pow_dist(costhetah, e);
         p = d / (4.f * dot(wo, wh));
     }
     return p;
@@ -1434,7 +1458,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         wh = normalize(wh);
         float cosThetaH = dot(wi, wh);
         float F = fresnel_dielectric(cosThetaH, 1.5f, 1.f);
-        float D = (b.exponent + 2) * HPT_INV_TWOPI * powf(abs_cos_theta(wh), b.exponent); // Blinn::D
+        float D = (b.exponent + 2) * HPT_INV_TWOPI * pow_dist(abs_cos_theta(wh), b.exponent); // Blinn::D
         float NdotWh = abs_cos_theta(wh), NdotWo = abs_cos_theta(wo), NdotWi = abs_cos_theta(wi);
         float WOdotWh = absdot(wo, wh);
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
@@ -1448,7 +1472,7 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
         wh = normalize(wh);
         float ci = fabsf(dot(wi, wh));
         f3 F = mk3(fr_cond1(ci, b.R0.x, b.R1.x), fr_cond1(ci, b.R0.y, b.R1.y), fr_cond1(ci, b.R0.z, b.R1.z));
-        float D = (b.exponent + 2) * HPT_INV_TWOPI * powf(abs_cos_theta(wh), b.exponent);
+        float D = (b.exponent + 2) * HPT_INV_TWOPI * pow_dist(abs_cos_theta(wh), b.exponent);
         float NdotWh = abs_cos_theta(wh), NdotWo = abs_cos_theta(wo), NdotWi = abs_cos_theta(wi);
         float WOdotWh = absdot(wo, wh);
         float G = minf(1.f, minf((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
@@ -1457,13 +1481,13 @@ HPT_FN f3 bxdf_f(const DScene &sc, const Bsdf &b, int i, f3 wo, f3 wi, LaneStack
     if ((MATS & MATS_SUBSTRATE) && kind == BX_FRESNELBLEND) {        // FresnelBlend::f (reflection.cpp:232-244)
         f3 Rd = b.R0, Rs = b.R1;
         f3 one_minus_rs = mk3(1.f - Rs.x, 1.f - Rs.y, 1.f - Rs.z);
-        f3 diffuse = (smul(Rd * (28.f / (23.f * HPT_PI)), one_minus_rs) * (1.f - powf(1.f - .5f * abs_cos_theta(wi), 5.f))) *
-                     (1.f - powf(1.f - .5f * abs_cos_theta(wo), 5.f));
+        f3 diffuse = (smul(Rd * (28.f / (23.f * HPT_PI)), one_minus_rs) * (1.f - pow5(1.f - .5f * abs_cos_theta(wi)))) *
+                     (1.f - pow5(1.f - .5f * abs_cos_theta(wo)));
         f3 wh = wi + wo;
         if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return S(0.f);
         wh = normalize(wh);
         float sc_ = aniso_D(b.exponent, b.ey, wh) / (4.f * absdot(wi, wh) * maxf(abs_cos_theta(wi), abs_cos_theta(wo)));
-        float pw = powf(1 - dot(wi, wh), 5.f);
+        float pw = pow5(1 - dot(wi, wh));
         f3 schlick = Rs + one_minus_rs * pw;                         // SchlickFresnel (reflection.h:468-470)
         return diffuse + schlick * sc_;
     }
@@ -1481,7 +1505,7 @@ HPT_FN float bxdf_pdf(const Bsdf &b, int i, f3 wo, f3 wi) {
         if (!same_hemisphere(wo, wi)) return 0.f;
         f3 wh = normalize(wo + wi);
         float costheta = abs_cos_theta(wh);
-        float p = ((b.exponent + 1.f) * powf(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
+        float p = ((b.exponent + 1.f) * pow_dist(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
         if (dot(wo, wh) <= 0.f) p = 0.f;
         return p;
     }
@@ -1554,7 +1578,7 @@ HPT_FN void bxdf_sample_dir(const Bsdf &b, int i, f3 wo, f3 *wi, float u1, float
         f3 wh = mk3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
         if (!same_hemisphere(wo, wh)) wh = -wh;
         *wi = (-wo) + wh * (2.f * dot(wo, wh));
-        float bp = ((b.exponent + 1.f) * powf(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
+        float bp = ((b.exponent + 1.f) * pow_dist(costheta, b.exponent)) / (2.f * HPT_PI * 4.f * dot(wo, wh));
         if (dot(wo, wh) <= 0.f) bp = 0.f;
         *pdf = bp;
         return;
