@@ -456,16 +456,18 @@ HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, D
         if (t0 < ray.mint) { thit = t1; if (thit > ray.maxt) return false; }
         f3 phit = ray_at(ray, thit);
         if (phit.x == 0.f && phit.y == 0.f) phit.x = 1e-5f * radius;
-        float phi = atan2f(phit.y, phit.x);
-        if (phi < 0.f) phi += 2.f * HPT_PI;
+        // (round 6: a FULL sphere tested for a hit only — the walk's pre-test of every ray, dg == nullptr — needs no phi: atan2f's result, wrapped, is <= 2.f * HPT_PI, so
+        //  `phi > phiMax` cannot hold when phiMax is that or more; with a dg, phi is the u coordinate)
+        const bool no_phi = dg == nullptr && phiMax >= 2.f * HPT_PI;
+        float phi = 0.f;
+        if (!no_phi) { phi = atan2f(phit.y, phit.x); if (phi < 0.f) phi += 2.f * HPT_PI; }
         if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) {
             if (thit == t1) return false;
             if (t1 > ray.maxt) return false;
             thit = t1;
             phit = ray_at(ray, thit);
             if (phit.x == 0.f && phit.y == 0.f) phit.x = 1e-5f * radius;
-            phi = atan2f(phit.y, phit.x);
-            if (phi < 0.f) phi += 2.f * HPT_PI;
+            if (!no_phi) { phi = atan2f(phit.y, phit.x); if (phi < 0.f) phi += 2.f * HPT_PI; }
             if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) return false;
         }
         if (dg) {
@@ -504,8 +506,11 @@ HPT_FN bool quadric_intersect(const hpt_quadric &q, const Ray &r, float *tHit, D
     f3 phit = ray_at(ray, thit);
     float d2 = phit.x * phit.x + phit.y * phit.y;
     if (d2 > q.radius * q.radius || d2 < q.inner_radius * q.inner_radius) return false;
-    float phi = atan2f(phit.y, phit.x);
-    if (phi < 0) phi = (float)((double)phi + 2. * (double)HPT_PI); // disk.cpp:75: `2. * M_PI` is double
+    float phi = 0.f;
+    if (!(dg == nullptr && q.phi_max >= 2.f * HPT_PI)) {             // (a full disk tested for a hit only: as for the sphere)
+        phi = atan2f(phit.y, phit.x);
+        if (phi < 0) phi = (float)((double)phi + 2. * (double)HPT_PI); // disk.cpp:75: `2. * M_PI` is double
+    }
     if (phi > q.phi_max) return false;
     if (dg) {
         float R = sqrtf(d2);
