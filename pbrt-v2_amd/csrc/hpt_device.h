@@ -1351,7 +1351,8 @@ HPT_FN float fr_cond1(float cosi, float e, float kk) {
 // instructions of metal.pbrt's kernel and 2.7 % of killeroo's, profiles/r06_lineprofile_*.md).  pow_dist(x, y), x = |cos theta_h| in [0, 1], y = the exponent > 0: on the
 // device exp2(y log2 x) on the hardware's v_log_f32 / v_exp_f32 (1 ulp each): wherever the value matters (x^y > 1e-6: |y log2 x| < 20) the result is within ~5e-6 relative of
 // powf's — the BSDF hooks' stated tolerance is 5e-4 — and where it does not, both are 0 to that tolerance's absolute floor.  pow5(x) = x^5 by multiplication (2 ulp).  The powers
-// that pick a sampled DIRECTION (Blinn::Sample_f, Anisotropic::sampleFirstQuadrant) keep powf: a direction decides which triangle a ray hits.  Host builds (oracle-side
+// that pick a sampled DIRECTION (Blinn::Sample_f, Anisotropic::sampleFirstQuadrant) keep powf: tried (GPU run T3: metal.pbrt +5.4 % more) and refused by the BSDF hooks'
+// tolerance — near u = 1 the hardware logarithm's error reaches sin(theta_h) through 1 - cos^2 and the sampled lobe's value is off by up to 1.6e-2.  Host builds (oracle-side
 // emulations) keep powf throughout.  -DHPT_LIBM_POW: powf everywhere (the A/B control).
 HPT_FN float pow_dist(float x, float y) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HPT_LIBM_POW)

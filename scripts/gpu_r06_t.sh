@@ -9,6 +9,6 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 run() { L=$V/libhpt_$2.so; [ $2 = default ] && L=$ROOT/pbrt-v2_amd/libhpt.so; HPT_LIB=$L timeout 900 python bench.py --workload $1 --steps 3 --warmup 1 $Q $X 2>/dev/null | line "$1 $2" | tee -a $O/ab.txt; }
 for i in 1 2; do
   X="--no-verify"; [ $i = 1 ] && X=""
-  for w in metal killeroo bunny anim; do for v in default pw; do run $w $v; done; done
+  for w in metal killeroo bunny anim; do for v in default pw2; do run $w $v; done; done
 done
-HPT_LIB=$V/libhpt_pw.so timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_pw.txt 2>&1; echo "pytest rc $?" >> $O/pytest_pw.txt; tail -8 $O/pytest_pw.txt | cut -c1-300
+HPT_LIB=$V/libhpt_pw2.so timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_pw.txt 2>&1; echo "pytest rc $?" >> $O/pytest_pw.txt; tail -8 $O/pytest_pw.txt | cut -c1-300
