@@ -2279,6 +2279,9 @@ HPT_FN f3 area_L(const hpt_light &l, f3 n, f3 w) { // DiffuseAreaLight::L (light
 // estimated in float, and the remainder corrected in integers — exact whatever the estimate, which only decides how often the loops turn
 // (never more than once for |a| < 2^22; larger values take the division).
 HPT_FN int mod_i(int a, int b) {
+    // (round 6: MIPMap levels are powers of two — the reference resamples to one, core/mipmap.h:150-180 — and so is every environment map it has resized: Mod(a, 2^k) is a mask,
+    //  for negative a too; the division below was 2.1 % of metal.pbrt's vector instructions)
+    if ((b & (b - 1)) == 0) return a & (b - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
     if ((unsigned)(a + (1 << 22)) < (1u << 23)) {
         const int q = (int)floorf((float)a * __builtin_amdgcn_rcpf((float)b));
