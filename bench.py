@@ -528,7 +528,10 @@ def measure(args, workload, spp, steps, warmup, world, rank, local, dist, torch,
     value = total_samples / dt / 1e6
     exch = None
     if comm is not None:
-        exch = comm.info()                      # the LAST timed frame's exchange as the library saw it: ncclCommCount, peers rank 0 received from, duration on the stream
+        try:
+            exch = comm.info()                  # the LAST timed frame's exchange as the library saw it: ncclCommCount, peers rank 0 received from, duration on the stream
+        except Exception as e:                  # (a report, not the product: an RCCL without ncclCommCount must not cost the driver its line)
+            exch = {"transport": "rccl", "ranks": world, "peers": None, "exchange_ms": None, "info_error": str(e)[:120]}
     if rank != 0:
         return None, scene, flt
     full_h = full.cpu().numpy()
