@@ -80,7 +80,9 @@ static void retrace_defaults(hpt::PathKernelArgs *a, const hpt_scene *s) {
     // a BVH that does not fit the caches (> 64 MB of nodes + triangle records: the 1 M-triangle soup) prefers earlier leaf phases — its node
     // steps wait for HBM, parked leaves pile up behind them — : same-box 2/1 against 4/8: soup 303 vs 296, the 7 MB scenes 1483 vs 1514 (bunny)
     const bool big = s && s->info.bvh_bytes + s->info.tri_bytes > ((int64_t)64 << 20);
-    a->leaf_q = lq ? atoi(lq) : big ? 2 : 4; a->block_q = bq ? atoi(bq) : big ? 1 : 8;
+    // (round 6, with cooperative leaf phases — a phase costs the same for 1 or 64 pairs, so fewer, fuller ones: 4 / 2 against 2 / 1: soup 374.8 vs 369.2, the 4 M-triangle soup
+    //  316.5 vs 311.4, profiles/r06_run_v_leaf_thresholds_soups.txt; the cache-resident scenes keep 4 / 8: run A)
+    a->leaf_q = lq ? atoi(lq) : 4; a->block_q = bq ? atoi(bq) : big ? 2 : 8;
 }
 
 // ---- on-disk cache of the kernel configuration ----------------------------------------------------------------------------------

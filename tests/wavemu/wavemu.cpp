@@ -78,7 +78,7 @@ static int prepare(const emu_scene *s, const hpt_camera *cam, const hpt_render_d
     a.retrace_min = knobs[1] > 0 ? knobs[1] : 8; a.retrace_max = knobs[2] >= 0 ? knobs[2] : 4;
     a.regen_min = knobs[0] > 0 ? knobs[0] : 16;
     const bool big = s->fs.n_tris >= 400000;
-    a.leaf_q = knobs[3] >= 0 ? knobs[3] : big ? 2 : 4; a.block_q = knobs[4] >= 0 ? knobs[4] : big ? 1 : 8;
+    a.leaf_q = knobs[3] >= 0 ? knobs[3] : 4; a.block_q = knobs[4] >= 0 ? knobs[4] : big ? 2 : 8;
     // kernel_residency of hpt_api.hip: [walk stack][stealing rows][cold rows]
     int scene_rows = s->fs.max_depth + 2;
     if (s->fs.has_measured && scene_rows < 12) scene_rows = 12;
