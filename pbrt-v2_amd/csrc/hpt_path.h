@@ -288,7 +288,11 @@ struct ColdLds {
 #ifdef HPT_NO_PARK
 #define HPT_PARK_MATS(mats) false
 #else
+#ifdef HPT_PARK_BASIC   /* (A/B: the matte / plastic kernels too) */
+#define HPT_PARK_MATS(mats) ((mats) == (MATS_PLASTIC | MATS_MEASURED) || (mats) == MATS_PLASTIC)
+#else
 #define HPT_PARK_MATS(mats) ((mats) == (MATS_PLASTIC | MATS_MEASURED))   /* the kernels of hpt_kernels_measured.hip */
+#endif
 #endif
 template <bool PARK> struct ColdSel;
 template <> struct ColdSel<false> { typedef ColdRegs type; static HPT_MFN void bind(ColdRegs &, HPT_LDS float *, int) {} };

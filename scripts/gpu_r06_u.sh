@@ -9,5 +9,5 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 run() { L=$V/libhpt_$2.so; [ $2 = default ] && L=$ROOT/pbrt-v2_amd/libhpt.so; HPT_LIB=$L timeout 900 python bench.py --workload $1 --steps 3 --warmup 1 $Q $X 2>/dev/null | line "$1 $2" | tee -a $O/ab.txt; }
 for i in 1 2; do
   X="--no-verify"; [ $i = 1 ] && X=""
-  for w in metal killeroo soup; do for v in default sc; do run $w $v; done; done
+  for w in killeroo soup; do for v in default park; do run $w $v; done; done
 done
