@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HPT_MAGIC   0x53545048u /* "HPTS" little endian */
-#define HPT_VERSION 8   /* blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights), 6 (no mesh tangents) and 7 (no animated spheres / disks: the same records, hpt_instance.quadric1 was padding) still load */
+#define HPT_VERSION 9   /* version 9: hpt_texture grew by the 2D mapping (spherical / cylindrical / planar); blobs of version 5 (round 1: no textures, no specular / regular-halfangle materials, no shape-set lights), 6 (no mesh tangents) and 7 (no animated spheres / disks: the same records, hpt_instance.quadric1 was padding) still load */
 
 enum {
     HPT_OK = 0,
@@ -62,11 +62,17 @@ enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_M
  * hpt_material.tex[slot] >= 0 — a texture of this table, evaluated at the hit's DifferentialGeometry like Texture::Evaluate.
  *   CONSTANT  textures/constant.h:45-55                 value
  *   IMAGEMAP  textures/imagemap.cpp:41-101              MIPMap::Lookup (core/mipmap.h:238-366: trilinear or EWA) of the pyramid the
- *             reference built (MIPMap ctor, mipmap.h:105-190), through a UVMapping2D (core/texture.cpp:44-57)
+ *             reference built (MIPMap ctor, mipmap.h:105-190), through the texture's TextureMapping2D (version 9: all four of
+ *             core/texture.cpp:88-164 — "uv", "spherical", "cylindrical", "planar", textures/imagemap.cpp:106-124)
  *   SCALE     textures/scale.h:46-60                    tex1 * tex2
  *   MIX       textures/mix.h:46-62                      (1 - amount) * tex1 + amount * tex2
- * Other texture plugins and other mappings are outside the hot-path scope (the host wrapper refuses them). */
+ * Other texture plugins are outside the hot-path scope (the host wrapper refuses them). */
 enum { HPT_TEX_CONSTANT = 1, HPT_TEX_IMAGEMAP = 2, HPT_TEX_SCALE = 3, HPT_TEX_MIX = 4 };
+/* TextureMapping2D (core/texture.h:47-113).  UV: (su * u + du, sv * v + dv).  SPHERICAL / CYLINDRICAL: the hit point through
+ * WorldToTexture (map_m, row-major 4 x 4), then (theta / pi, phi / 2 pi) resp. ((pi + atan2(y, x)) / 2 pi, z) of the normalized vector, with
+ * finite-difference derivatives over dpdx / dpdy (delta .1 resp. .01, core/texture.cpp:102-149).  PLANAR: (ds + p . vs, dt + p . vt) with
+ * map_m = {vs.x, vs.y, vs.z, vt.x, vt.y, vt.z, ds, dt} (core/texture.cpp:152-162). */
+enum { HPT_MAP_UV = 0, HPT_MAP_SPHERICAL = 1, HPT_MAP_CYLINDRICAL = 2, HPT_MAP_PLANAR = 3 };
 enum { HPT_WRAP_REPEAT = 0, HPT_WRAP_BLACK = 1, HPT_WRAP_CLAMP = 2 };   /* ImageWrap, core/mipmap.h:47-49 */
 typedef struct hpt_texture {
     int32_t kind;
@@ -82,6 +88,10 @@ typedef struct hpt_texture {
     int32_t do_trilinear;  /* MIPMap::doTrilinear */
     float max_aniso;       /* MIPMap::maxAnisotropy */
     float su, sv, du, dv;  /* UVMapping2D */
+    /* ---- version 9 ---- */
+    int32_t mapping;       /* HPT_MAP_* (0 = the UVMapping2D above: what every older blob holds) */
+    int32_t pad9;
+    float map_m[16];       /* SPHERICAL / CYLINDRICAL: WorldToTexture; PLANAR: vs, vt, ds, dt */
 } hpt_texture;
 /* hpt_material.tex[] slots */
 enum { HPT_TEXSLOT_KD = 0,        /* matte / plastic / substrate Kd; metal eta                 (spectrum) */

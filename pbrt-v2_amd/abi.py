@@ -9,13 +9,14 @@ import ctypes as C
 import numpy as np
 
 HPT_MAGIC = 0x53545048
-HPT_VERSION = 8
+HPT_VERSION = 9
 
 HPT_QUADRIC_SPHERE, HPT_QUADRIC_DISK = 1, 2
 HPT_MAT_MATTE, HPT_MAT_PLASTIC, HPT_MAT_MEASURED_IRREG, HPT_MAT_METAL, HPT_MAT_SUBSTRATE = 1, 2, 3, 4, 5
 HPT_MAT_GLASS, HPT_MAT_MIRROR, HPT_MAT_MEASURED_REGULAR = 6, 7, 8
 HPT_TEX_CONSTANT, HPT_TEX_IMAGEMAP, HPT_TEX_SCALE, HPT_TEX_MIX = 1, 2, 3, 4
 HPT_WRAP_REPEAT, HPT_WRAP_BLACK, HPT_WRAP_CLAMP = 0, 1, 2
+HPT_MAP_UV, HPT_MAP_SPHERICAL, HPT_MAP_CYLINDRICAL, HPT_MAP_PLANAR = 0, 1, 2, 3
 TEXSLOT_KD, TEXSLOT_KS, TEXSLOT_ROUGH, TEXSLOT_ROUGH_V, TEXSLOT_BUMP, TEXSLOT_KT, TEXSLOT_INDEX = 0, 1, 2, 3, 4, 5, 6
 HPT_N_TEXSLOTS = 8
 HPT_LIGHT_POINT, HPT_LIGHT_DIFFUSE_AREA, HPT_LIGHT_INFINITE, HPT_LIGHT_SPOT, HPT_LIGHT_DISTANT = 1, 2, 3, 4, 5
@@ -116,11 +117,19 @@ class Light(C.Structure):
     _fields_ = _LIGHT_V5 + [("set_off", i64), ("set_area_off", i64), ("set_n", i32), ("pad", i32)]
 
 
+_TEXTURE_V8 = [("kind", i32), ("channels", i32), ("value", f32 * 3), ("tex1", i32), ("tex2", i32), ("amount", i32),
+               ("pyr_off", i64), ("width", i32), ("height", i32), ("levels", i32), ("wrap", i32), ("do_trilinear", i32),
+               ("max_aniso", f32), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32)]
+
+
+class TextureV8(C.Structure):
+    """hpt_texture of versions 6 .. 8: every image map through its UVMapping2D"""
+    _fields_ = _TEXTURE_V8
+
+
 class Texture(C.Structure):
     """hpt_texture"""
-    _fields_ = [("kind", i32), ("channels", i32), ("value", f32 * 3), ("tex1", i32), ("tex2", i32), ("amount", i32),
-                ("pyr_off", i64), ("width", i32), ("height", i32), ("levels", i32), ("wrap", i32), ("do_trilinear", i32),
-                ("max_aniso", f32), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32)]
+    _fields_ = _TEXTURE_V8 + [("mapping", i32), ("pad9", i32), ("map_m", f32 * 16)]     # version 9: TextureMapping2D (0 = uv)
 
 
 def _upgrade(old, new_type):
@@ -349,7 +358,7 @@ class Scene:
         with _open(path, "rb") as f:
             raw = f.read()
         h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
-        if h.magic != HPT_MAGIC or h.version not in (5, 6, 7, HPT_VERSION):
+        if h.magic != HPT_MAGIC or h.version not in (5, 6, 7, 8, HPT_VERSION):
             raise ValueError(f"{path}: not an HPTS v5 .. v{HPT_VERSION} blob")
         v5 = h.version == 5          # round-1 fixtures: smaller material / light records, no texture table
         mat_t, light_t = (MaterialV5, LightV5) if v5 else (Material, Light)
@@ -385,6 +394,11 @@ class Scene:
             s.materials, s.lights = mats, lights
             for m in s.meshes:
                 m.alpha_tex = 0
+        elif h.version < 9:           # texture records without the 2D mapping block
+            old = take(TextureV8, h.n_textures)
+            s.textures = _arr(Texture, h.n_textures)
+            for i in range(h.n_textures):
+                s.textures[i] = _upgrade(old[i], Texture)
         else:
             s.textures = take(Texture, h.n_textures)
         s.fpool = np.frombuffer(raw, dtype=np.float32, count=h.n_f, offset=off).copy(); off += 4 * h.n_f

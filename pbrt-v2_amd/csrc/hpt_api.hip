@@ -386,6 +386,8 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.fpool = upload(s, &arena, fs.fpool.data(), fs.fpool.size(), &ok);
     s->d.ipool = upload(s, &arena, fs.ipool.data(), fs.ipool.size(), &ok);
     s->d.textures = upload(s, &arena, desc->textures, (size_t)desc->n_textures, &ok);
+    s->d.tex_mapped = 0;          // ABI 9: a point-reading 2D mapping anywhere in the table sends the scene's texture lookups through tex_eval_mapped (hpt_device.h)
+    for (int k = 0; k < desc->n_textures; ++k) if (desc->textures[k].kind == HPT_TEX_IMAGEMAP && desc->textures[k].mapping != HPT_MAP_UV) s->d.tex_mapped = 1;
     s->d.instances = upload(s, &arena, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;

@@ -52,6 +52,11 @@ struct hpt_mesh_v6 {   // versions 5 and 6: hpt_mesh without s_off
     float o2w[16]; float o2w_inv[16];
 };
 
+struct hpt_texture_v8 {   // versions 6 .. 8: hpt_texture without the 2D mapping (every image map through its UVMapping2D)
+    int32_t kind, channels; float value[3]; int32_t tex1, tex2, amount; int64_t pyr_off; int32_t width, height, levels, wrap, do_trilinear;
+    float max_aniso; float su, sv, du, dv;
+};
+
 struct hpt_blob {
     hpt_blob_header h;
     hpt_scene_desc desc;
@@ -97,6 +102,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                 hpt_set_error("texture %d: image pyramid out of range / not a power of two", t);
                 return HPT_E_INVALID;
             }
+            if (tx.mapping < HPT_MAP_UV || tx.mapping > HPT_MAP_PLANAR) { hpt_set_error("texture %d: unknown 2D mapping %d", t, tx.mapping); return HPT_E_INVALID; }
         } else if (tx.kind == HPT_TEX_SCALE || tx.kind == HPT_TEX_MIX) {
             // operands must come EARLIER in the table (the plugin emits them depth first): no cycles, bounded recursion
             if (tx.tex1 < 0 || tx.tex1 >= t || tx.tex2 < 0 || tx.tex2 >= t || (tx.kind == HPT_TEX_MIX && (tx.amount < 0 || tx.amount >= t || d->textures[tx.amount].channels != 1))) {
@@ -339,6 +345,8 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     const int64_t n_tex = v5 ? 0 : (int64_t)h.n_textures;
     const bool mesh6 = h.version < 7;                                    // meshes without tangents: records grow by s_off = -1
     const size_t sz_mesh = mesh6 ? sizeof(hpt_mesh_v6) : sizeof(hpt_mesh);
+    const bool tex8 = h.version < 9;                                     // textures without the mapping block: records grow by mapping = UV
+    const size_t sz_tex = tex8 ? sizeof(hpt_texture_v8) : sizeof(hpt_texture);
     if (h.sizeof_mesh != sz_mesh || h.sizeof_quadric != sizeof(hpt_quadric) || h.sizeof_material != sz_mat ||
         h.sizeof_light != sz_light || h.sizeof_instance != sizeof(hpt_instance)) {
         hpt_set_error("%s: record sizes differ from this build of the ABI", path);
@@ -349,7 +357,7 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     const uint64_t limit = (uint64_t)fsize - sizeof(b->h);
     bool ok = add_bytes(&bytes, sz_mesh, h.n_meshes, limit) && add_bytes(&bytes, sizeof(hpt_quadric), h.n_quadrics, limit) &&
               add_bytes(&bytes, sz_mat, h.n_materials, limit) && add_bytes(&bytes, sz_light, h.n_lights, limit) &&
-              add_bytes(&bytes, sizeof(hpt_instance), h.n_instances, limit) && add_bytes(&bytes, sizeof(hpt_texture), n_tex, limit) &&
+              add_bytes(&bytes, sizeof(hpt_instance), h.n_instances, limit) && add_bytes(&bytes, sz_tex, n_tex, limit) &&
               add_bytes(&bytes, sizeof(float), h.n_f, limit) && add_bytes(&bytes, sizeof(int32_t), h.n_i, limit);
     if (!ok || bytes != limit) {
         hpt_set_error("%s: header counts do not match the file size", path);
@@ -357,7 +365,7 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
     }
     // version 5: the material / light records grow to today's layout (new fields at their "absent" values)
     const size_t extra = (v5 ? (sizeof(hpt_material) - sz_mat) * (size_t)h.n_materials + (sizeof(hpt_light) - sz_light) * (size_t)h.n_lights : 0) +
-                         (sizeof(hpt_mesh) - sz_mesh) * (size_t)h.n_meshes;
+                         (sizeof(hpt_mesh) - sz_mesh) * (size_t)h.n_meshes + (sizeof(hpt_texture) - sz_tex) * (size_t)n_tex;
     b->storage = malloc((size_t)bytes + extra + 1);
     std::vector<char> raw((size_t)bytes + 1);
     if (!b->storage || fread(raw.data(), 1, (size_t)bytes, f) != (size_t)bytes) {
@@ -395,7 +403,12 @@ extern "C" hpt_blob *hpt_blob_load(const char *path) {
         for (int i = 0; i < h.n_meshes; ++i) ((hpt_mesh *)b->desc.meshes)[i].alpha_tex = 0;   // (the word was padding)
     }
     TAKE(instances, hpt_instance, h.n_instances);
-    TAKE(textures, hpt_texture, n_tex);
+    if (!tex8) TAKE(textures, hpt_texture, n_tex);
+    else {
+        hpt_texture *to = (hpt_texture *)p; b->desc.textures = to;
+        for (int64_t i = 0; i < n_tex; ++i) { memset(&to[i], 0, sizeof(hpt_texture)); memcpy(&to[i], src + sizeof(hpt_texture_v8) * (size_t)i, sizeof(hpt_texture_v8)); }
+        p += sizeof(hpt_texture) * (size_t)n_tex; src += sizeof(hpt_texture_v8) * (size_t)n_tex;
+    }
     TAKE(fpool, float, h.n_f);
     TAKE(ipool, int32_t, h.n_i);
     #undef TAKE

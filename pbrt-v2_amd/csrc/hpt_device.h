@@ -383,6 +383,7 @@ struct DScene {
     int32_t world_root4;
     uint32_t inst_quadric_mask;     // bit q (q < 31): quadric q is the primitive of an instance (hpt_instance.quadric1 == q + 1), not a primitive of the world; bit 31: an owned quadric has index >= 31 (those are looked up in the instance table)
     int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
+    int32_t tex_mapped;             // 1: some image map has a spherical / cylindrical / planar mapping (textures go through tex_eval_mapped).  (In what was the record's tail padding: its size is round 5's.)
 #ifdef HPT_DEBUG_CHECKS             /* `make debug` only (the whole library is built with the flag): table sizes for the bounds checks */
     int32_t n_nodes4, n_meshes, n_materials, n_textures;
 #endif
@@ -734,7 +735,7 @@ HPT_FN void trav_begin(const DScene &sc, TravState &ts, Ray &ray, bool anyhit, i
 
 // TriangleMesh::alphaTexture (shapes/trianglemesh.cpp:190-195, 246-276): a hit where the mesh's alpha texture evaluates to 0 is no hit
 // (defined with the textures below; only the MATS_EXT kernels instantiate the ALPHA walk)
-HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2);
+HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2, f3 p);
 // The two halves of a step, separately callable (the lock-step + stealing walk of the path kernel batches the leaf half: hpt_kernels_impl.h).
 // trav_node: ts.node >= 0 — one 64-byte node fetch, two slab tests, near child first, far child stacked; leaves ts.node at the next interior
 // node, at a leaf code, or — nothing hit, nothing stacked — HPT_TRAV_EMPTY.
@@ -851,7 +852,7 @@ HPT_FN bool trav_leaf(const DScene &sc, const f4 *tris, TravState &ts, Ray &ray,
         if (COUNT) cnt->tris++;
         float t, b1, b2;
         if (tri_test(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), ray, &t, &b1, &b2)) {
-            if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2)) continue;
+            if (ALPHA && (as_int(a.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(a.w), as_int(b.w), b1, b2, ray.o + ray.d * t)) continue;
             ts.hit.prim = (int32_t)(first + k);
             if (ts.anyhit) return true;
             ts.hit.t = t; ts.hit.b1 = b1; ts.hit.b2 = b2;
@@ -1682,6 +1683,10 @@ struct TexV { float c[3]; };
 // What a texture lookup reads of the scene and of the hit, by value (see irreg_eval on why not a reference to the scene record)
 struct TexPools { const hpt_texture *textures; const float *fpool; const float *ewa_lut; };
 struct TexUV { float u, v, dudx, dvdx, dudy, dvdy; };
+// ... and what the spherical / cylindrical / planar mappings read on top of it (round 6, ABI 9).  Nine more floats through the evaluators' calls cost
+// metal.pbrt 16 % (528 B more scratch a lane: every level of tex_eval keeps its copy across its calls), so they travel in a chain of their own
+// (tex_eval_mapped), entered only in scenes that HAVE such a texture (DScene::tex_mapped): a scene of uv maps runs the code of round 5.
+struct TexPt { TexUV uv; f3 p, dpdx, dpdy; };
 // MIPMap<T>::Texel (core/mipmap.h:204-223).  Level l of a pyramid starts right after level l - 1 (include/hpt.h).
 HPT_FN void mip_level(const hpt_texture &t, int level, int64_t *off, int *w, int *h) {
     int64_t o = t.pyr_off; int ww = t.width, hh = t.height;
@@ -1812,6 +1817,34 @@ HPT_FN_NOINLINE TexV mip_lookup(const TexPools sc, const hpt_texture &t, float s
 // ... and a call costs its callee's saved registers (50 scratch stores + loads for a level of tex_eval), so the two leaf kinds never pay for a
 // level of their own: a constant is read in place and an image map goes straight to mip_lookup — scale(imagemap, constant), the bump map of
 // scenes/metal.pbrt, is two calls instead of four.
+// TextureMapping2D::Map of the three mappings that read the hit POINT (core/texture.cpp:101-162, core/texture.h:93-97): spherical and
+// cylindrical take their derivatives as finite differences over dpdx / dpdy.  Out of line: a scene without such textures never enters it.
+HPT_FN void map_point(const hpt_texture &t, f3 p, float *s, float *tt) {
+    const f3 vec = normalize(xf_point(t.map_m, p));
+    if (t.mapping == HPT_MAP_SPHERICAL) { *s = spherical_theta(vec) * HPT_INV_PI; *tt = spherical_phi(vec) * HPT_INV_TWOPI; }
+    else { *s = (HPT_PI + atan2f(vec.y, vec.x)) / (2.f * HPT_PI); *tt = vec.z; }
+}
+HPT_FN TexV tex_image(const TexPools sc, const hpt_texture &t, const TexUV dg);
+HPT_FN_NOINLINE TexV tex_image_mapped(const TexPools sc, const hpt_texture &t, const TexPt dg) {
+    float s, tt, dsdx, dtdx, dsdy, dtdy;
+    if (t.mapping == HPT_MAP_UV) return tex_image(sc, t, dg.uv);
+    if (t.mapping == HPT_MAP_PLANAR) {
+        const f3 vs = mk3(t.map_m[0], t.map_m[1], t.map_m[2]), vt = mk3(t.map_m[3], t.map_m[4], t.map_m[5]);
+        s = t.map_m[6] + dot(dg.p, vs); tt = t.map_m[7] + dot(dg.p, vt);
+        dsdx = dot(dg.dpdx, vs); dtdx = dot(dg.dpdx, vt); dsdy = dot(dg.dpdy, vs); dtdy = dot(dg.dpdy, vt);
+    } else {
+        const float delta = t.mapping == HPT_MAP_SPHERICAL ? .1f : .01f;
+        float sx, tx, sy, ty;
+        map_point(t, dg.p, &s, &tt);
+        map_point(t, dg.p + dg.dpdx * delta, &sx, &tx);
+        dsdx = (sx - s) / delta; dtdx = (tx - tt) / delta;
+        if (dtdx > .5f) dtdx = 1.f - dtdx; else if (dtdx < -.5f) dtdx = -(dtdx + 1.f);
+        map_point(t, dg.p + dg.dpdy * delta, &sy, &ty);
+        dsdy = (sy - s) / delta; dtdy = (ty - tt) / delta;
+        if (dtdy > .5f) dtdy = 1.f - dtdy; else if (dtdy < -.5f) dtdy = -(dtdy + 1.f);
+    }
+    return mip_lookup(sc, t, s, tt, dsdx, dtdx, dsdy, dtdy);
+}
 HPT_FN TexV tex_image(const TexPools sc, const hpt_texture &t, const TexUV dg) {
     return mip_lookup(sc, t, t.su * dg.u + t.du, t.sv * dg.v + t.dv, t.su * dg.dudx, t.sv * dg.dvdx, t.su * dg.dudy, t.sv * dg.dvdy);
 }
@@ -1853,12 +1886,33 @@ HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg) {
     }
     return r;
 }
+// The same tree walk for a scene with point-reading mappings: out of line at every level, no leaf shortcuts (what it costs is paid by those scenes only).
+template <int DEPTH>
+HPT_FN_NOINLINE TexV tex_eval_mapped(const TexPools sc, int id, const TexPt dg) {
+    const hpt_texture &t = sc.textures[id];
+    TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
+    if (t.kind == HPT_TEX_CONSTANT) return r;
+    if (t.kind == HPT_TEX_IMAGEMAP) return tex_image_mapped(sc, t, dg);
+    if (DEPTH > 0) {
+        TexV a = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex1, dg), b = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex2, dg);
+        if (sc.textures[t.tex1].channels < t.channels) a.c[1] = a.c[2] = a.c[0];
+        if (sc.textures[t.tex2].channels < t.channels) b.c[1] = b.c[2] = b.c[0];
+        if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k]; return r; }
+        const float amt = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
+        for (int k = 0; k < 3; ++k) r.c[k] = (1.f - amt) * a.c[k] + amt * b.c[k];
+    }
+    return r;
+}
 HPT_FN TexPools tex_pools(const DScene &sc) { TexPools p; p.textures = sc.textures; p.fpool = sc.fpool; p.ewa_lut = sc.ewa_lut; return p; }
 HPT_FN TexUV tex_uv(const DGeomX &dg) { TexUV t; t.u = dg.u; t.v = dg.v; t.dudx = dg.dudx; t.dvdx = dg.dvdx; t.dudy = dg.dudy; t.dvdy = dg.dvdy; return t; }
-HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)).c[0]; }
-HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg)); return mk3(v.c[0], v.c[1], v.c[2]); }
+HPT_FN TexV tex_any(const DScene &sc, int id, const DGeomX &dg) {
+    if (sc.tex_mapped) { TexPt t; t.uv = tex_uv(dg); t.p = dg.p; t.dpdx = dg.dpdx; t.dpdy = dg.dpdy; return tex_eval_mapped<HPT_TEX_DEPTH>(tex_pools(sc), id, t); }
+    return tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg));
+}
+HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_any(sc, id, dg).c[0]; }
+HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_any(sc, id, dg); return mk3(v.c[0], v.c[1], v.c[2]); }
 
-HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2) {
+HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2, f3 p) {
     const DMesh &me = sc.meshes[mesh_word & HPT_TRI_MESH_MASK];
     const int32_t *idx = sc.ipool + me.idx_off + 3 * (int64_t)tri;
     float uv[3][2];
@@ -1871,6 +1925,7 @@ HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, f
     dg.u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     dg.v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
     dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.f;          // dgLocal: a fresh DifferentialGeometry has no screen-space derivatives (diffgeom.cpp:50)
+    dg.p = p; dg.dpdx = dg.dpdy = S(0.f);                 // (p = ray(t), trianglemesh.cpp:191: what a spherical / cylindrical / planar alpha map reads)
     return tex_float(sc, me.alpha_tex - 1, dg) != 0.f;
 }
 

@@ -357,7 +357,7 @@ __device__ __forceinline__ void traverse_steal(const DScene &sc, Ray &ray, float
                                 const f4 ta = tp[0], tb = tp[1], tcx = tp[2];
                                 if (COUNT) cnt->tris++;
                                 if (tri_test(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tcx.x, tcx.y, tcx.z), rr, &wt, &wb1, &wb2)
-                                    && !(ALPHA && (as_int(ta.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(ta.w), as_int(tb.w), wb1, wb2))) { wf = true; wprim = (int32_t)ti; }
+                                    && !(ALPHA && (as_int(ta.w) & HPT_TRI_ALPHA_BIT) && !tri_alpha_pass(sc, as_int(ta.w), as_int(tb.w), wb1, wb2, rr.o + rr.d * wt))) { wf = true; wprim = (int32_t)ti; }
                             }
                             if (__ballot(wf) != 0ull) {
                                 coop_found = true;

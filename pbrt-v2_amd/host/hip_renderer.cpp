@@ -117,14 +117,24 @@ struct Flattener {
     }
 
 
-    // ---- textures (core/texture.h): ConstantTexture, ImageTexture over a UVMapping2D, ScaleTexture, MixTexture -------------
+    // ---- textures (core/texture.h): ConstantTexture, ImageTexture over any TextureMapping2D, ScaleTexture, MixTexture -------------
     // Operands are emitted before the texture that uses them (hpt_validate_desc relies on it).
     template <typename Tmem, typename Tret> int AddImageTexture(const ImageTexture<Tmem, Tret> *it, int channels) {
         hpt_texture r; memset(&r, 0, sizeof(r));
         r.kind = HPT_TEX_IMAGEMAP; r.channels = channels; r.tex1 = r.tex2 = r.amount = -1;
-        const UVMapping2D *uv = dynamic_cast<const UVMapping2D *>(it->mapping);
-        if (!uv) Severe("hip renderer: only \"uv\" texture mappings are inside the hot-path scope");
-        r.su = uv->su; r.sv = uv->sv; r.du = uv->du; r.dv = uv->dv;
+        // TextureMapping2D (core/texture.h:47-113): the four mappings textures/imagemap.cpp:106-124 can create
+        if (const UVMapping2D *uv = dynamic_cast<const UVMapping2D *>(it->mapping)) {
+            r.mapping = HPT_MAP_UV; r.su = uv->su; r.sv = uv->sv; r.du = uv->du; r.dv = uv->dv;
+        } else if (const SphericalMapping2D *sp = dynamic_cast<const SphericalMapping2D *>(it->mapping)) {
+            r.mapping = HPT_MAP_SPHERICAL; CopyM(sp->WorldToTexture.m, r.map_m);
+        } else if (const CylindricalMapping2D *cy = dynamic_cast<const CylindricalMapping2D *>(it->mapping)) {
+            r.mapping = HPT_MAP_CYLINDRICAL; CopyM(cy->WorldToTexture.m, r.map_m);
+        } else if (const PlanarMapping2D *pl = dynamic_cast<const PlanarMapping2D *>(it->mapping)) {
+            r.mapping = HPT_MAP_PLANAR;
+            r.map_m[0] = pl->vs.x; r.map_m[1] = pl->vs.y; r.map_m[2] = pl->vs.z; r.map_m[3] = pl->vt.x; r.map_m[4] = pl->vt.y; r.map_m[5] = pl->vt.z;
+            r.map_m[6] = pl->ds; r.map_m[7] = pl->dt;
+        } else
+            Severe("hip renderer: unknown TextureMapping2D");
         const MIPMap<Tmem> *mm = it->mipmap;
         r.width = (int)mm->width; r.height = (int)mm->height; r.levels = (int)mm->nLevels;
         r.wrap = mm->wrapMode == TEXTURE_REPEAT ? HPT_WRAP_REPEAT : mm->wrapMode == TEXTURE_BLACK ? HPT_WRAP_BLACK : HPT_WRAP_CLAMP;
@@ -168,7 +178,7 @@ struct Flattener {
             r.kind = HPT_TEX_MIX; r.channels = channels; r.tex1 = a; r.tex2 = b; r.amount = am;
             textures.push_back(r); idx = (int)textures.size() - 1;
         } else
-            Severe("hip renderer: texture type outside the hot-path scope (supported: constant, imagemap with uv mapping, scale, mix)");
+            Severe("hip renderer: texture type outside the hot-path scope (supported: constant, imagemap, scale, mix)");
         textureIndex[(const void *)t] = idx;
         return idx;
     }

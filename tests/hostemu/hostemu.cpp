@@ -49,6 +49,8 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.n_instances = desc->n_instances; s->d.world_root = s->fs.world_root;
     for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) s->d.inst_quadric_mask |= 1u << std::min(desc->instances[k].quadric1 - 1, 31);
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
+    s->d.tex_mapped = 0;
+    for (size_t k = 0; k < s->textures.size(); ++k) if (s->textures[k].kind == HPT_TEX_IMAGEMAP && s->textures[k].mapping != HPT_MAP_UV) s->d.tex_mapped = 1;
     s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4; s->d.top_root4 = s->fs.top_root4;
     return s;
 }

@@ -58,7 +58,8 @@ def kernel_symbol(count, inst, mats, waves, ee, phased, dl, steal, win=False, to
 
 CALLEES = ["_ZN3hpt10mip_lookupENS_8TexPoolsERK11hpt_textureffffff", "_ZN3hpt8tex_evalILi0EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt8tex_evalILi1EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE",
            "_ZN3hpt8tex_evalILi2EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt8tex_evalILi3EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt10irreg_evalEPKfPK12hpt_materialNS_2f3E",
-           "_ZN3hpt11wave_kd_runEPKfPK12hpt_materialNS_9LaneStackEi"]
+           "_ZN3hpt11wave_kd_runEPKfPK12hpt_materialNS_9LaneStackEi", "_ZN3hpt16tex_image_mappedENS_8TexPoolsERK11hpt_textureNS_5TexPtE"] + \
+          ["_ZN3hpt15tex_eval_mappedILi%dEEENS_4TexVENS_8TexPoolsEiNS_5TexPtE" % k for k in range(4)]
 
 
 class BinaryRender:
@@ -68,6 +69,7 @@ class BinaryRender:
         rendered wrong films on the GPU in round 5 that way"""
         self.ws = w.WaveScene(scene, raw=True)
         self.co, self.symbol, self.kid = co_path, symbol, wave_kernel_id
+        self.legacy_textures = listing is not None
         if listing is not None:
             import json
             import lzma
@@ -107,6 +109,16 @@ class BinaryRender:
             import struct
             struct.pack_into("<IIIHHHHHH", args, (int(geom[0]) + 7) & ~7, int(geom[1]), 1, 1, 256, 1, 1, 0, 0, 0)
             struct.pack_into("<H", args, ((int(geom[0]) + 7) & ~7) + 64, 1)
+        if self.legacy_textures:                   # a binary compiled before ABI 9: its texture records are the first 80 bytes of today's (hpt_texture_v8, csrc/hpt_blob.cpp)
+            o = np.zeros(16, dtype=np.int32)
+            L.wavemu_args_offsets.argtypes = [C.c_void_p]
+            L.wavemu_args_offsets(o.ctypes.data)
+            ptr, ntex = C.c_uint64.from_buffer(args, int(o[10])), len(self.ws.scene.textures)
+            new_sz, old_sz = C.sizeof(w.abi.Texture), C.sizeof(w.abi.TextureV8)
+            self._tex_v8 = C.create_string_buffer(max(1, ntex) * old_sz)
+            for k in range(ntex):
+                C.memmove(C.addressof(self._tex_v8) + k * old_sz, ptr.value + k * new_sz, old_sz)
+            ptr.value = C.addressof(self._tex_v8)
         mem = g.HostMemory()
         lds = np.zeros(65536 // 4, dtype=np.uint32)
         self.lds_bytes = int(geom[2])

@@ -60,6 +60,36 @@ def test_blob_roundtrip_between_c_and_python(cases, tmp_path):
     assert np.array_equal(u.fpool, s.fpool) and bytes(u.materials) == bytes(s.materials)
 
 
+@pytest.mark.parametrize("name", ["tex.hpts.gz", "metal.hpts.gz", "texmap.hpts.gz", "killeroo_cfg1.hpts.gz"])
+def test_c_loader_upgrades_older_blobs_like_the_python_loader(name, tmp_path):
+    """ABI 9: the texture records of version-6 .. 8 blobs grow by the 2D mapping (uv) in hpt_blob_load exactly as in abi.Scene.load; a version-9 blob
+    (texmap: spherical / cylindrical / planar) passes through."""
+    import gzip
+    import os
+    from tests.util import GOLDEN
+    raw = gzip.open(os.path.join(GOLDEN, name), "rb").read()
+    p = str(tmp_path / "x.hpts")
+    open(p, "wb").write(raw)
+    L = hpt.lib()
+    L.hpt_blob_load.restype = C.c_void_p
+    L.hpt_blob_scene.restype = C.POINTER(abi.SceneDesc)
+    L.hpt_blob_scene.argtypes = [C.c_void_p]
+    L.hpt_blob_free.argtypes = [C.c_void_p]
+    b = L.hpt_blob_load(p.encode())
+    assert b, hpt.last_error()
+    try:
+        d = L.hpt_blob_scene(b).contents
+        s = abi.Scene.load(p)
+        assert d.n_textures == len(s.textures) and d.n_meshes == len(s.meshes)
+        if d.n_textures:
+            assert C.string_at(d.textures, C.sizeof(abi.Texture) * d.n_textures) == bytes(s.textures)
+        version = int(np.frombuffer(raw[4:8], dtype=np.uint32)[0])
+        mapped = [t.mapping for t in s.textures if t.kind == abi.HPT_TEX_IMAGEMAP]
+        assert (version == abi.HPT_VERSION and sorted(set(mapped)) == [1, 2, 3]) if name.startswith("texmap") else (version < 9 and not any(mapped))
+    finally:
+        L.hpt_blob_free(b)
+
+
 def test_invalid_descriptors_are_rejected(cases, tmp_path):
     s = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "env_soup.hpts.gz"))
     s.meshes[0].material = 99
@@ -74,6 +104,10 @@ def test_invalid_descriptors_are_rejected(cases, tmp_path):
     s.materials[0].kind = 77
     d = s.desc
     assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -3
+    s = abi.Scene.load(os.path.join(ROOT, "tests", "golden", "texmap.hpts.gz"))       # ABI 9: a 2D mapping the library does not know
+    next(t for t in s.textures if t.kind == abi.HPT_TEX_IMAGEMAP).mapping = 4
+    d = s.desc
+    assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -2 and "mapping" in hpt.last_error()
 
 
 def test_animated_quadric_records_are_validated(tmp_path):

@@ -185,7 +185,7 @@ def test_warmup_thread_starts_the_runtime_for_a_fresh_process(cases, dev, tmp_pa
     assert np.array_equal(np.load(out), fd)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -966,7 +966,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)
@@ -1006,7 +1006,7 @@ def test_round2_features_match_oracle_sample_for_sample(name):
         assert st2.tune_cfg == cfg and np.array_equal(f[..., 3], ref[..., 3]) and film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(ref)) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "on"])
+@pytest.mark.parametrize("name", ["tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "on", "texmap_lean"])
 def test_kernel_set_picked_by_scene_features_renders_the_full_sets_film(name, monkeypatch):
     """Round 4: hpt_scene_create picks the kernel instantiation from what the scene can reach — an extension-set scene without measured /
     specular materials, shape-set / spot / distant lights and animated instances runs the LEAN set (csrc/hpt_kernels_lean.hip, MATS_LEAN).

@@ -69,6 +69,13 @@ def load_case(name):
         s = abi.Scene.load(os.path.join(GOLDEN, "acam.hpts.gz"))
         s.camera_motion = abi.Instance.from_buffer_copy(np.load(os.path.join(GOLDEN, "acam.view.npz"))["camera_motion"].tobytes())
         return s
+    if name == "texmap_lean":    # `texmap` with its mirror painted matte: a scene of mapped textures the LEAN extension set can run (no golden: full set vs lean set)
+        s = load_case("texmap")
+        for m in s.materials:
+            if m.kind == abi.HPT_MAT_MIRROR:
+                m.kind = abi.HPT_MAT_MATTE
+                m.kd[0], m.kd[1], m.kd[2] = 0.5, 0.45, 0.4
+        return s
     if name in R2_CASES:
         s = abi.Scene.load(os.path.join(GOLDEN, R2_CASES[name]))
         if name == "merl":       # the 17.5 MB half-angle table is rebuilt from its formula instead of being committed
@@ -169,8 +176,12 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             "oinst": "oinst.hpts.gz",
             # round 3 (tests/golden/make_golden_abi8dl.py): everything ABI 8 added, together, under direct lighting "one" with the specular recursion
             # (run Z: on the device RMSE 1.7e-6 against the oracle, identical ray counts)
-            "abi8dl": "abi8dl.hpts.gz"}
-R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz"}     # same geometry, own camera / render descriptor / lights
+            "abi8dl": "abi8dl.hpts.gz",
+            # round 6 (tests/golden/make_golden_texmap.py): image maps through "spherical" (under a texture-space transform), "cylindrical" and "planar"
+            # TextureMapping2Ds — Kd, roughness, bump and alpha textures (ABI 9, hpt_texture.mapping / map_m); `texmapdl`: the same through a mirror
+            # under direct lighting (finite differences over the specular rays' dpdx / dpdy)
+            "texmap": "texmap.hpts.gz"}
+R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz", "texmapdl": "texmap.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
 def merl_table_doubles():

@@ -152,4 +152,6 @@ extern "C" void wavemu_args_offsets(int32_t *o) {
     o[3] = (int32_t)offsetof(PathKernelArgs, counters); o[4] = (int32_t)offsetof(PathKernelArgs, dbg); o[5] = (int32_t)offsetof(PathKernelArgs, stack_entries);
     o[6] = (int32_t)offsetof(PathKernelArgs, inst_xf); o[7] = (int32_t)offsetof(PathKernelArgs, regen_min); o[8] = (int32_t)offsetof(PathKernelArgs, cap_normal);
     o[9] = (int32_t)sizeof(PathKernelArgs);
+    // (the texture table: a binary saved before ABI 9 — tests/golden/isa — reads 80-byte records; tests/isaemu/run.py hands it a table of that layout)
+    o[10] = (int32_t)(offsetof(PathKernelArgs, sc) + offsetof(hpt::DScene, textures));
 }
