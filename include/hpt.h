@@ -66,6 +66,7 @@ enum { HPT_MAT_MATTE = 1, HPT_MAT_PLASTIC = 2, HPT_MAT_MEASURED_IRREG = 3, HPT_M
  *             core/texture.cpp:88-164 — "uv", "spherical", "cylindrical", "planar", textures/imagemap.cpp:106-124)
  *   SCALE     textures/scale.h:46-60                    tex1 * tex2
  *   MIX       textures/mix.h:46-62                      (1 - amount) * tex1 + amount * tex2
+ * SCALE / MIX operands precede the texture in the table; nesting up to 12 levels (hpt_scene_create refuses deeper tables).
  * Other texture plugins are outside the hot-path scope (the host wrapper refuses them). */
 enum { HPT_TEX_CONSTANT = 1, HPT_TEX_IMAGEMAP = 2, HPT_TEX_SCALE = 3, HPT_TEX_MIX = 4 };
 /* TextureMapping2D (core/texture.h:47-113).  UV: (su * u + du, sv * v + dv).  SPHERICAL / CYLINDRICAL: the hit point through

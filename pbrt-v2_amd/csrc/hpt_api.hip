@@ -249,7 +249,10 @@ extern "C" void hpt_scene_destroy(hpt_scene *s) {
 extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     const auto t_create0 = std::chrono::steady_clock::now();
     if (hpt_validate_desc(desc) != HPT_OK) return nullptr;
-    {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_DEPTH
+    bool tex_deep = false;           // -> tex_general below: the scene's textures need the general evaluator (hpt_device.h: tex_eval_general) — nesting beyond the templates' three levels, or
+    bool tex_general = false;        //    (ABI 9) an image map with a point-reading 2D mapping
+    for (int t = 0; t < desc->n_textures; ++t) if (desc->textures[t].kind == HPT_TEX_IMAGEMAP && desc->textures[t].mapping != HPT_MAP_UV) tex_general = true;
+    {   // what the device evaluates of the texture system: operand nesting up to HPT_TEX_MAX_DEPTH (above HPT_TEX_DEPTH through the general evaluator)
         std::vector<int> depth((size_t)desc->n_textures, 0);
         for (int t = 0; t < desc->n_textures; ++t) {
             const hpt_texture &tx = desc->textures[t];
@@ -257,10 +260,12 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
                 int d = depth[(size_t)tx.tex1] > depth[(size_t)tx.tex2] ? depth[(size_t)tx.tex1] : depth[(size_t)tx.tex2];
                 if (tx.kind == HPT_TEX_MIX && depth[(size_t)tx.amount] > d) d = depth[(size_t)tx.amount];
                 depth[(size_t)t] = d + 1;
-                if (d + 1 > HPT_TEX_DEPTH) { hpt_set_error("texture %d: scale / mix textures nested deeper than %d", t, HPT_TEX_DEPTH); return nullptr; }
+                if (d + 1 > HPT_TEX_MAX_DEPTH) { hpt_set_error("texture %d: scale / mix textures nested deeper than %d", t, HPT_TEX_MAX_DEPTH); return nullptr; }
+                if (d + 1 > HPT_TEX_DEPTH) tex_deep = true;
             }
         }
     }
+    tex_general = tex_general || tex_deep;
     int ndev = hpt_device_count();
     if (ndev <= 0) { hpt_set_error("no HIP device available (hipGetDeviceCount) — the path tracer has no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev) { hpt_set_error("device %d out of range (have %d)", device, ndev); return nullptr; }
@@ -308,7 +313,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     // BRDF, no specular material, no shape-set / spot / distant light.  Measured in round 3 (profiles/r03_ab.md, run Z2): metal.pbrt at 4K +4.8 %.
     // HPT_LEAN_EXT=0 keeps the full set (A/B).
     if (ext && desc->n_instances == 0 && !(getenv("HPT_LEAN_EXT") && atoi(getenv("HPT_LEAN_EXT")) == 0)) {
-        bool rare = s->has_specular;
+        bool rare = s->has_specular || tex_general;      // (the lean unit is compiled without the general texture evaluator)
         for (int m = 0; m < desc->n_materials; ++m) rare = rare || desc->materials[m].kind == HPT_MAT_MEASURED_IRREG || desc->materials[m].kind == HPT_MAT_MEASURED_REGULAR;
         for (int l = 0; l < desc->n_lights; ++l)
             rare = rare || desc->lights[l].kind == HPT_LIGHT_SPOT || desc->lights[l].kind == HPT_LIGHT_DISTANT || (desc->lights[l].kind == HPT_LIGHT_DIFFUSE_AREA && desc->lights[l].quadric < 0);
@@ -386,8 +391,7 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
     s->d.fpool = upload(s, &arena, fs.fpool.data(), fs.fpool.size(), &ok);
     s->d.ipool = upload(s, &arena, fs.ipool.data(), fs.ipool.size(), &ok);
     s->d.textures = upload(s, &arena, desc->textures, (size_t)desc->n_textures, &ok);
-    s->d.tex_mapped = 0;          // ABI 9: a point-reading 2D mapping anywhere in the table sends the scene's texture lookups through tex_eval_mapped (hpt_device.h)
-    for (int k = 0; k < desc->n_textures; ++k) if (desc->textures[k].kind == HPT_TEX_IMAGEMAP && desc->textures[k].mapping != HPT_MAP_UV) s->d.tex_mapped = 1;
+    s->d.tex_mapped = tex_general ? 1 : 0;   // ABI 9: a point-reading 2D mapping anywhere in the table (or nesting beyond the templates') sends the scene's texture lookups through tex_eval_general (hpt_device.h)
     s->d.instances = upload(s, &arena, desc->instances, (size_t)desc->n_instances, &ok);
     s->d.inst_root = upload(s, &arena, fs.inst_root.data(), fs.inst_root.size(), &ok);
     s->d.n_instances = desc->n_instances; s->d.world_root = fs.world_root;

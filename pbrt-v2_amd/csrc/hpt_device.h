@@ -32,6 +32,15 @@
 
 namespace hpt {
 
+// a branch the compiler should lay out, and allocate registers, as the exception (without it a two-way branch counts as 50 : 50 and the allocator spreads
+// the rare side's spills over the common one: HPT_NO_BRANCH_HINTS is the A/B control)
+#if defined(HPT_NO_BRANCH_HINTS)
+#define HPT_UNLIKELY(x) (x)
+#define HPT_COLD
+#else
+#define HPT_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define HPT_COLD __attribute__((cold))
+#endif
 // experiment switches: outline (noinline) the big cold shading blocks to cut code size / register peaks
 #if defined(__HIPCC__)
 #ifdef HPT_NI_SHADE
@@ -383,7 +392,7 @@ struct DScene {
     int32_t world_root4;
     uint32_t inst_quadric_mask;     // bit q (q < 31): quadric q is the primitive of an instance (hpt_instance.quadric1 == q + 1), not a primitive of the world; bit 31: an owned quadric has index >= 31 (those are looked up in the instance table)
     int32_t top_root4;              // root of the top-level tree in nodes4 (HPT_LEAF_SPECIAL): the world root's children + the instances; -1: nothing to hit
-    int32_t tex_mapped;             // 1: some image map has a spherical / cylindrical / planar mapping (textures go through tex_eval_mapped).  (In what was the record's tail padding: its size is round 5's.)
+    int32_t tex_mapped;             // 1: some image map has a spherical / cylindrical / planar mapping, or scale / mix textures nest deeper than HPT_TEX_DEPTH (textures go through tex_eval_general).  (In what was the record's tail padding: its size is round 5's.)
 #ifdef HPT_DEBUG_CHECKS             /* `make debug` only (the whole library is built with the flag): table sizes for the bounds checks */
     int32_t n_nodes4, n_meshes, n_materials, n_textures;
 #endif
@@ -1685,7 +1694,7 @@ struct TexPools { const hpt_texture *textures; const float *fpool; const float *
 struct TexUV { float u, v, dudx, dvdx, dudy, dvdy; };
 // ... and what the spherical / cylindrical / planar mappings read on top of it (round 6, ABI 9).  Nine more floats through the evaluators' calls cost
 // metal.pbrt 16 % (528 B more scratch a lane: every level of tex_eval keeps its copy across its calls), so they travel in a chain of their own
-// (tex_eval_mapped), entered only in scenes that HAVE such a texture (DScene::tex_mapped): a scene of uv maps runs the code of round 5.
+// (tex_eval_general), entered only in scenes that HAVE such a texture (DScene::tex_mapped): a scene of uv maps runs the code of round 5.
 struct TexPt { TexUV uv; f3 p, dpdx, dpdy; };
 // MIPMap<T>::Texel (core/mipmap.h:204-223).  Level l of a pyramid starts right after level l - 1 (include/hpt.h).
 HPT_FN void mip_level(const hpt_texture &t, int level, int64_t *off, int *w, int *h) {
@@ -1886,31 +1895,57 @@ HPT_FN_NOINLINE TexV tex_eval(const TexPools sc, int id, const TexUV dg) {
     }
     return r;
 }
-// The same tree walk for a scene with point-reading mappings: out of line at every level, no leaf shortcuts (what it costs is paid by those scenes only).
-template <int DEPTH>
-HPT_FN_NOINLINE TexV tex_eval_mapped(const TexPools sc, int id, const TexPt dg) {
-    const hpt_texture &t = sc.textures[id];
-    TexV r; r.c[0] = t.value[0]; r.c[1] = t.value[1]; r.c[2] = t.value[2];
-    if (t.kind == HPT_TEX_CONSTANT) return r;
-    if (t.kind == HPT_TEX_IMAGEMAP) return tex_image_mapped(sc, t, dg);
-    if (DEPTH > 0) {
-        TexV a = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex1, dg), b = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.tex2, dg);
-        if (sc.textures[t.tex1].channels < t.channels) a.c[1] = a.c[2] = a.c[0];
-        if (sc.textures[t.tex2].channels < t.channels) b.c[1] = b.c[2] = b.c[0];
-        if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) r.c[k] = a.c[k] * b.c[k]; return r; }
-        const float amt = tex_eval_mapped<(DEPTH > 0 ? DEPTH - 1 : 0)>(sc, t.amount, dg).c[0];
-        for (int k = 0; k < 3; ++k) r.c[k] = (1.f - amt) * a.c[k] + amt * b.c[k];
+// The general evaluator (round 6): any TextureMapping2D and operand nesting up to HPT_TEX_MAX_DEPTH, for the scenes whose table needs it
+// (DScene::tex_mapped: a point-reading mapping, or scale / mix textures nested deeper than HPT_TEX_DEPTH).  One out-of-line function walking the
+// operand tree over an explicit stack of pending nodes instead of a recursion per level: what it costs is paid by those scenes only.
+#define HPT_TEX_MAX_DEPTH 12
+struct TexFrame { int32_t id, stage; TexV a, b; };
+HPT_FN_NOINLINE TexV tex_eval_general(const TexPools sc, int id, const TexPt dg) {
+    TexFrame st[HPT_TEX_MAX_DEPTH + 1];
+    int sp = 0;
+    st[0].id = id; st[0].stage = 0;
+    TexV ret; ret.c[0] = ret.c[1] = ret.c[2] = 0.f;
+    for (;;) {
+        TexFrame &f = st[sp];
+        const hpt_texture &t = sc.textures[f.id];
+        int child = -1;
+        if (t.kind == HPT_TEX_CONSTANT) { ret.c[0] = t.value[0]; ret.c[1] = t.value[1]; ret.c[2] = t.value[2]; }
+        else if (t.kind == HPT_TEX_IMAGEMAP) ret = tex_image_mapped(sc, t, dg);
+        else if (f.stage == 0) { f.stage = 1; child = t.tex1; }
+        else if (f.stage == 1) {
+            f.a = ret;
+            if (sc.textures[t.tex1].channels < t.channels) f.a.c[1] = f.a.c[2] = f.a.c[0];   // a float operand of a spectrum texture acts on every channel
+            f.stage = 2; child = t.tex2;
+        } else if (f.stage == 2) {
+            f.b = ret;
+            if (sc.textures[t.tex2].channels < t.channels) f.b.c[1] = f.b.c[2] = f.b.c[0];
+            if (t.kind == HPT_TEX_SCALE) { for (int k = 0; k < 3; ++k) ret.c[k] = f.a.c[k] * f.b.c[k]; }
+            else { f.stage = 3; child = t.amount; }
+        } else {
+            const float amt = ret.c[0];
+            for (int k = 0; k < 3; ++k) ret.c[k] = (1.f - amt) * f.a.c[k] + amt * f.b.c[k];
+        }
+        if (child >= 0) {                              // (hpt_scene_create bounds the nesting: sp stays inside the array)
+            ++sp; st[sp].id = child; st[sp].stage = 0;
+            continue;
+        }
+        if (sp == 0) return ret;                       // the node is done: its value goes to the node that asked for it
+        --sp;
     }
-    return r;
 }
 HPT_FN TexPools tex_pools(const DScene &sc) { TexPools p; p.textures = sc.textures; p.fpool = sc.fpool; p.ewa_lut = sc.ewa_lut; return p; }
 HPT_FN TexUV tex_uv(const DGeomX &dg) { TexUV t; t.u = dg.u; t.v = dg.v; t.dudx = dg.dudx; t.dvdx = dg.dvdx; t.dudy = dg.dudy; t.dvdy = dg.dvdy; return t; }
-HPT_FN TexV tex_any(const DScene &sc, int id, const DGeomX &dg) {
-    if (sc.tex_mapped) { TexPt t; t.uv = tex_uv(dg); t.p = dg.p; t.dpdx = dg.dpdx; t.dpdy = dg.dpdy; return tex_eval_mapped<HPT_TEX_DEPTH>(tex_pools(sc), id, t); }
+// GEN: the scene's table needs the general evaluator (DScene::tex_mapped).  A template argument of everything between the hit and the BSDF, chosen ONCE a
+// shading point (shade_geometry_ext), not a branch a lookup — and not compiled at all into the lean unit (HPT_NO_TEX_GENERAL), whose scenes never need it.
+// Measured on metal.pbrt (lean set; profiles/r06_ab.md, runs Y1-Z2): nine more floats in TexUV -16 %; a branch at every lookup -16 %; the branch once a
+// shading point -9.5 %, with a cold hint -8 %, behind an out-of-line call by value -9.5 to -21 %: the code is never executed there, what it costs is the
+// register allocation of the code around it.  Without it: the rate of the commit before (1202 = 1203 Msamples/s).
+template <bool GEN> HPT_FN TexV tex_any(const DScene &sc, int id, const DGeomX &dg) {
+    if (GEN) { TexPt t; t.uv = tex_uv(dg); t.p = dg.p; t.dpdx = dg.dpdx; t.dpdy = dg.dpdy; return tex_eval_general(tex_pools(sc), id, t); }
     return tex_node<HPT_TEX_DEPTH>(tex_pools(sc), id, tex_uv(dg));
 }
-HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_any(sc, id, dg).c[0]; }
-HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_any(sc, id, dg); return mk3(v.c[0], v.c[1], v.c[2]); }
+template <bool GEN> HPT_FN float tex_float(const DScene &sc, int id, const DGeomX &dg) { return tex_any<GEN>(sc, id, dg).c[0]; }
+template <bool GEN> HPT_FN f3 tex_rgb(const DScene &sc, int id, const DGeomX &dg) { TexV v = tex_any<GEN>(sc, id, dg); return mk3(v.c[0], v.c[1], v.c[2]); }
 
 HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, float b2, f3 p) {
     const DMesh &me = sc.meshes[mesh_word & HPT_TRI_MESH_MASK];
@@ -1925,8 +1960,13 @@ HPT_FN bool tri_alpha_pass(const DScene &sc, int mesh_word, int tri, float b1, f
     dg.u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     dg.v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
     dg.dudx = dg.dvdx = dg.dudy = dg.dvdy = 0.f;          // dgLocal: a fresh DifferentialGeometry has no screen-space derivatives (diffgeom.cpp:50)
-    dg.p = p; dg.dpdx = dg.dpdy = S(0.f);                 // (p = ray(t), trianglemesh.cpp:191: what a spherical / cylindrical / planar alpha map reads)
-    return tex_float(sc, me.alpha_tex - 1, dg) != 0.f;
+#if !defined(HPT_NO_TEX_GENERAL)
+    if (HPT_UNLIKELY(sc.tex_mapped)) {
+        dg.p = p; dg.dpdx = dg.dpdy = S(0.f);             // (p = ray(t), trianglemesh.cpp:191: what a spherical / cylindrical / planar alpha map reads)
+        return tex_float<true>(sc, me.alpha_tex - 1, dg) != 0.f;
+    }
+#endif
+    return tex_float<false>(sc, me.alpha_tex - 1, dg) != 0.f;
 }
 
 // A ray's differentials (RayDifferential, core/geometry.h:322-381): only camera rays have them on this path
@@ -1963,22 +2003,22 @@ HPT_FN void compute_differentials(DGeomX *dg, const RayDiff &rd) {
     if (!solve2x2(A00, A01, A10, A11, By0, By1, &dg->dudy, &dg->dvdy)) { dg->dudy = 0.f; dg->dvdy = 0.f; }
 }
 // Material::Bump (core/material.cpp:46-85)
-HPT_FN void bump_geometry(const DScene &sc, int tex, f3 ngeom, const DGeomX &dgs, int flip, DGeomX *out) {
+template <bool GEN> HPT_FN void bump_geometry(const DScene &sc, int tex, f3 ngeom, const DGeomX &dgs, int flip, DGeomX *out) {
     DGeomX e = dgs;
     float du = .5f * (fabsf(dgs.dudx) + fabsf(dgs.dudy));
     if (du == 0.f) du = .01f;
     e.p = dgs.p + dgs.dpdu * du;
     e.u = dgs.u + du;
     e.nn = normalize(cross(dgs.dpdu, dgs.dpdv) + dgs.dndu * du);
-    const float uDisplace = tex_float(sc, tex, e);
+    const float uDisplace = tex_float<GEN>(sc, tex, e);
     float dv = .5f * (fabsf(dgs.dvdx) + fabsf(dgs.dvdy));
     if (dv == 0.f) dv = .01f;
     e.p = dgs.p + dgs.dpdv * dv;
     e.u = dgs.u;
     e.v = dgs.v + dv;
     e.nn = normalize(cross(dgs.dpdu, dgs.dpdv) + dgs.dndv * dv);
-    const float vDisplace = tex_float(sc, tex, e);
-    const float displace = tex_float(sc, tex, dgs);
+    const float vDisplace = tex_float<GEN>(sc, tex, e);
+    const float displace = tex_float<GEN>(sc, tex, dgs);
     *out = dgs;
     out->dpdu = (dgs.dpdu + dgs.nn * ((uDisplace - displace) / du)) + dgs.dndu * displace;
     out->dpdv = (dgs.dpdv + dgs.nn * ((vDisplace - displace) / dv)) + dgs.dndv * displace;
@@ -1988,20 +2028,20 @@ HPT_FN void bump_geometry(const DScene &sc, int tex, f3 ngeom, const DGeomX &dgs
 }
 // Material::GetBSDF with every parameter a Texture::Evaluate(dgs): the record's constant or the texture of its slot
 // (matte.cpp:42-63, plastic.cpp:42-66, measured.cpp:194-210, metal.cpp:51-68, substrate.cpp:42-58, glass.cpp:41-57, mirror.cpp:44-57)
-HPT_FN f3 mat_rgb(const DScene &sc, const hpt_material *m, int slot, const float *k, const DGeomX &dgs, bool clamp) {
+template <bool GEN> HPT_FN f3 mat_rgb(const DScene &sc, const hpt_material *m, int slot, const float *k, const DGeomX &dgs, bool clamp) {
     if (m->tex[slot] < 0) return mk3(k[0], k[1], k[2]);      // (constants arrive Clamp()ed where the material clamps)
-    const f3 v = tex_rgb(sc, m->tex[slot], dgs);
+    const f3 v = tex_rgb<GEN>(sc, m->tex[slot], dgs);
     return clamp ? sclamp0(v) : v;
 }
-HPT_FN float mat_float(const DScene &sc, const hpt_material *m, int slot, float k, const DGeomX &dgs) {
-    return m->tex[slot] < 0 ? k : tex_float(sc, m->tex[slot], dgs);
+template <bool GEN> HPT_FN float mat_float(const DScene &sc, const hpt_material *m, int slot, float k, const DGeomX &dgs) {
+    return m->tex[slot] < 0 ? k : tex_float<GEN>(sc, m->tex[slot], dgs);
 }
 HPT_FN float blinn_exponent(float roughness) { float e = 1.f / roughness; if (e > 10000.f || e != e) e = 10000.f; return e; }   // reflection.h:424
-HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material *m, const DGeomX &dgs) {
+template <bool GEN> HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material *m, const DGeomX &dgs) {
     b->mat = m;
     if (m->kind == HPT_MAT_MATTE) {
-        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true);
-        const float sig = clampf(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->sigma, dgs), 0.f, 90.f);
+        const f3 kd = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true);
+        const float sig = clampf(mat_float<GEN>(sc, m, HPT_TEXSLOT_ROUGH, m->sigma, dgs), 0.f, 90.f);
         if (!sblack(kd)) {
             if (sig == 0.f) bsdf_push(b, BX_LAMBERT, kd);
             else {                                                  // OrenNayar ctor, reflection.h:371-378
@@ -2012,35 +2052,47 @@ HPT_FN void bsdf_add_material_ext(Bsdf *b, const DScene &sc, const hpt_material 
             }
         }
     } else if (m->kind == HPT_MAT_PLASTIC) {
-        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        const f3 kd = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
         if (!sblack(kd)) bsdf_push(b, BX_LAMBERT, kd);
-        if (!sblack(ks)) { b->exponent = blinn_exponent(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs)); bsdf_push(b, BX_MICROFACET, ks); }
+        if (!sblack(ks)) { b->exponent = blinn_exponent(mat_float<GEN>(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs)); bsdf_push(b, BX_MICROFACET, ks); }
     } else if (m->kind == HPT_MAT_MEASURED_IRREG) {
         bsdf_push(b, BX_IRREG, S(0.f));
     } else if (m->kind == HPT_MAT_MEASURED_REGULAR) {
         bsdf_push(b, BX_REGULAR, S(0.f));
     } else if (m->kind == HPT_MAT_METAL) {
-        b->exponent = blinn_exponent(mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs));
-        bsdf_push(b, BX_MICROFACET_COND, mat_rgb(sc, m, HPT_TEXSLOT_KD, m->eta, dgs, false));
-        b->R1 = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->k, dgs, false);
+        b->exponent = blinn_exponent(mat_float<GEN>(sc, m, HPT_TEXSLOT_ROUGH, m->roughness, dgs));
+        bsdf_push(b, BX_MICROFACET_COND, mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KD, m->eta, dgs, false));
+        b->R1 = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KS, m->k, dgs, false);
     } else if (m->kind == HPT_MAT_SUBSTRATE) {
-        const f3 kd = mat_rgb(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
-        const float u = mat_float(sc, m, HPT_TEXSLOT_ROUGH, m->nu, dgs), v = mat_float(sc, m, HPT_TEXSLOT_ROUGH_V, m->nv, dgs);
+        const f3 kd = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KD, m->kd, dgs, true), ks = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        const float u = mat_float<GEN>(sc, m, HPT_TEXSLOT_ROUGH, m->nu, dgs), v = mat_float<GEN>(sc, m, HPT_TEXSLOT_ROUGH_V, m->nv, dgs);
         if (!sblack(kd) || !sblack(ks)) {
             b->exponent = blinn_exponent(u); b->ey = blinn_exponent(v);     // Anisotropic ctor (reflection.h:439-443): the same clamp
             bsdf_push(b, BX_FRESNELBLEND, kd);
             b->R1 = ks;
         }
     } else if (m->kind == HPT_MAT_GLASS) {
-        b->exponent = mat_float(sc, m, HPT_TEXSLOT_INDEX, m->index, dgs);
-        const f3 R = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true), T = mat_rgb(sc, m, HPT_TEXSLOT_KT, m->kt, dgs, true);
+        b->exponent = mat_float<GEN>(sc, m, HPT_TEXSLOT_INDEX, m->index, dgs);
+        const f3 R = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true), T = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KT, m->kt, dgs, true);
         if (!sblack(R)) bsdf_push(b, BX_SPEC_REFL, R);
         if (!sblack(T)) bsdf_push(b, BX_SPEC_TRANS, T);
     } else if (m->kind == HPT_MAT_MIRROR) {
-        const f3 R = mat_rgb(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
+        const f3 R = mat_rgb<GEN>(sc, m, HPT_TEXSLOT_KS, m->ks, dgs, true);
         b->exponent = 0.f;                                          // FresnelNoOp
         if (!sblack(R)) bsdf_push(b, BX_SPEC_REFL, R);
     }
+}
+
+// the tail of shade_geometry_ext: Material::Bump, the BSDF's frame, the material's (textured) parameters
+template <bool GEN>
+HPT_FN void shade_material_ext(const DScene &sc, const hpt_material *mat, f3 ngeom, int flip, DGeomX dgs, Bsdf *b, DGeom *dgo, DGeomX *dgs_out) {
+#ifndef HPT_DBG_NO_BUMP   /* timing experiment only (wrong images) */
+    if (mat->tex[HPT_TEXSLOT_BUMP] >= 0) { DGeomX db; bump_geometry<GEN>(sc, mat->tex[HPT_TEXSLOT_BUMP], ngeom, dgs, flip, &db); dgs = db; }
+#endif
+    dgo->p = dgs.p; dgo->nn = ngeom; dgo->dpdu = dgs.dpdu;
+    if (dgs_out) *dgs_out = dgs;
+    bsdf_frame(b, dgs.nn, dgs.dpdu, ngeom);
+    bsdf_add_material_ext<GEN>(b, sc, mat, dgs);
 }
 
 // Hit -> DifferentialGeometry -> shading geometry -> BSDF:
@@ -2286,13 +2338,12 @@ HPT_FN_SHADE void shade_geometry_ext(const DScene &sc, const Ray &wray, float ti
             dgs.dndu = xf_normal(minv, dndu); dgs.dndv = xf_normal(minv, dndv);
         }
     }
-#ifndef HPT_DBG_NO_BUMP   /* timing experiment only (wrong images) */
-    if (mat->tex[HPT_TEXSLOT_BUMP] >= 0) { DGeomX db; bump_geometry(sc, mat->tex[HPT_TEXSLOT_BUMP], dg.nn, dgs, flip, &db); dgs = db; }
+#if defined(HPT_NO_TEX_GENERAL)   /* the lean unit (hpt_kernels_lean.hip): hpt_scene_create never gives it a scene of the general evaluator */
+    shade_material_ext<false>(sc, mat, dg.nn, flip, dgs, b, dgo, dgs_out);
+#else
+    if (HPT_UNLIKELY(sc.tex_mapped)) shade_material_ext<true>(sc, mat, dg.nn, flip, dgs, b, dgo, dgs_out);     // (uniform: a property of the scene)
+    else shade_material_ext<false>(sc, mat, dg.nn, flip, dgs, b, dgo, dgs_out);
 #endif
-    dgo->p = dgs.p; dgo->nn = dg.nn; dgo->dpdu = dgs.dpdu;
-    if (dgs_out) *dgs_out = dgs;
-    bsdf_frame(b, dgs.nn, dgs.dpdu, dg.nn);
-    bsdf_add_material_ext(b, sc, mat, dgs);
 }
 // Ray differentials of the rays SpecularReflect / SpecularTransmit spawn (core/integrator.cpp:190-207, 229-250): rd of the incoming ray,
 // dgs / n of the shading geometry, wo = -ray.d, wi the specular direction, eta = the BSDF's index of refraction

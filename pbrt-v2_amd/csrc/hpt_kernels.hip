@@ -457,7 +457,8 @@ __global__ void hpt_bsdf_kernel(const DScene sc, int material, const float *in, 
         DGeomX dgs;
         dgs.p = S(0.f); dgs.nn = nn; dgs.dpdu = dpdu; dgs.dpdv = cross(nn, dpdu); dgs.dndu = dgs.dndv = dgs.dpdx = dgs.dpdy = S(0.f);
         dgs.u = q[6]; dgs.v = q[7]; dgs.dudx = dgs.dvdx = dgs.dudy = dgs.dvdy = 0.f;
-        bsdf_add_material_ext(&b, sc, &sc.materials[material], dgs);
+        if (sc.tex_mapped) bsdf_add_material_ext<true>(&b, sc, &sc.materials[material], dgs);
+        else bsdf_add_material_ext<false>(&b, sc, &sc.materials[material], dgs);
     }
     f3 f = bsdf_f<MATS_FULL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
     float pdf = bsdf_pdf<MATS_FULL>(b, wo, wi, BSDF_ALL_NOSPEC);

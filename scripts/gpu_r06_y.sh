@@ -7,7 +7,11 @@ O=$ROOT/gpurun_out/r06y; mkdir -p $O
 V=$ROOT/pbrt-v2_amd/build/variants
 Q="--no-cpu-baseline --no-extra --no-pmc --no-work --no-verify"
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['kernel']['avg_ms'], d['kernel']['tune_cfg'], d['kernel']['vgprs'], d['kernel']['scratch_B'])"; }
-timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt | cut -c1-300
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt | cut -c1-300
+# (the end-to-end test that failed once in run Y2: the same frame through the library, configuration by configuration)
+mkdir -p /tmp/amr && cp oracle/_ref/scenes/anim-moving-reflection.pbrt /tmp/amr/ && ln -sfn $ROOT/oracle/_ref/scenes/textures /tmp/amr/textures
+( cd /tmp/amr && PBRT_RENDERER_HIP=1 HPT_DUMP_SCENE=/tmp/amr/scene.hpts HPT_HOST_BVH=1 $ROOT/pbrt-v2_amd/host/_build/pbrt_hip --quiet --outfile /tmp/amr/unused.pfm anim-moving-reflection.pbrt ) > $O/amr_debug.txt 2>&1
+timeout 900 python scripts/gpu_r06_y_debug.py /tmp/amr/scene.hpts >> $O/amr_debug.txt 2>&1; tail -6 $O/amr_debug.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc $?" >> $O/smoke.txt; tail -3 $O/smoke.txt
 # (the old library reads 80-byte texture records: it runs from its own checkout — build/variants/head_tree = HEAD's bench.py, Python package and libhpt.so + the two fixtures)
 for i in 1 2; do for v in head default; do

@@ -7,6 +7,9 @@
   texmapdl  the same geometry under DirectLightingIntegrator with a mirror: the mappings' finite differences over the dpdx / dpdy of
             specular rays
 
+  texdeep   scale / mix textures nested SEVEN deep over uv image maps (the device's templates stop at three: the general evaluator's explicit
+            stack), a float chain under the bump map, a mix whose amount is itself nested
+
 scene.pbrt --oracle/_ref/pbrt--> reference image (*.ref.npy.gz); --pbrt_hip dumpscene--> blob (texmap.hpts.gz, texmapdl.view.npz).
 tests/test_oracle_pin.py replays them through the oracle's MT_REPLAY mode (bit-identical).  Build container only.
 """
@@ -43,8 +46,29 @@ MIRROR = ('AttributeBegin\nMaterial "mirror" "color Kr" [.85 .9 .8]\nShape "tria
           '"point P" [-3.9 0 -2  -3.5 0 2.5  -3.5 3 2.5  -3.9 3 -2]\nAttributeEnd\n')
 
 
+DEEP = ('Texture "pat" "color" "imagemap" "string filename" "%(t)s" "float uscale" [4] "float vscale" [4]\n'
+        'Texture "patf" "float" "imagemap" "string filename" "%(t)s" "float uscale" [3] "float vscale" [2] "bool trilinear" ["true"]\n'
+        'Texture "c1" "color" "scale" "texture tex1" "pat" "color tex2" [.97 .95 .99]\n'
+        'Texture "c2" "color" "mix" "texture tex1" "c1" "color tex2" [.2 .5 .3] "texture amount" "patf"\n'
+        'Texture "c3" "color" "scale" "texture tex1" "c2" "texture tex2" "c1"\n'
+        'Texture "c4" "color" "mix" "color tex1" [.8 .8 .7] "texture tex2" "c3" "float amount" [.85]\n'
+        'Texture "c5" "color" "scale" "texture tex1" "c4" "color tex2" [1.1 1.05 1.2]\n'
+        'Texture "f1" "float" "scale" "texture tex1" "patf" "float tex2" [.9]\n'
+        'Texture "f2" "float" "mix" "texture tex1" "f1" "float tex2" [.4] "float amount" [.7]\n'
+        'Texture "f3" "float" "scale" "texture tex1" "f2" "texture tex2" "f1"\n'
+        'Texture "f4" "float" "scale" "texture tex1" "f3" "float tex2" [1.3]\n'
+        'Texture "c6" "color" "mix" "texture tex1" "c5" "texture tex2" "pat" "texture amount" "f4"\n'
+        'Texture "c7" "color" "scale" "texture tex1" "c6" "color tex2" [.9 .9 .9]\n'
+        'Texture "bumpy" "float" "scale" "texture tex1" "f4" "float tex2" [-0.1]\n') % dict(t=TEX)
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
+        deep = (HEAD % dict(out="%OUT%", spp=8, integrator=PATH % 4) + POINT % (30, 30, 30, 1, 4, 4) + SPHERE_LIGHT % (10, 10, 10, 1, -2, 3, 1.5, 0.4) + DEEP
+                + FLOOR % 'Material "substrate" "texture Kd" "c7" "color Ks" [.3 .3 .3] "float uroughness" [.05] "float vroughness" [.08] "texture bumpmap" "bumpy"'
+                + WALL % 'Material "plastic" "texture Kd" "c5" "color Ks" [.3 .3 .3] "texture roughness" "f2"'
+                + OCTA % ('Material "matte" "texture Kd" "c3" "texture bumpmap" "bumpy"', 0.3, 0.9, 0.6) + "WorldEnd\n")
+        run("texdeep", deep, tmp).save(os.path.join(HERE, "texdeep.hpts.gz"))
         s = run("texmap", HEAD % dict(out="%OUT%", spp=8, integrator=PATH % 4) + BODY + MIRROR + "WorldEnd\n", tmp)
         assert sorted(set(t.mapping for t in s.textures if t.kind == 2)) == [1, 2, 3], [t.mapping for t in s.textures]
         s.save(os.path.join(HERE, "texmap.hpts.gz"))

@@ -50,6 +50,17 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     for (int k = 0; k < desc->n_instances; ++k) if (desc->instances[k].quadric1 > 0) s->d.inst_quadric_mask |= 1u << std::min(desc->instances[k].quadric1 - 1, 31);
     s->d.textures = s->textures.data(); s->d.ewa_lut = s->fpool.data() + s->fs.ewa_lut_off;
     s->d.tex_mapped = 0;
+    {   // (as hpt_scene_create: nesting beyond the templates' depth goes through the general evaluator too)
+        std::vector<int> depth(s->textures.size(), 0);
+        for (size_t k = 0; k < s->textures.size(); ++k) {
+            const hpt_texture &tx = s->textures[k];
+            if (tx.kind != HPT_TEX_SCALE && tx.kind != HPT_TEX_MIX) continue;
+            int d = std::max(depth[(size_t)tx.tex1], depth[(size_t)tx.tex2]);
+            if (tx.kind == HPT_TEX_MIX) d = std::max(d, depth[(size_t)tx.amount]);
+            depth[k] = d + 1;
+            if (d + 1 > HPT_TEX_DEPTH) s->d.tex_mapped = 1;
+        }
+    }
     for (size_t k = 0; k < s->textures.size(); ++k) if (s->textures[k].kind == HPT_TEX_IMAGEMAP && s->textures[k].mapping != HPT_MAP_UV) s->d.tex_mapped = 1;
     s->d.nodes4 = (const f4 *)s->fs.nodes4.data(); s->d.inst_root4 = s->fs.inst_root4.data(); s->d.world_root4 = s->fs.world_root4; s->d.top_root4 = s->fs.top_root4;
     return s;
@@ -364,7 +375,7 @@ extern "C" int emu_bsdf_tier(const emu_scene *s, int material, const float *in, 
         {   DGeomX dgs;
             dgs.p = S(0.f); dgs.nn = nn; dgs.dpdu = dpdu; dgs.dpdv = cross(nn, dpdu); dgs.dndu = dgs.dndv = dgs.dpdx = dgs.dpdy = S(0.f);
             dgs.u = q[6]; dgs.v = q[7]; dgs.dudx = dgs.dvdx = dgs.dudy = dgs.dvdy = 0.f;
-            bsdf_add_material_ext(&b, sc, &sc.materials[material], dgs); }
+            if (sc.tex_mapped) bsdf_add_material_ext<true>(&b, sc, &sc.materials[material], dgs); else bsdf_add_material_ext<false>(&b, sc, &sc.materials[material], dgs); }
         int32_t stk[64]; LaneStack ls; ls.p = stk; ls.stride = 1;
         f3 f = bsdf_f<MATS_FULL>(sc, b, wo, wi, BSDF_ALL_NOSPEC, ls);
         float pdf = bsdf_pdf<MATS_FULL>(b, wo, wi, BSDF_ALL_NOSPEC);

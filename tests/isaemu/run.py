@@ -58,8 +58,7 @@ def kernel_symbol(count, inst, mats, waves, ee, phased, dl, steal, win=False, to
 
 CALLEES = ["_ZN3hpt10mip_lookupENS_8TexPoolsERK11hpt_textureffffff", "_ZN3hpt8tex_evalILi0EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt8tex_evalILi1EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE",
            "_ZN3hpt8tex_evalILi2EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt8tex_evalILi3EEENS_4TexVENS_8TexPoolsEiNS_5TexUVE", "_ZN3hpt10irreg_evalEPKfPK12hpt_materialNS_2f3E",
-           "_ZN3hpt11wave_kd_runEPKfPK12hpt_materialNS_9LaneStackEi", "_ZN3hpt16tex_image_mappedENS_8TexPoolsERK11hpt_textureNS_5TexPtE"] + \
-          ["_ZN3hpt15tex_eval_mappedILi%dEEENS_4TexVENS_8TexPoolsEiNS_5TexPtE" % k for k in range(4)]
+           "_ZN3hpt11wave_kd_runEPKfPK12hpt_materialNS_9LaneStackEi", "_ZN3hpt16tex_image_mappedENS_8TexPoolsERK11hpt_textureNS_5TexPtE", "_ZN3hpt16tex_eval_generalENS_8TexPoolsEiNS_5TexPtE"]
 
 
 class BinaryRender:

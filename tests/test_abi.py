@@ -110,6 +110,22 @@ def test_invalid_descriptors_are_rejected(cases, tmp_path):
     assert hpt.lib().hpt_blob_save(str(tmp_path / "bad.hpts").encode(), C.byref(d), None, None) == -2 and "mapping" in hpt.last_error()
 
 
+def test_texture_tables_nested_deeper_than_the_general_evaluators_stack_are_refused():
+    """hpt_scene_create bounds the operand nesting of scale / mix textures (HPT_TEX_MAX_DEPTH 12, csrc/hpt_device.h) before it looks for a device: a table
+    13 deep is refused by name; one 12 deep gets as far as the device check."""
+    from tests.util import load_case, nest_textures
+    s = load_case("tex")
+    nest_textures(s, 10)                  # the wall's Kd was scale(imagemap, colour): 1 + 10 = 11 ... the deepest Kd of the scene decides
+    with pytest.raises(hpt.HptError) as e:
+        hpt.DeviceScene(s)
+    deep_ok = "nested deeper" not in str(e.value)
+    s = load_case("tex")
+    nest_textures(s, 13)
+    with pytest.raises(hpt.HptError) as e:
+        hpt.DeviceScene(s)
+    assert "nested deeper than 12" in str(e.value) and deep_ok
+
+
 def test_animated_quadric_records_are_validated(tmp_path):
     """ABI 8, hpt_instance.quadric1 (an animated sphere / disk: TransformedPrimitive over a bare GeometricPrimitive, core/api.cpp:1032-1042):
     the record it names must exist, carry the identity ObjectToWorld and no area light (api.cpp:1014-1021), and belong to one instance;

@@ -185,7 +185,7 @@ def test_warmup_thread_starts_the_runtime_for_a_fresh_process(cases, dev, tmp_pa
     assert np.array_equal(np.load(out), fd)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap", "texdeep"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -966,7 +966,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl", "texdeep"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)
@@ -1006,7 +1006,23 @@ def test_round2_features_match_oracle_sample_for_sample(name):
         assert st2.tune_cfg == cfg and np.array_equal(f[..., 3], ref[..., 3]) and film.rmse(film.xyzw_to_rgb(f), film.xyzw_to_rgb(ref)) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "on", "texmap_lean"])
+@pytest.mark.gpu
+def test_textures_nested_twelve_deep_match_the_oracle():
+    """the general evaluator's stack at its bound (HPT_TEX_MAX_DEPTH): `tex` with one Kd under ten more scale textures, against the oracle's recursion"""
+    from tests.util import nest_textures
+    s = load_case("tex")
+    nest_textures(s, 10)
+    rd = hash_rd(s, seed=3)
+    fo, so = orc.OracleScene(s).render(s.camera, rd)
+    fd, st = hpt.DeviceScene(s).render(s.camera, rd)
+    assert st.bad_samples == 0 and np.array_equal(fo[..., 3], fd[..., 3])
+    assert film.rmse(film.xyzw_to_rgb(fo), film.xyzw_to_rgb(fd)) < 1e-4
+    plain = load_case("tex")
+    fp, _ = hpt.DeviceScene(plain).render(plain.camera, rd)
+    assert film.rmse(film.xyzw_to_rgb(fp), film.xyzw_to_rgb(fd)) > 1e-3        # (0.98^10 on one surface: the nesting is not a no-op)
+
+
+@pytest.mark.parametrize("name", ["tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "on"])
 def test_kernel_set_picked_by_scene_features_renders_the_full_sets_film(name, monkeypatch):
     """Round 4: hpt_scene_create picks the kernel instantiation from what the scene can reach — an extension-set scene without measured /
     specular materials, shape-set / spot / distant lights and animated instances runs the LEAN set (csrc/hpt_kernels_lean.hip, MATS_LEAN).

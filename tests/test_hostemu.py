@@ -111,7 +111,7 @@ def test_top_level_tree_walk_finds_the_linear_walks_hits(name, copies, time):
         assert info["n_nodes4_top"] >= 5                      # 64 instances: several levels above the instances
 
 
-@pytest.mark.parametrize("name", ["metal", "metalg", "tex", "on", "alpha", "tang", "qtex", "lens", "texmap_lean"])
+@pytest.mark.parametrize("name", ["metal", "metalg", "tex", "on", "alpha", "tang", "qtex", "lens"])
 def test_lean_extension_set_renders_the_full_sets_film(name, monkeypatch):
     """The lean extension set (MATS_LEAN, csrc/hpt_kernels_lean.hip: the extension kernels without specular lobes / the direct-lighting recursion,
     the regular half-angle BRDF, shape-set area lights, spot / distant lights and the measured BRDF — opt-in on the device, HPT_LEAN_EXT=1) on every
@@ -197,7 +197,7 @@ def test_direct_lighting_render_matches_oracle(name):
     assert film.rmse(io, ie) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl"])
+@pytest.mark.parametrize("name", ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl", "texdeep"])
 def test_round2_features_render_matches_oracle(name):
     """The MATS_EXT device code (Oren-Nayar, glass / mirror with the path integrator's specular bounces, triangle-mesh emitters,
     RegularHalfangleBRDF, image textures with EWA / trilinear lookups + ray differentials + Material::Bump, alpha-textured triangles,
@@ -320,7 +320,7 @@ def test_forked_tree_build_equals_the_serial_build(cases, name, monkeypatch):
     assert hashes["1"] == hashes["2"] == hashes["16"], hashes
 
 
-@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap"])
+@pytest.mark.parametrize("name", ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap", "texdeep"])
 def test_replay_mode_reproduces_reference_images_of_the_extension_set(name):
     """Round 3: the MT_REPLAY sampler source over the FULL material set (Lane<MtReplaySrc, true, MATS_FULL>) — Oren-Nayar, glass / mirror,
     triangle-mesh emitters, the regular half-angle BRDF, EWA / trilinear image textures with camera-ray differentials, bump mapping, alpha

@@ -141,7 +141,7 @@ def test_interpreter_does_64_bit_integers_and_strided_global_memory(tmp_path):
     ("measured", R.kernel_symbol(False, False, 3, 4, 0, True, False, True), w.K_MEASURED_STEAL, "b8", 8),   # bunny's kernel — the headline (with its out-of-line kd-tree walk)
     ("lean", R.kernel_symbol(False, False, 61, 4, 0, True, False, True), w.K_LEAN_STEAL, "metal", 8),       # metal.pbrt's kernel
     ("basic", R.kernel_symbol(False, False, 1, 3, 0, True, False, True), w.K_BASIC_STEAL, "env", 8),        # the soup's kernel (configuration 6)
-    ("lean", R.kernel_symbol(False, False, 61, 4, 0, True, False, True), w.K_LEAN_STEAL, "texmap_lean", 12),   # round 6: the out-of-line spherical / cylindrical / planar mappings
+    ("ext", R.kernel_symbol(False, False, 31, 4, 0, True, False, True), w.K_EXT_STEAL_NOINST, "texmap", 12),     # round 6: the general texture evaluator (spherical / cylindrical / planar mappings) in the full set's configuration 5
 ])
 def test_shipped_kernel_binaries_render_the_oracles_film_in_the_interpreter(unit, symbol, kid, case, n):
     s = load_case(case)

@@ -63,7 +63,7 @@ MATRIX = [
     ("oinst", w.K_FREE, 32), ("oinst", w.K_STEAL, 24), ("oinst", w.K_STEAL_TOP, 24), ("oinst", w.K_LEAN_STEAL, 24),
     ("oinst64", w.K_STEAL_TOP, 24),
     ("tex", w.K_STEAL, 32), ("tex", w.K_LEAN_STEAL, 32),
-    ("texmap", w.K_STEAL, 40), ("texmap_lean", w.K_LEAN_STEAL, 40),      # round 6: spherical / cylindrical / planar mappings; the alpha cut-out through the cooperative leaves
+    ("texmap", w.K_STEAL, 40), ("texmap", w.K_EXT_STEAL_NOINST, 40), ("texdeep", w.K_EXT_STEAL_NOINST, 40),      # round 6: the general texture evaluator (spherical / cylindrical / planar mappings, nesting 7); the alpha cut-out through the cooperative leaves
 ]
 
 

@@ -69,13 +69,6 @@ def load_case(name):
         s = abi.Scene.load(os.path.join(GOLDEN, "acam.hpts.gz"))
         s.camera_motion = abi.Instance.from_buffer_copy(np.load(os.path.join(GOLDEN, "acam.view.npz"))["camera_motion"].tobytes())
         return s
-    if name == "texmap_lean":    # `texmap` with its mirror painted matte: a scene of mapped textures the LEAN extension set can run (no golden: full set vs lean set)
-        s = load_case("texmap")
-        for m in s.materials:
-            if m.kind == abi.HPT_MAT_MIRROR:
-                m.kind = abi.HPT_MAT_MATTE
-                m.kd[0], m.kd[1], m.kd[2] = 0.5, 0.45, 0.4
-        return s
     if name in R2_CASES:
         s = abi.Scene.load(os.path.join(GOLDEN, R2_CASES[name]))
         if name == "merl":       # the 17.5 MB half-angle table is rebuilt from its formula instead of being committed
@@ -180,8 +173,30 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             # round 6 (tests/golden/make_golden_texmap.py): image maps through "spherical" (under a texture-space transform), "cylindrical" and "planar"
             # TextureMapping2Ds — Kd, roughness, bump and alpha textures (ABI 9, hpt_texture.mapping / map_m); `texmapdl`: the same through a mirror
             # under direct lighting (finite differences over the specular rays' dpdx / dpdy)
-            "texmap": "texmap.hpts.gz"}
+            "texmap": "texmap.hpts.gz",
+            # round 6: scale / mix textures nested seven deep over uv maps (the general evaluator's explicit stack instead of the three template levels)
+            "texdeep": "texdeep.hpts.gz"}
 R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz", "texmapdl": "texmap.hpts.gz"}     # same geometry, own camera / render descriptor / lights
+
+
+def nest_textures(s, levels):
+    """`s` (a scene with an image map behind some material's Kd) with that Kd wrapped in `levels` more scale textures (x 0.98 a level): the depth of
+    the table is levels + the depth Kd had.  -> the deepest texture's index"""
+    m = next(m for m in s.materials if m.tex[abi.TEXSLOT_KD] >= 0)
+    tex = list(s.textures)
+    c = abi.Texture(); c.kind, c.channels = abi.HPT_TEX_CONSTANT, 3
+    c.value[0] = c.value[1] = c.value[2] = 0.98
+    c.tex1 = c.tex2 = c.amount = -1
+    tex.append(c)
+    const, top = len(tex) - 1, m.tex[abi.TEXSLOT_KD]
+    for _ in range(levels):
+        t = abi.Texture(); t.kind, t.channels, t.tex1, t.tex2, t.amount = abi.HPT_TEX_SCALE, 3, top, const, -1
+        tex.append(t); top = len(tex) - 1
+    s.textures = abi._arr(abi.Texture, len(tex))
+    for i, t in enumerate(tex):
+        s.textures[i] = t
+    m.tex[abi.TEXSLOT_KD] = top
+    return top
 
 
 def merl_table_doubles():
