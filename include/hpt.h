@@ -108,6 +108,8 @@ enum { HPT_TEXSLOT_KD = 0,        /* matte / plastic / substrate Kd; metal eta  
 enum { HPT_LIGHT_POINT = 1, HPT_LIGHT_DIFFUSE_AREA = 2, HPT_LIGHT_INFINITE = 3,
        HPT_LIGHT_SPOT = 4, HPT_LIGHT_DISTANT = 5 };   /* version 8: lights/spot.cpp, lights/distant.cpp (delta lights like POINT) */
 
+#define HPT_LIGHT_UNSAMPLED(l) ((l).kind == HPT_LIGHT_DIFFUSE_AREA && (l).quadric < 0 && (l).set_n == 0)
+
 /* One TriangleMesh (shapes/trianglemesh.cpp:42).  Offsets index the float / int pools of the
  * scene descriptor, in ELEMENTS; -1 = attribute absent.
  *   P   : nverts*3 floats, WORLD space (the reference transforms at construction, :70-71)
@@ -226,6 +228,10 @@ typedef struct hpt_light {
      * = Distribution1D::func), cdf[n + 1], then funcInt — ShapeSet::areas / areaDistribution as the reference built them;
      * `area` above is ShapeSet::sumArea */
     int64_t set_off, set_area_off;
+    /* set_n == 0 (with quadric == -1): an UNSAMPLED emitter — the area light of a shape inside an object instance, which pbrtShape leaves out of
+     * Scene::lights (core/api.cpp:1046-1049: "Area lights not supported with object instancing"): no integrator samples or counts it, but a camera ray
+     * or a specular bounce that hits one of its shapes adds Intersection::Le (core/intersection.cpp:54-57) = DiffuseAreaLight::L (`intensity`).  Such
+     * records stand AFTER every light of Scene::lights in the table; the meshes that emit name them in hpt_mesh.arealight. */
     int32_t set_n, pad;
 } hpt_light;
 

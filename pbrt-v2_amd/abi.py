@@ -127,6 +127,11 @@ class TextureV8(C.Structure):
     _fields_ = _TEXTURE_V8
 
 
+def light_unsampled(l):
+    """HPT_LIGHT_UNSAMPLED (include/hpt.h): a DIFFUSE_AREA record without quadric and without shape set — an emitter inside an object instance"""
+    return l.kind == HPT_LIGHT_DIFFUSE_AREA and l.quadric < 0 and l.set_n == 0
+
+
 class Texture(C.Structure):
     """hpt_texture"""
     _fields_ = _TEXTURE_V8 + [("mapping", i32), ("pad9", i32), ("map_m", f32 * 16)]     # version 9: TextureMapping2D (0 = uv)

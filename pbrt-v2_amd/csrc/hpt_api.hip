@@ -424,7 +424,10 @@ extern "C" hpt_scene *hpt_scene_create(const hpt_scene_desc *desc, int device) {
         if (hipMalloc(&p, sizeof(float) * 12 * (size_t)desc->n_instances * s->inst_xf_lanes) == hipSuccess) { s->inst_xf = (float *)p; s->allocs.push_back(p); }
         else ok = false;
     }
-    s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
+    s->d.n_tris = (int32_t)ntris; s->d.n_quadrics = desc->n_quadrics;
+    // the kernels sample, count and loop over Scene::lights: the unsampled emitters behind them in the table (include/hpt.h, HPT_LIGHT_UNSAMPLED) are reached through hpt_mesh.arealight only
+    s->d.n_lights = 0;
+    for (int l = 0; l < desc->n_lights; ++l) if (!HPT_LIGHT_UNSAMPLED(desc->lights[l])) s->d.n_lights = l + 1;
     s->d.n_nodes = (int32_t)fs.nodes.size();
 #ifdef HPT_DEBUG_CHECKS
     s->d.n_nodes4 = (int32_t)(fs.nodes4.size() / 2); s->d.n_meshes = (int32_t)fs.meshes.size(); s->d.n_materials = (int32_t)fs.materials.size(); s->d.n_textures = desc->n_textures;

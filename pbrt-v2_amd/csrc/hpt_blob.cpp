@@ -134,9 +134,10 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
             hpt_set_error("mesh %d: alpha texture %d is not a float texture of the table", m, me.alpha_tex - 1);
             return HPT_E_INVALID;
         }
-        if (me.arealight >= 0 && (d->lights[me.arealight].kind != HPT_LIGHT_DIFFUSE_AREA || me.instance >= 0)) {
-            hpt_set_error("mesh %d: emitting mesh must refer to a diffuse area light and live directly in the world", m);
-            return me.instance >= 0 ? HPT_E_UNSUPPORTED : HPT_E_INVALID;
+        // an emitting mesh names a diffuse area light; one of Scene::lights if it lives directly in the world, an UNSAMPLED one (include/hpt.h) inside an instance
+        if (me.arealight >= 0 && (d->lights[me.arealight].kind != HPT_LIGHT_DIFFUSE_AREA || (me.instance >= 0) != HPT_LIGHT_UNSAMPLED(d->lights[me.arealight]))) {
+            hpt_set_error("mesh %d: an emitting mesh refers to a diffuse area light — a sampled one in the world, an unsampled one (no shape set) inside an instance", m);
+            return HPT_E_INVALID;
         }
         const int32_t *idx = d->ipool + me.idx_off;
         for (int64_t i = 0; i < 3ll * me.ntris; ++i)
@@ -237,8 +238,18 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
             }
         } else { hpt_set_error("material %d: unknown kind %d", m, ma.kind); return HPT_E_UNSUPPORTED; }
     }
+    bool seen_unsampled = false;
     for (int l = 0; l < d->n_lights; ++l) {
         const hpt_light &li = d->lights[l];
+        if (HPT_LIGHT_UNSAMPLED(li)) {      // the area light of shapes inside an object instance: not one of Scene::lights (include/hpt.h) — its meshes must be instanced ones
+            seen_unsampled = true;
+            for (int m = 0; m < d->n_meshes; ++m)
+                if (d->meshes[m].arealight == l && d->meshes[m].instance < 0) { hpt_set_error("light %d: an emitter without a shape set (unsampled) named by mesh %d, which is not inside an instance", l, m); return HPT_E_INVALID; }
+            for (int q = 0; q < d->n_quadrics; ++q)
+                if (d->quadrics[q].arealight == l) { hpt_set_error("light %d: an emitter without a shape set (unsampled) named by quadric %d", l, q); return HPT_E_INVALID; }
+            continue;
+        }
+        if (seen_unsampled) { hpt_set_error("light %d: the lights of Scene::lights precede the unsampled emitters in the table", l); return HPT_E_INVALID; }
         if (li.kind == HPT_LIGHT_POINT || li.kind == HPT_LIGHT_DISTANT) {
         } else if (li.kind == HPT_LIGHT_SPOT) {     // cosTotalWidth in `area`, cosFalloffStart in `marg_int`: width >= falloff start, i.e. cosTotalWidth <= cosFalloffStart
             if (!(li.area <= li.marg_int) || li.area < -1.f || li.marg_int > 1.f) { hpt_set_error("light %d: spot light cone cosines out of order", l); return HPT_E_INVALID; }
@@ -249,7 +260,7 @@ int hpt_validate_desc(const hpt_scene_desc *d) {
                     return HPT_E_INVALID;
                 }
             } else {    // ShapeSet of several shapes
-                if (li.set_n <= 0 || !in_pool(li.set_off, 2ll * li.set_n, d->n_i) || !in_pool(li.set_area_off, 2ll * li.set_n + 2, d->n_f)) {
+                if (li.set_n < 0 || !in_pool(li.set_off, 2ll * li.set_n, d->n_i) || !in_pool(li.set_area_off, 2ll * li.set_n + 2, d->n_f)) {
                     hpt_set_error("light %d: shape set out of range", l);
                     return HPT_E_INVALID;
                 }

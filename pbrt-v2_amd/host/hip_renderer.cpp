@@ -286,16 +286,28 @@ struct Flattener {
     int LightOf(const AreaLight *a) {
         if (!a) return -1;
         std::map<const Light *, int>::iterator it = lightIndex.find(a);
-        if (it == lightIndex.end())
-            Severe("hip renderer: primitive refers to an area light that is not in Scene::lights");
-        return it->second;
+        if (it != lightIndex.end()) return it->second;
+        // Not one of Scene::lights: the area light of a shape inside an object instance (core/api.cpp:1046-1049 warns and leaves it out).  The reference never
+        // samples it, but a camera ray or a specular bounce that hits the shape picks up Intersection::Le: an UNSAMPLED record behind the scene's lights
+        // (include/hpt.h, HPT_LIGHT_UNSAMPLED: DIFFUSE_AREA, no quadric, an empty shape set)
+        const DiffuseAreaLight *dl = dynamic_cast<const DiffuseAreaLight *>(a);
+        if (!dl) Severe("hip renderer: primitive refers to an area light of an unknown class that is not in Scene::lights");
+        hpt_light r;
+        memset(&r, 0, sizeof(r));
+        r.kind = HPT_LIGHT_DIFFUSE_AREA; r.quadric = -1; r.set_n = 0; r.set_off = r.set_area_off = -1;
+        r.tex_off = r.cond_func_off = r.cond_cdf_off = r.cond_int_off = r.marg_func_off = r.marg_cdf_off = -1;
+        CopyM(a->LightToWorld.m, r.l2w); CopyM(a->LightToWorld.mInv, r.l2w_inv);
+        r.nsamples = a->nSamples;
+        dl->Lemit.ToRGB(r.intensity);
+        r.area = dl->area;
+        lights.push_back(r);
+        lightIndex[a] = (int)lights.size() - 1;
+        return (int)lights.size() - 1;
     }
 
     void AddTriangle(const Triangle *tri, const GeometricPrimitive *gp, int instance = -1) {
         const TriangleMesh *mesh = tri->mesh.GetPtr();
         if (meshIndex.find(mesh) != meshIndex.end()) return;
-        if (gp->areaLight && instance >= 0)
-            Severe("hip renderer: emitting meshes inside animated instances are outside the hot-path scope");
         hpt_mesh r;
         memset(&r, 0, sizeof(r));
         r.ntris = mesh->ntris;

@@ -42,7 +42,9 @@ extern "C" emu_scene *emu_scene_create(const hpt_scene_desc *desc, int max_leaf)
     s->d.meshes = s->fs.meshes.data();
     s->d.quadrics = s->quadrics.data(); s->d.materials = s->materials.data(); s->d.lights = s->lights.data();
     s->d.fpool = s->fpool.data(); s->d.ipool = s->ipool.data();
-    s->d.n_tris = (int32_t)s->fs.n_tris; s->d.n_quadrics = desc->n_quadrics; s->d.n_lights = desc->n_lights;
+    s->d.n_tris = (int32_t)s->fs.n_tris; s->d.n_quadrics = desc->n_quadrics;
+    s->d.n_lights = 0;      // (Scene::lights: without the unsampled emitters behind them, as hpt_scene_create)
+    for (int l = 0; l < desc->n_lights; ++l) if (!HPT_LIGHT_UNSAMPLED(desc->lights[l])) s->d.n_lights = l + 1;
     s->d.n_nodes = (int32_t)s->fs.nodes.size();
     s->instances.assign(desc->instances, desc->instances + desc->n_instances);
     s->d.instances = s->instances.data(); s->d.inst_root = s->fs.inst_root.data();

@@ -126,6 +126,23 @@ def test_texture_tables_nested_deeper_than_the_general_evaluators_stack_are_refu
     assert "nested deeper than 12" in str(e.value) and deep_ok
 
 
+def test_unsampled_emitter_records_are_validated(tmp_path):
+    """include/hpt.h, HPT_LIGHT_UNSAMPLED (the area light of a shape inside an object instance, core/api.cpp:1046-1049): such records stand behind Scene::lights in the
+    table, and only instanced meshes may name them — a world mesh that emits belongs to a sampled light's shape set."""
+    from tests.util import load_case
+    save = lambda s: hpt.lib().hpt_blob_save(str(tmp_path / "x.hpts").encode(), C.byref(s.desc), None, None)
+    s = load_case("oemit")
+    assert [abi.light_unsampled(l) for l in s.lights] == [False, False, True, True] and save(s) == 0, hpt.last_error()
+    more = abi._arr(abi.Light, 5)                                                                 # a sampled light (a copy of the point light) behind the unsampled records
+    for i in range(5):
+        more[i] = abi.copy_struct(s.lights[i if i < 4 else 0])
+    s.lights = more
+    assert save(s) == -2 and "precede" in hpt.last_error()
+    s = load_case("oemit")
+    next(m for m in s.meshes if m.instance < 0).arealight = 2                                     # a mesh of the world naming an unsampled emitter
+    assert save(s) == -2 and ("not inside an instance" in hpt.last_error() or "unsampled" in hpt.last_error())
+
+
 def test_animated_quadric_records_are_validated(tmp_path):
     """ABI 8, hpt_instance.quadric1 (an animated sphere / disk: TransformedPrimitive over a bare GeometricPrimitive, core/api.cpp:1032-1042):
     the record it names must exist, carry the identity ObjectToWorld and no area light (api.cpp:1014-1021), and belong to one instance;

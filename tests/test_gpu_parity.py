@@ -185,7 +185,7 @@ def test_warmup_thread_starts_the_runtime_for_a_fresh_process(cases, dev, tmp_pa
     assert np.array_equal(np.load(out), fd)
 
 
-R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap", "texdeep"]   # round-2 / round-3 scenes of the path integrator
+R2_REPLAY_CASES = ["on", "spec", "trilight", "merl", "tex", "alpha", "metal", "metalg", "lens", "tang", "qtex", "aquad", "lts", "oinst", "texmap", "texdeep", "oemit"]   # round-2 / round-3 scenes of the path integrator
 
 
 @pytest.mark.parametrize("name", CASES + R2_REPLAY_CASES)
@@ -966,7 +966,7 @@ def test_exr_environment_map_matches_oracle_sample_for_sample():
     assert np.isclose(io, idv, rtol=1e-4, atol=1e-5).all(axis=2).mean() > 0.99
 
 
-R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl", "texdeep"]
+R2_GPU = ["on", "spec", "specdl", "trilight", "trildl", "merl", "tex", "mirtex", "alpha", "metal", "lens", "metalg", "tang", "qtex", "aquad", "aquaddl", "lts", "ltsdl", "oinst", "abi8dl", "texmap", "texmapdl", "texdeep", "oemit", "oemitdl"]
 
 
 @pytest.mark.parametrize("name", R2_GPU)

@@ -63,6 +63,7 @@ MATRIX = [
     ("oinst", w.K_FREE, 32), ("oinst", w.K_STEAL, 24), ("oinst", w.K_STEAL_TOP, 24), ("oinst", w.K_LEAN_STEAL, 24),
     ("oinst64", w.K_STEAL_TOP, 24),
     ("tex", w.K_STEAL, 32), ("tex", w.K_LEAN_STEAL, 32),
+    ("oemit", w.K_STEAL, 32), ("oemit", w.K_STEAL_TOP, 32),      # round 6: unsampled emitters inside object instances
     ("texmap", w.K_STEAL, 40), ("texmap", w.K_EXT_STEAL_NOINST, 40), ("texdeep", w.K_EXT_STEAL_NOINST, 40),      # round 6: the general texture evaluator (spherical / cylindrical / planar mappings, nesting 7); the alpha cut-out through the cooperative leaves
 ]
 
@@ -80,7 +81,7 @@ def test_wave_level_kernel_renders_the_oracles_film(name, kernel, n):
         assert info["nodes"] > 0 and info["tris"] > 0
 
 
-DL = [("abi8dl", w.K_DL, 32), ("abi8dl", w.K_DL_TOP, 32), ("aquaddl", w.K_DL, 32), ("aquaddl", w.K_DL_TOP, 32), ("dl1", w.K_DL, 24), ("dlone", w.K_DL, 24), ("specdl", w.K_DL, 24), ("trildl", w.K_DL, 24), ("texmapdl", w.K_DL, 40)]
+DL = [("abi8dl", w.K_DL, 32), ("abi8dl", w.K_DL_TOP, 32), ("aquaddl", w.K_DL, 32), ("aquaddl", w.K_DL_TOP, 32), ("dl1", w.K_DL, 24), ("dlone", w.K_DL, 24), ("specdl", w.K_DL, 24), ("trildl", w.K_DL, 24), ("texmapdl", w.K_DL, 40), ("oemitdl", w.K_DL, 32)]
 
 
 @pytest.mark.parametrize("name,kernel,n", DL)

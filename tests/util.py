@@ -175,8 +175,11 @@ R2_CASES = {"on": "on.hpts.gz", "spec": "spec.hpts.gz", "trilight": "trilight.hp
             # under direct lighting (finite differences over the specular rays' dpdx / dpdy)
             "texmap": "texmap.hpts.gz",
             # round 6: scale / mix textures nested seven deep over uv maps (the general evaluator's explicit stack instead of the three template levels)
-            "texdeep": "texdeep.hpts.gz"}
-R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz", "texmapdl": "texmap.hpts.gz"}     # same geometry, own camera / render descriptor / lights
+            "texdeep": "texdeep.hpts.gz",
+            # round 6 (tests/golden/make_golden_oemit.py): EMITTERS INSIDE OBJECT INSTANCES — area lights the reference leaves out of Scene::lights (core/api.cpp:1046-1049) but
+            # whose shapes still emit at camera rays and specular bounces: unsampled light records behind the scene's lights (include/hpt.h, HPT_LIGHT_UNSAMPLED)
+            "oemit": "oemit.hpts.gz"}
+R2_VIEW_CASES = {"specdl": "spec.hpts.gz", "trildl": "trilight.hpts.gz", "lens": "tex.hpts.gz", "texmapdl": "texmap.hpts.gz", "oemitdl": "oemit.hpts.gz"}     # same geometry, own camera / render descriptor / lights
 
 
 def nest_textures(s, levels):
