@@ -23,4 +23,4 @@ done; done
 for w in anim bunny soup; do timeout 900 python bench.py --workload $w --steps 3 --warmup 1 $Q 2>/dev/null | line "$w default" | tee -a $O/ab.txt; done
 ( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.out 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; tail -c 400 $O/bench_driver_cmd.out; tail -3 $O/bench_driver_cmd.time
 cp gpurun_out/bench_full.json $O/bench_full.json 2>/dev/null
-bash scripts/gpu_profile.sh metal > $O/prof_metal.log 2>&1; tail -1 $O/prof_metal.log
+
