@@ -97,6 +97,8 @@ def dest_vgprs(text):
     parts = text.split(None, 1)
     if len(parts) < 2:
         return set()
+    if parts[0].startswith("v_swap_b32"):            # D <-> S0: both registers are written
+        return {int(x) for x in re.findall(r"\bv(\d+)\b", parts[1])}
     first = parts[1].split(",")[0].strip()
     m = re.match(r"^v\[(\d+):(\d+)\]$", first)
     if m:

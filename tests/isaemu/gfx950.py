@@ -1080,6 +1080,12 @@ def bind_vector(ins):
             np.copyto(w.V[ops[0].idx], lo, where=w.em)
             np.copyto(w.V[ops[0].idx + 1], hi, where=w.em)
         return fpm
+    if base == "v_swap_b32":          # D <-> S0 in the active lanes (two VGPRs)
+        def fsw(w, i):
+            a, b = w.V[ops[0].idx].copy(), w.V[ops[1].idx].copy()
+            np.copyto(w.V[ops[0].idx], b, where=w.em)
+            np.copyto(w.V[ops[1].idx], a, where=w.em)
+        return fsw
     # ---- lanes ----
     if base == "v_readlane_b32":
         return lambda w, i: w.ws32(ops[0], int(w.V[ops[1].idx][w.s32(ops[2]) & 63]))
